@@ -1,0 +1,228 @@
+/*
+ * dftpav_hip.h — C-ABI of the MI355X-native batched MINCO / L-BFGS trajectory solver.
+ *
+ * This is the drop-in boundary for Dftpav's traj_planner solve path.  The
+ * reference has no FFI layer: the boundary there is the C++ class
+ * PolyTrajOptimizer (traj_planner/include/plan_manage/traj_optimizer.h:100-120)
+ * plus the L-BFGS callback typedef (include/geo_utils2d/lbfgs.hpp:200-202).
+ * Every entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C PODs, caller-allocated buffers, no exceptions, no logging.
+ *   - all reals are IEEE fp64 (the reference computes in double throughout,
+ *     common/basics/basics.h:29 `decimal_t = double`).
+ *   - 2x3 boundary states are column-major [px,py, vx,vy, ax,ay]
+ *     (Eigen::MatrixXd(2,3) default storage, traj_optimizer.cpp:8).
+ *   - return value: DFTPAV_OK (0) or a negative DFTPAV_E_* code.  Per-trajectory
+ *     solver status uses the reference's lbfgs enum values (lbfgs.hpp:135-184).
+ *   - one handle = one HIP stream + its device buffers; single owner thread
+ *     (PolyTrajOptimizer is not re-entrant either, traj_optimizer.h:80-92).
+ */
+#ifndef DFTPAV_HIP_H
+#define DFTPAV_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library return codes ------------------------------------------------ */
+#define DFTPAV_OK 0
+#define DFTPAV_E_INVALID (-1)     /* bad argument / size mismatch (traj_optimizer.cpp:26-48) */
+#define DFTPAV_E_MINI_T (-2)      /* initTs.min < mini_T          (traj_optimizer.cpp:30-33) */
+#define DFTPAV_E_ONE_PIECE (-3)   /* a segment with <2 pieces     (traj_optimizer.cpp:38-41) */
+#define DFTPAV_E_NO_DEVICE (-4)   /* no HIP device / kernel image not loadable: never falls back to CPU */
+#define DFTPAV_E_HIP (-5)         /* a HIP runtime call failed (see dftpav_last_error) */
+#define DFTPAV_E_UNSUPPORTED (-6) /* layout exceeds a compiled limit */
+
+/* ---- per-trajectory solver status: values of lbfgs.hpp:135-184 ----------- */
+enum {
+  DFTPAV_LBFGS_CONVERGENCE = 0,
+  DFTPAV_LBFGS_STOP = 1,
+  DFTPAV_LBFGS_CANCELED = 2,
+  DFTPAV_LBFGSERR_UNKNOWNERROR = -1024,
+  DFTPAV_LBFGSERR_INVALID_N = -1023,
+  DFTPAV_LBFGSERR_INVALID_MEMSIZE = -1022,
+  DFTPAV_LBFGSERR_INVALID_GEPSILON = -1021,
+  DFTPAV_LBFGSERR_INVALID_TESTPERIOD = -1020,
+  DFTPAV_LBFGSERR_INVALID_DELTA = -1019,
+  DFTPAV_LBFGSERR_INVALID_MINSTEP = -1018,
+  DFTPAV_LBFGSERR_INVALID_MAXSTEP = -1017,
+  DFTPAV_LBFGSERR_INVALID_FDECCOEFF = -1016,
+  DFTPAV_LBFGSERR_INVALID_SCURVCOEFF = -1015,
+  DFTPAV_LBFGSERR_INVALID_MACHINEPREC = -1014,
+  DFTPAV_LBFGSERR_INVALID_MAXLINESEARCH = -1013,
+  DFTPAV_LBFGSERR_INVALID_FUNCVAL = -1012,
+  DFTPAV_LBFGSERR_MINIMUMSTEP = -1011,
+  DFTPAV_LBFGSERR_MAXIMUMSTEP = -1010,
+  DFTPAV_LBFGSERR_MAXIMUMLINESEARCH = -1009,
+  DFTPAV_LBFGSERR_MAXIMUMITERATION = -1008,
+  DFTPAV_LBFGSERR_WIDTHTOOSMALL = -1007,
+  DFTPAV_LBFGSERR_INVALIDPARAMETERS = -1006,
+  DFTPAV_LBFGSERR_INCREASEGRADIENT = -1005
+};
+
+/* ---- constants of the optimiser ------------------------------------------
+ * Replaces PolyTrajOptimizer::setParam (traj_optimizer.cpp:1713-1781), the
+ * protobuf OptCfg (proto/minco_config.proto:67-99, values
+ * config/minco_config.pb.txt:65-100), common::VehicleParam defaults
+ * (common/basics/semantics.h:66-76) and the constants hard-coded in
+ * traj_optimizer.h:68 / traj_optimizer.cpp:127-134,197. */
+typedef struct dftpav_params {
+  int traj_resolution;      /* K   : samples-1 on interior pieces        (pb.txt:66) */
+  int des_traj_resolution;  /* K_d : samples-1 on first/last piece       (pb.txt:67) */
+  double wei_obs;           /* wei_sta_obs  1000                         (pb.txt:68) */
+  double wei_surround;      /* wei_dyn_obs  5000                         (pb.txt:69) */
+  double wei_feas;          /* 2500                                      (pb.txt:70) */
+  double wei_sqrvar;        /* read, unused by the live path             (pb.txt:71) */
+  double wei_time;          /* 500                                       (pb.txt:72) */
+  double surround_clearance;/* dyn_obs_clearance 0.4                     (pb.txt:73) */
+  double half_margin;       /* 0.15 footprint inflation                  (pb.txt:74) */
+  double max_forward_vel, max_forward_acc, max_forward_cur;   /* 5 8 1 (pb.txt:83-85) */
+  double max_backward_vel, max_backward_acc, max_backward_cur;/* 2 4 1 (pb.txt:87-89) */
+  double max_latacc;        /* computed, penalty disabled in the reference (traj_optimizer.cpp:666-678) */
+  double max_phidot;        /* idem                                        (traj_optimizer.cpp:707-773) */
+  int gear_opt;             /* GearOpt true                              (pb.txt:95) */
+  double non_sinv;          /* 0.24, hard-coded traj_optimizer.h:68 */
+  double mini_T;            /* 0.1                                       (pb.txt:99) */
+  double fail_cost;         /* 50000, traj_optimizer.cpp:197 */
+  /* raw vehicle (semantics.h:66-76); inflated by 2*half_margin inside, as setParam does */
+  double veh_width, veh_length, veh_wheel_base, veh_d_cr;
+  /* L-BFGS (lbfgs.hpp:15-129 defaults overridden at traj_optimizer.cpp:127-134) */
+  int lbfgs_mem_size;       /* 256 (pb.txt:96) */
+  int lbfgs_past;           /* 3   (pb.txt:97) */
+  double lbfgs_delta;       /* 1e-4 (pb.txt:98) */
+  double lbfgs_g_epsilon;   /* 1e-16 */
+  int lbfgs_max_iterations; /* 12000 */
+  int lbfgs_max_linesearch; /* 64 */
+  double lbfgs_min_step;    /* 1e-32 */
+  double lbfgs_max_step;    /* 1e20 */
+  double lbfgs_f_dec_coeff; /* 1e-4 */
+  double lbfgs_s_curv_coeff;/* 0.9 */
+  double lbfgs_cautious_factor; /* 1e-6 */
+  double lbfgs_machine_prec;    /* 1e-16 */
+} dftpav_params;
+
+/* Fills the live values of the reference (files cited on each field above). */
+void dftpav_default_params(dftpav_params *p);
+
+/* ---- moving obstacles ----------------------------------------------------
+ * Replaces PolyTrajOptimizer::setSurroundTrajs(SurroundTrajData*)
+ * (traj_optimizer.h:108, traj_optimizer.cpp:1916) and the fields of
+ * plan_utils::LocalTrajData the hot path reads (traj_container.hpp:28-38):
+ * traj (pieces), duration, start_time.  A piece is {duration, 2x6 coeffMat}
+ * with column 0 multiplying t^5 (poly_traj_utils.hpp:77-87,993); coeffs are
+ * stored column-major per piece: [x5,y5, x4,y4, ... x0,y0]. All obstacles of
+ * one set share `n_pieces` rows in the flattened arrays via piece_offsets. */
+typedef struct dftpav_surround {
+  int S;                       /* number of moving obstacles (0 = none) */
+  const int *piece_offsets;    /* [S+1] prefix offsets into durations/coeffs */
+  const double *durations;     /* [piece_offsets[S]] */
+  const double *coeffs;        /* [piece_offsets[S]][12] */
+  const double *total_duration;/* [S]  LocalTrajData::duration */
+  const double *start_time;    /* [S]  LocalTrajData::start_time */
+} dftpav_surround;
+
+/* ---- structure shared by every trajectory of a batch ----------------------
+ * M gear segments (`trajnum`), N_i pieces each, singul_i = +1 forward / -1
+ * reverse (traj_optimizer.cpp:13-23).  n = 2*sum(N_i-1) + M + 3*(M-1)
+ * decision variables laid out [P_0..P_{M-1} | tau | gear xy | gear angle]
+ * (traj_optimizer.cpp:80-115). */
+typedef struct dftpav_layout {
+  int M;
+  const int *piece_nums; /* [M] */
+  const int *singuls;    /* [M] */
+  int H;                 /* half-planes per constraint point (4 on the live path, traj_manager.cpp:1225) */
+} dftpav_layout;
+
+/* ---- inputs of OptimizeTrajectory for B trajectories ----------------------
+ * Replaces the argument list of PolyTrajOptimizer::OptimizeTrajectory
+ * (traj_optimizer.h:118-120).  Every array is trajectory-major. */
+typedef struct dftpav_batch_data {
+  const double *ini_states; /* [B][M][6]  iniStates   */
+  const double *fin_states; /* [B][M][6]  finStates   */
+  const double *inner_pts;  /* [B][2*sum(N_i-1)] initInnerPts, segment after segment, (x,y) per waypoint */
+  const double *init_Ts;    /* [B][M]     initTs (segment totals, each >= mini_T) */
+  const double *corridor;   /* [B][Npts][H][4] hPoly columns (n_x,n_y,p_x,p_y), outward normal,
+                               NOT necessarily unit (normalised inside, traj_optimizer.cpp:49-52);
+                               Npts = sum_i (N_i-2)(K+1)+2(K_d+1) in sampling order */
+  double t_now;             /* `now`  (traj_optimizer.h:120) */
+  double help_eps;          /* `help_eps` -> epis (live value 0.0, traj_manager.cpp:610) */
+} dftpav_batch_data;
+
+typedef struct dftpav_handle dftpav_handle;
+typedef struct dftpav_batch dftpav_batch;
+
+/* number of decision variables / constraint points of a layout */
+int dftpav_num_vars(const dftpav_layout *l);
+int dftpav_num_points(const dftpav_params *p, const dftpav_layout *l);
+
+/* Replaces PolyTrajOptimizer construction + setParam (traj_optimizer.h:100).
+ * device: HIP ordinal.  Fails with DFTPAV_E_NO_DEVICE when no gfx950 device
+ * is usable — there is no CPU fallback in this library. */
+int dftpav_create(const dftpav_params *params, int device, dftpav_handle **out);
+void dftpav_destroy(dftpav_handle *h);
+const char *dftpav_last_error(const dftpav_handle *h);
+
+/* Replaces setSurroundTrajs (traj_optimizer.h:108). s==NULL or s->S==0 clears
+ * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied. */
+int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s);
+
+/* Device-resident batch of B trajectories with a common layout. */
+int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out);
+void dftpav_batch_destroy(dftpav_batch *b);
+
+/* The setup half of OptimizeTrajectory (traj_optimizer.cpp:26-115): validates,
+ * normalises corridor normals, clamps boundary |v|,|a|, packs x0, uploads to
+ * HBM.  After this call the batch is resident; solve/eval touch no host data. */
+int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
+
+/* Decision vectors x0 packed by upload ([B][n], host copy). */
+int dftpav_batch_get_x0(dftpav_batch *b, double *x0);
+
+/* L1 cut (unit-test boundary) == PolyTrajOptimizer::costFunctionCallback
+ * (traj_optimizer.cpp:206-350, type lbfgs.hpp:200-202) for B decision
+ * vectors at once: x [B][n] -> f [B], g [B][n].  Host buffers. */
+int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g);
+
+/* L2 cut (production) == lbfgs::lbfgs_optimize driven from
+ * OptimizeTrajectory (traj_optimizer.cpp:159-166, lbfgs.hpp:440-751): one
+ * persistent kernel launch runs every trajectory's whole L-BFGS solve on the
+ * device, starting from the resident x0.  Asynchronous on the handle's stream. */
+int dftpav_batch_solve_async(dftpav_batch *b);
+int dftpav_batch_sync(dftpav_batch *b);
+
+/* Results (any pointer may be NULL):
+ *   x          [B][n]  final decision vectors (x after lbfgs_optimize returns)
+ *   final_cost [B]     `final_cost` (traj_optimizer.cpp:160)
+ *   status     [B]     lbfgs_optimize return code (enum above)
+ *   success    [B]     flag_success of OptimizeTrajectory (traj_optimizer.cpp:176-201)
+ *   iters      [B]     L-BFGS iterations k
+ *   evals      [B]     cost/gradient evaluations (iter_num_, traj_optimizer.cpp:334)
+ *   hist_sum   [B]     sum over iterations of the history depth used by the
+ *                      two-loop recursion (input of the bytes model) */
+int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *status,
+                         int *success, int *iters, int *evals, long long *hist_sum);
+
+/* Replaces getMinJerkOptPtr()[i].getCoeffs()/getDt() (traj_optimizer.h:112,
+ * poly_traj_utils.hpp:1069-1074): regenerates the piece coefficients from the
+ * final x on the device.  coeffs [B][Ntot][6][2] (row k multiplies s^k, then
+ * x/y), piece_dt [B][M]. */
+int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piece_dt);
+
+/* Duration in ms of the last solve kernel, measured with HIP events recorded
+ * on the handle's stream around the launch. */
+int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms);
+
+/* One-shot convenience == OptimizeTrajectory for B trajectories. */
+int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B,
+                       const dftpav_batch_data *d, double *x, double *final_cost,
+                       int *status, int *success, int *iters, int *evals);
+
+/* The HIP stream of the handle as an opaque pointer (for callers that want to
+ * order their own work after a solve). */
+void *dftpav_stream(dftpav_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFTPAV_HIP_H */

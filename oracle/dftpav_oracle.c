@@ -1,0 +1,1633 @@
+/*
+ * dftpav_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see dftpav_oracle.h).
+ *
+ * fp64 CPU restatement of the Dftpav solve path.  PARITY UNPINNED: the
+ * reference has no golden vectors for this path and cannot be built here.
+ *
+ * Shorthand for citations:
+ *   OPT   = src/Plan/traj_planner/src/traj_optimizer.cpp
+ *   MINCO = src/Plan/traj_planner/include/plan_utils/poly_traj_utils.hpp
+ *   LBFGS = src/Plan/traj_planner/include/geo_utils2d/lbfgs.hpp
+ *
+ * Arithmetic is written scalar-by-scalar in the reference's left-to-right
+ * operator order.  Eigen's internal summation order inside fixed-size
+ * products/reductions is not pinned by the reference (Eigen version unpinned,
+ * TP/CMakeLists.txt:14), so agreement with a real build of the reference is
+ * expected at rounding level, not bit level.  Build with -ffp-contract=off
+ * (the reference is built -O3 without -march, i.e. no FMA contraction).
+ */
+#include "dftpav_oracle.h"
+
+#include <alloca.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ========================================================================= */
+/* constants: config/minco_config.pb.txt:65-100, semantics.h:66-76, OPT.h:68  */
+/* ========================================================================= */
+void oracle_default_params(dftpav_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->traj_resolution = 16;        /* pb.txt:66 */
+  p->des_traj_resolution = 32;    /* pb.txt:67 */
+  p->wei_obs = 1000.0;            /* pb.txt:68 */
+  p->wei_surround = 5000.0;       /* pb.txt:69 */
+  p->wei_feas = 2500.0;           /* pb.txt:70 */
+  p->wei_sqrvar = 500.0;          /* pb.txt:71 */
+  p->wei_time = 500.0;            /* pb.txt:72 */
+  p->surround_clearance = 0.4;    /* pb.txt:73 */
+  p->half_margin = 0.15;          /* pb.txt:74 */
+  p->max_forward_vel = 5.0;       /* pb.txt:83 */
+  p->max_forward_acc = 8.0;       /* pb.txt:84 */
+  p->max_forward_cur = 1.0;       /* pb.txt:85 */
+  p->max_backward_vel = 2.0;      /* pb.txt:87 */
+  p->max_backward_acc = 4.0;      /* pb.txt:88 */
+  p->max_backward_cur = 1.0;      /* pb.txt:89 */
+  p->max_latacc = 5.0;            /* pb.txt:91 */
+  p->max_phidot = 10000.0;        /* pb.txt:92 */
+  p->gear_opt = 1;                /* pb.txt:95 */
+  p->non_sinv = 0.24;             /* traj_optimizer.h:68 (pb.txt:94 max_nonsv is never read) */
+  p->mini_T = 0.1;                /* pb.txt:99 */
+  p->fail_cost = 50000.0;         /* OPT:197 */
+  p->veh_width = 1.90;            /* semantics.h:66 */
+  p->veh_length = 4.88;           /* semantics.h:67 */
+  p->veh_wheel_base = 2.85;       /* semantics.h:68 */
+  p->veh_d_cr = 1.015;            /* semantics.h:76 */
+  p->lbfgs_mem_size = 256;        /* pb.txt:96 */
+  p->lbfgs_past = 3;              /* pb.txt:97 */
+  p->lbfgs_delta = 1.0e-4;        /* pb.txt:98 */
+  p->lbfgs_g_epsilon = 1.0e-16;   /* OPT:130 */
+  p->lbfgs_max_iterations = 12000;/* OPT:134 */
+  p->lbfgs_max_linesearch = 64;   /* LBFGS:71 default */
+  p->lbfgs_min_step = 1.0e-32;    /* OPT:132 */
+  p->lbfgs_max_step = 1.0e+20;    /* LBFGS default */
+  p->lbfgs_f_dec_coeff = 1.0e-4;  /* LBFGS default */
+  p->lbfgs_s_curv_coeff = 0.9;    /* LBFGS default */
+  p->lbfgs_cautious_factor = 1.0e-6; /* LBFGS default */
+  p->lbfgs_machine_prec = 1.0e-16;   /* LBFGS default */
+}
+
+/* ========================================================================= */
+/* BandedSystem, MINCO:727-853                                                */
+/* ========================================================================= */
+typedef struct {
+  int N, lowerBw, upperBw;
+  double *ptr;
+} banded_t;
+
+#define BAND(A, i, j) ((A)->ptr[((i) - (j) + (A)->upperBw) * (A)->N + (j)])
+
+static void banded_create(banded_t *A, int n, int p, int q) { /* MINCO:731-741 */
+  A->N = n;
+  A->lowerBw = p;
+  A->upperBw = q;
+  A->ptr = (double *)calloc((size_t)n * (p + q + 1), sizeof(double));
+}
+static void banded_destroy(banded_t *A) {
+  free(A->ptr);
+  A->ptr = NULL;
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* in-place LU without pivoting, MINCO:776-800 */
+static void banded_factorizeLU(banded_t *A) {
+  int N = A->N;
+  for (int k = 0; k <= N - 2; k++) {
+    int iM = imin(k + A->lowerBw, N - 1);
+    double cVl = BAND(A, k, k);
+    for (int i = k + 1; i <= iM; i++) {
+      if (BAND(A, i, k) != 0.0) BAND(A, i, k) /= cVl;
+    }
+    int jM = imin(k + A->upperBw, N - 1);
+    for (int j = k + 1; j <= jM; j++) {
+      cVl = BAND(A, k, j);
+      if (cVl != 0.0) {
+        for (int i = k + 1; i <= iM; i++) {
+          if (BAND(A, i, k) != 0.0) BAND(A, i, j) -= BAND(A, i, k) * cVl;
+        }
+      }
+    }
+  }
+}
+
+/* solve A x = b for m=2 right-hand sides stored b[2*row+d], MINCO:805-826 */
+static void banded_solve(const banded_t *A, double *b) {
+  int N = A->N;
+  for (int j = 0; j <= N - 1; j++) {
+    int iM = imin(j + A->lowerBw, N - 1);
+    for (int i = j + 1; i <= iM; i++) {
+      double a = BAND(A, i, j);
+      if (a != 0.0) {
+        b[2 * i + 0] -= a * b[2 * j + 0];
+        b[2 * i + 1] -= a * b[2 * j + 1];
+      }
+    }
+  }
+  for (int j = N - 1; j >= 0; j--) {
+    double d = BAND(A, j, j);
+    b[2 * j + 0] /= d;
+    b[2 * j + 1] /= d;
+    int iM = imax(0, j - A->upperBw);
+    for (int i = iM; i <= j - 1; i++) {
+      double a = BAND(A, i, j);
+      if (a != 0.0) {
+        b[2 * i + 0] -= a * b[2 * j + 0];
+        b[2 * i + 1] -= a * b[2 * j + 1];
+      }
+    }
+  }
+}
+
+/* solve A^T x = b, MINCO:831-852 */
+static void banded_solveAdj(const banded_t *A, double *b) {
+  int N = A->N;
+  for (int j = 0; j <= N - 1; j++) {
+    double d = BAND(A, j, j);
+    b[2 * j + 0] /= d;
+    b[2 * j + 1] /= d;
+    int iM = imin(j + A->upperBw, N - 1);
+    for (int i = j + 1; i <= iM; i++) {
+      double a = BAND(A, j, i);
+      if (a != 0.0) {
+        b[2 * i + 0] -= a * b[2 * j + 0];
+        b[2 * i + 1] -= a * b[2 * j + 1];
+      }
+    }
+  }
+  for (int j = N - 1; j >= 0; j--) {
+    int iM = imax(0, j - A->lowerBw);
+    for (int i = iM; i <= j - 1; i++) {
+      double a = BAND(A, j, i);
+      if (a != 0.0) {
+        b[2 * i + 0] -= a * b[2 * j + 0];
+        b[2 * i + 1] -= a * b[2 * j + 1];
+      }
+    }
+  }
+}
+
+/* ========================================================================= */
+/* MinJerkOpt, MINCO:855-1095                                                 */
+/* All (6N)x2 matrices are stored m[2*row + d].                               */
+/* ========================================================================= */
+typedef struct {
+  int N;
+  double headPVA[6], tailPVA[6]; /* col-major 2x3 */
+  double *b, *c, *adj, *gdC;     /* 6N x 2 */
+  banded_t A;
+  double t[6], tInv[6];
+  double gdT;
+  double gdHead[6], gdTail[6]; /* 2x3 col-major */
+  double *gdP;                 /* 2 x (N-1) col-major */
+} minjerk_t;
+
+static void minjerk_fill_A(banded_t *A, int N) { /* MINCO:895-947 */
+  BAND(A, 0, 0) = 1.0;
+  BAND(A, 1, 1) = 1.0;
+  BAND(A, 2, 2) = 2.0;
+  for (int i = 0; i < N - 1; i++) {
+    BAND(A, 6 * i + 3, 6 * i + 3) = 6.0;
+    BAND(A, 6 * i + 3, 6 * i + 4) = 24.0;
+    BAND(A, 6 * i + 3, 6 * i + 5) = 60.0;
+    BAND(A, 6 * i + 3, 6 * i + 9) = -6.0;
+    BAND(A, 6 * i + 4, 6 * i + 4) = 24.0;
+    BAND(A, 6 * i + 4, 6 * i + 5) = 120.0;
+    BAND(A, 6 * i + 4, 6 * i + 10) = -24.0;
+    BAND(A, 6 * i + 5, 6 * i) = 1.0;
+    BAND(A, 6 * i + 5, 6 * i + 1) = 1.0;
+    BAND(A, 6 * i + 5, 6 * i + 2) = 1.0;
+    BAND(A, 6 * i + 5, 6 * i + 3) = 1.0;
+    BAND(A, 6 * i + 5, 6 * i + 4) = 1.0;
+    BAND(A, 6 * i + 5, 6 * i + 5) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i + 1) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i + 2) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i + 3) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i + 4) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i + 5) = 1.0;
+    BAND(A, 6 * i + 6, 6 * i + 6) = -1.0;
+    BAND(A, 6 * i + 7, 6 * i + 1) = 1.0;
+    BAND(A, 6 * i + 7, 6 * i + 2) = 2.0;
+    BAND(A, 6 * i + 7, 6 * i + 3) = 3.0;
+    BAND(A, 6 * i + 7, 6 * i + 4) = 4.0;
+    BAND(A, 6 * i + 7, 6 * i + 5) = 5.0;
+    BAND(A, 6 * i + 7, 6 * i + 7) = -1.0;
+    BAND(A, 6 * i + 8, 6 * i + 2) = 2.0;
+    BAND(A, 6 * i + 8, 6 * i + 3) = 6.0;
+    BAND(A, 6 * i + 8, 6 * i + 4) = 12.0;
+    BAND(A, 6 * i + 8, 6 * i + 5) = 20.0;
+    BAND(A, 6 * i + 8, 6 * i + 8) = -2.0;
+  }
+  BAND(A, 6 * N - 3, 6 * N - 6) = 1.0;
+  BAND(A, 6 * N - 3, 6 * N - 5) = 1.0;
+  BAND(A, 6 * N - 3, 6 * N - 4) = 1.0;
+  BAND(A, 6 * N - 3, 6 * N - 3) = 1.0;
+  BAND(A, 6 * N - 3, 6 * N - 2) = 1.0;
+  BAND(A, 6 * N - 3, 6 * N - 1) = 1.0;
+  BAND(A, 6 * N - 2, 6 * N - 5) = 1.0;
+  BAND(A, 6 * N - 2, 6 * N - 4) = 2.0;
+  BAND(A, 6 * N - 2, 6 * N - 3) = 3.0;
+  BAND(A, 6 * N - 2, 6 * N - 2) = 4.0;
+  BAND(A, 6 * N - 2, 6 * N - 1) = 5.0;
+  BAND(A, 6 * N - 1, 6 * N - 4) = 2.0;
+  BAND(A, 6 * N - 1, 6 * N - 3) = 6.0;
+  BAND(A, 6 * N - 1, 6 * N - 2) = 12.0;
+  BAND(A, 6 * N - 1, 6 * N - 1) = 20.0;
+}
+
+static void minjerk_reset(minjerk_t *mj, int pieceNum) { /* MINCO:880-951 */
+  int N = pieceNum;
+  mj->N = N;
+  banded_create(&mj->A, 6 * N, 6, 6);
+  mj->b = (double *)calloc((size_t)12 * N, sizeof(double));
+  mj->c = (double *)calloc((size_t)12 * N, sizeof(double));
+  mj->adj = (double *)calloc((size_t)12 * N, sizeof(double));
+  mj->gdC = (double *)calloc((size_t)12 * N, sizeof(double));
+  mj->gdP = (double *)calloc((size_t)2 * (N > 1 ? N - 1 : 1), sizeof(double));
+  mj->t[0] = 1.0;
+  minjerk_fill_A(&mj->A, N);
+  banded_factorizeLU(&mj->A);
+}
+
+static void minjerk_destroy(minjerk_t *mj) {
+  banded_destroy(&mj->A);
+  free(mj->b);
+  free(mj->c);
+  free(mj->adj);
+  free(mj->gdC);
+  free(mj->gdP);
+}
+
+/* MINCO:953-986 */
+static void minjerk_generate(minjerk_t *mj, const double *inPs, double dT, const double *headState,
+                             const double *tailState) {
+  int N = mj->N;
+  memcpy(mj->headPVA, headState, 6 * sizeof(double));
+  memcpy(mj->tailPVA, tailState, 6 * sizeof(double));
+  double *t = mj->t;
+  t[1] = dT;
+  t[2] = t[1] * t[1];
+  t[3] = t[2] * t[1];
+  t[4] = t[2] * t[2];
+  t[5] = t[4] * t[1];
+  for (int k = 0; k < 6; k++) mj->tInv[k] = 1.0 / t[k];
+
+  double *b = mj->b;
+  memset(b, 0, (size_t)12 * N * sizeof(double));
+  b[0] = mj->headPVA[0];
+  b[1] = mj->headPVA[1];
+  b[2] = mj->headPVA[2] * t[1];
+  b[3] = mj->headPVA[3] * t[1];
+  b[4] = mj->headPVA[4] * t[2];
+  b[5] = mj->headPVA[5] * t[2];
+  for (int i = 0; i < N - 1; i++) {
+    b[2 * (6 * i + 5) + 0] = inPs[2 * i + 0];
+    b[2 * (6 * i + 5) + 1] = inPs[2 * i + 1];
+  }
+  b[2 * (6 * N - 3) + 0] = mj->tailPVA[0];
+  b[2 * (6 * N - 3) + 1] = mj->tailPVA[1];
+  b[2 * (6 * N - 2) + 0] = mj->tailPVA[2] * t[1];
+  b[2 * (6 * N - 2) + 1] = mj->tailPVA[3] * t[1];
+  b[2 * (6 * N - 1) + 0] = mj->tailPVA[4] * t[2];
+  b[2 * (6 * N - 1) + 1] = mj->tailPVA[5] * t[2];
+
+  banded_solve(&mj->A, b);
+
+  for (int i = 0; i < N; i++)
+    for (int k = 0; k < 6; k++) {
+      mj->c[2 * (6 * i + k) + 0] = b[2 * (6 * i + k) + 0] * mj->tInv[k];
+      mj->c[2 * (6 * i + k) + 1] = b[2 * (6 * i + k) + 1] * mj->tInv[k];
+    }
+}
+
+#define CROW(m, r, d) ((m)[2 * (r) + (d)])
+static double row_sqn(const double *m, int r) { return m[2 * r] * m[2 * r] + m[2 * r + 1] * m[2 * r + 1]; }
+static double row_dot(const double *m, int r1, int r2) {
+  return m[2 * r1] * m[2 * r2] + m[2 * r1 + 1] * m[2 * r2 + 1];
+}
+
+/* MINCO:998-1009 */
+static double minjerk_getTrajJerkCost(const minjerk_t *mj) {
+  const double *c = mj->c, *t = mj->t;
+  double energy = 0.0;
+  for (int i = 0; i < mj->N; i++) {
+    energy += 36.0 * row_sqn(c, 6 * i + 3) * t[1] + 144.0 * row_dot(c, 6 * i + 4, 6 * i + 3) * t[2] +
+              192.0 * row_sqn(c, 6 * i + 4) * t[3] + 240.0 * row_dot(c, 6 * i + 5, 6 * i + 3) * t[3] +
+              720.0 * row_dot(c, 6 * i + 5, 6 * i + 4) * t[4] + 720.0 * row_sqn(c, 6 * i + 5) * t[5];
+  }
+  return energy;
+}
+
+/* MINCO:1012-1035 */
+static void minjerk_initSmGradCost(minjerk_t *mj) {
+  const double *c = mj->c, *t = mj->t;
+  double *gdC = mj->gdC;
+  for (int i = 0; i < mj->N; i++) {
+    for (int d = 0; d < 2; d++) {
+      CROW(gdC, 6 * i + 5, d) = 240.0 * CROW(c, 6 * i + 3, d) * t[3] + 720.0 * CROW(c, 6 * i + 4, d) * t[4] +
+                                1440.0 * CROW(c, 6 * i + 5, d) * t[5];
+      CROW(gdC, 6 * i + 4, d) = 144.0 * CROW(c, 6 * i + 3, d) * t[2] + 384.0 * CROW(c, 6 * i + 4, d) * t[3] +
+                                720.0 * CROW(c, 6 * i + 5, d) * t[4];
+      CROW(gdC, 6 * i + 3, d) = 72.0 * CROW(c, 6 * i + 3, d) * t[1] + 144.0 * CROW(c, 6 * i + 4, d) * t[2] +
+                                240.0 * CROW(c, 6 * i + 5, d) * t[3];
+      CROW(gdC, 6 * i + 0, d) = 0.0;
+      CROW(gdC, 6 * i + 1, d) = 0.0;
+      CROW(gdC, 6 * i + 2, d) = 0.0;
+    }
+  }
+  mj->gdT = 0.0;
+  for (int i = 0; i < mj->N; i++) {
+    mj->gdT += 36.0 * row_sqn(c, 6 * i + 3) + 288.0 * row_dot(c, 6 * i + 4, 6 * i + 3) * t[1] +
+               576.0 * row_sqn(c, 6 * i + 4) * t[2] + 720.0 * row_dot(c, 6 * i + 5, 6 * i + 3) * t[2] +
+               2880.0 * row_dot(c, 6 * i + 5, 6 * i + 4) * t[3] + 3600.0 * row_sqn(c, 6 * i + 5) * t[4];
+  }
+}
+
+/* MINCO:1037-1066 */
+static void minjerk_calGrads_PT(minjerk_t *mj) {
+  int N = mj->N;
+  const double *t = mj->t, *tInv = mj->tInv;
+  double *adj = mj->adj;
+  for (int i = 0; i < N; i++)
+    for (int k = 0; k < 6; k++) {
+      CROW(adj, 6 * i + k, 0) = CROW(mj->gdC, 6 * i + k, 0) * tInv[k];
+      CROW(adj, 6 * i + k, 1) = CROW(mj->gdC, 6 * i + k, 1) * tInv[k];
+    }
+  banded_solveAdj(&mj->A, adj);
+
+  for (int i = 0; i < N - 1; i++) {
+    mj->gdP[2 * i + 0] = CROW(adj, 6 * i + 5, 0);
+    mj->gdP[2 * i + 1] = CROW(adj, 6 * i + 5, 1);
+  }
+  for (int k = 0; k < 3; k++)
+    for (int d = 0; d < 2; d++) {
+      mj->gdHead[2 * k + d] = CROW(adj, k, d) * t[k];
+      mj->gdTail[2 * k + d] = CROW(adj, 6 * N - 3 + k, d) * t[k];
+    }
+
+  mj->gdT += mj->headPVA[2] * CROW(adj, 1, 0) + mj->headPVA[3] * CROW(adj, 1, 1);
+  mj->gdT += (mj->headPVA[4] * CROW(adj, 2, 0) + mj->headPVA[5] * CROW(adj, 2, 1)) * 2.0 * t[1];
+  mj->gdT += mj->tailPVA[2] * CROW(adj, 6 * N - 2, 0) + mj->tailPVA[3] * CROW(adj, 6 * N - 2, 1);
+  mj->gdT += (mj->tailPVA[4] * CROW(adj, 6 * N - 1, 0) + mj->tailPVA[5] * CROW(adj, 6 * N - 1, 1)) * 2.0 * t[1];
+  double gdtInv[6];
+  gdtInv[0] = 0.0;
+  gdtInv[1] = -1.0 * tInv[2];
+  gdtInv[2] = -2.0 * tInv[3];
+  gdtInv[3] = -3.0 * tInv[4];
+  gdtInv[4] = -4.0 * tInv[5];
+  gdtInv[5] = -5.0 * tInv[5] * tInv[1];
+  for (int i = 0; i < N; i++) {
+    double acc = 0.0;
+    for (int k = 0; k < 6; k++) {
+      double gdcol = CROW(mj->gdC, 6 * i + k, 0) * CROW(mj->b, 6 * i + k, 0) +
+                     CROW(mj->gdC, 6 * i + k, 1) * CROW(mj->b, 6 * i + k, 1);
+      acc += gdtInv[k] * gdcol;
+    }
+    mj->gdT += acc;
+  }
+}
+
+double oracle_minco_generate(int N, const double *inPs, double dT, const double *head, const double *tail,
+                             double *coeffs) {
+  minjerk_t mj;
+  minjerk_reset(&mj, N);
+  minjerk_generate(&mj, inPs, dT, head, tail);
+  double J = minjerk_getTrajJerkCost(&mj);
+  if (coeffs) memcpy(coeffs, mj.c, (size_t)12 * N * sizeof(double));
+  minjerk_destroy(&mj);
+  return J;
+}
+
+void oracle_minco_operator(int N, double *out) {
+  banded_t A;
+  banded_create(&A, 6 * N, 6, 6);
+  minjerk_fill_A(&A, N);
+  banded_factorizeLU(&A);
+  int ncol = N + 5;
+  double *b = (double *)malloc((size_t)12 * N * sizeof(double));
+  for (int col = 0; col < ncol; col++) {
+    int row;
+    if (col < 3) row = col;
+    else if (col < 3 + (N - 1)) row = 6 * (col - 3) + 5;
+    else row = 6 * N - 3 + (col - (N + 2));
+    memset(b, 0, (size_t)12 * N * sizeof(double));
+    b[2 * row] = 1.0;
+    banded_solve(&A, b);
+    for (int r = 0; r < 6 * N; r++) out[(size_t)r * ncol + col] = b[2 * r];
+  }
+  free(b);
+  banded_destroy(&A);
+}
+
+/* ========================================================================= */
+/* scalar helpers of the optimiser                                            */
+/* ========================================================================= */
+void oracle_smoothed_l1(double x, double *f, double *df) { /* OPT:783-806 */
+  const double pe = 1.0e-4;
+  const double half = 0.5 * pe;
+  const double f3c = 1.0 / (pe * pe);
+  const double f4c = -0.5 * f3c / pe;
+  const double d2c = 3.0 * f3c;
+  const double d3c = 4.0 * f4c;
+  if (x < pe) {
+    *f = (f4c * x + f3c) * x * x * x;
+    *df = (d3c * x + d2c) * x * x;
+  } else {
+    *f = x - half;
+    *df = 1.0;
+  }
+}
+
+double oracle_virtual_to_real_T(const dftpav_params *p, double vt) { /* OPT:371-379 */
+  return vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + p->mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + p->mini_T;
+}
+double oracle_real_to_virtual_T(const dftpav_params *p, double rt) { /* OPT:360-369 */
+  return rt > 1.0 + p->mini_T ? (sqrt(2.0 * rt - 1.0 - 2 * p->mini_T) - 1.0)
+                              : (1.0 - sqrt(2.0 / (rt - p->mini_T) - 1.0));
+}
+
+/* VirtualTGradCost(double...), OPT:405-419 */
+static void virtualT_grad_cost(const dftpav_params *p, double RT, double VT, double gdRT, double *gdVT,
+                               double *costT) {
+  double gdVT2Rt;
+  if (VT > 0) {
+    gdVT2Rt = VT + 1.0;
+  } else {
+    double denSqrt = (0.5 * VT - 1.0) * VT + 1.0;
+    gdVT2Rt = (1.0 - VT) / (denSqrt * denSqrt);
+  }
+  *gdVT = (gdRT + p->wei_time) * gdVT2Rt;
+  *costT = RT * p->wei_time;
+}
+
+/* log_sum_exp, OPT:1686-1707: mutates all_dists into the exp weights */
+static double log_sum_exp(double alpha, double *all_dists, int n, double *exp_sum) {
+  double d_0 = all_dists[0];
+  if (alpha > 0) {
+    for (int j = 1; j < n; j++)
+      if (all_dists[j] > d_0) d_0 = all_dists[j];
+  } else {
+    for (int j = 1; j < n; j++)
+      if (all_dists[j] < d_0) d_0 = all_dists[j];
+  }
+  *exp_sum = 0;
+  for (int j = 0; j < n; j++) {
+    all_dists[j] = exp(alpha * (all_dists[j] - d_0));
+    *exp_sum += all_dists[j];
+  }
+  return log(*exp_sum) / alpha + d_0;
+}
+
+/* ========================================================================= */
+/* Trajectory / Piece evaluators used for moving obstacles, MINCO:77-112,      */
+/* 179-211, 510-528, 554-603.  coeff: 2x6 col-major, col 0 multiplies t^5.     */
+/* ========================================================================= */
+static void piece_getPos(const double *cm, double t, double out[2]) { /* MINCO:77-87 */
+  out[0] = 0.0;
+  out[1] = 0.0;
+  double tn = 1.0;
+  for (int i = 5; i >= 0; i--) {
+    out[0] += tn * cm[2 * i + 0];
+    out[1] += tn * cm[2 * i + 1];
+    tn *= t;
+  }
+}
+static void piece_getdSigma(const double *cm, double t, double out[2]) { /* MINCO:179-194 */
+  out[0] = 0.0;
+  out[1] = 0.0;
+  double tn = 1.0;
+  int n = 1;
+  for (int i = 4; i >= 0; i--) {
+    out[0] += n * tn * cm[2 * i + 0];
+    out[1] += n * tn * cm[2 * i + 1];
+    tn *= t;
+    n++;
+  }
+}
+static void piece_getddSigma(const double *cm, double t, double out[2]) { /* MINCO:196-211 */
+  out[0] = 0.0;
+  out[1] = 0.0;
+  double tn = 1.0;
+  int m = 1, n = 2;
+  for (int i = 3; i >= 0; i--) {
+    out[0] += m * n * tn * cm[2 * i + 0];
+    out[1] += m * n * tn * cm[2 * i + 1];
+    tn *= t;
+    m++;
+    n++;
+  }
+}
+/* R[0]=r00 R[1]=r01 R[2]=r10 R[3]=r11 ; surround pieces have singul = +1 (traj_manager.cpp:775 getTraj(1)) */
+static void piece_getR(const double *cm, double t, double R[4]) { /* MINCO:89-98 */
+  double v[2];
+  piece_getdSigma(cm, t, v);
+  double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+  const int singul = 1;
+  R[0] = singul * v[0] / nv;
+  R[1] = singul * -v[1] / nv;
+  R[2] = singul * v[1] / nv;
+  R[3] = singul * v[0] / nv;
+}
+static void piece_getRdot(const double *cm, double t, double Rd[4]) { /* MINCO:100-112 */
+  double v[2], a[2];
+  piece_getdSigma(cm, t, v);
+  piece_getddSigma(cm, t, a);
+  double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+  double nv3 = pow(nv, 3);
+  double va = v[0] * a[0] + v[1] * a[1];
+  const int singul = 1;
+  double ta[4] = {a[0], -a[1], a[1], a[0]};
+  double tv[4] = {v[0], -v[1], v[1], v[0]};
+  for (int k = 0; k < 4; k++) Rd[k] = singul * (ta[k] / nv - tv[k] / nv3 * va);
+}
+/* Trajectory::locatePieceIdx, MINCO:510-528 (t by reference) */
+static int traj_locate(const double *durs, int N, double *t) {
+  int idx;
+  double dur;
+  for (idx = 0; idx < N && *t > (dur = durs[idx]); idx++) *t -= dur;
+  if (idx == N) {
+    idx--;
+    *t += durs[idx];
+  }
+  return idx;
+}
+
+typedef struct {
+  int n_pieces;
+  const double *durs;
+  const double *coeffs; /* [n_pieces][12] */
+  double duration, start_time;
+} sur_traj_t;
+
+static void traj_getPos(const sur_traj_t *s, double t, double o[2]) {
+  int i = traj_locate(s->durs, s->n_pieces, &t);
+  piece_getPos(s->coeffs + 12 * i, t, o);
+}
+static void traj_getdSigma(const sur_traj_t *s, double t, double o[2]) {
+  int i = traj_locate(s->durs, s->n_pieces, &t);
+  piece_getdSigma(s->coeffs + 12 * i, t, o);
+}
+static void traj_getddSigma(const sur_traj_t *s, double t, double o[2]) {
+  int i = traj_locate(s->durs, s->n_pieces, &t);
+  piece_getddSigma(s->coeffs + 12 * i, t, o);
+}
+static void traj_getR(const sur_traj_t *s, double t, double R[4]) {
+  int i = traj_locate(s->durs, s->n_pieces, &t);
+  piece_getR(s->coeffs + 12 * i, t, R);
+}
+static void traj_getRdot(const sur_traj_t *s, double t, double R[4]) {
+  int i = traj_locate(s->durs, s->n_pieces, &t);
+  piece_getRdot(s->coeffs + 12 * i, t, R);
+}
+
+/* ========================================================================= */
+/* prepared problem                                                           */
+/* ========================================================================= */
+struct oracle_ctx {
+  dftpav_params P;
+  int M, H, n, Npts_total, Ntot;
+  int *piece_nums, *singuls, *pt_offset; /* [M], [M], [M+1] */
+  double *iniS, *finS;                   /* clamped copies [M][6] */
+  double *inner_pts, *init_Ts;
+  double *cfgHs;                         /* normalised copy [Npts][H][4] */
+  double t_now, epis;
+  minjerk_t *mj;                         /* jerkOpt_container */
+  int S;
+  sur_traj_t *sur;
+  double *sur_durs, *sur_coeffs;
+  /* footprint, OPT:1749-1775 */
+  double veh_length_infl, veh_width_infl;
+  double vec_le[5][2], vec_lo[5][2];
+  int evals;
+  double cost_terms[5];
+};
+
+int oracle_num_vars(const oracle_problem *pb) { /* OPT:80-86 */
+  int n = 0;
+  for (int i = 0; i < pb->M; i++) n += 2 * (pb->piece_nums[i] - 1);
+  n += pb->M;
+  n += 2 * (pb->M - 1);
+  n += 1 * (pb->M - 1);
+  return n;
+}
+static int seg_points(const dftpav_params *p, int N) { /* OPT:44 */
+  return (N - 2) * (p->traj_resolution + 1) + 2 * (p->des_traj_resolution + 1);
+}
+int oracle_num_points(const dftpav_params *p, const oracle_problem *pb) {
+  int s = 0;
+  for (int i = 0; i < pb->M; i++) s += seg_points(p, pb->piece_nums[i]);
+  return s;
+}
+
+static void clamp_col(double *col, double lim) { /* OPT:65-76 */
+  double nrm = sqrt(col[0] * col[0] + col[1] * col[1]);
+  if (nrm >= lim) {
+    /* col.normalized()*(lim-1e-2) */
+    double nx = col[0] / nrm, ny = col[1] / nrm;
+    col[0] = nx * (lim - 1.0e-2);
+    col[1] = ny * (lim - 1.0e-2);
+  }
+}
+
+oracle_ctx *oracle_prepare(const dftpav_params *p, const oracle_problem *pb, int *err) {
+  int e = DFTPAV_OK;
+  if (pb->M < 1) e = DFTPAV_E_INVALID;
+  if (!e) {
+    double mn = pb->init_Ts[0];
+    for (int i = 1; i < pb->M; i++)
+      if (pb->init_Ts[i] < mn) mn = pb->init_Ts[i];
+    if (mn < p->mini_T) e = DFTPAV_E_MINI_T; /* OPT:30-33 */
+  }
+  if (!e)
+    for (int i = 0; i < pb->M; i++)
+      if (pb->piece_nums[i] < 2) e = DFTPAV_E_ONE_PIECE; /* OPT:38-41 */
+  if (e) {
+    if (err) *err = e;
+    return NULL;
+  }
+  oracle_ctx *c = (oracle_ctx *)calloc(1, sizeof(oracle_ctx));
+  c->P = *p;
+  c->M = pb->M;
+  c->H = pb->H;
+  c->n = oracle_num_vars(pb);
+  c->t_now = pb->t_now;
+  c->epis = pb->help_eps;
+  int M = c->M;
+  c->piece_nums = (int *)malloc(sizeof(int) * M);
+  c->singuls = (int *)malloc(sizeof(int) * M);
+  c->pt_offset = (int *)malloc(sizeof(int) * (M + 1));
+  c->iniS = (double *)malloc(sizeof(double) * 6 * M);
+  c->finS = (double *)malloc(sizeof(double) * 6 * M);
+  c->init_Ts = (double *)malloc(sizeof(double) * M);
+  memcpy(c->piece_nums, pb->piece_nums, sizeof(int) * M);
+  memcpy(c->singuls, pb->singuls, sizeof(int) * M);
+  memcpy(c->iniS, pb->ini_states, sizeof(double) * 6 * M);
+  memcpy(c->finS, pb->fin_states, sizeof(double) * 6 * M);
+  memcpy(c->init_Ts, pb->init_Ts, sizeof(double) * M);
+  int ninner = 0;
+  c->pt_offset[0] = 0;
+  c->Ntot = 0;
+  for (int i = 0; i < M; i++) {
+    ninner += 2 * (c->piece_nums[i] - 1);
+    c->pt_offset[i + 1] = c->pt_offset[i] + seg_points(p, c->piece_nums[i]);
+    c->Ntot += c->piece_nums[i];
+  }
+  c->Npts_total = c->pt_offset[M];
+  c->inner_pts = (double *)malloc(sizeof(double) * ninner);
+  memcpy(c->inner_pts, pb->inner_pts, sizeof(double) * ninner);
+  /* private corridor copy, normals normalised: OPT:15,49-52 */
+  size_t ncor = (size_t)c->Npts_total * c->H * 4;
+  c->cfgHs = (double *)malloc(sizeof(double) * ncor);
+  memcpy(c->cfgHs, pb->corridor, sizeof(double) * ncor);
+  for (size_t k = 0; k < (size_t)c->Npts_total * c->H; k++) {
+    double *col = c->cfgHs + 4 * k;
+    double nrm = sqrt(col[0] * col[0] + col[1] * col[1]);
+    col[0] /= nrm; /* Eigen normalize(): divides by the norm */
+    col[1] /= nrm;
+  }
+  /* clamp boundary v,a: OPT:55-76 */
+  c->mj = (minjerk_t *)calloc(M, sizeof(minjerk_t));
+  for (int i = 0; i < M; i++) {
+    double max_vel, max_acc;
+    if (c->singuls[i] > 0) {
+      max_vel = p->max_forward_vel;
+      max_acc = p->max_forward_acc;
+    } else {
+      max_vel = p->max_backward_vel;
+      max_acc = p->max_backward_acc;
+    }
+    clamp_col(c->iniS + 6 * i + 2, max_vel);
+    clamp_col(c->finS + 6 * i + 2, max_vel);
+    clamp_col(c->iniS + 6 * i + 4, max_acc);
+    clamp_col(c->finS + 6 * i + 4, max_acc);
+    minjerk_reset(&c->mj[i], c->piece_nums[i]); /* OPT:79 */
+  }
+  /* footprint: OPT:1749-1775 */
+  c->veh_width_infl = p->veh_width + 2 * p->half_margin;
+  c->veh_length_infl = p->veh_length + 2 * p->half_margin;
+  {
+    double W = c->veh_width_infl, L = c->veh_length_infl, dcr = p->veh_d_cr;
+    double le[4][2] = {{dcr + L / 2.0, W / 2.0}, {dcr + L / 2.0, -W / 2.0}, {dcr - L / 2.0, -W / 2.0},
+                       {dcr - L / 2.0, W / 2.0}};
+    for (int k = 0; k < 4; k++) {
+      c->vec_le[k][0] = le[k][0];
+      c->vec_le[k][1] = le[k][1];
+    }
+    c->vec_le[4][0] = le[0][0]; /* first vertex repeated, OPT:1772-1773 */
+    c->vec_le[4][1] = le[0][1];
+    memcpy(c->vec_lo, c->vec_le, sizeof(c->vec_le));
+  }
+  /* moving obstacles: copy */
+  c->S = 0;
+  if (pb->surround && pb->surround->S > 0) {
+    const dftpav_surround *s = pb->surround;
+    c->S = s->S;
+    int np = s->piece_offsets[s->S];
+    c->sur_durs = (double *)malloc(sizeof(double) * np);
+    c->sur_coeffs = (double *)malloc(sizeof(double) * 12 * np);
+    memcpy(c->sur_durs, s->durations, sizeof(double) * np);
+    memcpy(c->sur_coeffs, s->coeffs, sizeof(double) * 12 * np);
+    c->sur = (sur_traj_t *)calloc(s->S, sizeof(sur_traj_t));
+    for (int u = 0; u < s->S; u++) {
+      c->sur[u].n_pieces = s->piece_offsets[u + 1] - s->piece_offsets[u];
+      c->sur[u].durs = c->sur_durs + s->piece_offsets[u];
+      c->sur[u].coeffs = c->sur_coeffs + 12 * s->piece_offsets[u];
+      c->sur[u].duration = s->total_duration[u];
+      c->sur[u].start_time = s->start_time[u];
+    }
+  }
+  if (err) *err = DFTPAV_OK;
+  return c;
+}
+
+void oracle_free(oracle_ctx *c) {
+  if (!c) return;
+  for (int i = 0; i < c->M; i++) minjerk_destroy(&c->mj[i]);
+  free(c->mj);
+  free(c->piece_nums);
+  free(c->singuls);
+  free(c->pt_offset);
+  free(c->iniS);
+  free(c->finS);
+  free(c->inner_pts);
+  free(c->init_Ts);
+  free(c->cfgHs);
+  free(c->sur);
+  free(c->sur_durs);
+  free(c->sur_coeffs);
+  free(c);
+}
+
+void oracle_pack_x0(const oracle_ctx *c, double *x) { /* OPT:96-115 */
+  int offset = 0;
+  int ninner = 0;
+  for (int i = 0; i < c->M; i++) ninner += 2 * (c->piece_nums[i] - 1);
+  memcpy(x, c->inner_pts, sizeof(double) * ninner);
+  offset += ninner;
+  for (int i = 0; i < c->M; i++) x[offset + i] = oracle_real_to_virtual_T(&c->P, c->init_Ts[i]);
+  offset += c->M;
+  for (int i = 0; i < c->M - 1; i++) {
+    x[offset + 0] = c->finS[6 * i + 0];
+    x[offset + 1] = c->finS[6 * i + 1];
+    offset += 2;
+  }
+  for (int i = 0; i < c->M - 1; i++) {
+    x[offset + i] = atan2(c->finS[6 * i + 3], c->finS[6 * i + 2]);
+  }
+}
+
+/* ========================================================================= */
+/* dynamicObsGradCostP, OPT:1311-1684                                          */
+/* 2x2 matrices are m[0]=m00 m[1]=m01 m[2]=m10 m[3]=m11                        */
+/* ========================================================================= */
+static void mat_vec(const double m[4], const double v[2], double o[2]) {
+  o[0] = m[0] * v[0] + m[1] * v[1];
+  o[1] = m[2] * v[0] + m[3] * v[1];
+}
+static void mat_mat(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] + a[1] * b[2];
+  o[1] = a[0] * b[1] + a[1] * b[3];
+  o[2] = a[2] * b[0] + a[3] * b[2];
+  o[3] = a[2] * b[1] + a[3] * b[3];
+}
+static const double B_h[4] = {0.0, -1.0, 1.0, 0.0};  /* OPT:1741-1742 */
+static const double B_hT[4] = {0.0, 1.0, -1.0, 0.0};
+
+static double dynamicObsGradCostP(oracle_ctx *c, double omg, double step, double t, const double beta0[6],
+                                  const double beta1[6], double gama, int pieceid, int trajres,
+                                  const double sigma[2], const double dsigma[2], const double ddsigma[2],
+                                  const double ego_R[4], int trajid, double trajtime) {
+  const dftpav_params *P = &c->P;
+  int singul_ = c->singuls[trajid];
+  if (c->S < 1) return 0.0;
+  minjerk_t *mj = &c->mj[trajid];
+
+  double alpha = 100.0, d_min = P->surround_clearance + log(8.0) / alpha; /* OPT:1336 */
+  double temp0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
+  double temp0_reci = (temp0 != 0.0) ? 1.0 / temp0 : 0.0;
+  double temp3 = temp0_reci * temp0_reci;
+  const int nE = 4, nO = 4;
+  double totalPenalty = 0.0;
+
+  for (int sur_id = 0; sur_id < c->S; sur_id++) {
+    const sur_traj_t *st = &c->sur[sur_id];
+    double offsettime = c->t_now - st->start_time + trajtime; /* OPT:1367-1369 */
+    double pt_time = offsettime + t;
+    double surround_p[2], surround_v[2], surround_a[2];
+    if (pt_time < st->duration) {
+      traj_getPos(st, pt_time, surround_p);
+      traj_getdSigma(st, pt_time, surround_v);
+      traj_getddSigma(st, pt_time, surround_a);
+    } else { /* OPT:1379-1389 */
+      double vd[2], pd[2];
+      traj_getddSigma(st, st->duration, surround_a);
+      double exceed_time = pt_time - st->duration;
+      traj_getdSigma(st, st->duration, vd);
+      surround_v[0] = vd[0] + exceed_time * surround_a[0];
+      surround_v[1] = vd[1] + exceed_time * surround_a[1];
+      traj_getPos(st, st->duration, pd);
+      surround_p[0] = pd[0] + exceed_time * vd[0] + 0.5 * surround_a[0] * exceed_time * exceed_time;
+      surround_p[1] = pd[1] + exceed_time * vd[1] + 0.5 * surround_a[1] * exceed_time * exceed_time;
+    }
+    {
+      double dx = surround_p[0] - sigma[0], dy = surround_p[1] - sigma[1];
+      if (sqrt(dx * dx + dy * dy) > c->veh_length_infl * 1.5) continue; /* OPT:1393 */
+    }
+    double surround_R[4];
+    traj_getR(st, pt_time, surround_R); /* OPT:1410 */
+
+    double surround2ego_sum_exp_vec[4], d_U[4];
+    double ego_normal[4][2], vec_d_Uo_e[4][4], F_delta_le_v[4][4], F_le_v[4][4];
+    for (int e = 0; e < nE; e++) { /* OPT:1417-1461 */
+      const double *le = c->vec_le[e];
+      double delta_le[2] = {c->vec_le[e + 1][0] - le[0], c->vec_le[e + 1][1] - le[1]};
+      double delta_le_norm = sqrt(delta_le[0] * delta_le[0] + delta_le[1] * delta_le[1]);
+      double delta_le_norm_inverse = 1 / delta_le_norm;
+      double Rdl[2], Rle[2];
+      mat_vec(ego_R, delta_le, Rdl);
+      mat_vec(ego_R, le, Rle);
+      /* F(l) = singul*[l,Bl]^T*temp0_reci - dsigma*(R l)^T*temp3 */
+      {
+        double LT[4] = {delta_le[0], delta_le[1], -delta_le[1], delta_le[0]};
+        double *F = F_delta_le_v[e];
+        F[0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rdl[0] * temp3;
+        F[1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rdl[1] * temp3;
+        F[2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rdl[0] * temp3;
+        F[3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rdl[1] * temp3;
+      }
+      {
+        double LT[4] = {le[0], le[1], -le[1], le[0]};
+        double *F = F_le_v[e];
+        F[0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rle[0] * temp3;
+        F[1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rle[1] * temp3;
+        F[2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rle[0] * temp3;
+        F[3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rle[1] * temp3;
+      }
+      double BR[4], H_tilde[2];
+      mat_mat(B_h, ego_R, BR);
+      mat_vec(BR, delta_le, H_tilde);
+      H_tilde[0] *= delta_le_norm_inverse;
+      H_tilde[1] *= delta_le_norm_inverse;
+      ego_normal[e][0] = H_tilde[0];
+      ego_normal[e][1] = H_tilde[1];
+      double w[2] = {surround_p[0] - sigma[0] - Rle[0], surround_p[1] - sigma[1] - Rle[1]};
+      double d_U_e_tilde = H_tilde[0] * w[0] + H_tilde[1] * w[1];
+      double HtR[2] = {H_tilde[0] * surround_R[0] + H_tilde[1] * surround_R[2],
+                       H_tilde[0] * surround_R[1] + H_tilde[1] * surround_R[3]};
+      for (int o = 0; o < nO; o++) {
+        const double *lo = c->vec_lo[o];
+        vec_d_Uo_e[e][o] = HtR[0] * lo[0] + HtR[1] * lo[1];
+      }
+      double exp_sum;
+      d_U[e] = log_sum_exp(-alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_e_tilde;
+      surround2ego_sum_exp_vec[e] = exp_sum;
+    }
+
+    double ego2surround_sum_exp_vec[4], d_E[4];
+    double surround_normal[4][2], vec_d_Ee_o[4][4];
+    for (int o = 0; o < nO; o++) { /* OPT:1464-1496 */
+      const double *lo = c->vec_lo[o];
+      double delta_lo[2] = {c->vec_lo[o + 1][0] - lo[0], c->vec_lo[o + 1][1] - lo[1]};
+      double delta_lo_norm = sqrt(delta_lo[0] * delta_lo[0] + delta_lo[1] * delta_lo[1]);
+      double delta_lo_norm_inverse = 1 / delta_lo_norm;
+      double BR[4], H_tilde[2], Rlo[2];
+      mat_mat(B_h, surround_R, BR);
+      mat_vec(BR, delta_lo, H_tilde);
+      H_tilde[0] *= delta_lo_norm_inverse;
+      H_tilde[1] *= delta_lo_norm_inverse;
+      surround_normal[o][0] = H_tilde[0];
+      surround_normal[o][1] = H_tilde[1];
+      mat_vec(surround_R, lo, Rlo);
+      double w[2] = {sigma[0] - surround_p[0] - Rlo[0], sigma[1] - surround_p[1] - Rlo[1]};
+      double d_E_o_tilde = H_tilde[0] * w[0] + H_tilde[1] * w[1];
+      double HtR[2] = {H_tilde[0] * ego_R[0] + H_tilde[1] * ego_R[2], H_tilde[0] * ego_R[1] + H_tilde[1] * ego_R[3]};
+      for (int e = 0; e < nE; e++) {
+        const double *le = c->vec_le[e];
+        vec_d_Ee_o[o][e] = HtR[0] * le[0] + HtR[1] * le[1];
+      }
+      double exp_sum;
+      d_E[o] = log_sum_exp(-alpha, vec_d_Ee_o[o], nE, &exp_sum) + d_E_o_tilde;
+      ego2surround_sum_exp_vec[o] = exp_sum;
+    }
+
+    double d_test[8];
+    for (int e = 0; e < 4; e++) d_test[e] = d_U[e];
+    for (int o = 0; o < 4; o++) d_test[4 + o] = d_E[o];
+    double exp_sum_d = 0;
+    double d_value_test = d_min - log_sum_exp(alpha, d_test, 8, &exp_sum_d); /* OPT:1498-1502 */
+    double costp = d_value_test;
+    if (costp <= 0) continue;
+    double pena, penaD;
+    oracle_smoothed_l1(costp, &pena, &penaD);
+    totalPenalty += omg * step * P->wei_surround * pena;
+
+    /* dG/dsigma, OPT:1511-1523 */
+    double pGs[2] = {0.0, 0.0};
+    for (int e = 0; e < nE; e++) {
+      double w = d_test[e] / exp_sum_d;
+      pGs[0] -= w * (-ego_normal[e][0]);
+      pGs[1] -= w * (-ego_normal[e][1]);
+    }
+    for (int o = 0; o < nO; o++) {
+      double w = d_test[o + nE] / exp_sum_d;
+      pGs[0] -= w * surround_normal[o][0];
+      pGs[1] -= w * surround_normal[o][1];
+    }
+
+    /* dG/dsigma', OPT:1528-1573 */
+    double pGds[2] = {0.0, 0.0};
+    for (int e = 0; e < nE; e++) {
+      const double *F_delta_le = F_delta_le_v[e], *F_le = F_le_v[e];
+      const double *le = c->vec_le[e];
+      double delta_le[2] = {c->vec_le[e + 1][0] - le[0], c->vec_le[e + 1][1] - le[1]};
+      double dln = sqrt(delta_le[0] * delta_le[0] + delta_le[1] * delta_le[1]);
+      double d_Uo_e_exp_sum = surround2ego_sum_exp_vec[e];
+      double Rle[2];
+      mat_vec(ego_R, le, Rle);
+      double u[2] = {-surround_p[0] + sigma[0] + Rle[0], -surround_p[1] + sigma[1] + Rle[1]};
+      double FB[4], t1[2], FlB[4], FlBR[4], t2[2];
+      mat_mat(F_delta_le, B_h, FB);
+      mat_vec(FB, u, t1);
+      mat_mat(F_le, B_h, FlB);
+      mat_mat(FlB, ego_R, FlBR);
+      mat_vec(FlBR, delta_le, t2);
+      double pdU[2] = {(t1[0] - t2[0]) / dln, (t1[1] - t2[1]) / dln};
+      double FBT[4];
+      mat_mat(F_delta_le, B_hT, FBT);
+      for (int o = 0; o < nO; o++) {
+        double d_Uo_e = vec_d_Uo_e[e][o];
+        double Rlo[2], q[2];
+        mat_vec(surround_R, c->vec_lo[o], Rlo);
+        mat_vec(FBT, Rlo, q);
+        q[0] /= dln;
+        q[1] /= dln;
+        double w = d_Uo_e / d_Uo_e_exp_sum;
+        pdU[0] += w * q[0];
+        pdU[1] += w * q[1];
+      }
+      double w = d_test[e] / exp_sum_d;
+      pGds[0] -= w * pdU[0];
+      pGds[1] -= w * pdU[1];
+    }
+    for (int o = 0; o < nO; o++) {
+      const double *lo = c->vec_lo[o];
+      double delta_lo[2] = {c->vec_lo[o + 1][0] - lo[0], c->vec_lo[o + 1][1] - lo[1]};
+      double dln = sqrt(delta_lo[0] * delta_lo[0] + delta_lo[1] * delta_lo[1]);
+      double d_Ee_o_exp_sum = ego2surround_sum_exp_vec[o];
+      double pdE[2] = {0.0, 0.0};
+      for (int e = 0; e < nE; e++) {
+        const double *F_le = F_le_v[e];
+        double d_Ee_o = vec_d_Ee_o[o][e];
+        double FB[4], FBR[4], q[2];
+        mat_mat(F_le, B_h, FB);
+        mat_mat(FB, surround_R, FBR);
+        mat_vec(FBR, delta_lo, q);
+        q[0] /= dln;
+        q[1] /= dln;
+        double w = d_Ee_o / d_Ee_o_exp_sum;
+        pdE[0] += w * q[0];
+        pdE[1] += w * q[1];
+      }
+      double w = d_test[o + nE] / exp_sum_d;
+      pGds[0] -= w * pdE[0];
+      pGds[1] -= w * pdE[1];
+    }
+
+    /* dG/dt_bar, OPT:1578-1580 */
+    double pGtbar = (pGs[0] * dsigma[0] + pGs[1] * dsigma[1]) + (pGds[0] * ddsigma[0] + pGds[1] * ddsigma[1]);
+
+    /* dG/dt_hat, OPT:1586-1646 */
+    double pGthat = 0.0;
+    double Rud[4];
+    traj_getRdot(st, pt_time, Rud); /* OPT:1599 */
+    for (int e = 0; e < nE; e++) {
+      double d_Uo_e_exp_sum = surround2ego_sum_exp_vec[e];
+      const double *Hn = ego_normal[e];
+      double acc = Hn[0] * surround_v[0] + Hn[1] * surround_v[1];
+      double HtRd[2] = {Hn[0] * Rud[0] + Hn[1] * Rud[2], Hn[0] * Rud[1] + Hn[1] * Rud[3]};
+      for (int o = 0; o < nO; o++) {
+        const double *lo = c->vec_lo[o];
+        double pt = HtRd[0] * lo[0] + HtRd[1] * lo[1];
+        double d_Uo_e = vec_d_Uo_e[e][o];
+        acc += d_Uo_e / d_Uo_e_exp_sum * pt;
+      }
+      pGthat -= d_test[e] / exp_sum_d * acc;
+    }
+    for (int o = 0; o < nO; o++) {
+      double d_Ee_o_exp_sum = ego2surround_sum_exp_vec[o];
+      const double *lo = c->vec_lo[o];
+      double delta_lo[2] = {c->vec_lo[o + 1][0] - lo[0], c->vec_lo[o + 1][1] - lo[1]};
+      double dln = sqrt(delta_lo[0] * delta_lo[0] + delta_lo[1] * delta_lo[1]);
+      double BRd[4], BR[4], a1[2], a2[2], Rlo[2], Rdlo[2];
+      mat_mat(B_h, Rud, BRd);
+      mat_vec(BRd, delta_lo, a1);
+      mat_mat(B_h, surround_R, BR);
+      mat_vec(BR, delta_lo, a2);
+      mat_vec(surround_R, lo, Rlo);
+      mat_vec(Rud, lo, Rdlo);
+      double w1[2] = {sigma[0] - surround_p[0] - Rlo[0], sigma[1] - surround_p[1] - Rlo[1]};
+      double w2[2] = {-surround_v[0] - Rdlo[0], -surround_v[1] - Rdlo[1]};
+      double acc = ((a1[0] / dln) * w1[0] + (a1[1] / dln) * w1[1]) + ((a2[0] / dln) * w2[0] + (a2[1] / dln) * w2[1]);
+      for (int e = 0; e < nE; e++) {
+        double d_Ee_o = vec_d_Ee_o[o][e];
+        double Rle[2];
+        mat_vec(ego_R, c->vec_le[e], Rle);
+        double r1[2] = {Rle[0] * B_h[0] + Rle[1] * B_h[2], Rle[0] * B_h[1] + Rle[1] * B_h[3]};
+        double r2[2] = {r1[0] * Rud[0] + r1[1] * Rud[2], r1[0] * Rud[1] + r1[1] * Rud[3]};
+        double pt = (r2[0] * delta_lo[0] + r2[1] * delta_lo[1]) / dln;
+        acc += d_Ee_o / d_Ee_o_exp_sum * pt;
+      }
+      pGthat -= d_test[o + nE] / exp_sum_d * acc;
+    }
+
+    /* accumulate, OPT:1649-1676 */
+    double gradViolaPt = gama * pGtbar;
+    double scale = omg * step * P->wei_surround * penaD;
+    for (int k = 0; k < 6; k++) {
+      CROW(mj->gdC, pieceid * 6 + k, 0) += scale * (beta0[k] * pGs[0] + beta1[k] * pGds[0]);
+      CROW(mj->gdC, pieceid * 6 + k, 1) += scale * (beta0[k] * pGs[1] + beta1[k] * pGds[1]);
+    }
+    mj->gdT += omg * P->wei_surround * (pena / trajres + penaD * gradViolaPt * step);
+    mj->gdT += omg * step * P->wei_surround * pGthat * penaD * pieceid;
+    mj->gdT += omg * step * P->wei_surround * gama * pGthat * penaD;
+    for (int idx = 0; idx < trajid; idx++) {
+      mj->gdT += omg * step * P->wei_surround * pGthat * penaD * c->piece_nums[trajid];
+    }
+  }
+  return totalPenalty;
+}
+
+/* ========================================================================= */
+/* addPVAGradCost2CT, OPT:422-779                                              */
+/* costs[0]=corridor costs[1]=surround costs[2]=feasibility                    */
+/* ========================================================================= */
+static void addPVAGradCost2CT(oracle_ctx *c, double costs[3], int trajid, double trajtime) {
+  const dftpav_params *P = &c->P;
+  minjerk_t *mj = &c->mj[trajid];
+  int N = c->piece_nums[trajid];
+  const double *cfgHs = c->cfgHs + (size_t)c->pt_offset[trajid] * c->H * 4;
+  int singul_ = c->singuls[trajid];
+  double max_vel, max_cur, max_acc;
+  if (singul_ > 0) {
+    max_vel = P->max_forward_vel;
+    max_cur = P->max_forward_cur;
+    max_acc = P->max_forward_acc;
+  } else {
+    max_vel = P->max_backward_vel;
+    max_cur = P->max_backward_cur;
+    max_acc = P->max_backward_acc;
+  }
+  costs[0] = costs[1] = costs[2] = 0.0;
+  double t = 0;
+  int pointid = -1;
+  const double epis = c->epis;
+
+  for (int i = 0; i < N; ++i) {
+    int K = (i == 0 || i == N - 1) ? P->des_traj_resolution : P->traj_resolution;
+    const double *cc = mj->c + 12 * i; /* 6x2 block, cc[2*k+d] */
+    double step = mj->t[1] / K;
+    double s1 = 0.0;
+    for (int j = 0; j <= K; ++j) {
+      double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+      double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+      double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+      double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+      double beta3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+      double alpha = 1.0 / K * j;
+      s1 += step; /* OPT:513 */
+      pointid++;
+      double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0}, dddsigma[2] = {0, 0};
+      for (int k = 0; k < 6; k++)
+        for (int d = 0; d < 2; d++) {
+          sigma[d] += cc[2 * k + d] * beta0[k];
+          dsigma[d] += cc[2 * k + d] * beta1[k];
+          ddsigma[d] += cc[2 * k + d] * beta2[k];
+          dddsigma[d] += cc[2 * k + d] * beta3[k];
+        }
+      double omg = (j == 0 || j == K) ? 0.5 : 1.0;
+      double z_h0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
+      double z_h1 = ddsigma[0] * dsigma[0] + ddsigma[1] * dsigma[1];
+      double z_h2 = dddsigma[0] * dsigma[0] + dddsigma[1] * dsigma[1];
+      /* z_h3 = ddsigma^T * B_h * dsigma, OPT:529 */
+      double z_h3 = ddsigma[1] * dsigma[0] + (-ddsigma[0]) * dsigma[1];
+      double z1 = dddsigma[1] * dsigma[0] + (-dddsigma[0]) * dsigma[1]; /* OPT:538 */
+
+      if (z_h0 < 1e-4 || (j == 0 && i == 0) || (i == N - 1 && j == K)) continue; /* OPT:550-553 */
+
+      double vel2_reci = 1.0 / (z_h0 * z_h0);
+      double vel2_reci_e = 1.0 / (z_h0 * z_h0 + epis);
+      double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);
+      z_h0 = 1.0 / z_h0;
+      double z_h4 = z_h1 * vel2_reci;
+      double violaVel = 1.0 / vel2_reci - max_vel * max_vel;
+      double acc2 = z_h1 * z_h1 * vel2_reci;
+      double cur = z_h3 * vel3_2_reci_e;
+      double violaAcc = acc2 - max_acc * max_acc;
+      double violaCurL = cur - max_cur;
+      double violaCurR = -cur - max_cur;
+
+      double ego_R[4] = {singul_ * dsigma[0] * z_h0, singul_ * -dsigma[1] * z_h0, singul_ * dsigma[1] * z_h0,
+                         singul_ * dsigma[0] * z_h0}; /* OPT:581-583 */
+      double temp_a[4] = {ddsigma[0], -ddsigma[1], ddsigma[1], ddsigma[0]};
+      double temp_v[4] = {dsigma[0], -dsigma[1], dsigma[1], dsigma[0]};
+      double R_dot[4];
+      for (int k = 0; k < 4; k++) R_dot[k] = singul_ * (temp_a[k] * z_h0 - temp_v[k] * vel2_reci * z_h0 * z_h1);
+
+      double *gdC = mj->gdC + 12 * i;
+      const double *hp = cfgHs + (size_t)pointid * c->H * 4;
+      for (int v = 0; v < 5; v++) { /* for(auto le : vec_le_), OPT:592 */
+        const double *le = c->vec_le[v];
+        double Rle[2];
+        mat_vec(ego_R, le, Rle);
+        double bpt[2] = {sigma[0] + Rle[0], sigma[1] + Rle[1]};
+        double tl[4] = {le[0], -le[1], le[1], le[0]};
+        for (int k = 0; k < c->H; k++) {
+          const double *col = hp + 4 * k;
+          double on[2] = {col[0], col[1]};
+          double violaPos = on[0] * (bpt[0] - col[2]) + on[1] * (bpt[1] - col[3]);
+          if (violaPos > 0) {
+            double pena, penaD;
+            oracle_smoothed_l1(violaPos, &pena, &penaD);
+            /* Mm = singul*temp_l_Bl*z_h0 - ego_R*le*dsigma^T*vel2_reci */
+            double Mm[4];
+            Mm[0] = singul_ * tl[0] * z_h0 - Rle[0] * dsigma[0] * vel2_reci;
+            Mm[1] = singul_ * tl[1] * z_h0 - Rle[0] * dsigma[1] * vel2_reci;
+            Mm[2] = singul_ * tl[2] * z_h0 - Rle[1] * dsigma[0] * vel2_reci;
+            Mm[3] = singul_ * tl[3] * z_h0 - Rle[1] * dsigma[1] * vel2_reci;
+            double w[2] = {dsigma[0] + (R_dot[0] * le[0] + R_dot[1] * le[1]),
+                           dsigma[1] + (R_dot[2] * le[0] + R_dot[3] * le[1])};
+            double gradViolaPt = (alpha * on[0]) * w[0] + (alpha * on[1]) * w[1];
+            double sc = omg * step * P->wei_obs * penaD;
+            for (int r = 0; r < 6; r++) {
+              double b1n0 = beta1[r] * on[0], b1n1 = beta1[r] * on[1];
+              double g0 = beta0[r] * on[0] + (b1n0 * Mm[0] + b1n1 * Mm[2]);
+              double g1 = beta0[r] * on[1] + (b1n0 * Mm[1] + b1n1 * Mm[3]);
+              gdC[2 * r + 0] += sc * g0;
+              gdC[2 * r + 1] += sc * g1;
+            }
+            mj->gdT += omg * P->wei_obs * (penaD * gradViolaPt * step + pena / K);
+            costs[0] += omg * step * P->wei_obs * pena;
+          }
+        }
+      }
+
+      if (c->S > 0) { /* OPT:636-638 */
+        costs[1] += dynamicObsGradCostP(c, omg, step, t + step * j, beta0, beta1, alpha, i, K, sigma, dsigma,
+                                        ddsigma, ego_R, trajid, trajtime);
+      }
+
+      if (violaVel > 0.0) { /* OPT:642-653 */
+        double pena, penaD;
+        oracle_smoothed_l1(violaVel, &pena, &penaD);
+        double gradViolaVt = 2.0 * alpha * z_h1;
+        double sc = omg * step * P->wei_feas * penaD;
+        for (int r = 0; r < 6; r++) {
+          gdC[2 * r + 0] += sc * (2.0 * beta1[r] * dsigma[0]);
+          gdC[2 * r + 1] += sc * (2.0 * beta1[r] * dsigma[1]);
+        }
+        mj->gdT += omg * P->wei_feas * (penaD * gradViolaVt * step + pena / K);
+        costs[2] += omg * step * P->wei_feas * pena;
+      }
+      if (violaAcc > 0.0) { /* OPT:655-665 */
+        double pena, penaD;
+        oracle_smoothed_l1(violaAcc, &pena, &penaD);
+        double u[2] = {z_h4 * ddsigma[0] - z_h4 * z_h4 * dsigma[0], z_h4 * ddsigma[1] - z_h4 * z_h4 * dsigma[1]};
+        double sqn = ddsigma[0] * ddsigma[0] + ddsigma[1] * ddsigma[1];
+        double gradViolaAt = 2.0 * alpha * (z_h4 * (sqn + z_h2) - z_h4 * z_h4 * z_h1);
+        double sc = omg * step * P->wei_feas * penaD;
+        for (int r = 0; r < 6; r++) {
+          gdC[2 * r + 0] += sc * (2.0 * beta1[r] * u[0] + 2.0 * beta2[r] * z_h4 * dsigma[0]);
+          gdC[2 * r + 1] += sc * (2.0 * beta1[r] * u[1] + 2.0 * beta2[r] * z_h4 * dsigma[1]);
+        }
+        mj->gdT += omg * P->wei_feas * (penaD * gradViolaAt * step + pena / K);
+        costs[2] += omg * step * P->wei_feas * pena;
+      }
+      /* curvature, OPT:684-705; u = r3e*dd^T*B_h - 3*r3e*r2e*z_h3*d^T ; w = r3e*d^T*B_h^T */
+      double ku[2] = {vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0],
+                      vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1]};
+      /* beta2*r3e*d^T*B_h^T is evaluated ((beta2*r3e)*d^T)*B_h^T, B_h^T = [0 1; -1 0] */
+#define KW0(r) (-((beta2[r] * vel3_2_reci_e) * dsigma[1]))
+#define KW1(r) ((beta2[r] * vel3_2_reci_e) * dsigma[0])
+      double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
+      if (violaCurL > 0.0) {
+        double pena, penaD;
+        oracle_smoothed_l1(violaCurL, &pena, &penaD);
+        double sc = omg * step * P->wei_feas * 10.0 * penaD;
+        for (int r = 0; r < 6; r++) {
+          gdC[2 * r + 0] += sc * (beta1[r] * ku[0] + KW0(r));
+          gdC[2 * r + 1] += sc * (beta1[r] * ku[1] + KW1(r));
+        }
+        mj->gdT += omg * P->wei_feas * 10.0 * (penaD * kt * step + pena / K);
+        costs[2] += omg * step * P->wei_feas * 10.0 * pena;
+      }
+      if (violaCurR > 0.0) {
+        double pena, penaD;
+        oracle_smoothed_l1(violaCurR, &pena, &penaD);
+        double sc = omg * step * P->wei_feas * 10.0 * penaD;
+        for (int r = 0; r < 6; r++) {
+          gdC[2 * r + 0] += sc * -(beta1[r] * ku[0] + KW0(r));
+          gdC[2 * r + 1] += sc * -(beta1[r] * ku[1] + KW1(r));
+        }
+        mj->gdT += omg * P->wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
+        costs[2] += omg * step * P->wei_feas * 10.0 * pena;
+      }
+    }
+    t += mj->t[1];
+  }
+}
+
+/* ========================================================================= */
+/* costFunctionCallback, OPT:206-350                                           */
+/* ========================================================================= */
+double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
+  const dftpav_params *P = &c->P;
+  int M = c->M;
+  double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
+  int offset = 0;
+  int *Poff = (int *)alloca(sizeof(int) * M);
+  for (int i = 0; i < M; i++) {
+    Poff[i] = offset;
+    offset += 2 * (c->piece_nums[i] - 1);
+  }
+  for (int k = 0; k < c->n; k++) grad[k] = 0.0;
+  const double *tvar = x + offset;
+  double *gradt = grad + offset;
+  offset += M;
+  double *T = (double *)alloca(sizeof(double) * M);
+  double *trajtimes = (double *)alloca(sizeof(double) * (M + 1));
+  for (int i = 0; i < M; i++) T[i] = oracle_virtual_to_real_T(P, tvar[i]);
+  trajtimes[0] = 0.0;
+  for (int i = 0; i < M; i++) trajtimes[i + 1] = T[i]; /* OPT:230-234: T[i-1], not a cumulative sum */
+  const double *Gear = x + offset;
+  double *gradGear = grad + offset;
+  offset += 2 * (M - 1);
+  const double *Angles = x + offset;
+  double *gradAngles = grad + offset;
+
+  double term_corr = 0, term_sur = 0, term_feas = 0;
+  for (int trajid = 0; trajid < M; trajid++) {
+    double costs[3];
+    double IniS[6], FinS[6];
+    memcpy(IniS, c->iniS + 6 * trajid, sizeof(IniS));
+    memcpy(FinS, c->finS + 6 * trajid, sizeof(FinS));
+    if (trajid > 0) { /* OPT:273-277 */
+      double theta = Angles[trajid - 1];
+      IniS[0] = Gear[2 * (trajid - 1) + 0];
+      IniS[1] = Gear[2 * (trajid - 1) + 1];
+      IniS[2] = -P->non_sinv * cos(theta);
+      IniS[3] = -P->non_sinv * sin(theta);
+    }
+    if (trajid < M - 1) { /* OPT:278-282 */
+      double theta = Angles[trajid];
+      FinS[0] = Gear[2 * trajid + 0];
+      FinS[1] = Gear[2 * trajid + 1];
+      FinS[2] = P->non_sinv * cos(theta);
+      FinS[3] = P->non_sinv * sin(theta);
+    }
+    minjerk_t *mj = &c->mj[trajid];
+    minjerk_generate(mj, x + Poff[trajid], T[trajid] / c->piece_nums[trajid], IniS, FinS);
+    minjerk_initSmGradCost(mj);
+    double smoo_cost = minjerk_getTrajJerkCost(mj);
+    addPVAGradCost2CT(c, costs, trajid, trajtimes[trajid]);
+    total_smcost += smoo_cost;
+    penalty_cost += (costs[0] + costs[1]) + costs[2]; /* VectorXd(3).sum() */
+    term_corr += costs[0];
+    term_sur += costs[1];
+    term_feas += costs[2];
+  }
+
+  for (int trajid = 0; trajid < M; trajid++) {
+    double time_cost = 0.0;
+    minjerk_t *mj = &c->mj[trajid];
+    minjerk_calGrads_PT(mj);
+    memcpy(grad + Poff[trajid], mj->gdP, sizeof(double) * 2 * (c->piece_nums[trajid] - 1));
+    const double *gradIni = mj->gdHead, *gradFin = mj->gdTail;
+    if (P->gear_opt) { /* OPT:307-320 */
+      if (trajid > 0) {
+        double theta = Angles[trajid - 1];
+        gradGear[2 * (trajid - 1) + 0] += gradIni[0];
+        gradGear[2 * (trajid - 1) + 1] += gradIni[1];
+        gradAngles[trajid - 1] += gradIni[2] * (P->non_sinv * sin(theta)) + gradIni[3] * (-P->non_sinv * cos(theta));
+      }
+      if (trajid < M - 1) {
+        double theta = Angles[trajid];
+        gradGear[2 * trajid + 0] += gradFin[0];
+        gradGear[2 * trajid + 1] += gradFin[1];
+        gradAngles[trajid] += gradFin[2] * (-P->non_sinv * sin(theta)) + gradFin[3] * (P->non_sinv * cos(theta));
+      }
+    }
+    virtualT_grad_cost(P, T[trajid], tvar[trajid], mj->gdT / c->piece_nums[trajid], &gradt[trajid], &time_cost);
+    total_timecost += time_cost;
+  }
+  c->evals += 1; /* iter_num_, OPT:334 */
+  c->cost_terms[0] = total_smcost;
+  c->cost_terms[1] = total_timecost;
+  c->cost_terms[2] = term_corr;
+  c->cost_terms[3] = term_sur;
+  c->cost_terms[4] = term_feas;
+  return total_smcost + total_timecost + penalty_cost;
+}
+
+void oracle_last_cost_terms(const oracle_ctx *c, double out[5]) { memcpy(out, c->cost_terms, sizeof(double) * 5); }
+
+void oracle_last_coeffs(const oracle_ctx *c, double *coeffs, double *piece_dt) {
+  int off = 0;
+  for (int i = 0; i < c->M; i++) {
+    memcpy(coeffs + 12 * off, c->mj[i].c, sizeof(double) * 12 * c->piece_nums[i]);
+    piece_dt[i] = c->mj[i].t[1];
+    off += c->piece_nums[i];
+  }
+}
+
+/* ========================================================================= */
+/* L-BFGS, LBFGS:276-390 and 440-751                                          */
+/* ========================================================================= */
+typedef struct {
+  oracle_eval_fn fn;
+  void *instance;
+  int n;
+  int evals;
+} cb_t;
+
+static double vdot(const double *a, const double *b, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+static double vabsmax(const double *a, int n) {
+  double m = fabs(a[0]);
+  for (int i = 1; i < n; i++)
+    if (fabs(a[i]) > m) m = fabs(a[i]);
+  return m;
+}
+
+/* line_search_lewisoverton, LBFGS:276-390 */
+static int line_search_lewisoverton(int n, double *x, double *f, double *g, double *stp, const double *s,
+                                    const double *xp, const double *gp, double stpmin, double stpmax, cb_t *cd,
+                                    const dftpav_params *param) {
+  int count = 0;
+  int brackt = 0, touched = 0;
+  double finit, dginit, dgtest, dstest;
+  double mu = 0.0, nu = stpmax;
+  if (!(*stp > 0.0)) return DFTPAV_LBFGSERR_INVALIDPARAMETERS;
+  dginit = vdot(gp, s, n);
+  if (0.0 < dginit) return DFTPAV_LBFGSERR_INCREASEGRADIENT;
+  finit = *f;
+  dgtest = param->lbfgs_f_dec_coeff * dginit;
+  dstest = param->lbfgs_s_curv_coeff * dginit;
+  while (1) {
+    for (int i = 0; i < n; i++) x[i] = xp[i] + *stp * s[i];
+    *f = cd->fn(cd->instance, x, g, n);
+    cd->evals++;
+    ++count;
+    if (isinf(*f) || isnan(*f)) return DFTPAV_LBFGSERR_INVALID_FUNCVAL;
+    /* non-standard early exit, LBFGS:326-329 */
+    if (param->lbfgs_past > 0 && fabs(finit - *f) / (fabs(finit) + 1.0) < param->lbfgs_delta / param->lbfgs_past)
+      return count;
+    if (*f > finit + *stp * dgtest) {
+      nu = *stp;
+      brackt = 1;
+    } else {
+      if (vdot(g, s, n) < dstest) {
+        mu = *stp;
+      } else {
+        return count;
+      }
+    }
+    if (param->lbfgs_max_linesearch <= count) return DFTPAV_LBFGSERR_MAXIMUMLINESEARCH;
+    if (brackt && (nu - mu) < param->lbfgs_machine_prec * nu) return DFTPAV_LBFGSERR_WIDTHTOOSMALL;
+    if (brackt)
+      *stp = 0.5 * (mu + nu);
+    else
+      *stp *= 2.0;
+    if (*stp < stpmin) return DFTPAV_LBFGSERR_MINIMUMSTEP;
+    if (*stp > stpmax) {
+      if (touched) return DFTPAV_LBFGSERR_MAXIMUMSTEP;
+      touched = 1;
+      *stp = stpmax;
+    }
+  }
+}
+
+/* lbfgs_optimize, LBFGS:440-751 */
+int oracle_lbfgs(int n, double *x, double *f, oracle_eval_fn fn, void *instance, const dftpav_params *param,
+                 int *iters_out, int *evals_out, long long *hist_sum_out) {
+  int ret, i, j, k, ls, end, bound;
+  double step, step_min, step_max, fx, ys, yy;
+  double gnorm_inf, xnorm_inf, beta, rate, cau;
+  const int m = param->lbfgs_mem_size;
+  const int past = param->lbfgs_past;
+  long long hist_sum = 0;
+  cb_t cd = {fn, instance, n, 0};
+  k = 0;
+
+  if (n <= 0) return DFTPAV_LBFGSERR_INVALID_N;
+  if (m <= 0) return DFTPAV_LBFGSERR_INVALID_MEMSIZE;
+  if (param->lbfgs_g_epsilon < 0.0) return DFTPAV_LBFGSERR_INVALID_GEPSILON;
+  if (past < 0) return DFTPAV_LBFGSERR_INVALID_TESTPERIOD;
+  if (param->lbfgs_delta < 0.0) return DFTPAV_LBFGSERR_INVALID_DELTA;
+  if (param->lbfgs_min_step < 0.0) return DFTPAV_LBFGSERR_INVALID_MINSTEP;
+  if (param->lbfgs_max_step < param->lbfgs_min_step) return DFTPAV_LBFGSERR_INVALID_MAXSTEP;
+  if (!(param->lbfgs_f_dec_coeff > 0.0 && param->lbfgs_f_dec_coeff < 1.0)) return DFTPAV_LBFGSERR_INVALID_FDECCOEFF;
+  if (!(param->lbfgs_s_curv_coeff < 1.0 && param->lbfgs_s_curv_coeff > param->lbfgs_f_dec_coeff))
+    return DFTPAV_LBFGSERR_INVALID_SCURVCOEFF;
+  if (!(param->lbfgs_machine_prec > 0.0)) return DFTPAV_LBFGSERR_INVALID_MACHINEPREC;
+  if (param->lbfgs_max_linesearch <= 0) return DFTPAV_LBFGSERR_INVALID_MAXLINESEARCH;
+
+  double *xp = (double *)malloc(sizeof(double) * n);
+  double *g = (double *)malloc(sizeof(double) * n);
+  double *gp = (double *)malloc(sizeof(double) * n);
+  double *d = (double *)malloc(sizeof(double) * n);
+  double *pf = (double *)malloc(sizeof(double) * (past > 1 ? past : 1));
+  double *lm_alpha = (double *)calloc(m, sizeof(double));
+  double *lm_s = (double *)calloc((size_t)n * m, sizeof(double)); /* column j at lm_s + j*n */
+  double *lm_y = (double *)calloc((size_t)n * m, sizeof(double));
+  double *lm_ys = (double *)calloc(m, sizeof(double));
+
+  fx = fn(instance, x, g, n);
+  cd.evals++;
+  pf[0] = fx;
+  for (i = 0; i < n; i++) d[i] = -g[i];
+  gnorm_inf = vabsmax(g, n);
+  xnorm_inf = vabsmax(x, n);
+  if (gnorm_inf / fmax(1.0, xnorm_inf) < param->lbfgs_g_epsilon) {
+    ret = DFTPAV_LBFGS_CONVERGENCE;
+  } else {
+    step = 1.0 / sqrt(vdot(d, d, n));
+    k = 1;
+    end = 0;
+    bound = 0;
+    while (1) {
+      memcpy(xp, x, sizeof(double) * n);
+      memcpy(gp, g, sizeof(double) * n);
+      step_min = param->lbfgs_min_step;
+      step_max = param->lbfgs_max_step;
+      ls = line_search_lewisoverton(n, x, &fx, g, &step, d, xp, gp, step_min, step_max, &cd, param);
+      if (ls < 0) { /* LBFGS:604-611: x,g reverted, fx is NOT */
+        memcpy(x, xp, sizeof(double) * n);
+        memcpy(g, gp, sizeof(double) * n);
+        ret = ls;
+        break;
+      }
+      gnorm_inf = vabsmax(g, n);
+      xnorm_inf = vabsmax(x, n);
+      if (gnorm_inf / fmax(1.0, xnorm_inf) < param->lbfgs_g_epsilon) {
+        ret = DFTPAV_LBFGS_CONVERGENCE;
+        break;
+      }
+      if (0 < past) {
+        if (past <= k) {
+          rate = fabs(pf[k % past] - fx) / fmax(1.0, fabs(fx));
+          if (rate < param->lbfgs_delta) {
+            ret = DFTPAV_LBFGS_STOP;
+            break;
+          }
+        }
+        pf[k % past] = fx;
+      }
+      if (param->lbfgs_max_iterations != 0 && param->lbfgs_max_iterations <= k) {
+        ret = DFTPAV_LBFGSERR_MAXIMUMITERATION;
+        break;
+      }
+      ++k;
+      double *sc = lm_s + (size_t)end * n, *yc = lm_y + (size_t)end * n;
+      for (i = 0; i < n; i++) {
+        sc[i] = x[i] - xp[i];
+        yc[i] = g[i] - gp[i];
+      }
+      ys = vdot(yc, sc, n);
+      yy = vdot(yc, yc, n);
+      lm_ys[end] = ys;
+      for (i = 0; i < n; i++) d[i] = -g[i];
+      cau = vdot(sc, sc, n) * sqrt(vdot(gp, gp, n)) * param->lbfgs_cautious_factor;
+      if (ys > cau) {
+        ++bound;
+        bound = m < bound ? m : bound;
+        end = (end + 1) % m;
+        j = end;
+        for (i = 0; i < bound; ++i) {
+          j = (j + m - 1) % m;
+          lm_alpha[j] = vdot(lm_s + (size_t)j * n, d, n) / lm_ys[j];
+          double na = -lm_alpha[j];
+          const double *yj = lm_y + (size_t)j * n;
+          for (int e = 0; e < n; e++) d[e] += na * yj[e];
+        }
+        double sc0 = ys / yy;
+        for (int e = 0; e < n; e++) d[e] *= sc0;
+        for (i = 0; i < bound; ++i) {
+          beta = vdot(lm_y + (size_t)j * n, d, n) / lm_ys[j];
+          double cf = lm_alpha[j] - beta;
+          const double *sj = lm_s + (size_t)j * n;
+          for (int e = 0; e < n; e++) d[e] += cf * sj[e];
+          j = (j + 1) % m;
+        }
+        hist_sum += bound;
+      }
+      step = 1.0;
+    }
+  }
+  *f = fx;
+  if (iters_out) *iters_out = k;
+  if (evals_out) *evals_out = cd.evals;
+  if (hist_sum_out) *hist_sum_out = hist_sum;
+  free(xp);
+  free(g);
+  free(gp);
+  free(d);
+  free(pf);
+  free(lm_alpha);
+  free(lm_s);
+  free(lm_y);
+  free(lm_ys);
+  return ret;
+}
+
+static double eval_tramp(void *inst, const double *x, double *g, int n) {
+  (void)n;
+  return oracle_eval((oracle_ctx *)inst, x, g);
+}
+
+/* the solve half of OptimizeTrajectory, OPT:127-201 */
+void oracle_solve(oracle_ctx *c, double *x, oracle_result *r) {
+  double final_cost = 0.0;
+  c->evals = 0;
+  int result = oracle_lbfgs(c->n, x, &final_cost, eval_tramp, c, &c->P, &r->iters, NULL, &r->hist_sum);
+  r->evals = c->evals;
+  r->final_cost = final_cost;
+  r->status = result;
+  int ok = 0;
+  if (result == DFTPAV_LBFGS_CONVERGENCE || result == DFTPAV_LBFGS_CANCELED || result == DFTPAV_LBFGS_STOP ||
+      result == DFTPAV_LBFGSERR_MAXIMUMITERATION)
+    ok = 1;
+  else if (result == DFTPAV_LBFGSERR_MAXIMUMLINESEARCH)
+    ok = 1;
+  if (final_cost >= c->P.fail_cost) ok = 0; /* OPT:197-200 */
+  r->success = ok;
+}
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, const dftpav_batch_data *d,
+                       const dftpav_surround *s, int nthreads, double *x, double *final_cost, int *status,
+                       int *success, int *iters, int *evals, long long *hist_sum, double *seconds_each) {
+  oracle_problem proto;
+  memset(&proto, 0, sizeof(proto));
+  proto.M = l->M;
+  proto.piece_nums = l->piece_nums;
+  proto.singuls = l->singuls;
+  proto.H = l->H;
+  int n = oracle_num_vars(&proto);
+  int npts = oracle_num_points(p, &proto);
+  int ninner = 0;
+  for (int i = 0; i < l->M; i++) ninner += 2 * (l->piece_nums[i] - 1);
+  int err_any = 0;
+#ifdef _OPENMP
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+  for (int b = 0; b < B; b++) {
+    oracle_problem pb = proto;
+    pb.ini_states = d->ini_states + (size_t)b * 6 * l->M;
+    pb.fin_states = d->fin_states + (size_t)b * 6 * l->M;
+    pb.inner_pts = d->inner_pts + (size_t)b * ninner;
+    pb.init_Ts = d->init_Ts + (size_t)b * l->M;
+    pb.corridor = d->corridor + (size_t)b * npts * l->H * 4;
+    pb.t_now = d->t_now;
+    pb.help_eps = d->help_eps;
+    pb.surround = s;
+    int err = 0;
+    double t0 = now_s();
+    oracle_ctx *c = oracle_prepare(p, &pb, &err);
+    if (!c) {
+      err_any = err;
+      if (status) status[b] = DFTPAV_LBFGSERR_UNKNOWNERROR;
+      if (success) success[b] = 0;
+      continue;
+    }
+    double *xb = x + (size_t)b * n;
+    oracle_pack_x0(c, xb);
+    oracle_result r;
+    oracle_solve(c, xb, &r);
+    double t1 = now_s();
+    if (final_cost) final_cost[b] = r.final_cost;
+    if (status) status[b] = r.status;
+    if (success) success[b] = r.success;
+    if (iters) iters[b] = r.iters;
+    if (evals) evals[b] = r.evals;
+    if (hist_sum) hist_sum[b] = r.hist_sum;
+    if (seconds_each) seconds_each[b] = t1 - t0;
+    oracle_free(c);
+  }
+  (void)nthreads;
+  return err_any;
+}

@@ -1,0 +1,221 @@
+"""ctypes loader of the CPU oracle — TEST INFRASTRUCTURE (see dftpav_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from dftpav_amd.pods import (BatchData, Layout, Params, Surround, c_double_p, c_int_p, c_ll_p, dptr, iptr,
+                             llptr)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("M", C.c_int),
+        ("piece_nums", c_int_p),
+        ("singuls", c_int_p),
+        ("ini_states", c_double_p),
+        ("fin_states", c_double_p),
+        ("inner_pts", c_double_p),
+        ("init_Ts", c_double_p),
+        ("H", C.c_int),
+        ("corridor", c_double_p),
+        ("t_now", C.c_double),
+        ("help_eps", C.c_double),
+        ("surround", C.POINTER(Surround)),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("final_cost", C.c_double),
+        ("status", C.c_int),
+        ("success", C.c_int),
+        ("iters", C.c_int),
+        ("evals", C.c_int),
+        ("hist_sum", C.c_longlong),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libdftpav_oracle.so")
+    src = os.path.join(_HERE, "dftpav_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libdftpav_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.oracle_default_params.argtypes = [C.POINTER(Params)]
+        L.oracle_num_vars.argtypes = [C.POINTER(Problem)]
+        L.oracle_num_points.argtypes = [C.POINTER(Params), C.POINTER(Problem)]
+        L.oracle_prepare.restype = C.c_void_p
+        L.oracle_prepare.argtypes = [C.POINTER(Params), C.POINTER(Problem), c_int_p]
+        L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_pack_x0.argtypes = [C.c_void_p, c_double_p]
+        L.oracle_eval.restype = C.c_double
+        L.oracle_eval.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.oracle_last_cost_terms.argtypes = [C.c_void_p, c_double_p]
+        L.oracle_last_coeffs.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.oracle_solve.argtypes = [C.c_void_p, c_double_p, C.POINTER(Result)]
+        L.oracle_solve_batch.argtypes = [C.POINTER(Params), C.POINTER(Layout), C.c_int, C.POINTER(BatchData),
+                                         C.POINTER(Surround), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p,
+                                         c_int_p, c_int_p, c_ll_p, c_double_p]
+        L.oracle_minco_generate.restype = C.c_double
+        L.oracle_minco_generate.argtypes = [C.c_int, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]
+        L.oracle_minco_operator.argtypes = [C.c_int, c_double_p]
+        L.oracle_smoothed_l1.argtypes = [C.c_double, c_double_p, c_double_p]
+        L.oracle_virtual_to_real_T.restype = C.c_double
+        L.oracle_virtual_to_real_T.argtypes = [C.POINTER(Params), C.c_double]
+        L.oracle_real_to_virtual_T.restype = C.c_double
+        L.oracle_real_to_virtual_T.argtypes = [C.POINTER(Params), C.c_double]
+        L.oracle_lbfgs.argtypes = [C.c_int, c_double_p, c_double_p, C.c_void_p, C.c_void_p, C.POINTER(Params),
+                                   c_int_p, c_int_p, c_ll_p]
+        _LIB = L
+    return _LIB
+
+
+EVAL_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, c_double_p, c_double_p, C.c_int)
+
+
+def default_params():
+    p = Params()
+    lib().oracle_default_params(C.byref(p))
+    return p
+
+
+class OracleProblem:
+    """One prepared trajectory (element b of a Scenario)."""
+
+    def __init__(self, params, scen, b=0):
+        self.params = params
+        self.scen = scen
+        lay = scen.layout
+        self._keep = dict(
+            ini=np.ascontiguousarray(scen.ini_states[b]), fin=np.ascontiguousarray(scen.fin_states[b]),
+            inner=np.ascontiguousarray(scen.inner_pts[b]), Ts=np.ascontiguousarray(scen.init_Ts[b]),
+            cor=np.ascontiguousarray(scen.corridor[b]))
+        pb = Problem()
+        pb.M = lay.M
+        pb.piece_nums = iptr(lay.piece_nums)
+        pb.singuls = iptr(lay.singuls)
+        pb.ini_states = dptr(self._keep["ini"])
+        pb.fin_states = dptr(self._keep["fin"])
+        pb.inner_pts = dptr(self._keep["inner"])
+        pb.init_Ts = dptr(self._keep["Ts"])
+        pb.H = lay.H
+        pb.corridor = dptr(self._keep["cor"])
+        pb.t_now = scen.t_now
+        pb.help_eps = scen.help_eps
+        self._sur = scen.surround.c_struct() if scen.surround is not None else None
+        pb.surround = C.pointer(self._sur) if self._sur is not None else None
+        self.pb = pb
+        self.n = lay.n_vars
+        err = C.c_int(0)
+        self.ctx = lib().oracle_prepare(C.byref(params), C.byref(pb), C.byref(err))
+        self.err = err.value
+        if not self.ctx:
+            raise ValueError("oracle_prepare failed: %d" % err.value)
+
+    def __del__(self):
+        if getattr(self, "ctx", None):
+            lib().oracle_free(self.ctx)
+            self.ctx = None
+
+    def x0(self):
+        x = np.zeros(self.n)
+        lib().oracle_pack_x0(self.ctx, dptr(x))
+        return x
+
+    def eval(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        g = np.zeros(self.n)
+        f = lib().oracle_eval(self.ctx, dptr(x), dptr(g))
+        return f, g
+
+    def cost_terms(self):
+        t = np.zeros(5)
+        lib().oracle_last_cost_terms(self.ctx, dptr(t))
+        return t
+
+    def coeffs(self):
+        c = np.zeros((self.scen.layout.n_pieces, 6, 2))
+        dt = np.zeros(self.scen.layout.M)
+        lib().oracle_last_coeffs(self.ctx, dptr(c), dptr(dt))
+        return c, dt
+
+    def solve(self, x=None):
+        x = self.x0() if x is None else np.ascontiguousarray(x, dtype=np.float64).copy()
+        r = Result()
+        lib().oracle_solve(self.ctx, dptr(x), C.byref(r))
+        return x, r
+
+
+def solve_batch(params, scen, nthreads=1):
+    """oracle_solve_batch over every element of a Scenario. Returns a dict of arrays."""
+    B, n = scen.B, scen.layout.n_vars
+    x = np.zeros((B, n))
+    fc = np.zeros(B)
+    status = np.zeros(B, dtype=np.int32)
+    success = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    evals = np.zeros(B, dtype=np.int32)
+    hist = np.zeros(B, dtype=np.int64)
+    secs = np.zeros(B)
+    lay = scen.layout.c_struct()
+    d = scen.batch_data()
+    sur = scen.surround.c_struct() if scen.surround is not None else None
+    rc = lib().oracle_solve_batch(C.byref(params), C.byref(lay), B, C.byref(d),
+                                  C.byref(sur) if sur is not None else None, nthreads, dptr(x), dptr(fc),
+                                  iptr(status), iptr(success), iptr(iters), iptr(evals), llptr(hist), dptr(secs))
+    return dict(rc=rc, x=x, final_cost=fc, status=status, success=success, iters=iters, evals=evals,
+                hist_sum=hist, seconds=secs)
+
+
+def lbfgs(fn, x0, params=None):
+    """oracle_lbfgs with a Python callback fn(x)->(f,g)."""
+    params = params or default_params()
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    n = len(x)
+
+    def tramp(inst, xp, gp, nn):
+        xv = np.ctypeslib.as_array(xp, shape=(nn,))
+        f, g = fn(xv.copy())
+        np.ctypeslib.as_array(gp, shape=(nn,))[:] = g
+        return float(f)
+
+    cb = EVAL_FN(tramp)
+    f = C.c_double(0)
+    it = C.c_int(0)
+    ev = C.c_int(0)
+    hs = C.c_longlong(0)
+    ret = lib().oracle_lbfgs(n, dptr(x), C.byref(f), C.cast(cb, C.c_void_p), None, C.byref(params), C.byref(it),
+                             C.byref(ev), C.byref(hs))
+    return dict(ret=ret, x=x, f=f.value, iters=it.value, evals=ev.value, hist_sum=hs.value)
+
+
+def minco_operator(N):
+    out = np.zeros((6 * N, N + 5))
+    lib().oracle_minco_operator(N, dptr(out))
+    return out
+
+
+def minco_generate(inner, dT, head, tail):
+    inner = np.ascontiguousarray(inner, dtype=np.float64)
+    N = inner.shape[0] + 1
+    c = np.zeros((N, 6, 2))
+    J = lib().oracle_minco_generate(N, dptr(inner), dT, dptr(np.ascontiguousarray(head, dtype=np.float64)),
+                                    dptr(np.ascontiguousarray(tail, dtype=np.float64)), dptr(c))
+    return c, J
