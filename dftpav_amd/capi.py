@@ -1,0 +1,206 @@
+"""ctypes binding of libdftpav_hip.so (the C-ABI of include/dftpav_hip.h).
+
+This is the Python host side used by tests and bench.py; the mirror of the
+reference's class interface lives in optimizer.py.  The library is built
+in-tree by dftpav_amd/csrc/Makefile; if it is missing this module raises — there
+is no fallback path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .pods import (BatchData, Layout, Params, Surround, c_double_p, c_int_p, c_ll_p, dptr, iptr, llptr)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdftpav_hip.so")
+_LIB = None
+
+OK = 0
+E_INVALID, E_MINI_T, E_ONE_PIECE, E_NO_DEVICE, E_HIP, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+
+# every symbol include/dftpav_hip.h declares
+EXPORTS = [
+    "dftpav_default_params", "dftpav_num_vars", "dftpav_num_points", "dftpav_create", "dftpav_destroy",
+    "dftpav_last_error", "dftpav_set_surround", "dftpav_batch_create", "dftpav_batch_destroy",
+    "dftpav_batch_upload", "dftpav_batch_get_x0", "dftpav_batch_eval", "dftpav_batch_solve_async",
+    "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
+    "dftpav_solve_batch", "dftpav_stream",
+]
+
+
+class DftpavError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("dftpav error %d %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile libdftpav_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("solver.hip", "capi.cpp", "device_types.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "dftpav_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libdftpav_hip.so is not built (run python -c 'import __graft_entry__ as g; g.build()'); "
+                              "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.dftpav_default_params.argtypes = [C.POINTER(Params)]
+        L.dftpav_default_params.restype = None
+        L.dftpav_num_vars.argtypes = [C.POINTER(Layout)]
+        L.dftpav_num_points.argtypes = [C.POINTER(Params), C.POINTER(Layout)]
+        L.dftpav_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp)]
+        L.dftpav_destroy.argtypes = [vp]
+        L.dftpav_destroy.restype = None
+        L.dftpav_last_error.argtypes = [vp]
+        L.dftpav_last_error.restype = C.c_char_p
+        L.dftpav_set_surround.argtypes = [vp, C.POINTER(Surround)]
+        L.dftpav_batch_create.argtypes = [vp, C.POINTER(Layout), C.c_int, C.POINTER(vp)]
+        L.dftpav_batch_destroy.argtypes = [vp]
+        L.dftpav_batch_destroy.restype = None
+        L.dftpav_batch_upload.argtypes = [vp, C.POINTER(BatchData)]
+        L.dftpav_batch_get_x0.argtypes = [vp, c_double_p]
+        L.dftpav_batch_eval.argtypes = [vp, c_double_p, c_double_p, c_double_p]
+        L.dftpav_batch_solve_async.argtypes = [vp]
+        L.dftpav_batch_sync.argtypes = [vp]
+        L.dftpav_batch_results.argtypes = [vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_ll_p]
+        L.dftpav_batch_coeffs.argtypes = [vp, c_double_p, c_double_p]
+        L.dftpav_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.dftpav_solve_batch.argtypes = [vp, C.POINTER(Layout), C.c_int, C.POINTER(BatchData), c_double_p,
+                                         c_double_p, c_int_p, c_int_p, c_int_p, c_int_p]
+        L.dftpav_stream.argtypes = [vp]
+        L.dftpav_stream.restype = vp
+        for nm in ("params", "layout", "batch_data", "surround"):
+            getattr(L, "dftpav_abi_sizeof_" + nm).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def default_params():
+    p = Params()
+    lib().dftpav_default_params(C.byref(p))
+    return p
+
+
+class Handle:
+    """dftpav_handle: one HIP stream + the optimiser constants (== a PolyTrajOptimizer after setParam)."""
+
+    def __init__(self, params=None, device=0):
+        self.params = params if params is not None else default_params()
+        self._h = C.c_void_p()
+        rc = lib().dftpav_create(C.byref(self.params), device, C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise DftpavError(rc, "dftpav_create (no usable HIP device?)" if rc == E_NO_DEVICE else "dftpav_create")
+        self._sur_keep = None
+
+    def _check(self, rc, what):
+        if rc != OK:
+            msg = lib().dftpav_last_error(self._h)
+            raise DftpavError(rc, "%s: %s" % (what, msg.decode() if msg else ""))
+
+    def set_surround(self, surround_set):
+        if surround_set is None:
+            self._check(lib().dftpav_set_surround(self._h, None), "set_surround")
+            self._sur_keep = None
+            return
+        s = surround_set.c_struct()
+        self._check(lib().dftpav_set_surround(self._h, C.byref(s)), "set_surround")
+        self._sur_keep = surround_set
+
+    def close(self):
+        if self._h:
+            lib().dftpav_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """dftpav_batch: B trajectories of one layout, resident in HBM."""
+
+    def __init__(self, handle, layout_spec, B):
+        self.handle = handle
+        self.layout = layout_spec
+        self.B = B
+        self.n = layout_spec.n_vars
+        self._b = C.c_void_p()
+        lay = layout_spec.c_struct()
+        rc = lib().dftpav_batch_create(handle._h, C.byref(lay), B, C.byref(self._b))
+        if rc != OK:
+            self._b = None
+            handle._check(rc, "batch_create")
+
+    def upload(self, scen_or_data):
+        d = scen_or_data.batch_data() if hasattr(scen_or_data, "batch_data") else scen_or_data
+        self._keep = scen_or_data
+        rc = lib().dftpav_batch_upload(self._b, C.byref(d))
+        self.handle._check(rc, "batch_upload")
+
+    def x0(self):
+        x = np.zeros((self.B, self.n))
+        self.handle._check(lib().dftpav_batch_get_x0(self._b, dptr(x)), "get_x0")
+        return x
+
+    def eval(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(self.B, self.n)
+        f = np.zeros(self.B)
+        g = np.zeros((self.B, self.n))
+        self.handle._check(lib().dftpav_batch_eval(self._b, dptr(x), dptr(f), dptr(g)), "batch_eval")
+        return f, g
+
+    def solve_async(self):
+        self.handle._check(lib().dftpav_batch_solve_async(self._b), "solve_async")
+
+    def sync(self):
+        self.handle._check(lib().dftpav_batch_sync(self._b), "sync")
+
+    def last_solve_ms(self):
+        ms = C.c_float(0)
+        self.handle._check(lib().dftpav_batch_last_solve_ms(self._b, C.byref(ms)), "last_solve_ms")
+        return ms.value
+
+    def results(self):
+        B, n = self.B, self.n
+        r = dict(x=np.zeros((B, n)), final_cost=np.zeros(B), status=np.zeros(B, dtype=np.int32),
+                 success=np.zeros(B, dtype=np.int32), iters=np.zeros(B, dtype=np.int32),
+                 evals=np.zeros(B, dtype=np.int32), hist_sum=np.zeros(B, dtype=np.int64))
+        rc = lib().dftpav_batch_results(self._b, dptr(r["x"]), dptr(r["final_cost"]), iptr(r["status"]),
+                                        iptr(r["success"]), iptr(r["iters"]), iptr(r["evals"]), llptr(r["hist_sum"]))
+        self.handle._check(rc, "results")
+        return r
+
+    def solve(self):
+        self.solve_async()
+        return self.results()
+
+    def coeffs(self):
+        c = np.zeros((self.B, self.layout.n_pieces, 6, 2))
+        dt = np.zeros((self.B, self.layout.M))
+        self.handle._check(lib().dftpav_batch_coeffs(self._b, dptr(c), dptr(dt)), "coeffs")
+        return c, dt
+
+    def close(self):
+        if self._b:
+            lib().dftpav_batch_destroy(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

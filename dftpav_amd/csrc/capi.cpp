@@ -1,0 +1,622 @@
+// capi.cpp — host half of the C-ABI declared in include/dftpav_hip.h.
+//
+// Holds what PolyTrajOptimizer::OptimizeTrajectory does before and after the
+// L-BFGS call (traj_optimizer.cpp:7-134, 176-201): validation, corridor normal
+// normalisation, boundary clamping, decision-vector packing, status mapping.
+// Everything between (the solve itself) is the kernel in solver.hip.
+// There is deliberately no CPU fallback: without a usable HIP device every
+// entry point that needs one fails with DFTPAV_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dftpav_hip.h"
+#include "device_types.h"
+#include "traj_math.h"
+
+namespace dftpav {
+hipError_t launch_solver(const DevBatch &D, int mode, int threads, hipStream_t stream);
+}
+using namespace dftpav;
+
+struct dftpav_handle {
+  dftpav_params params;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // moving obstacles (device copies)
+  int S = 0;
+  int *d_sur_off = nullptr;
+  double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr;
+};
+
+struct dftpav_batch {
+  dftpav_handle *h = nullptr;
+  int B = 0;
+  DevLayout L{};
+  DevParams P{};
+  int threads = 0;
+  int NptsPad = 0;
+  std::vector<double> x0_host;
+  bool uploaded = false;
+  double t_now = 0.0, epis = 0.0;
+  // device buffers
+  double *d_x0 = nullptr, *d_iniS = nullptr, *d_finS = nullptr, *d_corridor = nullptr;
+  int16_t *d_pt_piece = nullptr, *d_pt_j = nullptr;
+  double *d_opM[kMaxSeg] = {nullptr}, *d_opMT[kMaxSeg] = {nullptr};
+  double *d_histS = nullptr, *d_histY = nullptr;
+  double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
+  int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
+  long long *d_hist = nullptr;
+  double *d_coef = nullptr, *d_dt = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+};
+
+#define HIPCHK(h, call)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return DFTPAV_E_HIP;                                                               \
+    }                                                                                    \
+  } while (0)
+
+// ------------------------------------------------------------------ params
+extern "C" void dftpav_default_params(dftpav_params *p) {
+  std::memset(p, 0, sizeof(*p));
+  // config/minco_config.pb.txt:65-100
+  p->traj_resolution = 16;
+  p->des_traj_resolution = 32;
+  p->wei_obs = 1000.0;
+  p->wei_surround = 5000.0;
+  p->wei_feas = 2500.0;
+  p->wei_sqrvar = 500.0;
+  p->wei_time = 500.0;
+  p->surround_clearance = 0.4;
+  p->half_margin = 0.15;
+  p->max_forward_vel = 5.0;
+  p->max_forward_acc = 8.0;
+  p->max_forward_cur = 1.0;
+  p->max_backward_vel = 2.0;
+  p->max_backward_acc = 4.0;
+  p->max_backward_cur = 1.0;
+  p->max_latacc = 5.0;
+  p->max_phidot = 10000.0;
+  p->gear_opt = 1;
+  p->non_sinv = 0.24; // traj_optimizer.h:68
+  p->mini_T = 0.1;
+  p->fail_cost = 50000.0; // traj_optimizer.cpp:197
+  // common/basics/semantics.h:66-76
+  p->veh_width = 1.90;
+  p->veh_length = 4.88;
+  p->veh_wheel_base = 2.85;
+  p->veh_d_cr = 1.015;
+  // traj_optimizer.cpp:127-134 over lbfgs.hpp:15-129
+  p->lbfgs_mem_size = 256;
+  p->lbfgs_past = 3;
+  p->lbfgs_delta = 1.0e-4;
+  p->lbfgs_g_epsilon = 1.0e-16;
+  p->lbfgs_max_iterations = 12000;
+  p->lbfgs_max_linesearch = 64;
+  p->lbfgs_min_step = 1.0e-32;
+  p->lbfgs_max_step = 1.0e+20;
+  p->lbfgs_f_dec_coeff = 1.0e-4;
+  p->lbfgs_s_curv_coeff = 0.9;
+  p->lbfgs_cautious_factor = 1.0e-6;
+  p->lbfgs_machine_prec = 1.0e-16;
+}
+
+extern "C" int dftpav_num_vars(const dftpav_layout *l) { // traj_optimizer.cpp:80-86
+  if (!l || l->M < 1) return DFTPAV_E_INVALID;
+  int n = 0;
+  for (int i = 0; i < l->M; i++) n += 2 * (l->piece_nums[i] - 1);
+  n += l->M;
+  n += 2 * (l->M - 1);
+  n += 1 * (l->M - 1);
+  return n;
+}
+
+extern "C" int dftpav_num_points(const dftpav_params *p, const dftpav_layout *l) { // traj_optimizer.cpp:44
+  if (!p || !l || l->M < 1) return DFTPAV_E_INVALID;
+  int s = 0;
+  for (int i = 0; i < l->M; i++)
+    s += (l->piece_nums[i] - 2) * (p->traj_resolution + 1) + 2 * (p->des_traj_resolution + 1);
+  return s;
+}
+
+// sizeof probes so the Python mirror of the PODs can be checked against the compiled layout
+extern "C" int dftpav_abi_sizeof_params(void) { return (int)sizeof(dftpav_params); }
+extern "C" int dftpav_abi_sizeof_layout(void) { return (int)sizeof(dftpav_layout); }
+extern "C" int dftpav_abi_sizeof_batch_data(void) { return (int)sizeof(dftpav_batch_data); }
+extern "C" int dftpav_abi_sizeof_surround(void) { return (int)sizeof(dftpav_surround); }
+
+// ------------------------------------------------------------------ handle
+extern "C" int dftpav_create(const dftpav_params *params, int device, dftpav_handle **out) {
+  if (!params || !out) return DFTPAV_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DFTPAV_E_NO_DEVICE;
+  if (params->lbfgs_past > 8 || params->lbfgs_past < 0) return DFTPAV_E_UNSUPPORTED;
+  if (params->lbfgs_mem_size <= 0 || params->lbfgs_mem_size > 1024) return DFTPAV_E_UNSUPPORTED;
+  if (hipSetDevice(device) != hipSuccess) return DFTPAV_E_NO_DEVICE;
+  auto *h = new dftpav_handle();
+  h->params = *params;
+  h->device = device;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return DFTPAV_E_NO_DEVICE;
+  }
+  *out = h;
+  return DFTPAV_OK;
+}
+
+static void free_surround(dftpav_handle *h) {
+  if (h->d_sur_off) (void)hipFree(h->d_sur_off);
+  if (h->d_sur_dur) (void)hipFree(h->d_sur_dur);
+  if (h->d_sur_coef) (void)hipFree(h->d_sur_coef);
+  if (h->d_sur_total) (void)hipFree(h->d_sur_total);
+  if (h->d_sur_start) (void)hipFree(h->d_sur_start);
+  h->d_sur_off = nullptr;
+  h->d_sur_dur = h->d_sur_coef = h->d_sur_total = h->d_sur_start = nullptr;
+  h->S = 0;
+}
+
+extern "C" void dftpav_destroy(dftpav_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  free_surround(h);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" const char *dftpav_last_error(const dftpav_handle *h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" void *dftpav_stream(dftpav_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
+  if (!h) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_surround(h);
+  if (!s || s->S <= 0) return DFTPAV_OK;
+  int S = s->S, np = s->piece_offsets[S];
+  if (np <= 0) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipMalloc(&h->d_sur_off, sizeof(int) * (S + 1)));
+  HIPCHK(h, hipMalloc(&h->d_sur_dur, sizeof(double) * np));
+  HIPCHK(h, hipMalloc(&h->d_sur_coef, sizeof(double) * 12 * np));
+  HIPCHK(h, hipMalloc(&h->d_sur_total, sizeof(double) * S));
+  HIPCHK(h, hipMalloc(&h->d_sur_start, sizeof(double) * S));
+  HIPCHK(h, hipMemcpy(h->d_sur_off, s->piece_offsets, sizeof(int) * (S + 1), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_sur_dur, s->durations, sizeof(double) * np, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_sur_coef, s->coeffs, sizeof(double) * 12 * np, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_sur_total, s->total_duration, sizeof(double) * S, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_sur_start, s->start_time, sizeof(double) * S, hipMemcpyHostToDevice));
+  h->S = S;
+  return DFTPAV_OK;
+}
+
+// ------------------------------------------------- constant MINCO operator
+// Columns of A_N^{-1} for the N+5 RHS rows that can be non-zero
+// (poly_traj_utils.hpp:968-977): the reference's own banded LU
+// (poly_traj_utils.hpp:776-826, restated in traj_math.h) applied to unit
+// vectors, once per distinct N at batch creation.  fp64, fixed operation order:
+// the operator's bits are part of the reproducible program (tests compare them
+// with the oracle's).
+static void minco_operator(int N, std::vector<double> &Mop, std::vector<double> &MopT) {
+  const int n6 = 6 * N, nc = N + 5;
+  std::vector<double> band((size_t)n6 * 13, 0.0);
+  BandedLU A{n6, 6, 6, band.data()};
+  minco_fill(A, N);
+  banded_factorize(A);
+  Mop.assign((size_t)n6 * nc, 0.0);
+  MopT.assign((size_t)n6 * nc, 0.0);
+  std::vector<double> col(n6);
+  for (int c = 0; c < nc; c++) {
+    int row = c < 3 ? c : (c < N + 2 ? 6 * (c - 3) + 5 : n6 - 3 + (c - (N + 2)));
+    std::fill(col.begin(), col.end(), 0.0);
+    col[row] = 1.0;
+    banded_solve1(A, col.data());
+    for (int r = 0; r < n6; r++) {
+      Mop[(size_t)r * nc + c] = col[r];
+      MopT[(size_t)c * n6 + r] = col[r];
+    }
+  }
+}
+
+// debug/test hook: the operator the kernels use for a segment of N pieces, [6N][N+5] row-major
+extern "C" int dftpav_debug_minco_operator(int N, double *out) {
+  if (N < 2 || !out) return DFTPAV_E_INVALID;
+  std::vector<double> M, MT;
+  minco_operator(N, M, MT);
+  std::memcpy(out, M.data(), sizeof(double) * M.size());
+  return DFTPAV_OK;
+}
+
+// -------------------------------------------------------------------- batch
+static void fill_dev_params(const dftpav_params &p, DevParams &P) {
+  P.wei_obs = p.wei_obs;
+  P.wei_surround = p.wei_surround;
+  P.wei_feas = p.wei_feas;
+  P.wei_time = p.wei_time;
+  P.surround_clearance = p.surround_clearance;
+  P.max_vel[0] = p.max_forward_vel; P.max_vel[1] = p.max_backward_vel;
+  P.max_acc[0] = p.max_forward_acc; P.max_acc[1] = p.max_backward_acc;
+  P.max_cur[0] = p.max_forward_cur; P.max_cur[1] = p.max_backward_cur;
+  P.non_sinv = p.non_sinv;
+  P.mini_T = p.mini_T;
+  P.fail_cost = p.fail_cost;
+  // footprint, traj_optimizer.cpp:1749-1775
+  double W = p.veh_width + 2 * p.half_margin, Lh = p.veh_length + 2 * p.half_margin, dcr = p.veh_d_cr;
+  P.veh_length_infl = Lh;
+  double le[4][2] = {{dcr + Lh / 2.0, W / 2.0}, {dcr + Lh / 2.0, -W / 2.0}, {dcr - Lh / 2.0, -W / 2.0},
+                     {dcr - Lh / 2.0, W / 2.0}};
+  for (int k = 0; k < 4; k++) { P.vec_le[k][0] = le[k][0]; P.vec_le[k][1] = le[k][1]; }
+  P.vec_le[4][0] = le[0][0]; P.vec_le[4][1] = le[0][1];
+  P.gear_opt = p.gear_opt;
+  P.mem_size = p.lbfgs_mem_size;
+  P.past = p.lbfgs_past;
+  P.max_iterations = p.lbfgs_max_iterations;
+  P.max_linesearch = p.lbfgs_max_linesearch;
+  P.delta = p.lbfgs_delta;
+  P.g_epsilon = p.lbfgs_g_epsilon;
+  P.min_step = p.lbfgs_min_step;
+  P.max_step = p.lbfgs_max_step;
+  P.f_dec_coeff = p.lbfgs_f_dec_coeff;
+  P.s_curv_coeff = p.lbfgs_s_curv_coeff;
+  P.cautious_factor = p.lbfgs_cautious_factor;
+  P.machine_prec = p.lbfgs_machine_prec;
+}
+
+extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->h->device);
+  (void)hipStreamSynchronize(b->h->stream);
+  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY,
+                  b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
+                  b->d_hist, b->d_coef, b->d_dt};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  for (int i = 0; i < kMaxSeg; i++) {
+    if (b->d_opM[i]) (void)hipFree(b->d_opM[i]);
+    if (b->d_opMT[i]) (void)hipFree(b->d_opMT[i]);
+  }
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out) {
+  if (!h || !layout || !out || B < 1) return DFTPAV_E_INVALID;
+  *out = nullptr;
+  if (layout->M < 1 || layout->M > kMaxSeg || layout->H < 1) return DFTPAV_E_UNSUPPORTED;
+  for (int i = 0; i < layout->M; i++) {
+    if (layout->piece_nums[i] < 2) return DFTPAV_E_ONE_PIECE; // "There is only a piece?", traj_optimizer.cpp:38-41
+  }
+  const dftpav_params &p = h->params;
+  if (p.traj_resolution < 1 || p.des_traj_resolution < 1) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  auto *b = new dftpav_batch();
+  b->h = h;
+  b->B = B;
+  DevLayout &L = b->L;
+  L.M = layout->M;
+  L.H = layout->H;
+  L.K = p.traj_resolution;
+  L.Kd = p.des_traj_resolution;
+  L.Kmax = L.K > L.Kd ? L.K : L.Kd;
+  int xoff = 0, poff = 0, roff = 0, ptoff = 0;
+  for (int i = 0; i < L.M; i++) {
+    int N = layout->piece_nums[i];
+    L.piece_nums[i] = N;
+    L.singuls[i] = layout->singuls[i];
+    L.seg_piece0[i] = poff;
+    L.seg_x0[i] = xoff;
+    L.seg_rhs0[i] = roff;
+    L.seg_pt0[i] = ptoff;
+    poff += N;
+    xoff += 2 * (N - 1);
+    roff += N + 5;
+    ptoff += (N - 2) * (L.K + 1) + 2 * (L.Kd + 1);
+  }
+  L.seg_piece0[L.M] = poff;
+  L.seg_rhs0[L.M] = roff;
+  L.seg_pt0[L.M] = ptoff;
+  L.Ntot = poff;
+  L.rhs_tot = roff;
+  L.Npts = ptoff;
+  L.x_tau0 = xoff;
+  L.x_gear0 = xoff + L.M;
+  L.x_ang0 = L.x_gear0 + 2 * (L.M - 1);
+  L.n = L.x_ang0 + (L.M - 1);
+  L.npad = ((L.n + 63) / 64) * 64;
+  if (L.n > 256 || L.Ntot > 1024 || L.Npts > 32767) {
+    delete b;
+    return DFTPAV_E_UNSUPPORTED;
+  }
+  fill_dev_params(p, b->P);
+  b->threads = solver_threads(L);
+  size_t lds = solver_lds_bytes(L, b->P, b->threads);
+  if (lds > 160 * 1024) {
+    delete b;
+    return DFTPAV_E_UNSUPPORTED;
+  }
+  b->NptsPad = ((L.Npts + 63) / 64) * 64;
+  const int n = L.n, M = L.M;
+  int rc = DFTPAV_OK;
+  auto fail = [&](int code) {
+    dftpav_batch_destroy(b);
+    return code;
+  };
+#define BCHK(call)                                                             \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);              \
+      return fail(DFTPAV_E_HIP);                                               \
+    }                                                                          \
+  } while (0)
+  BCHK(hipMalloc(&b->d_x0, sizeof(double) * (size_t)B * n));
+  BCHK(hipMalloc(&b->d_iniS, sizeof(double) * (size_t)B * M * 6));
+  BCHK(hipMalloc(&b->d_finS, sizeof(double) * (size_t)B * M * 6));
+  BCHK(hipMalloc(&b->d_corridor, sizeof(double) * (size_t)B * L.H * 4 * b->NptsPad));
+  BCHK(hipMalloc(&b->d_pt_piece, sizeof(int16_t) * L.Npts));
+  BCHK(hipMalloc(&b->d_pt_j, sizeof(int16_t) * L.Npts));
+  BCHK(hipMalloc(&b->d_histS, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMalloc(&b->d_histY, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMalloc(&b->d_x_in, sizeof(double) * (size_t)B * n));
+  BCHK(hipMalloc(&b->d_x_out, sizeof(double) * (size_t)B * n));
+  BCHK(hipMalloc(&b->d_f, sizeof(double) * (size_t)B));
+  BCHK(hipMalloc(&b->d_g, sizeof(double) * (size_t)B * n));
+  BCHK(hipMalloc(&b->d_status, sizeof(int) * (size_t)B));
+  BCHK(hipMalloc(&b->d_success, sizeof(int) * (size_t)B));
+  BCHK(hipMalloc(&b->d_iters, sizeof(int) * (size_t)B));
+  BCHK(hipMalloc(&b->d_evals, sizeof(int) * (size_t)B));
+  BCHK(hipMalloc(&b->d_hist, sizeof(long long) * (size_t)B));
+  BCHK(hipMalloc(&b->d_coef, sizeof(double) * (size_t)B * 12 * L.Ntot));
+  BCHK(hipMalloc(&b->d_dt, sizeof(double) * (size_t)B * M));
+  BCHK(hipEventCreate(&b->ev0));
+  BCHK(hipEventCreate(&b->ev1));
+  // constraint point -> (piece, j) tables, the pointid order of traj_optimizer.cpp:486-514
+  {
+    std::vector<int16_t> pp(L.Npts), pj(L.Npts);
+    int pt = 0;
+    for (int sg = 0; sg < M; sg++)
+      for (int lp = 0; lp < L.piece_nums[sg]; lp++) {
+        int K = (lp == 0 || lp == L.piece_nums[sg] - 1) ? L.Kd : L.K;
+        for (int j = 0; j <= K; j++, pt++) {
+          pp[pt] = (int16_t)(L.seg_piece0[sg] + lp);
+          pj[pt] = (int16_t)j;
+        }
+      }
+    BCHK(hipMemcpy(b->d_pt_piece, pp.data(), sizeof(int16_t) * L.Npts, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(b->d_pt_j, pj.data(), sizeof(int16_t) * L.Npts, hipMemcpyHostToDevice));
+  }
+  for (int sg = 0; sg < M; sg++) {
+    int N = L.piece_nums[sg];
+    std::vector<double> Mop, MopT;
+    minco_operator(N, Mop, MopT);
+    BCHK(hipMalloc(&b->d_opM[sg], sizeof(double) * Mop.size()));
+    BCHK(hipMalloc(&b->d_opMT[sg], sizeof(double) * MopT.size()));
+    BCHK(hipMemcpy(b->d_opM[sg], Mop.data(), sizeof(double) * Mop.size(), hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(b->d_opMT[sg], MopT.data(), sizeof(double) * MopT.size(), hipMemcpyHostToDevice));
+  }
+#undef BCHK
+  (void)rc;
+  *out = b;
+  return DFTPAV_OK;
+}
+
+// RealT2VirtualT, traj_optimizer.cpp:360-369
+static double real_to_virtual(double rt, double mini_T) {
+  return rt > 1.0 + mini_T ? (std::sqrt(2.0 * rt - 1.0 - 2 * mini_T) - 1.0)
+                           : (1.0 - std::sqrt(2.0 / (rt - mini_T) - 1.0));
+}
+
+static void clamp_col(double *col, double lim) { // traj_optimizer.cpp:65-76
+  double nrm = std::sqrt(col[0] * col[0] + col[1] * col[1]);
+  if (nrm >= lim) {
+    double nx = col[0] / nrm, ny = col[1] / nrm;
+    col[0] = nx * (lim - 1.0e-2);
+    col[1] = ny * (lim - 1.0e-2);
+  }
+}
+
+extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) {
+  if (!b || !d || !d->ini_states || !d->fin_states || !d->inner_pts || !d->init_Ts || !d->corridor)
+    return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  const dftpav_params &p = h->params;
+  const DevLayout &L = b->L;
+  const int B = b->B, M = L.M, n = L.n;
+  const int ninner = L.x_tau0;
+  // initTs.minCoeff() < mini_T, traj_optimizer.cpp:30-33
+  for (size_t i = 0; i < (size_t)B * M; i++)
+    if (d->init_Ts[i] < p.mini_T) return DFTPAV_E_MINI_T;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<double> ini(d->ini_states, d->ini_states + (size_t)B * M * 6);
+  std::vector<double> fin(d->fin_states, d->fin_states + (size_t)B * M * 6);
+  for (int t = 0; t < B; t++)
+    for (int i = 0; i < M; i++) {
+      double mv = L.singuls[i] > 0 ? p.max_forward_vel : p.max_backward_vel;
+      double ma = L.singuls[i] > 0 ? p.max_forward_acc : p.max_backward_acc;
+      double *I = ini.data() + ((size_t)t * M + i) * 6, *F = fin.data() + ((size_t)t * M + i) * 6;
+      clamp_col(I + 2, mv);
+      clamp_col(F + 2, mv);
+      clamp_col(I + 4, ma);
+      clamp_col(F + 4, ma);
+    }
+  // x0 packing, traj_optimizer.cpp:96-115
+  b->x0_host.assign((size_t)B * n, 0.0);
+  for (int t = 0; t < B; t++) {
+    double *x = b->x0_host.data() + (size_t)t * n;
+    std::memcpy(x, d->inner_pts + (size_t)t * ninner, sizeof(double) * ninner);
+    for (int i = 0; i < M; i++) x[L.x_tau0 + i] = real_to_virtual(d->init_Ts[(size_t)t * M + i], p.mini_T);
+    for (int i = 0; i < M - 1; i++) {
+      const double *F = fin.data() + ((size_t)t * M + i) * 6;
+      x[L.x_gear0 + 2 * i + 0] = F[0];
+      x[L.x_gear0 + 2 * i + 1] = F[1];
+      x[L.x_ang0 + i] = std::atan2(F[3], F[2]);
+    }
+  }
+  // corridor: private normalised copy (traj_optimizer.cpp:15,49-52), transposed to
+  // [trajectory][plane*4+component][point] so that lanes (points) read contiguous doubles
+  const size_t per = (size_t)L.H * 4 * b->NptsPad;
+  std::vector<double> cor((size_t)B * per, 0.0);
+  for (int t = 0; t < B; t++)
+    for (int pt = 0; pt < L.Npts; pt++)
+      for (int k = 0; k < L.H; k++) {
+        const double *col = d->corridor + (((size_t)t * L.Npts + pt) * L.H + k) * 4;
+        double nrm = std::sqrt(col[0] * col[0] + col[1] * col[1]);
+        double *dst = cor.data() + (size_t)t * per + (size_t)(4 * k) * b->NptsPad + pt;
+        dst[0] = col[0] / nrm;
+        dst[(size_t)b->NptsPad] = col[1] / nrm;
+        dst[(size_t)2 * b->NptsPad] = col[2];
+        dst[(size_t)3 * b->NptsPad] = col[3];
+      }
+  HIPCHK(h, hipMemcpy(b->d_x0, b->x0_host.data(), sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(b->d_iniS, ini.data(), sizeof(double) * ini.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(b->d_finS, fin.data(), sizeof(double) * fin.size(), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(b->d_corridor, cor.data(), sizeof(double) * cor.size(), hipMemcpyHostToDevice));
+  b->t_now = d->t_now;
+  b->epis = d->help_eps;
+  b->uploaded = true;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_get_x0(dftpav_batch *b, double *x0) {
+  if (!b || !x0 || !b->uploaded) return DFTPAV_E_INVALID;
+  std::memcpy(x0, b->x0_host.data(), sizeof(double) * b->x0_host.size());
+  return DFTPAV_OK;
+}
+
+static DevBatch make_dev(dftpav_batch *b) {
+  DevBatch D{};
+  D.L = b->L;
+  D.P = b->P;
+  D.B = b->B;
+  D.x0 = b->d_x0;
+  D.iniS = b->d_iniS;
+  D.finS = b->d_finS;
+  D.corridor = b->d_corridor;
+  D.NptsPad = b->NptsPad;
+  D.pt_piece = b->d_pt_piece;
+  D.pt_j = b->d_pt_j;
+  for (int i = 0; i < kMaxSeg; i++) {
+    D.opM[i] = b->d_opM[i];
+    D.opMT[i] = b->d_opMT[i];
+  }
+  dftpav_handle *h = b->h;
+  D.sur.S = h->S;
+  D.sur.piece_off = h->d_sur_off;
+  D.sur.durations = h->d_sur_dur;
+  D.sur.coeffs = h->d_sur_coef;
+  D.sur.total = h->d_sur_total;
+  D.sur.start = h->d_sur_start;
+  D.t_now = b->t_now;
+  D.epis = b->epis;
+  D.histS = b->d_histS;
+  D.histY = b->d_histY;
+  D.x_in = b->d_x_in;
+  D.x_out = b->d_x_out;
+  D.f_out = b->d_f;
+  D.g_out = b->d_g;
+  D.status = b->d_status;
+  D.success = b->d_success;
+  D.iters = b->d_iters;
+  D.evals = b->d_evals;
+  D.hist_sum = b->d_hist;
+  D.coef_out = b->d_coef;
+  D.dt_out = b->d_dt;
+  return D;
+}
+
+extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g) {
+  if (!b || !x || !b->uploaded) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  const size_t nb = (size_t)b->B * b->L.n;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(b->d_x_in, x, sizeof(double) * nb, hipMemcpyHostToDevice, h->stream));
+  DevBatch D = make_dev(b);
+  HIPCHK(h, launch_solver(D, kModeEval, b->threads, h->stream));
+  if (f) HIPCHK(h, hipMemcpyAsync(f, b->d_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, h->stream));
+  if (g) HIPCHK(h, hipMemcpyAsync(g, b->d_g, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_solve_async(dftpav_batch *b) {
+  if (!b || !b->uploaded) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBatch D = make_dev(b);
+  HIPCHK(h, hipEventRecord(b->ev0, h->stream));
+  HIPCHK(h, launch_solver(D, kModeSolve, b->threads, h->stream));
+  HIPCHK(h, hipEventRecord(b->ev1, h->stream));
+  b->timed = true;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_sync(dftpav_batch *b) {
+  if (!b) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms) {
+  if (!b || !ms || !b->timed) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventSynchronize(b->ev1));
+  HIPCHK(h, hipEventElapsedTime(ms, b->ev0, b->ev1));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *status, int *success,
+                                    int *iters, int *evals, long long *hist_sum) {
+  if (!b) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  const int B = b->B;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (x) HIPCHK(h, hipMemcpy(x, b->d_x_out, sizeof(double) * (size_t)B * b->L.n, hipMemcpyDeviceToHost));
+  if (final_cost) HIPCHK(h, hipMemcpy(final_cost, b->d_f, sizeof(double) * B, hipMemcpyDeviceToHost));
+  if (status) HIPCHK(h, hipMemcpy(status, b->d_status, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (success) HIPCHK(h, hipMemcpy(success, b->d_success, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (iters) HIPCHK(h, hipMemcpy(iters, b->d_iters, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (evals) HIPCHK(h, hipMemcpy(evals, b->d_evals, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (hist_sum) HIPCHK(h, hipMemcpy(hist_sum, b->d_hist, sizeof(long long) * B, hipMemcpyDeviceToHost));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piece_dt) {
+  if (!b || !b->uploaded) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBatch D = make_dev(b);
+  HIPCHK(h, launch_solver(D, kModeCoeffs, b->threads, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (coeffs)
+    HIPCHK(h, hipMemcpy(coeffs, b->d_coef, sizeof(double) * (size_t)b->B * 12 * b->L.Ntot, hipMemcpyDeviceToHost));
+  if (piece_dt) HIPCHK(h, hipMemcpy(piece_dt, b->d_dt, sizeof(double) * (size_t)b->B * b->L.M, hipMemcpyDeviceToHost));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B, const dftpav_batch_data *d,
+                                  double *x, double *final_cost, int *status, int *success, int *iters, int *evals) {
+  dftpav_batch *b = nullptr;
+  int rc = dftpav_batch_create(h, layout, B, &b);
+  if (rc != DFTPAV_OK) return rc;
+  rc = dftpav_batch_upload(b, d);
+  if (rc == DFTPAV_OK) rc = dftpav_batch_solve_async(b);
+  if (rc == DFTPAV_OK) rc = dftpav_batch_results(b, x, final_cost, status, success, iters, evals, nullptr);
+  dftpav_batch_destroy(b);
+  return rc;
+}

@@ -1,0 +1,85 @@
+// device_types.h — PODs passed by value from the host C-ABI layer to the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+namespace dftpav {
+
+constexpr int kMaxSeg = 8;        // gear segments per trajectory (trajnum)
+constexpr int kWave = 64;         // CDNA wavefront
+constexpr int kMaxThreads = 1024; // workgroup size limit
+
+// Subset of dftpav_params the kernels read (traj_optimizer.cpp:1713-1736).
+struct DevParams {
+  double wei_obs, wei_surround, wei_feas, wei_time;
+  double surround_clearance;
+  double max_vel[2], max_acc[2], max_cur[2]; // [0]=forward (singul>0) [1]=backward, traj_optimizer.cpp:448-457
+  double non_sinv, mini_T, fail_cost;
+  double veh_length_infl;    // inflated length, gate of traj_optimizer.cpp:1393
+  double vec_le[5][2];       // inflated footprint, first vertex repeated (traj_optimizer.cpp:1765-1775)
+  int gear_opt;
+  // lbfgs_parameter_t (lbfgs.hpp:15-129) as set at traj_optimizer.cpp:127-134
+  int mem_size, past, max_iterations, max_linesearch;
+  double delta, g_epsilon, min_step, max_step, f_dec_coeff, s_curv_coeff, cautious_factor, machine_prec;
+};
+
+// Structure shared by all trajectories of a batch.
+struct DevLayout {
+  int M, H, n, npad;           // npad = n rounded up to 64 (history row pitch)
+  int Ntot, Npts, K, Kd, Kmax; // pieces, constraint points, resolutions
+  int rhs_tot;                 // sum_i (N_i + 5): non-zero RHS rows of the MINCO systems
+  int piece_nums[kMaxSeg], singuls[kMaxSeg];
+  int seg_piece0[kMaxSeg + 1]; // first global piece of segment
+  int seg_x0[kMaxSeg];         // offset of P_i inside x
+  int seg_rhs0[kMaxSeg + 1];   // offset of the segment's RHS rows
+  int seg_pt0[kMaxSeg + 1];    // first constraint point of segment
+  int x_tau0, x_gear0, x_ang0; // offsets of tau | gear xy | gear angle inside x
+};
+
+struct DevSurround {
+  int S;
+  const int *piece_off;    // [S+1]
+  const double *durations; // [np]
+  const double *coeffs;    // [np][12], col 0 multiplies t^5 (poly_traj_utils.hpp:993)
+  const double *total;     // [S]
+  const double *start;     // [S]
+};
+
+// Everything one launch needs. Device pointers.
+struct DevBatch {
+  DevLayout L;
+  DevParams P;
+  int B;
+  // problem data (resident after dftpav_batch_upload)
+  const double *x0;       // [B][n]
+  const double *iniS;     // [B][M][6] clamped (traj_optimizer.cpp:55-76)
+  const double *finS;     // [B][M][6]
+  const double *corridor; // [B][H*4][NptsPad] normalised, component-major for coalesced loads
+  int NptsPad;
+  // layout tables
+  const int16_t *pt_piece; // [Npts] global piece index of a constraint point
+  const int16_t *pt_j;     // [Npts] sample index j inside the piece
+  const double *opM[kMaxSeg];  // A_N^{-1} restricted to the N+5 non-zero RHS rows, [6N][N+5] row-major
+  const double *opMT[kMaxSeg]; // its transpose [N+5][6N]
+  DevSurround sur;
+  double t_now, epis;
+  // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
+  double *histS, *histY; // [B][mem][npad]
+  // in/out
+  const double *x_in; // eval mode: [B][n]
+  double *x_out;      // [B][n]
+  double *f_out;      // [B]
+  double *g_out;      // eval mode: [B][n]
+  int *status, *success, *iters, *evals;
+  long long *hist_sum;
+  double *coef_out; // [B][Ntot][6][2]
+  double *dt_out;   // [B][M]
+};
+
+enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };
+
+// size in bytes of the dynamic LDS a launch needs
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads);
+// picks the workgroup size for a layout
+int solver_threads(const DevLayout &L);
+
+} // namespace dftpav

@@ -1,0 +1,786 @@
+// traj_math.h — the per-constraint-point mathematics of the solve path, written
+// once for host and device.
+//
+// Everything here is straight-line fp64 arithmetic built from + - * / sqrt and
+// comparisons only (transcendentals are the portable routines below, not libm),
+// evaluated in the written left-to-right order with floating-point contraction
+// disabled (-ffp-contract=off on both compilers).  gfx950 and x86-64 then
+// produce the same bits (scripts/ieee_probe.hip: sqrt, /, 1/x, a*b+c identical
+// on 4M random operands), which is what makes the L-BFGS iterate sequence of
+// the GPU reproducible on a CPU: the reference solver is chaotic — one ulp on
+// x0 changes its final cost by up to 16 % — so "same result"
+// can only mean "same floating-point program".
+//
+// The kernels in solver.hip include this header; so does the *device-order*
+// mode of the CPU oracle (oracle/dftpav_oracle_dev.cpp), which replays the
+// kernel's summation order on the host.  The oracle's *literal* mode
+// (oracle/dftpav_oracle.c) is independent code and cross-checks this file to
+// rounding level.
+#pragma once
+#include "device_types.h"
+
+#if defined(__HIPCC__)
+#define DFTPAV_HD __host__ __device__
+#else
+#define DFTPAV_HD
+#endif
+
+namespace dftpav {
+
+// ------------------------------------------------------------ portable math
+DFTPAV_HD inline double p_abs(double x) { return x < 0.0 ? -x : x; }
+
+// sin/cos after fdlibm's k_sin.c / k_cos.c polynomial kernels with a
+// two-term Cody-Waite reduction by pi/2 (|x| < ~1e5 is plenty for a heading
+// angle).  Accuracy ~1 ulp; what matters is that host and device run the same
+// operations.
+DFTPAV_HD inline void p_rem_pio2(double x, int &quad, double &y0, double &y1) {
+  const double invpio2 = 6.36619772367581382433e-01;
+  const double pio2_1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
+  const double pio2_1t = 6.07710050650619224932e-11; // pi/2 - pio2_1
+  double fnr = x * invpio2;
+  int n = (int)(fnr < 0.0 ? fnr - 0.5 : fnr + 0.5);
+  double fn = (double)n;
+  double r = x - fn * pio2_1;
+  double w = fn * pio2_1t;
+  y0 = r - w;
+  y1 = (r - y0) - w;
+  quad = n & 3;
+}
+DFTPAV_HD inline double p_ksin(double x, double y) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = x * x;
+  double v = z * x;
+  double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+DFTPAV_HD inline double p_kcos(double x, double y) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = x * x;
+  double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double hz = 0.5 * z;
+  double w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+DFTPAV_HD inline double p_sin(double x) {
+  int q;
+  double y0, y1;
+  p_rem_pio2(x, q, y0, y1);
+  switch (q) {
+    case 0: return p_ksin(y0, y1);
+    case 1: return p_kcos(y0, y1);
+    case 2: return -p_ksin(y0, y1);
+    default: return -p_kcos(y0, y1);
+  }
+}
+DFTPAV_HD inline double p_cos(double x) {
+  int q;
+  double y0, y1;
+  p_rem_pio2(x, q, y0, y1);
+  switch (q) {
+    case 0: return p_kcos(y0, y1);
+    case 1: return -p_ksin(y0, y1);
+    case 2: return -p_kcos(y0, y1);
+    default: return p_ksin(y0, y1);
+  }
+}
+
+// exp after fdlibm e_exp.c (argument reduction by ln2, degree-5 rational core);
+// the range here is alpha*(d - d0) <= 0 with |arg| up to a few hundred.
+DFTPAV_HD inline double p_exp(double x) {
+  const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+               invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+               P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+  if (x < -745.0) return 0.0;
+  if (x > 709.0) return 1.0e308 * 1.0e308;
+  double kr = invln2 * x;
+  int k = (int)(kr < 0.0 ? kr - 0.5 : kr + 0.5);
+  double t = (double)k;
+  double hi = x - t * ln2HI;
+  double lo = t * ln2LO;
+  double xr = hi - lo;
+  double tt = xr * xr;
+  double c = xr - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+  double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
+  // scale by 2^k exactly (two steps keep the multiplier normal for k in [-1074, 1023])
+  int k1 = k / 2, k2 = k - k1;
+  union { double d; unsigned long long u; } a, b;
+  a.u = (unsigned long long)(1023 + k1) << 52;
+  b.u = (unsigned long long)(1023 + k2) << 52;
+  return (y * a.d) * b.d;
+}
+
+// log after fdlibm e_log.c
+DFTPAV_HD inline double p_log(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  union { double d; unsigned long long u; } v;
+  v.d = x;
+  int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+  v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; // mantissa in [1,2)
+  double m = v.d;
+  if (m > 1.41421356237309514547) { // sqrt(2): keep f = m-1 in [-0.293, 0.414]
+    m = m * 0.5;
+    e += 1;
+  }
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double w = z * z;
+  double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  double dk = (double)e;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// ------------------------------------------------------------ scalar helpers
+// positiveSmoothedL1, traj_optimizer.cpp:783-806
+DFTPAV_HD inline void smoothed_l1(double x, double &f, double &df) {
+  const double pe = 1.0e-4;
+  const double half = 0.5 * pe;
+  const double f3c = 1.0 / (pe * pe);
+  const double f4c = -0.5 * f3c / pe;
+  const double d2c = 3.0 * f3c;
+  const double d3c = 4.0 * f4c;
+  if (x < pe) {
+    f = (f4c * x + f3c) * x * x * x;
+    df = (d3c * x + d2c) * x * x;
+  } else {
+    f = x - half;
+    df = 1.0;
+  }
+}
+
+// VirtualT2RealT, traj_optimizer.cpp:371-379
+DFTPAV_HD inline double virtual_to_real(double vt, double mini_T) {
+  return vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + mini_T;
+}
+// d RealT / d VirtualT, traj_optimizer.cpp:405-416
+DFTPAV_HD inline double virtual_to_real_grad(double VT) {
+  if (VT > 0) return VT + 1.0;
+  double den = (0.5 * VT - 1.0) * VT + 1.0;
+  return (1.0 - VT) / (den * den);
+}
+
+// powers of the piece duration, poly_traj_utils.hpp:961-966. s[0..5] = t^k, s[6..11] = t^-k
+DFTPAV_HD inline void duration_powers(double dt, double *s) {
+  double t1 = dt, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+  s[0] = 1.0; s[1] = t1; s[2] = t2; s[3] = t3; s[4] = t4; s[5] = t5;
+  s[6] = 1.0 / 1.0; s[7] = 1.0 / t1; s[8] = 1.0 / t2; s[9] = 1.0 / t3; s[10] = 1.0 / t4; s[11] = 1.0 / t5;
+}
+
+// jerk energy of one piece and its partials (poly_traj_utils.hpp:998-1035).
+// c: 6x2 block c[2k+d]; t: powers t^k; gc receives d(energy)/dc (rows 0..2 zero).
+DFTPAV_HD inline void piece_smoothness(const double *c, const double *t, double &energy, double &gdT, double *gc) {
+  double c3x = c[6], c3y = c[7], c4x = c[8], c4y = c[9], c5x = c[10], c5y = c[11];
+  double n33 = c3x * c3x + c3y * c3y, n44 = c4x * c4x + c4y * c4y, n55 = c5x * c5x + c5y * c5y;
+  double d43 = c4x * c3x + c4y * c3y, d53 = c5x * c3x + c5y * c3y, d54 = c5x * c4x + c5y * c4y;
+  energy = 36.0 * n33 * t[1] + 144.0 * d43 * t[2] + 192.0 * n44 * t[3] + 240.0 * d53 * t[3] + 720.0 * d54 * t[4] +
+           720.0 * n55 * t[5];
+  gdT = 36.0 * n33 + 288.0 * d43 * t[1] + 576.0 * n44 * t[2] + 720.0 * d53 * t[2] + 2880.0 * d54 * t[3] +
+        3600.0 * n55 * t[4];
+  for (int d = 0; d < 2; d++) {
+    double c3 = c[6 + d], c4 = c[8 + d], c5 = c[10 + d];
+    gc[10 + d] = 240.0 * c3 * t[3] + 720.0 * c4 * t[4] + 1440.0 * c5 * t[5];
+    gc[8 + d] = 144.0 * c3 * t[2] + 384.0 * c4 * t[3] + 720.0 * c5 * t[4];
+    gc[6 + d] = 72.0 * c3 * t[1] + 144.0 * c4 * t[2] + 240.0 * c5 * t[3];
+    gc[d] = 0.0;
+    gc[2 + d] = 0.0;
+    gc[4 + d] = 0.0;
+  }
+}
+
+// k-th entries of beta0, beta1, beta2 at offset s1 (traj_optimizer.cpp:505-507)
+DFTPAV_HD inline void beta_row(int k, double s1, double &b0, double &b1, double &b2) {
+  double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  switch (k) {
+    case 0: b0 = 1.0; b1 = 0.0; b2 = 0.0; break;
+    case 1: b0 = s1; b1 = 1.0; b2 = 0.0; break;
+    case 2: b0 = s2; b1 = 2.0 * s1; b2 = 2.0; break;
+    case 3: b0 = s3; b1 = 3.0 * s2; b2 = 6.0 * s1; break;
+    case 4: b0 = s4; b1 = 4.0 * s3; b2 = 12.0 * s2; break;
+    default: b0 = s5; b1 = 5.0 * s4; b2 = 20.0 * s3; break;
+  }
+}
+
+// 2x2 helpers, m = {m00, m01, m10, m11}
+DFTPAV_HD inline void mat_vec(const double m[4], const double v[2], double o[2]) {
+  o[0] = m[0] * v[0] + m[1] * v[1];
+  o[1] = m[2] * v[0] + m[3] * v[1];
+}
+DFTPAV_HD inline void mat_mat(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] + a[1] * b[2];
+  o[1] = a[0] * b[1] + a[1] * b[3];
+  o[2] = a[2] * b[0] + a[3] * b[2];
+  o[3] = a[2] * b[1] + a[3] * b[3];
+}
+
+// ------------------------------------- moving-obstacle trajectories (R12)
+// Piece evaluators, poly_traj_utils.hpp:77-112,179-211; locatePieceIdx :510-528.
+struct SurEval {
+  const double *cm; // 2x6 col-major, col 0 = t^5
+  double t;         // local time inside the piece
+};
+DFTPAV_HD inline SurEval sur_locate(const DevSurround &S, int u, double t) {
+  int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
+  const double *durs = S.durations + p0;
+  int idx;
+  double dur = 0.0;
+  for (idx = 0; idx < np && t > (dur = durs[idx]); idx++) t -= dur;
+  if (idx == np) {
+    idx--;
+    t += durs[idx];
+  }
+  SurEval e;
+  e.cm = S.coeffs + 12 * (size_t)(p0 + idx);
+  e.t = t;
+  return e;
+}
+DFTPAV_HD inline void piece_pos(const SurEval &e, double o[2]) {
+  o[0] = 0.0; o[1] = 0.0;
+  double tn = 1.0;
+  for (int i = 5; i >= 0; i--) {
+    o[0] += tn * e.cm[2 * i];
+    o[1] += tn * e.cm[2 * i + 1];
+    tn *= e.t;
+  }
+}
+DFTPAV_HD inline void piece_vel(const SurEval &e, double o[2]) {
+  o[0] = 0.0; o[1] = 0.0;
+  double tn = 1.0;
+  int n = 1;
+  for (int i = 4; i >= 0; i--) {
+    o[0] += n * tn * e.cm[2 * i];
+    o[1] += n * tn * e.cm[2 * i + 1];
+    tn *= e.t;
+    n++;
+  }
+}
+DFTPAV_HD inline void piece_acc(const SurEval &e, double o[2]) {
+  o[0] = 0.0; o[1] = 0.0;
+  double tn = 1.0;
+  int m = 1, n = 2;
+  for (int i = 3; i >= 0; i--) {
+    o[0] += m * n * tn * e.cm[2 * i];
+    o[1] += m * n * tn * e.cm[2 * i + 1];
+    tn *= e.t;
+    m++;
+    n++;
+  }
+}
+
+// log_sum_exp, traj_optimizer.cpp:1686-1707 (mutates v into the exp weights)
+template <int NV>
+DFTPAV_HD inline double log_sum_exp(double alpha, double *v, double &exp_sum) {
+  double d0 = v[0];
+  if (alpha > 0) {
+    for (int j = 1; j < NV; j++) d0 = v[j] > d0 ? v[j] : d0;
+  } else {
+    for (int j = 1; j < NV; j++) d0 = v[j] < d0 ? v[j] : d0;
+  }
+  exp_sum = 0;
+  for (int j = 0; j < NV; j++) {
+    v[j] = p_exp(alpha * (v[j] - d0));
+    exp_sum += v[j];
+  }
+  return p_log(exp_sum) / alpha + d0;
+}
+
+// dynamicObsGradCostP, traj_optimizer.cpp:1311-1684.
+// Adds d/dsigma into A, d/dsigma' into Bv, the duration gradient into gdT; returns the cost.
+DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, double t_now, double omg, double step,
+                                    double t, double gama, int pieceid, int trajres, const double sigma[2],
+                                    const double dsigma[2], const double ddsigma[2], const double ego_R[4],
+                                    int singul_, int trajid, int Ntraj, double trajtime, double A[2], double Bv[2],
+                                    double &gdT) {
+  const double B_h[4] = {0.0, -1.0, 1.0, 0.0};
+  const double B_hT[4] = {0.0, 1.0, -1.0, 0.0};
+  const double alpha = 100.0;
+  const double ln8 = 2.07944154167983574766e+00; // std::log(8.0)
+  const double d_min = P.surround_clearance + ln8 / alpha; // traj_optimizer.cpp:1336
+  double temp0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
+  double temp0_reci = (temp0 != 0.0) ? 1.0 / temp0 : 0.0;
+  double temp3 = temp0_reci * temp0_reci;
+  double totalPenalty = 0.0;
+  const double(*vle)[2] = P.vec_le; // vec_lo_ == vec_le_, traj_optimizer.cpp:1769
+
+  for (int u = 0; u < S.S; u++) {
+    double dur = S.total[u];
+    double offsettime = t_now - S.start[u] + trajtime; // traj_optimizer.cpp:1367-1369
+    double pt_time = offsettime + t;
+    double sp[2], sv[2], sa[2];
+    if (pt_time < dur) {
+      SurEval e = sur_locate(S, u, pt_time);
+      piece_pos(e, sp);
+      piece_vel(e, sv);
+      piece_acc(e, sa);
+    } else { // traj_optimizer.cpp:1379-1389
+      SurEval e = sur_locate(S, u, dur);
+      double vd[2], pd[2];
+      piece_acc(e, sa);
+      piece_vel(e, vd);
+      piece_pos(e, pd);
+      double ex = pt_time - dur;
+      sv[0] = vd[0] + ex * sa[0];
+      sv[1] = vd[1] + ex * sa[1];
+      sp[0] = pd[0] + ex * vd[0] + 0.5 * sa[0] * ex * ex;
+      sp[1] = pd[1] + ex * vd[1] + 0.5 * sa[1] * ex * ex;
+    }
+    {
+      double dx = sp[0] - sigma[0], dy = sp[1] - sigma[1];
+      if (sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5) continue; // traj_optimizer.cpp:1393
+    }
+    // getR / getRdot extrapolate the last polynomial piece past the duration (traj_optimizer.cpp:1410,1599)
+    double sR[4], Rud[4];
+    {
+      SurEval e = sur_locate(S, u, pt_time);
+      double v[2], a[2];
+      piece_vel(e, v);
+      piece_acc(e, a);
+      double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+      sR[0] = v[0] / nv; sR[1] = -v[1] / nv; sR[2] = v[1] / nv; sR[3] = v[0] / nv;
+      double nv3 = nv * nv * nv; // pow(norm, 3), poly_traj_utils.hpp:109
+      double va = v[0] * a[0] + v[1] * a[1];
+      Rud[0] = (a[0] / nv - v[0] / nv3 * va);
+      Rud[1] = (-a[1] / nv - (-v[1]) / nv3 * va);
+      Rud[2] = (a[1] / nv - v[1] / nv3 * va);
+      Rud[3] = (a[0] / nv - v[0] / nv3 * va);
+    }
+
+    double s2e_sum[4], d_test[8];
+    double egoN[4][2], dUo[4][4], Fdl[4][4], Fl[4][4];
+    for (int e = 0; e < 4; e++) { // traj_optimizer.cpp:1417-1461
+      const double *le = vle[e];
+      double dl[2] = {vle[e + 1][0] - le[0], vle[e + 1][1] - le[1]};
+      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      double dlni = 1 / dln;
+      double Rdl[2], Rle[2];
+      mat_vec(ego_R, dl, Rdl);
+      mat_vec(ego_R, le, Rle);
+      {
+        double LT[4] = {dl[0], dl[1], -dl[1], dl[0]};
+        Fdl[e][0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rdl[0] * temp3;
+        Fdl[e][1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rdl[1] * temp3;
+        Fdl[e][2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rdl[0] * temp3;
+        Fdl[e][3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rdl[1] * temp3;
+      }
+      {
+        double LT[4] = {le[0], le[1], -le[1], le[0]};
+        Fl[e][0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rle[0] * temp3;
+        Fl[e][1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rle[1] * temp3;
+        Fl[e][2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rle[0] * temp3;
+        Fl[e][3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rle[1] * temp3;
+      }
+      double BR[4], Ht[2];
+      mat_mat(B_h, ego_R, BR);
+      mat_vec(BR, dl, Ht);
+      Ht[0] *= dlni;
+      Ht[1] *= dlni;
+      egoN[e][0] = Ht[0];
+      egoN[e][1] = Ht[1];
+      double w[2] = {sp[0] - sigma[0] - Rle[0], sp[1] - sigma[1] - Rle[1]};
+      double dUt = Ht[0] * w[0] + Ht[1] * w[1];
+      double HtR[2] = {Ht[0] * sR[0] + Ht[1] * sR[2], Ht[0] * sR[1] + Ht[1] * sR[3]};
+      for (int o = 0; o < 4; o++) dUo[e][o] = HtR[0] * vle[o][0] + HtR[1] * vle[o][1];
+      double es;
+      d_test[e] = log_sum_exp<4>(-alpha, dUo[e], es) + dUt;
+      s2e_sum[e] = es;
+    }
+    double e2s_sum[4];
+    double surN[4][2], dEe[4][4];
+    for (int o = 0; o < 4; o++) { // traj_optimizer.cpp:1464-1496
+      const double *lo = vle[o];
+      double dl[2] = {vle[o + 1][0] - lo[0], vle[o + 1][1] - lo[1]};
+      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      double dlni = 1 / dln;
+      double BR[4], Ht[2], Rlo[2];
+      mat_mat(B_h, sR, BR);
+      mat_vec(BR, dl, Ht);
+      Ht[0] *= dlni;
+      Ht[1] *= dlni;
+      surN[o][0] = Ht[0];
+      surN[o][1] = Ht[1];
+      mat_vec(sR, lo, Rlo);
+      double w[2] = {sigma[0] - sp[0] - Rlo[0], sigma[1] - sp[1] - Rlo[1]};
+      double dEt = Ht[0] * w[0] + Ht[1] * w[1];
+      double HtR[2] = {Ht[0] * ego_R[0] + Ht[1] * ego_R[2], Ht[0] * ego_R[1] + Ht[1] * ego_R[3]};
+      for (int e = 0; e < 4; e++) dEe[o][e] = HtR[0] * vle[e][0] + HtR[1] * vle[e][1];
+      double es;
+      d_test[4 + o] = log_sum_exp<4>(-alpha, dEe[o], es) + dEt;
+      e2s_sum[o] = es;
+    }
+    double exp_sum_d = 0;
+    double costp = d_min - log_sum_exp<8>(alpha, d_test, exp_sum_d); // traj_optimizer.cpp:1498-1502
+    if (costp <= 0) continue;
+    double pena, penaD;
+    smoothed_l1(costp, pena, penaD);
+    totalPenalty += omg * step * P.wei_surround * pena;
+
+    double pGs[2] = {0.0, 0.0}; // traj_optimizer.cpp:1511-1523
+    for (int e = 0; e < 4; e++) {
+      double w = d_test[e] / exp_sum_d;
+      pGs[0] -= w * (-egoN[e][0]);
+      pGs[1] -= w * (-egoN[e][1]);
+    }
+    for (int o = 0; o < 4; o++) {
+      double w = d_test[o + 4] / exp_sum_d;
+      pGs[0] -= w * surN[o][0];
+      pGs[1] -= w * surN[o][1];
+    }
+    double pGds[2] = {0.0, 0.0}; // traj_optimizer.cpp:1528-1573
+    for (int e = 0; e < 4; e++) {
+      const double *le = vle[e];
+      double dl[2] = {vle[e + 1][0] - le[0], vle[e + 1][1] - le[1]};
+      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      double Rle[2];
+      mat_vec(ego_R, le, Rle);
+      double uu[2] = {-sp[0] + sigma[0] + Rle[0], -sp[1] + sigma[1] + Rle[1]};
+      double FB[4], t1[2], FlB[4], FlBR[4], t2[2];
+      mat_mat(Fdl[e], B_h, FB);
+      mat_vec(FB, uu, t1);
+      mat_mat(Fl[e], B_h, FlB);
+      mat_mat(FlB, ego_R, FlBR);
+      mat_vec(FlBR, dl, t2);
+      double pdU[2] = {(t1[0] - t2[0]) / dln, (t1[1] - t2[1]) / dln};
+      double FBT[4];
+      mat_mat(Fdl[e], B_hT, FBT);
+      for (int o = 0; o < 4; o++) {
+        double Rlo[2], q[2];
+        mat_vec(sR, vle[o], Rlo);
+        mat_vec(FBT, Rlo, q);
+        q[0] /= dln;
+        q[1] /= dln;
+        double w = dUo[e][o] / s2e_sum[e];
+        pdU[0] += w * q[0];
+        pdU[1] += w * q[1];
+      }
+      double w = d_test[e] / exp_sum_d;
+      pGds[0] -= w * pdU[0];
+      pGds[1] -= w * pdU[1];
+    }
+    for (int o = 0; o < 4; o++) {
+      const double *lo = vle[o];
+      double dl[2] = {vle[o + 1][0] - lo[0], vle[o + 1][1] - lo[1]};
+      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      double pdE[2] = {0.0, 0.0};
+      for (int e = 0; e < 4; e++) {
+        double FB[4], FBR[4], q[2];
+        mat_mat(Fl[e], B_h, FB);
+        mat_mat(FB, sR, FBR);
+        mat_vec(FBR, dl, q);
+        q[0] /= dln;
+        q[1] /= dln;
+        double w = dEe[o][e] / e2s_sum[o];
+        pdE[0] += w * q[0];
+        pdE[1] += w * q[1];
+      }
+      double w = d_test[o + 4] / exp_sum_d;
+      pGds[0] -= w * pdE[0];
+      pGds[1] -= w * pdE[1];
+    }
+    double pGtbar = (pGs[0] * dsigma[0] + pGs[1] * dsigma[1]) + (pGds[0] * ddsigma[0] + pGds[1] * ddsigma[1]);
+
+    double pGthat = 0.0; // traj_optimizer.cpp:1586-1646
+    for (int e = 0; e < 4; e++) {
+      const double *Hn = egoN[e];
+      double acc = Hn[0] * sv[0] + Hn[1] * sv[1];
+      double HtRd[2] = {Hn[0] * Rud[0] + Hn[1] * Rud[2], Hn[0] * Rud[1] + Hn[1] * Rud[3]};
+      for (int o = 0; o < 4; o++) {
+        double ptv = HtRd[0] * vle[o][0] + HtRd[1] * vle[o][1];
+        acc += dUo[e][o] / s2e_sum[e] * ptv;
+      }
+      pGthat -= d_test[e] / exp_sum_d * acc;
+    }
+    for (int o = 0; o < 4; o++) {
+      const double *lo = vle[o];
+      double dl[2] = {vle[o + 1][0] - lo[0], vle[o + 1][1] - lo[1]};
+      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      double BRd[4], BR[4], a1[2], a2[2], Rlo[2], Rdlo[2];
+      mat_mat(B_h, Rud, BRd);
+      mat_vec(BRd, dl, a1);
+      mat_mat(B_h, sR, BR);
+      mat_vec(BR, dl, a2);
+      mat_vec(sR, lo, Rlo);
+      mat_vec(Rud, lo, Rdlo);
+      double w1[2] = {sigma[0] - sp[0] - Rlo[0], sigma[1] - sp[1] - Rlo[1]};
+      double w2[2] = {-sv[0] - Rdlo[0], -sv[1] - Rdlo[1]};
+      double acc = ((a1[0] / dln) * w1[0] + (a1[1] / dln) * w1[1]) + ((a2[0] / dln) * w2[0] + (a2[1] / dln) * w2[1]);
+      for (int e = 0; e < 4; e++) {
+        double Rle[2];
+        mat_vec(ego_R, vle[e], Rle);
+        double r1[2] = {Rle[0] * B_h[0] + Rle[1] * B_h[2], Rle[0] * B_h[1] + Rle[1] * B_h[3]};
+        double r2[2] = {r1[0] * Rud[0] + r1[1] * Rud[2], r1[0] * Rud[1] + r1[1] * Rud[3]};
+        double ptv = (r2[0] * dl[0] + r2[1] * dl[1]) / dln;
+        acc += dEe[o][e] / e2s_sum[o] * ptv;
+      }
+      pGthat -= d_test[o + 4] / exp_sum_d * acc;
+    }
+
+    double gradViolaPt = gama * pGtbar; // traj_optimizer.cpp:1649-1676
+    double scale = omg * step * P.wei_surround * penaD;
+    A[0] += scale * pGs[0];
+    A[1] += scale * pGs[1];
+    Bv[0] += scale * pGds[0];
+    Bv[1] += scale * pGds[1];
+    gdT += omg * P.wei_surround * (pena / trajres + penaD * gradViolaPt * step);
+    gdT += omg * step * P.wei_surround * pGthat * penaD * pieceid;
+    gdT += omg * step * P.wei_surround * gama * pGthat * penaD;
+    for (int idx = 0; idx < trajid; idx++) gdT += omg * step * P.wei_surround * pGthat * penaD * Ntraj;
+  }
+  return totalPenalty;
+}
+
+// -------------------------------------------------- one constraint point
+struct SampleIn {
+  const double *cc; // 6x2 coefficient block of the piece, cc[2k+d]
+  double s1;        // accumulated sample offset (s1 += step, traj_optimizer.cpp:513)
+  int j, K;         // sample index and resolution of the piece
+  int lp, N;        // piece index inside its segment, pieces of the segment
+  double dt;        // piece duration
+  int singul;       // +1 forward / -1 reverse
+  double epis;      // help_eps
+  int H;            // half-planes per point
+  int trajid;       // segment index (moving obstacles only)
+  double trajtime;  // trajtimes[trajid] (traj_optimizer.cpp:230-234,291)
+  double t_now;
+};
+
+// The body of the j-loop of addPVAGradCost2CT (traj_optimizer.cpp:499-706) for one
+// constraint point.  Gradients are returned with respect to sigma, sigma',
+// sigma'' (each penalty's dviol/dc is beta0 a^T + beta1 b^T + beta2 c^T, so
+// out = {a (2), b (2), c (2), gdT, cost}); the caller chains them onto the piece
+// coefficients.  `plane(k, n0, n1, q0, q1)` loads half-plane k of this point.
+template <bool SUR, class PlaneLoader>
+DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S, const SampleIn &in, PlaneLoader plane,
+                                        double out[8]) {
+  for (int k = 0; k < 8; k++) out[k] = 0.0;
+  const int j = in.j, K = in.K, lp = in.lp, N = in.N;
+  const double dt = in.dt;
+  const double step = dt / K;
+  const double s1 = in.s1;
+  double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+  double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+  double beta3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+  double alpha = 1.0 / K * j;
+  const double *cc = in.cc;
+  double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0}, dddsigma[2] = {0, 0};
+  for (int k = 0; k < 6; k++) {
+    double c0 = cc[2 * k], c1 = cc[2 * k + 1];
+    sigma[0] += c0 * beta0[k];
+    sigma[1] += c1 * beta0[k];
+    dsigma[0] += c0 * beta1[k];
+    dsigma[1] += c1 * beta1[k];
+    ddsigma[0] += c0 * beta2[k];
+    ddsigma[1] += c1 * beta2[k];
+    dddsigma[0] += c0 * beta3[k];
+    dddsigma[1] += c1 * beta3[k];
+  }
+  double omg = (j == 0 || j == K) ? 0.5 : 1.0;
+  double z_h0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
+  double z_h1 = ddsigma[0] * dsigma[0] + ddsigma[1] * dsigma[1];
+  double z_h2 = dddsigma[0] * dsigma[0] + dddsigma[1] * dsigma[1];
+  double z_h3 = ddsigma[1] * dsigma[0] + (-ddsigma[0]) * dsigma[1];
+  double z1 = dddsigma[1] * dsigma[0] + (-dddsigma[0]) * dsigma[1];
+  if (z_h0 < 1e-4 || (j == 0 && lp == 0) || (lp == N - 1 && j == K)) return; // traj_optimizer.cpp:550-553
+
+  const int singul_ = in.singul;
+  const int dir = singul_ > 0 ? 0 : 1;
+  double max_vel = P.max_vel[dir], max_acc = P.max_acc[dir], max_cur = P.max_cur[dir];
+  double vel2_reci = 1.0 / (z_h0 * z_h0);
+  double vel2_reci_e = 1.0 / (z_h0 * z_h0 + in.epis);
+  double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);
+  z_h0 = 1.0 / z_h0;
+  double z_h4 = z_h1 * vel2_reci;
+  double violaVel = 1.0 / vel2_reci - max_vel * max_vel;
+  double acc2 = z_h1 * z_h1 * vel2_reci;
+  double cur = z_h3 * vel3_2_reci_e;
+  double violaAcc = acc2 - max_acc * max_acc;
+  double violaCurL = cur - max_cur;
+  double violaCurR = -cur - max_cur;
+  double ego_R[4] = {singul_ * dsigma[0] * z_h0, singul_ * -dsigma[1] * z_h0, singul_ * dsigma[1] * z_h0,
+                     singul_ * dsigma[0] * z_h0};
+  double R_dot[4];
+  {
+    double ta[4] = {ddsigma[0], -ddsigma[1], ddsigma[1], ddsigma[0]};
+    double tv[4] = {dsigma[0], -dsigma[1], dsigma[1], dsigma[0]};
+    for (int k = 0; k < 4; k++) R_dot[k] = singul_ * (ta[k] * z_h0 - tv[k] * vel2_reci * z_h0 * z_h1);
+  }
+  double A[2] = {0, 0}, Bv[2] = {0, 0}, Cv[2] = {0, 0}, gdT = 0.0, cost = 0.0;
+
+  // ---- safe corridor, traj_optimizer.cpp:592-622 (5 footprint entries, vertex 0 repeated)
+  for (int k = 0; k < in.H; k++) {
+    double on0, on1, q0, q1;
+    plane(k, on0, on1, q0, q1);
+    for (int v = 0; v < 5; v++) {
+      const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
+      double Rle[2] = {ego_R[0] * le0 + ego_R[1] * le1, ego_R[2] * le0 + ego_R[3] * le1};
+      double bpt[2] = {sigma[0] + Rle[0], sigma[1] + Rle[1]};
+      double violaPos = on0 * (bpt[0] - q0) + on1 * (bpt[1] - q1);
+      if (violaPos > 0) {
+        double pena, penaD;
+        smoothed_l1(violaPos, pena, penaD);
+        double tl[4] = {le0, -le1, le1, le0};
+        double Mm[4];
+        Mm[0] = singul_ * tl[0] * z_h0 - Rle[0] * dsigma[0] * vel2_reci;
+        Mm[1] = singul_ * tl[1] * z_h0 - Rle[0] * dsigma[1] * vel2_reci;
+        Mm[2] = singul_ * tl[2] * z_h0 - Rle[1] * dsigma[0] * vel2_reci;
+        Mm[3] = singul_ * tl[3] * z_h0 - Rle[1] * dsigma[1] * vel2_reci;
+        double w[2] = {dsigma[0] + (R_dot[0] * le0 + R_dot[1] * le1), dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1)};
+        double gradViolaPt = (alpha * on0) * w[0] + (alpha * on1) * w[1];
+        double sc = omg * step * P.wei_obs * penaD;
+        A[0] += sc * on0;
+        A[1] += sc * on1;
+        Bv[0] += sc * (on0 * Mm[0] + on1 * Mm[2]);
+        Bv[1] += sc * (on0 * Mm[1] + on1 * Mm[3]);
+        gdT += omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
+        cost += omg * step * P.wei_obs * pena;
+      }
+    }
+  }
+
+  // ---- moving obstacles, traj_optimizer.cpp:636-638
+  if (SUR) {
+    if (S.S > 0) {
+      double t = 0.0;
+      for (int q = 0; q < lp; q++) t += dt; // t += getDt() per piece, traj_optimizer.cpp:775
+      cost += dynamic_obs(P, S, in.t_now, omg, step, t + step * j, alpha, lp, K, sigma, dsigma, ddsigma, ego_R, singul_,
+                          in.trajid, N, in.trajtime, A, Bv, gdT);
+    }
+  }
+
+  // ---- velocity, traj_optimizer.cpp:642-653
+  if (violaVel > 0.0) {
+    double pena, penaD;
+    smoothed_l1(violaVel, pena, penaD);
+    double gradViolaVt = 2.0 * alpha * z_h1;
+    double sc = omg * step * P.wei_feas * penaD;
+    Bv[0] += sc * (2.0 * dsigma[0]);
+    Bv[1] += sc * (2.0 * dsigma[1]);
+    gdT += omg * P.wei_feas * (penaD * gradViolaVt * step + pena / K);
+    cost += omg * step * P.wei_feas * pena;
+  }
+  // ---- longitudinal acceleration, traj_optimizer.cpp:655-665
+  if (violaAcc > 0.0) {
+    double pena, penaD;
+    smoothed_l1(violaAcc, pena, penaD);
+    double u0 = z_h4 * ddsigma[0] - z_h4 * z_h4 * dsigma[0];
+    double u1 = z_h4 * ddsigma[1] - z_h4 * z_h4 * dsigma[1];
+    double sqn = ddsigma[0] * ddsigma[0] + ddsigma[1] * ddsigma[1];
+    double gradViolaAt = 2.0 * alpha * (z_h4 * (sqn + z_h2) - z_h4 * z_h4 * z_h1);
+    double sc = omg * step * P.wei_feas * penaD;
+    Bv[0] += sc * (2.0 * u0);
+    Bv[1] += sc * (2.0 * u1);
+    Cv[0] += sc * (2.0 * z_h4 * dsigma[0]);
+    Cv[1] += sc * (2.0 * z_h4 * dsigma[1]);
+    gdT += omg * P.wei_feas * (penaD * gradViolaAt * step + pena / K);
+    cost += omg * step * P.wei_feas * pena;
+  }
+  // ---- curvature, two one-sided penalties weighted x10, traj_optimizer.cpp:684-705
+  if (violaCurL > 0.0 || violaCurR > 0.0) {
+    double ku0 = vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0];
+    double ku1 = vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1];
+    double kw0 = -(vel3_2_reci_e * dsigma[1]);
+    double kw1 = vel3_2_reci_e * dsigma[0];
+    double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
+    if (violaCurL > 0.0) {
+      double pena, penaD;
+      smoothed_l1(violaCurL, pena, penaD);
+      double sc = omg * step * P.wei_feas * 10.0 * penaD;
+      Bv[0] += sc * ku0;
+      Bv[1] += sc * ku1;
+      Cv[0] += sc * kw0;
+      Cv[1] += sc * kw1;
+      gdT += omg * P.wei_feas * 10.0 * (penaD * kt * step + pena / K);
+      cost += omg * step * P.wei_feas * 10.0 * pena;
+    }
+    if (violaCurR > 0.0) {
+      double pena, penaD;
+      smoothed_l1(violaCurR, pena, penaD);
+      double sc = omg * step * P.wei_feas * 10.0 * penaD;
+      Bv[0] += sc * -ku0;
+      Bv[1] += sc * -ku1;
+      Cv[0] += sc * -kw0;
+      Cv[1] += sc * -kw1;
+      gdT += omg * P.wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
+      cost += omg * step * P.wei_feas * 10.0 * pena;
+    }
+  }
+  out[0] = A[0]; out[1] = A[1];
+  out[2] = Bv[0]; out[3] = Bv[1];
+  out[4] = Cv[0]; out[5] = Cv[1];
+  out[6] = gdT;
+  out[7] = cost;
+}
+
+// -------------------------------------------- constant MINCO operator
+// BandedSystem (poly_traj_utils.hpp:727-826) restated for the set-up step that
+// builds the dense operator: A_N^{-1} applied to the N+5 unit vectors of the
+// RHS rows that can be non-zero (poly_traj_utils.hpp:968-977).  Host only.
+struct BandedLU {
+  int N, lowerBw, upperBw;
+  double *ptr;
+  double &at(int i, int j) { return ptr[(i - j + upperBw) * N + j]; }
+};
+inline void banded_factorize(BandedLU &A) { // poly_traj_utils.hpp:776-800, no pivoting
+  int N = A.N;
+  for (int k = 0; k <= N - 2; k++) {
+    int iM = k + A.lowerBw < N - 1 ? k + A.lowerBw : N - 1;
+    double cVl = A.at(k, k);
+    for (int i = k + 1; i <= iM; i++)
+      if (A.at(i, k) != 0.0) A.at(i, k) /= cVl;
+    int jM = k + A.upperBw < N - 1 ? k + A.upperBw : N - 1;
+    for (int j = k + 1; j <= jM; j++) {
+      cVl = A.at(k, j);
+      if (cVl != 0.0)
+        for (int i = k + 1; i <= iM; i++)
+          if (A.at(i, k) != 0.0) A.at(i, j) -= A.at(i, k) * cVl;
+    }
+  }
+}
+inline void banded_solve1(BandedLU &A, double *b) { // poly_traj_utils.hpp:805-826, one column
+  int N = A.N;
+  for (int j = 0; j <= N - 1; j++) {
+    int iM = j + A.lowerBw < N - 1 ? j + A.lowerBw : N - 1;
+    for (int i = j + 1; i <= iM; i++)
+      if (A.at(i, j) != 0.0) b[i] -= A.at(i, j) * b[j];
+  }
+  for (int j = N - 1; j >= 0; j--) {
+    b[j] /= A.at(j, j);
+    int iM = 0 > j - A.upperBw ? 0 : j - A.upperBw;
+    for (int i = iM; i <= j - 1; i++)
+      if (A.at(i, j) != 0.0) b[i] -= A.at(i, j) * b[j];
+  }
+}
+// fills the band matrix of MinJerkOpt::reset (poly_traj_utils.hpp:895-947)
+inline void minco_fill(BandedLU &A, int N) {
+  A.at(0, 0) = 1.0;
+  A.at(1, 1) = 1.0;
+  A.at(2, 2) = 2.0;
+  for (int i = 0; i < N - 1; i++) {
+    int r = 6 * i;
+    A.at(r + 3, r + 3) = 6.0; A.at(r + 3, r + 4) = 24.0; A.at(r + 3, r + 5) = 60.0; A.at(r + 3, r + 9) = -6.0;
+    A.at(r + 4, r + 4) = 24.0; A.at(r + 4, r + 5) = 120.0; A.at(r + 4, r + 10) = -24.0;
+    for (int k = 0; k < 6; k++) A.at(r + 5, r + k) = 1.0;
+    for (int k = 0; k < 6; k++) A.at(r + 6, r + k) = 1.0;
+    A.at(r + 6, r + 6) = -1.0;
+    A.at(r + 7, r + 1) = 1.0; A.at(r + 7, r + 2) = 2.0; A.at(r + 7, r + 3) = 3.0; A.at(r + 7, r + 4) = 4.0;
+    A.at(r + 7, r + 5) = 5.0; A.at(r + 7, r + 7) = -1.0;
+    A.at(r + 8, r + 2) = 2.0; A.at(r + 8, r + 3) = 6.0; A.at(r + 8, r + 4) = 12.0; A.at(r + 8, r + 5) = 20.0;
+    A.at(r + 8, r + 8) = -2.0;
+  }
+  int n6 = 6 * N;
+  for (int k = 0; k < 6; k++) A.at(n6 - 3, n6 - 6 + k) = 1.0;
+  for (int k = 1; k < 6; k++) A.at(n6 - 2, n6 - 6 + k) = (double)k;
+  A.at(n6 - 1, n6 - 4) = 2.0; A.at(n6 - 1, n6 - 3) = 6.0; A.at(n6 - 1, n6 - 2) = 12.0; A.at(n6 - 1, n6 - 1) = 20.0;
+}
+
+} // namespace dftpav

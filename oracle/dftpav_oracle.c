@@ -16,7 +16,7 @@
  * expected at rounding level, not bit level.  Build with -ffp-contract=off
  * (the reference is built -O3 without -march, i.e. no FMA contraction).
  */
-#include "dftpav_oracle.h"
+#include "oracle_internal.h"
 
 #include <alloca.h>
 #include <math.h>
@@ -74,10 +74,7 @@ void oracle_default_params(dftpav_params *p) {
 /* ========================================================================= */
 /* BandedSystem, MINCO:727-853                                                */
 /* ========================================================================= */
-typedef struct {
-  int N, lowerBw, upperBw;
-  double *ptr;
-} banded_t;
+/* banded_t: oracle_internal.h */
 
 #define BAND(A, i, j) ((A)->ptr[((i) - (j) + (A)->upperBw) * (A)->N + (j)])
 
@@ -176,16 +173,7 @@ static void banded_solveAdj(const banded_t *A, double *b) {
 /* MinJerkOpt, MINCO:855-1095                                                 */
 /* All (6N)x2 matrices are stored m[2*row + d].                               */
 /* ========================================================================= */
-typedef struct {
-  int N;
-  double headPVA[6], tailPVA[6]; /* col-major 2x3 */
-  double *b, *c, *adj, *gdC;     /* 6N x 2 */
-  banded_t A;
-  double t[6], tInv[6];
-  double gdT;
-  double gdHead[6], gdTail[6]; /* 2x3 col-major */
-  double *gdP;                 /* 2 x (N-1) col-major */
-} minjerk_t;
+/* minjerk_t: oracle_internal.h */
 
 static void minjerk_fill_A(banded_t *A, int N) { /* MINCO:895-947 */
   BAND(A, 0, 0) = 1.0;
@@ -558,12 +546,7 @@ static int traj_locate(const double *durs, int N, double *t) {
   return idx;
 }
 
-typedef struct {
-  int n_pieces;
-  const double *durs;
-  const double *coeffs; /* [n_pieces][12] */
-  double duration, start_time;
-} sur_traj_t;
+/* sur_traj_t: oracle_internal.h */
 
 static void traj_getPos(const sur_traj_t *s, double t, double o[2]) {
   int i = traj_locate(s->durs, s->n_pieces, &t);
@@ -589,24 +572,7 @@ static void traj_getRdot(const sur_traj_t *s, double t, double R[4]) {
 /* ========================================================================= */
 /* prepared problem                                                           */
 /* ========================================================================= */
-struct oracle_ctx {
-  dftpav_params P;
-  int M, H, n, Npts_total, Ntot;
-  int *piece_nums, *singuls, *pt_offset; /* [M], [M], [M+1] */
-  double *iniS, *finS;                   /* clamped copies [M][6] */
-  double *inner_pts, *init_Ts;
-  double *cfgHs;                         /* normalised copy [Npts][H][4] */
-  double t_now, epis;
-  minjerk_t *mj;                         /* jerkOpt_container */
-  int S;
-  sur_traj_t *sur;
-  double *sur_durs, *sur_coeffs;
-  /* footprint, OPT:1749-1775 */
-  double veh_length_infl, veh_width_infl;
-  double vec_le[5][2], vec_lo[5][2];
-  int evals;
-  double cost_terms[5];
-};
+/* struct oracle_ctx: oracle_internal.h */
 
 int oracle_num_vars(const oracle_problem *pb) { /* OPT:80-86 */
   int n = 0;
@@ -746,8 +712,14 @@ oracle_ctx *oracle_prepare(const dftpav_params *p, const oracle_problem *pb, int
   return c;
 }
 
+void oracle_set_order(oracle_ctx *c, int order) {
+  c->order = order;
+  if (order == 1 && !c->dev) oracle_dev_init(c);
+}
+
 void oracle_free(oracle_ctx *c) {
   if (!c) return;
+  if (c->dev) oracle_dev_free(c);
   for (int i = 0; i < c->M; i++) minjerk_destroy(&c->mj[i]);
   free(c->mj);
   free(c->piece_nums);
@@ -1246,6 +1218,10 @@ static void addPVAGradCost2CT(oracle_ctx *c, double costs[3], int trajid, double
 /* costFunctionCallback, OPT:206-350                                           */
 /* ========================================================================= */
 double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
+  if (c->order == 1) {
+    c->evals += 1;
+    return oracle_dev_eval(c, x, grad);
+  }
   const dftpav_params *P = &c->P;
   int M = c->M;
   double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
@@ -1337,6 +1313,10 @@ double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
 void oracle_last_cost_terms(const oracle_ctx *c, double out[5]) { memcpy(out, c->cost_terms, sizeof(double) * 5); }
 
 void oracle_last_coeffs(const oracle_ctx *c, double *coeffs, double *piece_dt) {
+  if (c->order == 1) {
+    oracle_dev_coeffs(c, coeffs, piece_dt);
+    return;
+  }
   int off = 0;
   for (int i = 0; i < c->M; i++) {
     memcpy(coeffs + 12 * off, c->mj[i].c, sizeof(double) * 12 * c->piece_nums[i]);
@@ -1555,6 +1535,10 @@ static double eval_tramp(void *inst, const double *x, double *g, int n) {
 
 /* the solve half of OptimizeTrajectory, OPT:127-201 */
 void oracle_solve(oracle_ctx *c, double *x, oracle_result *r) {
+  if (c->order == 1) {
+    oracle_dev_solve(c, x, r);
+    return;
+  }
   double final_cost = 0.0;
   c->evals = 0;
   int result = oracle_lbfgs(c->n, x, &final_cost, eval_tramp, c, &c->P, &r->iters, NULL, &r->hist_sum);
@@ -1578,8 +1562,9 @@ static double now_s(void) {
 }
 
 int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, const dftpav_batch_data *d,
-                       const dftpav_surround *s, int nthreads, double *x, double *final_cost, int *status,
-                       int *success, int *iters, int *evals, long long *hist_sum, double *seconds_each) {
+                       const dftpav_surround *s, int nthreads, int order, double *x, double *final_cost,
+                       int *status, int *success, int *iters, int *evals, long long *hist_sum,
+                       double *seconds_each) {
   oracle_problem proto;
   memset(&proto, 0, sizeof(proto));
   proto.M = l->M;
@@ -1615,6 +1600,7 @@ int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, co
       continue;
     }
     double *xb = x + (size_t)b * n;
+    oracle_set_order(c, order);
     oracle_pack_x0(c, xb);
     oracle_result r;
     oracle_solve(c, xb, &r);

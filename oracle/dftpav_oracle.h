@@ -55,6 +55,16 @@ typedef struct oracle_ctx oracle_ctx;
 /* returns NULL and sets *err (DFTPAV_E_*) on the validation failures of traj_optimizer.cpp:26-48 */
 oracle_ctx *oracle_prepare(const dftpav_params *p, const oracle_problem *pb, int *err);
 void oracle_free(oracle_ctx *c);
+/* Summation order used by oracle_eval / oracle_solve on this problem:
+ *   0 = LITERAL (default): every statement in the reference's program order
+ *       (banded LU substitution, += chains over samples, sequential dots).
+ *   1 = DEVICE ORDER: the same algorithm with the summation orders the gfx950
+ *       kernel uses (dense MINCO operator built from that same banded LU,
+ *       per-sample subtotals chained per piece, 64-lane butterfly dots,
+ *       portable sin/cos/exp/log) — see dftpav_oracle_dev.cpp.  The kernel is
+ *       required to match this mode BIT FOR BIT; mode 0 cross-checks mode 1 to
+ *       rounding level on single evaluations. */
+void oracle_set_order(oracle_ctx *c, int order);
 /* x0 packing of traj_optimizer.cpp:96-115 */
 void oracle_pack_x0(const oracle_ctx *c, double *x0);
 /* costFunctionCallback, traj_optimizer.cpp:206-350 */
@@ -80,7 +90,7 @@ void oracle_solve(oracle_ctx *c, double *x, oracle_result *r);
  * trajectory-major exactly as dftpav_batch_data; OpenMP over trajectories when
  * nthreads > 1.  Used by bench.py's cpu_baseline leg. */
 int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B,
-                       const dftpav_batch_data *d, const dftpav_surround *s, int nthreads,
+                       const dftpav_batch_data *d, const dftpav_surround *s, int nthreads, int order,
                        double *x, double *final_cost, int *status, int *success, int *iters,
                        int *evals, long long *hist_sum, double *seconds_each);
 

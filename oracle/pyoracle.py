@@ -45,8 +45,10 @@ class Result(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libdftpav_oracle.so")
-    src = os.path.join(_HERE, "dftpav_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("dftpav_oracle.c", "dftpav_oracle_dev.cpp", "dftpav_oracle.h",
+                                             "oracle_internal.h")]
+    srcs.append(os.path.join(_HERE, "..", "dftpav_amd", "csrc", "traj_math.h"))
+    if force or not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -64,6 +66,7 @@ def lib():
         L.oracle_prepare.restype = C.c_void_p
         L.oracle_prepare.argtypes = [C.POINTER(Params), C.POINTER(Problem), c_int_p]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_set_order.argtypes = [C.c_void_p, C.c_int]
         L.oracle_pack_x0.argtypes = [C.c_void_p, c_double_p]
         L.oracle_eval.restype = C.c_double
         L.oracle_eval.argtypes = [C.c_void_p, c_double_p, c_double_p]
@@ -71,7 +74,7 @@ def lib():
         L.oracle_last_coeffs.argtypes = [C.c_void_p, c_double_p, c_double_p]
         L.oracle_solve.argtypes = [C.c_void_p, c_double_p, C.POINTER(Result)]
         L.oracle_solve_batch.argtypes = [C.POINTER(Params), C.POINTER(Layout), C.c_int, C.POINTER(BatchData),
-                                         C.POINTER(Surround), C.c_int, c_double_p, c_double_p, c_int_p, c_int_p,
+                                         C.POINTER(Surround), C.c_int, C.c_int, c_double_p, c_double_p, c_int_p, c_int_p,
                                          c_int_p, c_int_p, c_ll_p, c_double_p]
         L.oracle_minco_generate.restype = C.c_double
         L.oracle_minco_generate.argtypes = [C.c_int, c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]
@@ -99,7 +102,7 @@ def default_params():
 class OracleProblem:
     """One prepared trajectory (element b of a Scenario)."""
 
-    def __init__(self, params, scen, b=0):
+    def __init__(self, params, scen, b=0, order=0):
         self.params = params
         self.scen = scen
         lay = scen.layout
@@ -128,6 +131,12 @@ class OracleProblem:
         self.err = err.value
         if not self.ctx:
             raise ValueError("oracle_prepare failed: %d" % err.value)
+        if order:
+            self.set_order(order)
+
+    def set_order(self, order):
+        """0 = literal reference statement order, 1 = device order (see dftpav_oracle.h)."""
+        lib().oracle_set_order(self.ctx, order)
 
     def __del__(self):
         if getattr(self, "ctx", None):
@@ -163,7 +172,10 @@ class OracleProblem:
         return x, r
 
 
-def solve_batch(params, scen, nthreads=1):
+LITERAL, DEVICE_ORDER = 0, 1
+
+
+def solve_batch(params, scen, nthreads=1, order=0):
     """oracle_solve_batch over every element of a Scenario. Returns a dict of arrays."""
     B, n = scen.B, scen.layout.n_vars
     x = np.zeros((B, n))
@@ -178,7 +190,7 @@ def solve_batch(params, scen, nthreads=1):
     d = scen.batch_data()
     sur = scen.surround.c_struct() if scen.surround is not None else None
     rc = lib().oracle_solve_batch(C.byref(params), C.byref(lay), B, C.byref(d),
-                                  C.byref(sur) if sur is not None else None, nthreads, dptr(x), dptr(fc),
+                                  C.byref(sur) if sur is not None else None, nthreads, order, dptr(x), dptr(fc),
                                   iptr(status), iptr(success), iptr(iters), iptr(evals), llptr(hist), dptr(secs))
     return dict(rc=rc, x=x, final_cost=fc, status=status, success=success, iters=iters, evals=evals,
                 hist_sum=hist, seconds=secs)
