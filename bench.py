@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""bench.py — batched trajectory solves/sec of the MINCO/L-BFGS solve path on MI355X.
+
+A "step" = one pass of the hot path over one resident batch: every rank launches the
+persistent solve kernel on its shard (inputs already in HBM), packs {cost,status,iters}
+records on the device and — for N>1 — joins the single RCCL all-gather of SURVEY §8(e).
+
+Workload (config.workload): BASELINE.json configs[2] — 256 random-restart trajectories per GPU,
+16 MINCO pieces, 32 pts/piece (33 samples), 50 static obstacles; weak scaling (per-GPU batch fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from dftpav_amd import capi, distributed as dd, scenarios as sc  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak BW 8.0 TB/s
+
+
+def algorithmic_bytes(lay, npts, H, M, iters, evals, hist_sum, w=8):
+    """BASELINE.md §4 / SURVEY §8(d): E_solve = evals*E_eval + (4*sum_k h_k*n + 14*n*iters)*w."""
+    n = lay.n_vars
+    e_eval = (npts * H * 4 + 2 * n + 12 * M + 1) * w
+    return evals.astype(np.float64) * e_eval + (4.0 * hist_sum * n + 14.0 * n * iters) * w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE config (1-based) used as the workload")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="trajectories timed on the host cores (0 = skip)")
+    ap.add_argument("--seed", type=int, default=20240)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: the whole job is generated from the seed on every rank, each keeps its shard
+    B_total = args.batch_per_gpu * world
+    params = capi.default_params()
+    scen = sc.baseline_config(args.config, B=B_total, seed=args.seed)
+    scen.apply_resolution(params)
+    lo, hi = dd.shard_range(B_total, rank, world)
+    shard = scen.subset(np.arange(lo, hi))
+    h = capi.Handle(params, device=local_rank)
+    h.set_surround(shard.surround)
+    bt = capi.Batch(h, shard.layout, shard.B)
+    bt.upload(shard)  # resident in HBM from here on
+    rec_dev = torch.zeros((shard.B, dd.RECORD_BYTES), dtype=torch.uint8, device="cuda")
+
+    def step():
+        bt.solve_async()
+        bt.pack_results(rec_dev.data_ptr())
+        bt.sync()
+        if distributed:
+            return dd.allgather_records(rec_dev, B_total)
+        return rec_dev
+
+    for _ in range(args.warmup):
+        step()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        allrec = step()
+        kern_ms.append(bt.last_solve_ms())  # HIP events on the library's own stream
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    r = bt.results()
+    cost_all, status_all, iters_all = dd.unpack_records(allrec.cpu().numpy())
+    assert len(cost_all) == B_total and np.array_equal(cost_all[lo:hi], r["final_cost"])
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = B_total * args.steps / elapsed
+        lay = shard.layout
+        ebytes = algorithmic_bytes(lay, shard.n_points, lay.H, lay.M, r["iters"], r["evals"], r["hist_sum"])
+        kms = float(np.mean(kern_ms))
+        achieved = float(ebytes.sum()) / (kms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "trajectory solves/sec (batched), 16-piece MINCO",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: %s, %d trajectories/GPU x %d pieces x %d pts/piece, "
+                                   "50 static obstacles, H=4 rectangle corridor" %
+                                   (args.config - 1, scen.name, args.batch_per_gpu, lay.n_pieces, scen.K + 1),
+                       "global_batch": B_total, "pieces": lay.n_pieces, "pts_per_piece": scen.K + 1,
+                       "n_vars": lay.n_vars, "parallelism": "batch-sharded x%d, 1 all-gather of 16B records" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "solver_kernel", "kernel_ms": kms,
+                         "algorithmic_bytes_per_launch": float(ebytes.sum())},
+            "p50_ms_per_solve": float(np.median(r["latency_us"])) * 1e-3,
+            "p95_ms_per_solve": float(np.percentile(r["latency_us"], 95)) * 1e-3,
+            "mean_iters": float(r["iters"].mean()), "mean_evals": float(r["evals"].mean()),
+            "mean_hist_depth": float(r["hist_sum"].sum() / max(1, r["iters"].sum())),
+            "success_rate": float(r["success"].mean()),
+        }
+        # ---- reference CPU path beside it (rank 0, N=1 only): the oracle's literal restatement on the host cores
+        if world == 1 and args.cpu_sample > 0:
+            from oracle import pyoracle as po
+            po.build()
+            ns = min(args.cpu_sample, shard.B)
+            sub = shard.subset(np.arange(ns))
+            cores = os.cpu_count() or 1
+            tc = time.perf_counter()
+            rc = po.solve_batch(params, sub, nthreads=cores, order=0)
+            wall = time.perf_counter() - tc
+            rd = po.solve_batch(params, sub.subset(np.arange(min(ns, 32))), nthreads=cores, order=1)
+            match = bool(np.array_equal(rd["final_cost"], r["final_cost"][:len(rd["final_cost"])]))
+            out["cpu_baseline"] = {"value": ns / wall, "unit": "solves/s", "cores": cores, "kind": "port",
+                                   "sample": "first %d trajectories of the same batch, literal-order oracle, "
+                                             "OpenMP over trajectories" % ns,
+                                   "p50_ms_per_solve_1thread": float(np.median(rc["seconds"])) * 1e3,
+                                   "mean_iters": float(rc["iters"].mean())}
+            out["parity"] = {"device_order_oracle_bit_exact_on_first_32": match}
+        print(json.dumps(out), flush=True)
+    bt.close()
+    h.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

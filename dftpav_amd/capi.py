@@ -25,7 +25,7 @@ EXPORTS = [
     "dftpav_default_params", "dftpav_num_vars", "dftpav_num_points", "dftpav_create", "dftpav_destroy",
     "dftpav_last_error", "dftpav_set_surround", "dftpav_batch_create", "dftpav_batch_destroy",
     "dftpav_batch_upload", "dftpav_batch_get_x0", "dftpav_batch_eval", "dftpav_batch_solve_async",
-    "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
+    "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
     "dftpav_solve_batch", "dftpav_stream",
 ]
 
@@ -73,7 +73,9 @@ def lib():
         L.dftpav_batch_eval.argtypes = [vp, c_double_p, c_double_p, c_double_p]
         L.dftpav_batch_solve_async.argtypes = [vp]
         L.dftpav_batch_sync.argtypes = [vp]
-        L.dftpav_batch_results.argtypes = [vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_ll_p]
+        L.dftpav_batch_results.argtypes = [vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_ll_p,
+                                           c_double_p]
+        L.dftpav_batch_pack_results.argtypes = [vp, vp]
         L.dftpav_batch_coeffs.argtypes = [vp, c_double_p, c_double_p]
         L.dftpav_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.dftpav_solve_batch.argtypes = [vp, C.POINTER(Layout), C.c_int, C.POINTER(BatchData), c_double_p,
@@ -178,15 +180,20 @@ class Batch:
         B, n = self.B, self.n
         r = dict(x=np.zeros((B, n)), final_cost=np.zeros(B), status=np.zeros(B, dtype=np.int32),
                  success=np.zeros(B, dtype=np.int32), iters=np.zeros(B, dtype=np.int32),
-                 evals=np.zeros(B, dtype=np.int32), hist_sum=np.zeros(B, dtype=np.int64))
+                 evals=np.zeros(B, dtype=np.int32), hist_sum=np.zeros(B, dtype=np.int64), latency_us=np.zeros(B))
         rc = lib().dftpav_batch_results(self._b, dptr(r["x"]), dptr(r["final_cost"]), iptr(r["status"]),
-                                        iptr(r["success"]), iptr(r["iters"]), iptr(r["evals"]), llptr(r["hist_sum"]))
+                                        iptr(r["success"]), iptr(r["iters"]), iptr(r["evals"]), llptr(r["hist_sum"]),
+                                        dptr(r["latency_us"]))
         self.handle._check(rc, "results")
         return r
 
     def solve(self):
         self.solve_async()
         return self.results()
+
+    def pack_results(self, device_ptr):
+        """16-byte {f64 cost, i32 status, i32 iters} records into device memory (async on the handle's stream)."""
+        self.handle._check(lib().dftpav_batch_pack_results(self._b, C.c_void_p(device_ptr)), "pack_results")
 
     def coeffs(self):
         c = np.zeros((self.B, self.layout.n_pieces, 6, 2))

@@ -21,6 +21,7 @@
 
 namespace dftpav {
 hipError_t launch_solver(const DevBatch &D, int mode, int threads, hipStream_t stream);
+hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
 
@@ -52,7 +53,7 @@ struct dftpav_batch {
   double *d_histS = nullptr, *d_histY = nullptr;
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
-  long long *d_hist = nullptr;
+  long long *d_hist = nullptr, *d_ticks = nullptr;
   double *d_coef = nullptr, *d_dt = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -278,7 +279,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   (void)hipStreamSynchronize(b->h->stream);
   void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
-                  b->d_hist, b->d_coef, b->d_dt};
+                  b->d_hist, b->d_ticks, b->d_coef, b->d_dt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < kMaxSeg; i++) {
@@ -377,6 +378,7 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_iters, sizeof(int) * (size_t)B));
   BCHK(hipMalloc(&b->d_evals, sizeof(int) * (size_t)B));
   BCHK(hipMalloc(&b->d_hist, sizeof(long long) * (size_t)B));
+  BCHK(hipMalloc(&b->d_ticks, sizeof(long long) * (size_t)B));
   BCHK(hipMalloc(&b->d_coef, sizeof(double) * (size_t)B * 12 * L.Ntot));
   BCHK(hipMalloc(&b->d_dt, sizeof(double) * (size_t)B * M));
   BCHK(hipEventCreate(&b->ev0));
@@ -531,6 +533,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.iters = b->d_iters;
   D.evals = b->d_evals;
   D.hist_sum = b->d_hist;
+  D.ticks = b->d_ticks;
   D.coef_out = b->d_coef;
   D.dt_out = b->d_dt;
   return D;
@@ -580,7 +583,7 @@ extern "C" int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms) {
 }
 
 extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *status, int *success,
-                                    int *iters, int *evals, long long *hist_sum) {
+                                    int *iters, int *evals, long long *hist_sum, double *latency_us) {
   if (!b) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   const int B = b->B;
@@ -593,6 +596,20 @@ extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_co
   if (iters) HIPCHK(h, hipMemcpy(iters, b->d_iters, sizeof(int) * B, hipMemcpyDeviceToHost));
   if (evals) HIPCHK(h, hipMemcpy(evals, b->d_evals, sizeof(int) * B, hipMemcpyDeviceToHost));
   if (hist_sum) HIPCHK(h, hipMemcpy(hist_sum, b->d_hist, sizeof(long long) * B, hipMemcpyDeviceToHost));
+  if (latency_us) {
+    std::vector<long long> t(B);
+    HIPCHK(h, hipMemcpy(t.data(), b->d_ticks, sizeof(long long) * B, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B; i++) latency_us[i] = (double)t[i] * 0.01; // wall_clock64: 100 MHz
+  }
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst) {
+  if (!b || !device_dst) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBatch D = make_dev(b);
+  HIPCHK(h, launch_pack(D, device_dst, h->stream));
   return DFTPAV_OK;
 }
 
@@ -616,7 +633,7 @@ extern "C" int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout,
   if (rc != DFTPAV_OK) return rc;
   rc = dftpav_batch_upload(b, d);
   if (rc == DFTPAV_OK) rc = dftpav_batch_solve_async(b);
-  if (rc == DFTPAV_OK) rc = dftpav_batch_results(b, x, final_cost, status, success, iters, evals, nullptr);
+  if (rc == DFTPAV_OK) rc = dftpav_batch_results(b, x, final_cost, status, success, iters, evals, nullptr, nullptr);
   dftpav_batch_destroy(b);
   return rc;
 }

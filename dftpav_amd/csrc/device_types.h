@@ -71,6 +71,7 @@ struct DevBatch {
   double *g_out;      // eval mode: [B][n]
   int *status, *success, *iters, *evals;
   long long *hist_sum;
+  long long *ticks; // per-trajectory solve time in wall_clock64 ticks (100 MHz)
   double *coef_out; // [B][Ntot][6][2]
   double *dt_out;   // [B][M]
 };

@@ -451,6 +451,7 @@ __global__ void __launch_bounds__(kMaxThreads) solver_kernel(DevBatch D, int mod
   const int n = L.n;
   Smem sm;
   carve(sm, lds_raw, L, P.mem_size, T);
+  const long long tick0 = wall_clock64();
 
   const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
   for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
@@ -723,11 +724,29 @@ __global__ void __launch_bounds__(kMaxThreads) solver_kernel(DevBatch D, int mod
     D.iters[b] = k;
     D.evals[b] = evals;
     D.hist_sum[b] = hist_sum;
+    D.ticks[b] = wall_clock64() - tick0;
     // flag_success, traj_optimizer.cpp:176-201
     int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
     if (fx >= P.fail_cost) ok = 0;
     D.success[b] = ok;
   }
+}
+
+// {f64 cost, i32 status, i32 iters} records for the all-gather of SURVEY §8(e)
+__global__ void pack_results_kernel(const double *f, const int *status, const int *iters, int B, unsigned char *dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    double *rec = reinterpret_cast<double *>(dst + (size_t)16 * i);
+    rec[0] = f[i];
+    int *ri = reinterpret_cast<int *>(rec + 1);
+    ri[0] = status[i];
+    ri[1] = iters[i];
+  }
+}
+hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_results_kernel, dim3((D.B + 255) / 256), dim3(256), 0, stream, D.f_out, D.status, D.iters, D.B,
+                     static_cast<unsigned char *>(dst));
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------- host launchers

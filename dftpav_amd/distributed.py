@@ -1,0 +1,67 @@
+"""Multi-GPU layer of the solve path.
+
+Trajectories are independent, so the batch is the only shard axis: rank r of G
+owns the contiguous block [r*B/G, (r+1)*B/G), solves it with no communication,
+and ONE all-gather of 16-byte records {f64 final_cost, i32 status, i32 iters}
+makes every rank see every result (tens of KB: latency-bound, so a single small
+collective over xGMI, not a ring of large chunks).  Backend "nccl" is RCCL on
+ROCm; "gloo" is used by the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD_BYTES = 16
+
+
+def shard_range(B, rank, world):
+    """Contiguous block of rank `rank`: [lo, hi)."""
+    lo = (B * rank) // world
+    hi = (B * (rank + 1)) // world
+    return lo, hi
+
+
+def pack_records(final_cost, status, iters):
+    """Host-side twin of dftpav_batch_pack_results: uint8 [n][16]."""
+    n = len(final_cost)
+    rec = np.zeros((n, RECORD_BYTES), dtype=np.uint8)
+    rec[:, :8] = np.ascontiguousarray(final_cost, dtype=np.float64).view(np.uint8).reshape(n, 8)
+    rec[:, 8:12] = np.ascontiguousarray(status, dtype=np.int32).view(np.uint8).reshape(n, 4)
+    rec[:, 12:16] = np.ascontiguousarray(iters, dtype=np.int32).view(np.uint8).reshape(n, 4)
+    return rec
+
+
+def unpack_records(rec):
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1, RECORD_BYTES)
+    cost = rec[:, :8].copy().view(np.float64).reshape(-1)
+    status = rec[:, 8:12].copy().view(np.int32).reshape(-1)
+    iters = rec[:, 12:16].copy().view(np.int32).reshape(-1)
+    return cost, status, iters
+
+
+def allgather_records(local_rec, B, group=None):
+    """One all-gather of the per-rank record blocks.
+
+    local_rec: uint8 tensor [n_local][16] on the device of the backend.  Shards may
+    differ by one trajectory when B % world != 0, so blocks are padded to the
+    largest shard.  Returns a uint8 tensor [B][16] identical on every rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
+    nmax = max(sizes)
+    assert local_rec.shape[0] == sizes[rank]
+    send = torch.zeros((nmax, RECORD_BYTES), dtype=torch.uint8, device=local_rec.device)
+    send[:sizes[rank]] = local_rec
+    recv = torch.empty((world * nmax, RECORD_BYTES), dtype=torch.uint8, device=local_rec.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, nmax, RECORD_BYTES)
+    return torch.cat([recv[r, :sizes[r]] for r in range(world)], dim=0)
+
+
+def best_of(cost, status):
+    """Host-side argmin over successful restarts (status as lbfgs.hpp:135-184;
+    success rule of traj_optimizer.cpp:176-201 without the cost cap)."""
+    ok = np.isin(status, (0, 1, 2, -1008, -1009))
+    c = np.where(ok, cost, np.inf)
+    i = int(np.argmin(c))
+    return i if np.isfinite(c[i]) else -1

@@ -199,9 +199,17 @@ int dftpav_batch_sync(dftpav_batch *b);
  *   iters      [B]     L-BFGS iterations k
  *   evals      [B]     cost/gradient evaluations (iter_num_, traj_optimizer.cpp:334)
  *   hist_sum   [B]     sum over iterations of the history depth used by the
- *                      two-loop recursion (input of the bytes model) */
+ *                      two-loop recursion (input of the bytes model)
+ *   latency_us [B]     in-kernel wall time of each trajectory's solve (100 MHz
+ *                      constant counter; OPT.cpp:157-169 computes the same and drops it) */
 int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *status,
-                         int *success, int *iters, int *evals, long long *hist_sum);
+                         int *success, int *iters, int *evals, long long *hist_sum,
+                         double *latency_us);
+
+/* Multi-GPU hand-off: packs one 16-byte record {f64 final_cost, i32 status, i32 iters}
+ * per trajectory into caller-owned DEVICE memory (asynchronously, on the handle's
+ * stream) — the send buffer of the single all-gather of SURVEY §8(e). */
+int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst);
 
 /* Replaces getMinJerkOptPtr()[i].getCoeffs()/getDt() (traj_optimizer.h:112,
  * poly_traj_utils.hpp:1069-1074): regenerates the piece coefficients from the

@@ -1,0 +1,81 @@
+"""C-ABI surface: the library loads without a GPU, exports every symbol of
+include/dftpav_hip.h, PODs have the documented layout, and there is no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dftpav_amd import pods
+
+
+def test_exports_every_declared_symbol(hiplib):
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dftpav_hip.h")).read()
+    declared = set(re.findall(r"\b(dftpav_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(hiplib.EXPORTS)
+    L = hiplib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None, name
+
+
+def test_pod_sizes_match_compiled_layout(hiplib):
+    L = hiplib.lib()
+    assert L.dftpav_abi_sizeof_params() == C.sizeof(pods.Params)
+    assert L.dftpav_abi_sizeof_layout() == C.sizeof(pods.Layout)
+    assert L.dftpav_abi_sizeof_batch_data() == C.sizeof(pods.BatchData)
+    assert L.dftpav_abi_sizeof_surround() == C.sizeof(pods.Surround)
+
+
+def test_default_params_are_the_reference_values(hiplib, oracle):
+    """Product and oracle restate config/minco_config.pb.txt:65-100 independently; they must agree."""
+    a = hiplib.default_params().as_dict()
+    b = oracle.default_params().as_dict()
+    assert a == b
+    assert a["traj_resolution"] == 16 and a["des_traj_resolution"] == 32
+    assert a["wei_obs"] == 1000.0 and a["wei_surround"] == 5000.0 and a["wei_feas"] == 2500.0
+    assert a["wei_time"] == 500.0 and a["lbfgs_mem_size"] == 256 and a["lbfgs_past"] == 3
+    assert a["lbfgs_delta"] == 1e-4 and a["non_sinv"] == 0.24 and a["mini_T"] == 0.1
+
+
+def test_num_vars_and_points(hiplib):
+    p = hiplib.default_params()
+    for pieces, n, npts in (([8], 15, 168), ([8, 8], 33, None), ([16], 31, None)):
+        lay = pods.LayoutSpec(pieces, [1] * len(pieces))
+        ls = lay.c_struct()
+        assert hiplib.lib().dftpav_num_vars(C.byref(ls)) == n == lay.n_vars
+        if npts is not None:  # 6*17 + 2*33
+            assert hiplib.lib().dftpav_num_points(C.byref(p), C.byref(ls)) == npts
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 16, 32])
+def test_minco_operator_bits_equal_oracle(hiplib, oracle, N):
+    """The kernels' dense MINCO operator is built with the reference's banded LU
+    (poly_traj_utils.hpp:776-826); product and oracle must produce the same bits."""
+    out = np.zeros((6 * N, N + 5))
+    fn = hiplib.lib().dftpav_debug_minco_operator
+    fn.argtypes = [C.c_int, pods.c_double_p]
+    assert fn(N, pods.dptr(out)) == 0
+    ref = oracle.minco_operator(N)
+    assert np.array_equal(out, ref)
+
+
+def test_no_cpu_fallback(hiplib):
+    """Without a usable HIP device the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hiplib.DftpavError) as e:
+        hiplib.Handle(hiplib.default_params())
+    assert e.value.code == hiplib.E_NO_DEVICE
+
+
+def test_product_does_not_reference_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    root = os.path.join(os.path.dirname(__file__), "..", "dftpav_amd")
+    for dp, _, fns in os.walk(root):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "pyoracle" not in txt and "dftpav_oracle.h" not in txt and "libdftpav_oracle" not in txt, fn
