@@ -39,7 +39,7 @@ class DftpavError(RuntimeError):
 def build(force=False):
     """Compile libdftpav_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("solver.hip", "capi.cpp", "device_types.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("solver.hip", "capi.cpp", "device_types.h", "traj_math.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "dftpav_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -190,6 +190,19 @@ class Batch:
     def solve(self):
         self.solve_async()
         return self.results()
+
+    def profile(self, enable=True):
+        """Debug: switch the in-kernel phase profiler (thread 0 shader-clock deltas) on or off."""
+        fn = lib().dftpav_debug_profile
+        fn.argtypes = [C.c_void_p, C.c_int, c_ll_p]
+        self.handle._check(fn(self._b, int(enable), None), "profile")
+
+    def read_profile(self):
+        fn = lib().dftpav_debug_profile
+        fn.argtypes = [C.c_void_p, C.c_int, c_ll_p]
+        out = np.zeros((self.B, 12), dtype=np.int64)
+        self.handle._check(fn(self._b, 1, llptr(out)), "read_profile")
+        return out
 
     def pack_results(self, device_ptr):
         """16-byte {f64 cost, i32 status, i32 iters} records into device memory (async on the handle's stream)."""

@@ -20,7 +20,7 @@
 #include "traj_math.h"
 
 namespace dftpav {
-hipError_t launch_solver(const DevBatch &D, int mode, int threads, hipStream_t stream);
+hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
@@ -32,6 +32,7 @@ struct dftpav_handle {
   std::string err;
   // moving obstacles (device copies)
   int S = 0;
+  int sur_version = 0; // bumped by dftpav_set_surround so batches refresh their device descriptor
   int *d_sur_off = nullptr;
   double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr;
 };
@@ -42,6 +43,8 @@ struct dftpav_batch {
   DevLayout L{};
   DevParams P{};
   int threads = 0;
+  bool op_in_lds = false;
+  int ppt = 1;
   int NptsPad = 0;
   std::vector<double> x0_host;
   bool uploaded = false;
@@ -53,7 +56,10 @@ struct dftpav_batch {
   double *d_histS = nullptr, *d_histY = nullptr;
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
-  long long *d_hist = nullptr, *d_ticks = nullptr;
+  long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
+  DevBatch *d_dev = nullptr; // device copy of the launch descriptor
+  int dev_version = -1;
+  bool prof_on = false;
   double *d_coef = nullptr, *d_dt = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -184,6 +190,7 @@ extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_surround(h);
+  h->sur_version++;
   if (!s || s->S <= 0) return DFTPAV_OK;
   int S = s->S, np = s->piece_offsets[S];
   if (np <= 0) return DFTPAV_E_INVALID;
@@ -279,7 +286,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   (void)hipStreamSynchronize(b->h->stream);
   void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
-                  b->d_hist, b->d_ticks, b->d_coef, b->d_dt};
+                  b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < kMaxSeg; i++) {
@@ -341,7 +348,9 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   }
   fill_dev_params(p, b->P);
   b->threads = solver_threads(L);
-  size_t lds = solver_lds_bytes(L, b->P, b->threads);
+  b->ppt = solver_ppt(L, b->threads);
+  b->op_in_lds = solver_ops_in_lds(L, b->P, b->threads, b->ppt);
+  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds) + 64;
   if (lds > 160 * 1024) {
     delete b;
     return DFTPAV_E_UNSUPPORTED;
@@ -379,6 +388,8 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_evals, sizeof(int) * (size_t)B));
   BCHK(hipMalloc(&b->d_hist, sizeof(long long) * (size_t)B));
   BCHK(hipMalloc(&b->d_ticks, sizeof(long long) * (size_t)B));
+  BCHK(hipMalloc(&b->d_prof, sizeof(long long) * (size_t)B * 12));
+  BCHK(hipMalloc(&b->d_dev, sizeof(DevBatch)));
   BCHK(hipMalloc(&b->d_coef, sizeof(double) * (size_t)B * 12 * L.Ntot));
   BCHK(hipMalloc(&b->d_dt, sizeof(double) * (size_t)B * M));
   BCHK(hipEventCreate(&b->ev0));
@@ -509,9 +520,14 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.NptsPad = b->NptsPad;
   D.pt_piece = b->d_pt_piece;
   D.pt_j = b->d_pt_j;
+  D.op_in_lds = b->op_in_lds ? 1 : 0;
+  D.ppt = b->ppt;
+  int off = 0;
   for (int i = 0; i < kMaxSeg; i++) {
     D.opM[i] = b->d_opM[i];
     D.opMT[i] = b->d_opMT[i];
+    D.op_off[i] = off;
+    if (i < b->L.M) off += 6 * b->L.piece_nums[i] * (b->L.piece_nums[i] + 5);
   }
   dftpav_handle *h = b->h;
   D.sur.S = h->S;
@@ -534,9 +550,36 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.evals = b->d_evals;
   D.hist_sum = b->d_hist;
   D.ticks = b->d_ticks;
+  D.prof = b->prof_on ? b->d_prof : nullptr;
   D.coef_out = b->d_coef;
   D.dt_out = b->d_dt;
   return D;
+}
+
+// refreshes the device copy of the launch descriptor when something it captures changed
+static int sync_dev(dftpav_batch *b, DevBatch &D) {
+  dftpav_handle *h = b->h;
+  D = make_dev(b);
+  int version = h->sur_version * 4 + (b->prof_on ? 1 : 0) + (b->uploaded ? 2 : 0);
+  if (version != b->dev_version) {
+    HIPCHK(h, hipMemcpyAsync(b->d_dev, &D, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // D lives on this stack frame
+    b->dev_version = version;
+  }
+  return DFTPAV_OK;
+}
+
+// debug/test hook: switch the in-kernel phase profiler on/off and read it back ([B][12] shader clocks)
+extern "C" int dftpav_debug_profile(dftpav_batch *b, int enable, long long *out) {
+  if (!b) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (out) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, b->d_prof, sizeof(long long) * (size_t)b->B * 12, hipMemcpyDeviceToHost));
+  }
+  b->prof_on = enable != 0;
+  return DFTPAV_OK;
 }
 
 extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g) {
@@ -545,8 +588,9 @@ extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, do
   const size_t nb = (size_t)b->B * b->L.n;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(b->d_x_in, x, sizeof(double) * nb, hipMemcpyHostToDevice, h->stream));
-  DevBatch D = make_dev(b);
-  HIPCHK(h, launch_solver(D, kModeEval, b->threads, h->stream));
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeEval, b->threads, h->stream));
   if (f) HIPCHK(h, hipMemcpyAsync(f, b->d_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, h->stream));
   if (g) HIPCHK(h, hipMemcpyAsync(g, b->d_g, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -557,9 +601,10 @@ extern "C" int dftpav_batch_solve_async(dftpav_batch *b) {
   if (!b || !b->uploaded) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
-  DevBatch D = make_dev(b);
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
-  HIPCHK(h, launch_solver(D, kModeSolve, b->threads, h->stream));
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, h->stream));
   HIPCHK(h, hipEventRecord(b->ev1, h->stream));
   b->timed = true;
   return DFTPAV_OK;
@@ -617,8 +662,9 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
   if (!b || !b->uploaded) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
-  DevBatch D = make_dev(b);
-  HIPCHK(h, launch_solver(D, kModeCoeffs, b->threads, h->stream));
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (coeffs)
     HIPCHK(h, hipMemcpy(coeffs, b->d_coef, sizeof(double) * (size_t)b->B * 12 * b->L.Ntot, hipMemcpyDeviceToHost));

@@ -60,6 +60,9 @@ struct DevBatch {
   const int16_t *pt_j;     // [Npts] sample index j inside the piece
   const double *opM[kMaxSeg];  // A_N^{-1} restricted to the N+5 non-zero RHS rows, [6N][N+5] row-major
   const double *opMT[kMaxSeg]; // its transpose [N+5][6N]
+  int op_in_lds;               // operators are staged in LDS at kernel start
+  int ppt;                     // constraint points per thread and chunk (chunk = ppt * blockDim)
+  int op_off[kMaxSeg];         // offset (doubles) of each segment's operator inside the LDS copy
   DevSurround sur;
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
@@ -72,6 +75,7 @@ struct DevBatch {
   int *status, *success, *iters, *evals;
   long long *hist_sum;
   long long *ticks; // per-trajectory solve time in wall_clock64 ticks (100 MHz)
+  long long *prof;  // optional [B][12] shader-clock phase profile (nullptr = off)
   double *coef_out; // [B][Ntot][6][2]
   double *dt_out;   // [B][M]
 };
@@ -79,7 +83,11 @@ struct DevBatch {
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };
 
 // size in bytes of the dynamic LDS a launch needs
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads);
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds);
+// whether the MINCO operators fit next to the working set
+bool solver_ops_in_lds(const DevLayout &L, const DevParams &P, int threads, int ppt);
+// constraint points each thread handles per chunk
+int solver_ppt(const DevLayout &L, int threads);
 // picks the workgroup size for a layout
 int solver_threads(const DevLayout &L);
 

@@ -5,20 +5,26 @@
 // two-loop recursion all run inside a single launch with no host round trip.
 //
 //   * threads <-> constraint points (the sample loop of
-//     PolyTrajOptimizer::addPVAGradCost2CT, traj_optimizer.cpp:486-779)
+//     PolyTrajOptimizer::addPVAGradCost2CT, traj_optimizer.cpp:486-779), a few
+//     points per thread so that the workgroup stays at <= 8 waves and every wave
+//     gets the full 256-VGPR budget (the per-point mathematics is register hungry
+//     in fp64; spilling it costs far more than the second point)
 //   * MINCO forward/adjoint banded solves (poly_traj_utils.hpp:805-852) are
-//     applied as the precomputed dense operator A_N^{-1}|_{N+5 columns}: the band
-//     matrix depends only on N (poly_traj_utils.hpp:895-947) and only N+5 RHS
-//     rows are ever non-zero (poly_traj_utils.hpp:968-977), so both solves become
-//     small lane-parallel mat-vecs instead of a 6N-step sequential substitution
+//     applied as the precomputed dense operator A_N^{-1}|_{N+5 columns}, staged in
+//     LDS: the band matrix depends only on N (poly_traj_utils.hpp:895-947) and
+//     only N+5 RHS rows are ever non-zero (poly_traj_utils.hpp:968-977), so both
+//     solves become small lane-parallel mat-vecs instead of a 6N-step substitution
 //   * per-sample gradients are kept as d/dsigma, d/dsigma', d/dsigma'' (6 values)
 //     and expanded onto the 6x2 piece coefficients by a transposed LDS reduction
-//     with a fixed summation order (deterministic run to run)
-//   * wave 0 runs the L-BFGS vector algebra (n <= 256 decision variables, lanes
-//     over elements, cross-lane reductions) while the other waves wait at the
-//     workgroup barrier
+//     with a fixed summation order
+//   * the whole L-BFGS state lives in LDS and wave 0 advances it as a state
+//     machine between evaluations (one decision variable per lane, DPP /
+//     permlane-swap butterflies for the dot products, history columns streamed
+//     from global memory through a register prefetch ring); nothing but LDS
+//     offsets is live in registers across an evaluation
 //
-// All arithmetic is fp64, as in the reference.
+// All arithmetic is fp64 with contraction off; every sum has a defined order
+// that oracle/dftpav_oracle_dev.cpp replays, and the two agree bit for bit.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
@@ -27,53 +33,89 @@
 namespace dftpav {
 
 // ------------------------------------------------------------------ LDS carve
+// scalar L-BFGS state kept in Smem::st (doubles) and Smem::ist (ints)
+enum { sFX = 0, sFINIT, sDGINIT, sDGTEST, sDSTEST, sMU, sNU, sSTP, sSTEP, sF, sPF0 /* .. sPF0+7 */, sNUM = 24 };
+enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iNUM = 16 };
+enum { kActEval = 0, kActDone = 1 };
+
 struct Smem {
   double *x, *xp, *g, *gp, *d;
   double *seg;  // [M][16]  0:T 1:dt 2..7:t^k 8..13:t^-k
-  double *stab; // [M][2][Kmax+1] accumulated sample offsets (s1 += step, traj_optimizer.cpp:513)
+  double *spow; // [M][2][Kmax+1][6] powers of the accumulated sample offset (s1 += step, traj_optimizer.cpp:513)
   double *rhs;  // [rhs_tot][2]
   double *b, *c, *gdC; // [6*Ntot][2]
   double *adj;  // [rhs_tot][2]
-  double *part; // [8][T]
-  double *pE, *pGsm, *pGdT, *pCost, *pChain; // [Ntot]
-  double *ys, *alpha; // [mem]
-  double *scal; // [16]
-  int *flag;    // [8]
+  double *part; // [8][chunk]
+  double *pE, *pGsm, *pGdT, *pCost; // [Ntot]
+  double *ys, *rinv, *alpha; // [mem]
+  double *st;     // [sNUM] scalar solver state
+  double *segsum; // [M][8] per-segment sums: 0 jerk energy, 1 penalty cost, 2 d(jerk)/dT, 3 penalty gdT, 4 chain-rule gdT
+  double *opM, *opMT; // operators of all segments back to back (only when D.op_in_lds)
+  int *ist;     // [iNUM]
+  int *ptinfo;  // [Npts] piece | j<<16
+  int *pcinfo;  // [Ntot][8] pt0, K, tab, segment, lp, N, singul, operator offset
+  int *rowinfo; // [rhs_tot][4] segment, column, N, first piece of the segment
 };
 
-__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T) {
+__host__ __device__ inline size_t op_doubles(const DevLayout &L) {
+  size_t n = 0;
+  for (int i = 0; i < L.M; i++) n += (size_t)6 * L.piece_nums[i] * (L.piece_nums[i] + 5);
+  return n;
+}
+__host__ __device__ inline int chunk_points(const DevLayout &L, int T, int ppt) {
+  int c = T * ppt;
+  return c < L.Npts ? c : ((L.Npts + 63) / 64) * 64;
+}
+
+__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T, int ppt, bool op_lds) {
   size_t n = 0;
   n += 5 * (size_t)L.npad;
   n += (size_t)L.M * 16;
-  n += (size_t)L.M * 2 * (L.Kmax + 1);
+  n += (size_t)L.M * 2 * (L.Kmax + 1) * 6;
   n += (size_t)L.rhs_tot * 2;
   n += 3 * (size_t)L.Ntot * 12;
   n += (size_t)L.rhs_tot * 2;
-  n += 8 * (size_t)T;
-  n += 5 * (size_t)L.Ntot;
-  n += 2 * (size_t)mem;
-  n += 16;
+  n += 8 * (size_t)chunk_points(L, T, ppt);
+  n += 4 * (size_t)L.Ntot;
+  n += 3 * (size_t)mem;
+  n += sNUM;
+  n += (size_t)L.M * 8;
+  if (op_lds) n += 2 * op_doubles(L);
   return n;
 }
+__host__ __device__ inline size_t smem_ints(const DevLayout &L) {
+  return iNUM + (size_t)L.Npts + 8 * (size_t)L.Ntot + 4 * (size_t)L.rhs_tot;
+}
 
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads) {
-  return smem_doubles(L, P.mem_size, threads) * sizeof(double) + 8 * sizeof(int);
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds) {
+  return smem_doubles(L, P.mem_size, threads, ppt, op_lds) * sizeof(double) + smem_ints(L) * sizeof(int);
+}
+
+bool solver_ops_in_lds(const DevLayout &L, const DevParams &P, int threads, int ppt) {
+  return solver_lds_bytes(L, P, threads, ppt, true) <= 100 * 1024;
 }
 
 int solver_threads(const DevLayout &L) {
-  // one pass over the constraint points when they fit a workgroup, otherwise
-  // the fewest passes with the least idle lanes
-  int passes = (L.Npts + kMaxThreads - 1) / kMaxThreads;
-  int per = (L.Npts + passes - 1) / passes;
-  int T = ((per + kWave - 1) / kWave) * kWave;
-  int need = 14 * L.Ntot; // the reduction stage likes 14 threads per piece
-  if (T < need) T = ((need + kWave - 1) / kWave) * kWave;
+  // at most 8 waves (two per SIMD: the full 256-VGPR budget), two constraint points per thread
+  // when there are more points than that; never fewer threads than the reduction stages use
+  int T = ((L.Npts + 1) / 2 + kWave - 1) / kWave * kWave;
+  int need = 16 * L.Ntot; // 16 threads per piece
+  if (T < need) T = (need + kWave - 1) / kWave * kWave;
+  int need5 = ((8 * L.rhs_tot + 63) / 64) * 64 + 128; // adjoint stage: 4 lanes per output + two summing waves
+  if (T < need5) T = need5;
   if (T < 128) T = 128;
-  if (T > kMaxThreads) T = kMaxThreads;
+  if (T > 512) T = 512;
   return T;
 }
 
-__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T) {
+int solver_ppt(const DevLayout &L, int threads) {
+  int ppt = (L.Npts + threads - 1) / threads;
+  // keep the per-chunk partials (64 B per point) within ~48 KB of LDS
+  while (ppt > 1 && (size_t)ppt * threads * 64 > 48 * 1024) --ppt;
+  return ppt;
+}
+
+__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int ppt, bool op_lds) {
   double *p = base;
   s.x = p; p += L.npad;
   s.xp = p; p += L.npad;
@@ -81,45 +123,142 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.gp = p; p += L.npad;
   s.d = p; p += L.npad;
   s.seg = p; p += L.M * 16;
-  s.stab = p; p += L.M * 2 * (L.Kmax + 1);
+  s.spow = p; p += L.M * 2 * (L.Kmax + 1) * 6;
   s.rhs = p; p += L.rhs_tot * 2;
   s.b = p; p += L.Ntot * 12;
   s.c = p; p += L.Ntot * 12;
   s.gdC = p; p += L.Ntot * 12;
   s.adj = p; p += L.rhs_tot * 2;
-  s.part = p; p += 8 * T;
+  s.part = p; p += 8 * chunk_points(L, T, ppt);
   s.pE = p; p += L.Ntot;
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
   s.pCost = p; p += L.Ntot;
-  s.pChain = p; p += L.Ntot;
   s.ys = p; p += mem;
+  s.rinv = p; p += mem;
   s.alpha = p; p += mem;
-  s.scal = p; p += 16;
-  s.flag = reinterpret_cast<int *>(p);
+  s.st = p; p += sNUM;
+  s.segsum = p; p += L.M * 8;
+  s.opM = p;
+  s.opMT = p;
+  if (op_lds) {
+    size_t nop = op_doubles(L);
+    s.opMT = p + nop;
+    p += 2 * nop;
+  }
+  s.ist = reinterpret_cast<int *>(p);
+  s.ptinfo = s.ist + iNUM;
+  s.pcinfo = s.ptinfo + L.Npts;
+  s.rowinfo = s.pcinfo + 8 * L.Ntot;
 }
 
 // ------------------------------------------------------------ device helpers
-__device__ inline int seg_of_piece(const DevLayout &L, int p) {
-  int s = 0;
-  while (s + 1 < L.M && p >= L.seg_piece0[s + 1]) ++s;
-  return s;
+// Cross-lane butterfly over a wave, pairing lanes at distance 1, 2, 4, 8, 16, 32
+// in that order: two quad permutes, row_half_mirror and row_mirror (after the
+// quad steps every lane of a quad holds the same value, so mirroring pairs the
+// same partial sums an xor would), then gfx950's v_permlane16_swap /
+// v_permlane32_swap.  3 VALU instructions per level, no LDS traffic.  LV is the
+// number of levels: vectors of n <= 16 / 32 / 64 elements use 4 / 5 / 6, the
+// upper lanes holding zeros are simply never folded in.  fp addition is
+// commutative, so every participating lane ends with the same bits; the CPU
+// oracle's device-order mode replays this tree (oracle/dftpav_oracle_dev.cpp).
+template <int CTRL>
+__device__ inline double mov_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-
-// Cross-lane butterfly over the 64 lanes of a wave: v += v(lane ^ o) for o = 32,16,..,1.
-// fp addition is commutative, so every lane ends with the same bits; the CPU
-// oracle's device-order mode replays exactly this tree (oracle/dftpav_oracle_dev.cpp).
+__device__ inline void swap16(double v, double &x, double &y) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  x = __hiloint2double(b[0], a[0]);
+  y = __hiloint2double(b[1], a[1]);
+}
+__device__ inline void swap32(double v, double &x, double &y) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  x = __hiloint2double(b[0], a[0]);
+  y = __hiloint2double(b[1], a[1]);
+}
+template <int LV>
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  double x, y;
+  v += mov_dpp<0xB1>(v);  // quad_perm [1,0,3,2]
+  v += mov_dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+  v += mov_dpp<0x141>(v); // row_half_mirror
+  v += mov_dpp<0x140>(v); // row_mirror
+  if (LV >= 5) {
+    swap16(v, x, y);
+    v = x + y;
+  }
+  if (LV >= 6) {
+    swap32(v, x, y);
+    v = x + y;
+  }
   return v;
 }
+template <int LV>
 __device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  double x, y;
+  v = fmax(v, mov_dpp<0xB1>(v));
+  v = fmax(v, mov_dpp<0x4E>(v));
+  v = fmax(v, mov_dpp<0x141>(v));
+  v = fmax(v, mov_dpp<0x140>(v));
+  if (LV >= 5) {
+    swap16(v, x, y);
+    v = fmax(x, y);
+  }
+  if (LV >= 6) {
+    swap32(v, x, y);
+    v = fmax(x, y);
+  }
   return v;
 }
 
+// a / b from the correctly rounded reciprocal y = 1/b (Markstein): q0 = a*y,
+// r = a - b*q0 (exact in an FMA), q = q0 + r*y.  With y correctly rounded and
+// no over/underflow this is the correctly rounded quotient — the same bits as
+// a / b (2^31 random and edge-mantissa pairs checked on gfx950, 0 mismatches) —
+// in 3 dependent instructions instead of the ~12 of the division expansion.
+__device__ inline double div_by_rcp(double a, double b, double y) {
+  double q0 = a * y;
+  double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, y, q0);
+}
+
+// optional in-kernel phase timer (thread 0, shader clock); D.prof == nullptr turns it off
+struct Prof {
+  long long acc[12];
+  long long last;
+  bool on;
+  __device__ inline void start(bool enable) {
+    on = enable && threadIdx.x == 0;
+    for (int i = 0; i < 12; i++) acc[i] = 0;
+    last = on ? clock64() : 0;
+  }
+  __device__ inline void tick(int i) {
+    if (on) {
+      long long t = clock64();
+      acc[i] += t - last;
+      last = t;
+    }
+  }
+};
+enum { kPE1 = 0, kPE2, kPE3S, kPE4R, kPE5, kPE6, kPLS, kPHIST, kPLOOP, kPX, kPMISC };
+
+// half-planes of one constraint point held in registers (up to 4 planes)
+struct RegPlanes {
+  const double *c; // 16 values: [plane][n0,n1,q0,q1]
+  __device__ inline void operator()(int k, double &n0, double &n1, double &q0, double &q1) const {
+    n0 = c[4 * k];
+    n1 = c[4 * k + 1];
+    q0 = c[4 * k + 2];
+    q1 = c[4 * k + 3];
+  }
+};
 // strided plane loader over the component-major corridor of one trajectory
 struct GlobalPlanes {
   const double *base; // &corridor[b][0][pt]
@@ -132,132 +271,133 @@ struct GlobalPlanes {
   }
 };
 
-// constraint point `pt` of trajectory b -> {dJ/dsigma, dJ/dsigma', dJ/dsigma'', gdT, cost}
-template <bool SUR>
-__device__ inline void sample_point(const DevBatch &D, int b, const Smem &sm, int pt, double out[8]) {
-  const DevLayout &L = D.L;
-  int p = D.pt_piece[pt];
-  SampleIn in;
-  in.j = D.pt_j[pt];
-  int sg = seg_of_piece(L, p);
-  in.lp = p - L.seg_piece0[sg];
-  in.N = L.piece_nums[sg];
-  bool edge = (in.lp == 0 || in.lp == in.N - 1);
-  in.K = edge ? L.Kd : L.K;
-  in.dt = sm.seg[sg * 16 + 1];
-  in.s1 = sm.stab[(sg * 2 + (edge ? 1 : 0)) * (L.Kmax + 1) + in.j];
-  in.cc = sm.c + 12 * p;
-  in.singul = L.singuls[sg];
-  in.epis = D.epis;
-  in.H = L.H;
-  in.trajid = sg;
-  in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg - 1) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
-  in.t_now = D.t_now;
-  GlobalPlanes pl{D.corridor + (size_t)b * L.H * 4 * D.NptsPad + pt, (size_t)D.NptsPad};
-  sample_point_math<SUR>(D.P, D.sur, in, pl, out);
-}
-
 // ----------------------------------------------------- cost + gradient
 // PolyTrajOptimizer::costFunctionCallback (traj_optimizer.cpp:206-350) for the
-// decision vector x (LDS) of trajectory b; writes g (LDS), returns f to every thread.
+// decision vector x (LDS) of trajectory b; writes g (LDS) and f (sm.st[sF]).
+// D is read through scalar loads (uniform); per-lane lookups go through the LDS tables.
 template <bool SUR>
-__device__ double block_eval(const DevBatch &D, int b, const Smem &sm, const double *x, double *g) {
-  const DevLayout &L = D.L;
+__device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem &sm, const double *x, double *g, Prof &pr) {
+  const DevLayout &L = D.L; // uniform accesses only (scalar loads)
   const DevParams &P = D.P;
   const int tid = threadIdx.x, T = blockDim.x;
-  const double *iniS = D.iniS + (size_t)b * L.M * 6;
-  const double *finS = D.finS + (size_t)b * L.M * 6;
+  const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, rhs_tot = L.rhs_tot, Kmax1 = L.Kmax + 1;
+  const double *iniS = D.iniS + (size_t)b * M * 6;
+  const double *finS = D.finS + (size_t)b * M * 6;
 
-  // ---- E1: segment durations, sample-offset tables, MINCO right-hand sides
-  for (int w = tid; w < L.M + 2 * L.M + 2 * L.rhs_tot; w += T) {
-    if (w < L.M) {
-      int sg = w;
-      double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
-      double dt = Tr / L.piece_nums[sg];
-      double *s = sm.seg + sg * 16;
-      s[0] = Tr;
-      s[1] = dt;
-      duration_powers(dt, s + 2); // poly_traj_utils.hpp:961-966
-    } else if (w < 3 * L.M) {
-      int q = w - L.M, sg = q >> 1, which = q & 1;
-      int K = which ? L.Kd : L.K;
-      double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
-      double dt = Tr / L.piece_nums[sg];
-      double step = dt / K;
-      double *tab = sm.stab + (sg * 2 + which) * (L.Kmax + 1);
-      double s1 = 0.0;
-      for (int j = 0; j <= K; j++) {
-        tab[j] = s1;
-        s1 += step; // traj_optimizer.cpp:513
-      }
-    } else {
-      int q = w - 3 * L.M;
-      int row = q >> 1, d = q & 1;
-      int sg = 0;
-      while (sg + 1 < L.M && row >= L.seg_rhs0[sg + 1]) ++sg;
-      int col = row - L.seg_rhs0[sg];
-      int N = L.piece_nums[sg];
-      double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
-      double dt = Tr / N;
-      double v;
-      if (col < 3) { // head p, v*dt, a*dt^2 (poly_traj_utils.hpp:969-971), junction override traj_optimizer.cpp:273-277
-        if (col == 0) {
-          v = sg > 0 ? x[L.x_gear0 + 2 * (sg - 1) + d] : iniS[sg * 6 + d];
-        } else if (col == 1) {
-          double hv;
-          if (sg > 0) {
-            double th = x[L.x_ang0 + sg - 1];
-            hv = d == 0 ? -P.non_sinv * p_cos(th) : -P.non_sinv * p_sin(th);
+  // ---- E1: segment durations, sample-offset power tables, MINCO right-hand sides
+  {
+    const int n_rhs = 2 * rhs_tot;
+    for (int w = tid; w < n_rhs + 3 * M; w += T) {
+      if (w < n_rhs) {
+        int row = w >> 1, d = w & 1;
+        const int *ri = sm.rowinfo + 4 * row;
+        int sg = ri[0], col = ri[1], N = ri[2];
+        double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
+        double dt = Tr / N;
+        double v;
+        if (col < 3) { // head p, v*dt, a*dt^2 (poly_traj_utils.hpp:969-971), junction override traj_optimizer.cpp:273-277
+          if (col == 0) {
+            v = sg > 0 ? x[L.x_gear0 + 2 * (sg - 1) + d] : iniS[sg * 6 + d];
+          } else if (col == 1) {
+            double hv;
+            if (sg > 0) {
+              double th = x[L.x_ang0 + sg - 1];
+              hv = d == 0 ? -P.non_sinv * p_cos(th) : -P.non_sinv * p_sin(th);
+            } else {
+              hv = iniS[sg * 6 + 2 + d];
+            }
+            v = hv * dt;
           } else {
-            hv = iniS[sg * 6 + 2 + d];
+            v = iniS[sg * 6 + 4 + d] * (dt * dt);
           }
-          v = hv * dt;
-        } else {
-          v = iniS[sg * 6 + 4 + d] * (dt * dt);
-        }
-      } else if (col < N + 2) {
-        v = x[L.seg_x0[sg] + 2 * (col - 3) + d];
-      } else { // tail, poly_traj_utils.hpp:975-977, junction override traj_optimizer.cpp:278-282
-        int k = col - (N + 2);
-        if (k == 0) {
-          v = sg < L.M - 1 ? x[L.x_gear0 + 2 * sg + d] : finS[sg * 6 + d];
-        } else if (k == 1) {
-          double tv;
-          if (sg < L.M - 1) {
-            double th = x[L.x_ang0 + sg];
-            tv = d == 0 ? P.non_sinv * p_cos(th) : P.non_sinv * p_sin(th);
+        } else if (col < N + 2) {
+          v = x[ri[3] + 2 * (col - 3) + d]; // ri[3] = offset of the segment's waypoints inside x
+        } else { // tail, poly_traj_utils.hpp:975-977, junction override traj_optimizer.cpp:278-282
+          int k = col - (N + 2);
+          if (k == 0) {
+            v = sg < M - 1 ? x[L.x_gear0 + 2 * sg + d] : finS[sg * 6 + d];
+          } else if (k == 1) {
+            double tv;
+            if (sg < M - 1) {
+              double th = x[L.x_ang0 + sg];
+              tv = d == 0 ? P.non_sinv * p_cos(th) : P.non_sinv * p_sin(th);
+            } else {
+              tv = finS[sg * 6 + 2 + d];
+            }
+            v = tv * dt;
           } else {
-            tv = finS[sg * 6 + 2 + d];
+            v = finS[sg * 6 + 4 + d] * (dt * dt);
           }
-          v = tv * dt;
+        }
+        sm.rhs[w] = v;
+      } else {
+        int q = w - n_rhs; // 3 workers per segment: 0 duration powers, 1/2 offset tables (K / Kd)
+        int sg = q / 3, role = q - 3 * sg;
+        int N = 0;
+        for (int s = 0; s < M; s++) N = (s == sg) ? L.piece_nums[s] : N;
+        double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
+        double dt = Tr / N;
+        if (role == 0) {
+          double *s = sm.seg + sg * 16;
+          s[0] = Tr;
+          s[1] = dt;
+          duration_powers(dt, s + 2); // poly_traj_utils.hpp:961-966
         } else {
-          v = finS[sg * 6 + 4 + d] * (dt * dt);
+          int which = role - 1;
+          int K = which ? L.Kd : L.K;
+          double step = dt / K;
+          double *tab = sm.spow + (size_t)(sg * 2 + which) * Kmax1 * 6;
+          double s1 = 0.0;
+          for (int j = 0; j <= K; j++) {
+            tab[6 * j + 1] = s1;
+            s1 += step; // traj_optimizer.cpp:513
+          }
         }
       }
-      sm.rhs[2 * row + d] = v;
+    }
+    __syncthreads();
+    // powers of the offsets (the beta vectors of traj_optimizer.cpp:500-509 are built from these)
+    for (int w = tid; w < 2 * M * Kmax1; w += T) {
+      double *e = sm.spow + (size_t)w * 6;
+      double s1 = e[1];
+      double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+      e[0] = 1.0; e[2] = s2; e[3] = s3; e[4] = s4; e[5] = s5;
+    }
+  }
+  pr.tick(kPE1);
+
+  // ---- E2: b = A^{-1} rhs (dense operator), c = b * t^-k   (MinJerkOpt::generate, poly_traj_utils.hpp:979-984)
+  // 16 threads per piece, 12 of them active: (row k, dimension d)
+  for (int w = tid; w < 16 * Ntot; w += T) {
+    int p = w >> 4, q = w & 15;
+    if (q < 12) {
+      int k = q >> 1, d = q & 1;
+      const int *pc = sm.pcinfo + 8 * p;
+      int sg = pc[3], lp = pc[4], N = pc[5];
+      const double *Mop;
+      if (D.op_in_lds) {
+        Mop = sm.opM + pc[7];
+      } else {
+        Mop = D.opM[0];
+        for (int s = 1; s < M; s++) Mop = (s == sg) ? D.opM[s] : Mop;
+      }
+      const double *Mrow = Mop + (size_t)(6 * lp + k) * (N + 5);
+      int r0 = 0; // first RHS row of the segment
+      for (int s = 0; s < M; s++) r0 = (s == sg) ? L.seg_rhs0[s] : r0;
+      const double *rh = sm.rhs + 2 * r0 + d;
+      double acc = 0.0;
+#pragma unroll 8
+      for (int col = 0; col < N + 5; col++) acc += Mrow[col] * rh[2 * col];
+      sm.b[12 * p + q] = acc;
+      sm.c[12 * p + q] = acc * sm.seg[sg * 16 + 8 + k];
     }
   }
   __syncthreads();
-
-  // ---- E2: b = A^{-1} rhs (dense operator), c = b * t^-k   (MinJerkOpt::generate, poly_traj_utils.hpp:979-984)
-  for (int w = tid; w < 12 * L.Ntot; w += T) {
-    int r = w >> 1, d = w & 1;
-    int p = r / 6, k = r - 6 * p;
-    int sg = seg_of_piece(L, p);
-    int N = L.piece_nums[sg];
-    int lr = r - 6 * L.seg_piece0[sg];
-    const double *Mrow = D.opM[sg] + (size_t)lr * (N + 5);
-    const double *rh = sm.rhs + 2 * L.seg_rhs0[sg] + d;
-    double acc = 0.0;
-    for (int col = 0; col < N + 5; col++) acc += Mrow[col] * rh[2 * col];
-    sm.b[w] = acc;
-    sm.c[w] = acc * sm.seg[sg * 16 + 8 + k];
-  }
-  __syncthreads();
+  pr.tick(kPE2);
 
   // ---- E3: jerk energy and its partials per piece (poly_traj_utils.hpp:998-1035)
-  for (int p = tid; p < L.Ntot; p += T) {
-    int sg = seg_of_piece(L, p);
+  for (int p = tid; p < Ntot; p += T) {
+    int sg = sm.pcinfo[8 * p + 3];
     double en, gsm;
     piece_smoothness(sm.c + 12 * p, sm.seg + sg * 16 + 2, en, gsm, sm.gdC + 12 * p);
     sm.pE[p] = en;
@@ -266,121 +406,216 @@ __device__ double block_eval(const DevBatch &D, int b, const Smem &sm, const dou
     sm.pCost[p] = 0.0;
   }
 
-  // ---- E4: penalty integral over the constraint points (traj_optimizer.cpp:486-779)
-  for (int base = 0; base < L.Npts; base += T) {
-    int pt = base + tid;
-    double o[8];
-    if (pt < L.Npts) {
-      sample_point<SUR>(D, b, sm, pt, o);
-    } else {
+  // ---- E4: penalty integral over the constraint points (traj_optimizer.cpp:486-779), in chunks
+  const int chunk = chunk_points(L, T, D.ppt);
+  for (int base = 0; base < Npts; base += chunk) {
+    for (int r = 0; r < D.ppt; r++) {
+      int loc = tid + r * T;
+      int pt = base + loc;
+      if (loc >= chunk) break;
+      double o[8];
+      if (pt < Npts) {
+        int info = sm.ptinfo[pt];
+        int p = info & 0xffff;
+        const int *pc = sm.pcinfo + 8 * p;
+        SampleIn in;
+        in.j = info >> 16;
+        in.K = pc[1];
+        int sg = pc[3];
+        in.lp = pc[4];
+        in.N = pc[5];
+        in.singul = pc[6];
+        in.dt = sm.seg[sg * 16 + 1];
+        in.s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+        in.cc = sm.c + 12 * p;
+        in.epis = D.epis;
+        in.H = L.H;
+        in.trajid = sg;
+        in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
+        in.t_now = D.t_now;
+        const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad + pt;
+        if (L.H <= 4) {
+          double cor[16]; // all half-plane loads issued up front, consumed after the state evaluation
 #pragma unroll
-      for (int k = 0; k < 8; k++) o[k] = 0.0;
+          for (int k = 0; k < 16; k++) cor[k] = (k < 4 * L.H) ? cb[(size_t)k * D.NptsPad] : 0.0;
+          RegPlanes pl{cor};
+          sample_point_math<SUR>(P, D.sur, in, pl, o);
+        } else {
+          GlobalPlanes pl{cb, (size_t)D.NptsPad};
+          sample_point_math<SUR>(P, D.sur, in, pl, o);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) sm.part[k * chunk + loc] = o[k];
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++) sm.part[k * T + tid] = o[k];
     __syncthreads();
-    // transposed reduction: 12 threads per piece expand (A,B,C) onto gdC, 2 more sum gdT and cost
-    int lim = base + T < L.Npts ? base + T : L.Npts;
-    for (int w = tid; w < 14 * L.Ntot; w += T) {
-      int p = w / 14, q = w - 14 * p;
-      int sg = seg_of_piece(L, p);
-      int lp = p - L.seg_piece0[sg];
-      int N = L.piece_nums[sg];
-      bool edge = (lp == 0 || lp == N - 1);
-      int K = edge ? L.Kd : L.K;
-      // first constraint point of piece p: pieces of a segment are [Kd+1, K+1, ..., K+1, Kd+1] long
-      int pt0 = L.seg_pt0[sg] + (lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1));
+    pr.tick(kPE3S);
+    // transposed reduction, 16 threads per piece: 12 chain (A,B,C) onto gdC, 2 more chain gdT and cost
+    int lim = base + chunk < Npts ? base + chunk : Npts;
+    for (int w = tid; w < 16 * Ntot; w += T) {
+      int p = w >> 4, q = w & 15;
+      if (q >= 14) continue;
+      const int *pc = sm.pcinfo + 8 * p;
+      int pt0 = pc[0], K = pc[1];
       int j0 = base > pt0 ? base - pt0 : 0;
       int j1 = (pt0 + K + 1 < lim ? pt0 + K + 1 : lim) - pt0; // exclusive
       if (j1 <= j0) continue;
-      const double *tab = sm.stab + (sg * 2 + (edge ? 1 : 0)) * (L.Kmax + 1);
       if (q < 12) {
         int k = q >> 1, d = q & 1;
-        const double *pa = sm.part + (0 + d) * T + (pt0 - base);
-        const double *pb = sm.part + (2 + d) * T + (pt0 - base);
-        const double *pc = sm.part + (4 + d) * T + (pt0 - base);
+        const double *pa = sm.part + (0 + d) * chunk + (pt0 - base);
+        const double *pb = sm.part + (2 + d) * chunk + (pt0 - base);
+        const double *pc2 = sm.part + (4 + d) * chunk + (pt0 - base);
+        // beta0[k] = s^k, beta1[k] = k s^(k-1), beta2[k] = k(k-1) s^(k-2): the same products as
+        // traj_optimizer.cpp:505-507 (x1.0 and x0.0 are exact), read from the power table without branching
+        const double *tab = sm.spow + (size_t)pc[2] * Kmax1 * 6;
+        const int k1 = k >= 1 ? k - 1 : 0, k2 = k >= 2 ? k - 2 : 0;
+        const double kd = (double)k, kkd = (double)(k * (k - 1));
         double acc = sm.gdC[12 * p + q]; // continue the chain that starts at the smoothness gradient
+#pragma unroll 4
         for (int j = j0; j < j1; j++) {
-          double b0, b1, b2;
-          beta_row(k, tab[j], b0, b1, b2);
-          acc += b0 * pa[j] + b1 * pb[j] + b2 * pc[j];
+          const double *e = tab + 6 * j;
+          double b0 = e[k], b1 = kd * e[k1], b2 = kkd * e[k2];
+          acc += b0 * pa[j] + b1 * pb[j] + b2 * pc2[j];
         }
         sm.gdC[12 * p + q] = acc;
       } else {
-        const double *pv = sm.part + (q == 12 ? 6 : 7) * T + (pt0 - base);
+        const double *pv = sm.part + (q == 12 ? 6 : 7) * chunk + (pt0 - base);
         double acc = q == 12 ? sm.pGdT[p] : sm.pCost[p];
+#pragma unroll 8
         for (int j = j0; j < j1; j++) acc += pv[j];
         if (q == 12) sm.pGdT[p] = acc;
         else sm.pCost[p] = acc;
       }
     }
     __syncthreads();
+    pr.tick(kPE4R);
   }
 
   // ---- E5: adjoint through A^{-T} (MinJerkOpt::calGrads_PT, poly_traj_utils.hpp:1037-1064)
-  for (int w = tid; w < 2 * L.rhs_tot + L.Ntot; w += T) {
-    if (w < 2 * L.rhs_tot) {
-      int row = w >> 1, d = w & 1;
-      int sg = 0;
-      while (sg + 1 < L.M && row >= L.seg_rhs0[sg + 1]) ++sg;
-      int col = row - L.seg_rhs0[sg];
-      int N = L.piece_nums[sg];
-      const double *MT = D.opMT[sg] + (size_t)col * 6 * N;
-      const double *gc = sm.gdC + 12 * L.seg_piece0[sg] + d;
-      const double *tInv = sm.seg + sg * 16 + 8;
-      double acc = 0.0;
-      for (int p = 0; p < N; p++) {
+  // waves [0, span/64): 4 lanes per output, lane q sums rows q, q+4, q+8, ... in order, then (p0+p1)+(p2+p3)
+  // next wave: chain-rule duration terms per piece, summed per segment by a 64-lane butterfly
+  // next wave: the other per-piece quantities (jerk energy, penalty cost, gdT parts), same butterfly
+  {
+    const int n_out = 2 * rhs_tot;
+    const int span = ((4 * n_out + 63) >> 6) << 6; // whole waves: the quad butterfly needs all 4 lanes alive
+    for (int w = tid; w < span + 128; w += T) {
+      if (w < span) {
+        int o = w >> 2, q = w & 3;
+        double acc = 0.0;
+        if (o < n_out) {
+          int row = o >> 1, d = o & 1;
+          const int *ri = sm.rowinfo + 4 * row;
+          int sg = ri[0], col = ri[1], N = ri[2];
+          int p0 = 0, ooff = 0;
+          for (int s = 0, a = 0; s < M; s++) {
+            p0 = (s == sg) ? L.seg_piece0[s] : p0;
+            ooff = (s == sg) ? a : ooff;
+            a += 6 * L.piece_nums[s] * (L.piece_nums[s] + 5);
+          }
+          const double *MTb;
+          if (D.op_in_lds) {
+            MTb = sm.opMT + ooff;
+          } else {
+            MTb = D.opMT[0];
+            for (int s = 1; s < M; s++) MTb = (s == sg) ? D.opMT[s] : MTb;
+          }
+          const double *MT = MTb + (size_t)col * 6 * N;
+          const double *gc = sm.gdC + 12 * p0 + d;
+          const double *tInv = sm.seg + sg * 16 + 8;
+          int k = q; // r mod 6, stepped without a division
+#pragma unroll 6
+          for (int r = q; r < 6 * N; r += 4) {
+            acc += MT[r] * (gc[2 * r] * tInv[k]);
+            k += 4;
+            if (k >= 6) k -= 6;
+          }
+        }
+        acc += mov_dpp<0xB1>(acc);
+        acc += mov_dpp<0x4E>(acc);
+        if (o < n_out && q == 0) sm.adj[o] = acc;
+      } else if (w < span + 64) {
+        int ln = w - span;
+        for (int sg = 0; sg < M; sg++) {
+          const double *tInv = sm.seg + sg * 16 + 8;
+          double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5],
+                              -5.0 * tInv[5] * tInv[1]}; // poly_traj_utils.hpp:1054-1060
+          double v = 0.0;
+          for (int p = L.seg_piece0[sg] + ln; p < L.seg_piece0[sg + 1]; p += 64) {
+            const double *gc = sm.gdC + 12 * p;
+            const double *bb = sm.b + 12 * p;
+            double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) acc += MT[6 * p + k] * (gc[2 * (6 * p + k)] * tInv[k]);
+            for (int k = 0; k < 6; k++) acc += gdtInv[k] * (gc[2 * k] * bb[2 * k] + gc[2 * k + 1] * bb[2 * k + 1]);
+            v += acc;
+          }
+          v = wave_sum<6>(v);
+          if (ln == 0) sm.segsum[sg * 8 + 4] = v;
+        }
+      } else {
+        int ln = w - span - 64;
+        for (int sg = 0; sg < M; sg++) {
+          double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+          for (int p = L.seg_piece0[sg] + ln; p < L.seg_piece0[sg + 1]; p += 64) {
+            v0 += sm.pE[p];
+            v1 += sm.pCost[p];
+            v2 += sm.pGsm[p];
+            v3 += sm.pGdT[p];
+          }
+          v0 = wave_sum<6>(v0);
+          v1 = wave_sum<6>(v1);
+          v2 = wave_sum<6>(v2);
+          v3 = wave_sum<6>(v3);
+          if (ln == 0) {
+            sm.segsum[sg * 8 + 0] = v0;
+            sm.segsum[sg * 8 + 1] = v1;
+            sm.segsum[sg * 8 + 2] = v2;
+            sm.segsum[sg * 8 + 3] = v3;
+          }
+        }
       }
-      sm.adj[w] = acc;
-    } else {
-      int p = w - 2 * L.rhs_tot;
-      int sg = seg_of_piece(L, p);
-      const double *tInv = sm.seg + sg * 16 + 8;
-      double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5],
-                          -5.0 * tInv[5] * tInv[1]}; // poly_traj_utils.hpp:1054-1060
-      const double *gc = sm.gdC + 12 * p;
-      const double *bb = sm.b + 12 * p;
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc += gdtInv[k] * (gc[2 * k] * bb[2 * k] + gc[2 * k + 1] * bb[2 * k + 1]);
-      sm.pChain[p] = acc;
     }
   }
   __syncthreads();
+  pr.tick(kPE5);
 
   // ---- E6: assemble g and f (traj_optimizer.cpp:299-344)
   for (int e = tid; e < L.n + 1; e += T) {
     if (e == L.n) {
       double sm_cost = 0.0, pen = 0.0, tc = 0.0;
-      for (int sg = 0; sg < L.M; sg++) {
-        double en = 0.0, pc = 0.0;
-        for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) {
-          en += sm.pE[p];
-          pc += sm.pCost[p];
-        }
-        sm_cost += en;
-        pen += pc;
+      for (int sg = 0; sg < M; sg++) {
+        sm_cost += sm.segsum[sg * 8 + 0];
+        pen += sm.segsum[sg * 8 + 1];
         tc += sm.seg[sg * 16] * P.wei_time;
       }
-      sm.scal[0] = sm_cost + tc + pen;
+      sm.st[sF] = sm_cost + tc + pen;
     } else if (e < L.x_tau0) { // waypoints: gdP = rows 6i+5 of the adjoint
-      int sg = 0;
-      while (sg + 1 < L.M && e >= L.seg_x0[sg + 1]) ++sg;
-      int q = e - L.seg_x0[sg];
+      int sg = 0, x0 = 0, r0 = 0;
+      for (int s = 0; s < M; s++) {
+        bool in = e >= L.seg_x0[s];
+        sg = in ? s : sg;
+        x0 = in ? L.seg_x0[s] : x0;
+        r0 = in ? L.seg_rhs0[s] : r0;
+      }
+      int q = e - x0;
       int wp = q >> 1, d = q & 1;
-      g[e] = sm.adj[2 * (L.seg_rhs0[sg] + 3 + wp) + d];
+      g[e] = sm.adj[2 * (r0 + 3 + wp) + d];
     } else if (e < L.x_gear0) { // tau: VirtualTGradCost, traj_optimizer.cpp:405-419
       int sg = e - L.x_tau0;
-      int N = L.piece_nums[sg];
+      int N = 0, r0 = 0;
+      for (int s = 0; s < M; s++) {
+        N = (s == sg) ? L.piece_nums[s] : N;
+        r0 = (s == sg) ? L.seg_rhs0[s] : r0;
+      }
       const double *seg = sm.seg + sg * 16;
       double dt = seg[1];
       double gdT = 0.0;
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) gdT += sm.pGsm[p];
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) gdT += sm.pGdT[p];
+      gdT += sm.segsum[sg * 8 + 2];
+      gdT += sm.segsum[sg * 8 + 3];
       // boundary-scaling terms, poly_traj_utils.hpp:1050-1053 (with the junction-overridden head/tail v)
-      const double *ad = sm.adj + 2 * L.seg_rhs0[sg];
+      const double *ad = sm.adj + 2 * r0;
       double hv[2], tv[2];
       if (sg > 0) {
         double th = x[L.x_ang0 + sg - 1];
@@ -390,7 +625,7 @@ __device__ double block_eval(const DevBatch &D, int b, const Smem &sm, const dou
         hv[0] = iniS[sg * 6 + 2];
         hv[1] = iniS[sg * 6 + 3];
       }
-      if (sg < L.M - 1) {
+      if (sg < M - 1) {
         double th = x[L.x_ang0 + sg];
         tv[0] = P.non_sinv * p_cos(th);
         tv[1] = P.non_sinv * p_sin(th);
@@ -403,86 +638,180 @@ __device__ double block_eval(const DevBatch &D, int b, const Smem &sm, const dou
       gdT += (iniS[sg * 6 + 4] * ad[2 * 2] + iniS[sg * 6 + 5] * ad[2 * 2 + 1]) * 2.0 * dt;
       gdT += tv[0] * ad[2 * (rt + 1)] + tv[1] * ad[2 * (rt + 1) + 1];
       gdT += (finS[sg * 6 + 4] * ad[2 * (rt + 2)] + finS[sg * 6 + 5] * ad[2 * (rt + 2) + 1]) * 2.0 * dt;
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) gdT += sm.pChain[p];
+      gdT += sm.segsum[sg * 8 + 4];
       g[e] = (gdT / N + P.wei_time) * virtual_to_real_grad(x[e]);
-    } else if (e < L.x_ang0) { // gear position, traj_optimizer.cpp:307-320
-      int q = e - L.x_gear0;
-      int i = q >> 1, d = q & 1;
-      double v = 0.0;
-      if (P.gear_opt) {
-        int Ni = L.piece_nums[i];
-        v += sm.adj[2 * (L.seg_rhs0[i] + Ni + 2) + d] * 1.0; // gdTail.col(0) of segment i
-        v += sm.adj[2 * (L.seg_rhs0[i + 1] + 0) + d] * 1.0;  // gdHead.col(0) of segment i+1
+    } else { // gear position (traj_optimizer.cpp:307-320) and gear angle
+      bool is_ang = e >= L.x_ang0;
+      int i = is_ang ? e - L.x_ang0 : (e - L.x_gear0) >> 1;
+      int d = (e - L.x_gear0) & 1;
+      int Ni = 0, r0i = 0, r0n = 0;
+      for (int s = 0; s < M; s++) {
+        Ni = (s == i) ? L.piece_nums[s] : Ni;
+        r0i = (s == i) ? L.seg_rhs0[s] : r0i;
+        r0n = (s == i + 1) ? L.seg_rhs0[s] : r0n;
       }
-      g[e] = v;
-    } else { // gear angle
-      int i = e - L.x_ang0;
       double v = 0.0;
       if (P.gear_opt) {
-        double th = x[e];
-        int Ni = L.piece_nums[i];
-        double dti = sm.seg[i * 16 + 1], dtn = sm.seg[(i + 1) * 16 + 1];
-        double ft0 = sm.adj[2 * (L.seg_rhs0[i] + Ni + 3) + 0] * dti, ft1 = sm.adj[2 * (L.seg_rhs0[i] + Ni + 3) + 1] * dti;
-        double hd0 = sm.adj[2 * (L.seg_rhs0[i + 1] + 1) + 0] * dtn, hd1 = sm.adj[2 * (L.seg_rhs0[i + 1] + 1) + 1] * dtn;
-        v += ft0 * (-P.non_sinv * p_sin(th)) + ft1 * (P.non_sinv * p_cos(th));
-        v += hd0 * (P.non_sinv * p_sin(th)) + hd1 * (-P.non_sinv * p_cos(th));
+        if (!is_ang) {
+          v += sm.adj[2 * (r0i + Ni + 2) + d] * 1.0; // gdTail.col(0) of segment i
+          v += sm.adj[2 * (r0n + 0) + d] * 1.0;      // gdHead.col(0) of segment i+1
+        } else {
+          double th = x[e];
+          double dti = sm.seg[i * 16 + 1], dtn = sm.seg[(i + 1) * 16 + 1];
+          double ft0 = sm.adj[2 * (r0i + Ni + 3) + 0] * dti, ft1 = sm.adj[2 * (r0i + Ni + 3) + 1] * dti;
+          double hd0 = sm.adj[2 * (r0n + 1) + 0] * dtn, hd1 = sm.adj[2 * (r0n + 1) + 1] * dtn;
+          v += ft0 * (-P.non_sinv * p_sin(th)) + ft1 * (P.non_sinv * p_cos(th));
+          v += hd0 * (P.non_sinv * p_sin(th)) + hd1 * (-P.non_sinv * p_cos(th));
+        }
       }
       g[e] = v;
     }
   }
   __syncthreads();
-  return sm.scal[0];
+  pr.tick(kPE6);
 }
 
-// ------------------------------------------------------------- the solver
-enum LsState { kLsContinue = 0, kLsDone = 1 };
+// ------------------------------------------------------------- two-loop
+// Two-loop recursion (lbfgs.hpp:716-739) for n <= 64: one element of the
+// direction per lane.  History columns, 1/ys and alpha are streamed through a
+// PF-deep register ring so that the loads of step i+PF are in flight while step
+// i reduces.  Ring refills are unconditional loads from always-valid addresses
+// (lane clamped into the padded row, slot into the ring) followed by a select:
+// no divergent region, so the loads stay in flight instead of being waited on
+// at a branch join; slot indices advance with wrap-around (no integer division).
+typedef const double __attribute__((address_space(1))) *gptr_t; // global (not flat) loads: vmcnt only
 
-// lbfgs_optimize (lbfgs.hpp:440-751) + line_search_lewisoverton (lbfgs.hpp:276-390).
-// Vector algebra on wave 0: element e of an n-vector lives at LDS index e, lanes stride over e.
-template <bool SUR>
-__global__ void __launch_bounds__(kMaxThreads) solver_kernel(DevBatch D, int mode) {
-  extern __shared__ double lds_raw[];
-  const DevLayout &L = D.L;
+template <int LV, int PF>
+__device__ __forceinline__ double two_loop_lane(const Smem &sm, const double *hS_, const double *hY_, int npad, int n, int m,
+                                                int nb, int ne, double ys_new, double yy_new, int lane, double dreg) {
+  gptr_t hS = (gptr_t)hS_;
+  gptr_t hY = (gptr_t)hY_;
+  const bool act = lane < n;
+  const int ln = act ? lane : 0;
+  // raw loaded values stay untouched in the ring until their step (the lane mask is applied at
+  // the point of use), so nothing forces a wait on a load right after it was issued
+  double sreg[PF], yreg[PF], vys[PF], vri[PF], val[PF];
+  // ---- first loop: newest -> oldest (slot ne-1, ne-2, ...)
+  int jl = ne; // slot the ring was last loaded for
+#pragma unroll
+  for (int q = 0; q < PF; q++) {
+    jl = jl == 0 ? m - 1 : jl - 1;
+    sreg[q] = hS[(size_t)jl * npad + ln];
+    yreg[q] = hY[(size_t)jl * npad + ln];
+    vys[q] = sm.ys[jl];
+    vri[q] = sm.rinv[jl];
+  }
+  int j = ne;
+  for (int i0 = 0; i0 < nb; i0 += PF) {
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+      if (i0 + q < nb) {
+        j = j == 0 ? m - 1 : j - 1;
+        double sv = act ? sreg[q] : 0.0, yv = act ? yreg[q] : 0.0;
+        double acc = wave_sum<LV>(sv * dreg);
+        double a = div_by_rcp(acc, vys[q], vri[q]); // lm_s.col(j).dot(d) / lm_ys(j)
+        if (lane == 0) sm.alpha[j] = a;
+        double na = -a;
+        dreg += na * yv;
+        jl = jl == 0 ? m - 1 : jl - 1;
+        sreg[q] = hS[(size_t)jl * npad + ln];
+        yreg[q] = hY[(size_t)jl * npad + ln];
+        vys[q] = sm.ys[jl];
+        vri[q] = sm.rinv[jl];
+      }
+    }
+  }
+  dreg *= ys_new / yy_new;
+  // ---- second loop: oldest -> newest, starting at the slot the first loop ended on
+  jl = j;
+#pragma unroll
+  for (int q = 0; q < PF; q++) {
+    sreg[q] = hS[(size_t)jl * npad + ln];
+    yreg[q] = hY[(size_t)jl * npad + ln];
+    vys[q] = sm.ys[jl];
+    vri[q] = sm.rinv[jl];
+    val[q] = sm.alpha[jl];
+    jl = jl == m - 1 ? 0 : jl + 1;
+  }
+  for (int i0 = 0; i0 < nb; i0 += PF) {
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+      if (i0 + q < nb) {
+        double sv = act ? sreg[q] : 0.0, yv = act ? yreg[q] : 0.0;
+        double acc = wave_sum<LV>(yv * dreg);
+        double beta = div_by_rcp(acc, vys[q], vri[q]); // lm_y.col(j).dot(d) / lm_ys(j)
+        double cf = val[q] - beta;
+        dreg += cf * sv;
+        sreg[q] = hS[(size_t)jl * npad + ln];
+        yreg[q] = hY[(size_t)jl * npad + ln];
+        vys[q] = sm.ys[jl];
+        vri[q] = sm.rinv[jl];
+        val[q] = sm.alpha[jl];
+        jl = jl == m - 1 ? 0 : jl + 1;
+      }
+    }
+  }
+  return dreg;
+}
+
+// dot products of wave 0 over LDS vectors: lane l accumulates elements l, l+64, ... from 0.0, then the butterfly
+template <int LV>
+__device__ inline double wave_dot(const double *a, const double *b, int n, int lane) {
+  double acc = 0.0;
+  for (int e = lane; e < n; e += 64) acc += a[e] * b[e];
+  return wave_sum<LV>(acc);
+}
+
+// ---------------------------------------------------- L-BFGS state machine
+// Start of an outer iteration (lbfgs.hpp:559-574 and the head of
+// line_search_lewisoverton, lbfgs.hpp:290-315): xp = x, gp = g, dginit, first trial point.
+// Returns false when the line search cannot start (negative return code in iRET).
+template <int LV>
+__device__ __forceinline__ bool begin_iteration(const DevParams &P, const Smem &sm, int n, int lane) {
+  double acc = 0.0;
+  for (int e = lane; e < n; e += 64) {
+    sm.xp[e] = sm.x[e];
+    double gv = sm.g[e];
+    sm.gp[e] = gv;
+    acc += gv * sm.d[e];
+  }
+  double dginit = wave_sum<LV>(acc);
+  double step = sm.st[sSTEP];
+  if (!(step > 0.0)) {
+    if (lane == 0) sm.ist[iRET] = -1006; // LBFGSERR_INVALIDPARAMETERS
+    return false;
+  }
+  if (0.0 < dginit) {
+    if (lane == 0) sm.ist[iRET] = -1005; // LBFGSERR_INCREASEGRADIENT
+    return false;
+  }
+  if (lane == 0) {
+    sm.st[sFINIT] = sm.st[sFX];
+    sm.st[sDGINIT] = dginit;
+    sm.st[sDGTEST] = P.f_dec_coeff * dginit;
+    sm.st[sDSTEST] = P.s_curv_coeff * dginit;
+    sm.st[sMU] = 0.0;
+    sm.st[sNU] = P.max_step;
+    sm.st[sSTP] = step;
+    sm.ist[iCOUNT] = 0;
+    sm.ist[iBRACKT] = 0;
+    sm.ist[iTOUCHED] = 0;
+  }
+  for (int e = lane; e < n; e += 64) sm.x[e] = sm.xp[e] + step * sm.d[e];
+  return true;
+}
+
+// Everything lbfgs_optimize does between two evaluations (lbfgs.hpp:524-745 with the line
+// search of lbfgs.hpp:312-389 unrolled into it).  Runs on wave 0, every lane computing the same
+// scalars from LDS; sets iACTION to kActEval (a new trial x is in sm.x) or kActDone.
+template <int LV>
+__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, int b, int lane, Prof &pr) {
   const DevParams &P = D.P;
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x, T = blockDim.x;
-  const int lane = tid & 63;
-  const bool w0 = tid < 64;
-  const int n = L.n;
-  Smem sm;
-  carve(sm, lds_raw, L, P.mem_size, T);
-  const long long tick0 = wall_clock64();
-
-  const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
-  for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
-  __syncthreads();
-
-  double fx = block_eval<SUR>(D, b, sm, sm.x, sm.g);
-
-  if (mode == kModeEval) {
-    for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
-    if (tid == 0) D.f_out[b] = fx;
-    return;
-  }
-  if (mode == kModeCoeffs) {
-    for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
-    for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[sg * 16 + 1];
-    return;
-  }
-
-  // ---------------- L-BFGS state (uniform across the workgroup)
-  const int m = P.mem_size;
-  double *hS = D.histS + (size_t)b * m * L.npad;
-  double *hY = D.histY + (size_t)b * m * L.npad;
-  int evals = 1;
-  int k = 0, end = 0, bound = 0, ret = 0;
-  long long hist_sum = 0;
-  double step = 0.0;
-  double pf[8]; // past <= 8
-  pf[0] = fx;
-
-  // initial direction and stationarity test, lbfgs.hpp:533-547
-  if (w0) {
+  const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
+  const double f = sm.st[sF];
+  int action = kActEval;
+  if (sm.ist[iPHASE] == 0) {
+    // ---- after the first evaluation: lbfgs.hpp:524-551
     double gmax = 0.0, xmax = 0.0, dd = 0.0;
     for (int e = lane; e < n; e += 64) {
       double gv = sm.g[e];
@@ -491,244 +820,353 @@ __global__ void __launch_bounds__(kMaxThreads) solver_kernel(DevBatch D, int mod
       xmax = fmax(xmax, fabs(sm.x[e]));
       dd += gv * gv;
     }
-    gmax = wave_max(gmax);
-    xmax = wave_max(xmax);
-    dd = wave_sum(dd);
+    gmax = wave_max<LV>(gmax);
+    xmax = wave_max<LV>(xmax);
+    dd = wave_sum<LV>(dd);
     if (lane == 0) {
-      sm.flag[0] = (gmax / fmax(1.0, xmax) < P.g_epsilon) ? 1 : 0;
-      sm.scal[1] = 1.0 / sqrt(dd);
+      sm.st[sFX] = f;
+      sm.st[sPF0] = f;
+      sm.ist[iEVALS] = 1;
+      sm.ist[iEND] = 0;
+      sm.ist[iBOUND] = 0;
+      sm.ist[iHISTLO] = 0;
+      sm.ist[iHISTHI] = 0;
+      sm.ist[iPHASE] = 1;
     }
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      if (lane == 0) {
+        sm.ist[iRET] = 0; // LBFGS_CONVERGENCE
+        sm.ist[iK] = 0;
+      }
+      action = kActDone;
+    } else {
+      if (lane == 0) {
+        sm.st[sSTEP] = 1.0 / sqrt(dd);
+        sm.ist[iK] = 1;
+      }
+      if (!begin_iteration<LV>(P, sm, n, lane)) action = kActDone; // x == xp, g == gp here: nothing to revert
+    }
+    if (lane == 0) sm.ist[iACTION] = action;
+    pr.tick(kPMISC);
+    return;
   }
-  __syncthreads();
-  bool done = sm.flag[0] != 0;
-  if (done) {
-    ret = 0; // LBFGS_CONVERGENCE
+
+  // ---- after a line-search trial: lbfgs.hpp:317-389
+  const double fx = f;
+  const double finit = sm.st[sFINIT];
+  double stp = sm.st[sSTP];
+  int count = sm.ist[iCOUNT] + 1;
+  int ls = 0;
+  bool decided = false; // true: the search ended (ls holds count or an error), false: try another step
+  if (lane == 0) {
+    sm.st[sFX] = fx;
+    sm.ist[iEVALS] = sm.ist[iEVALS] + 1;
+    sm.ist[iCOUNT] = count;
+  }
+  if (isinf(fx) || isnan(fx)) {
+    ls = -1012; // LBFGSERR_INVALID_FUNCVAL
+    decided = true;
+  } else if (P.past > 0 && fabs(finit - fx) / (fabs(finit) + 1.0) < P.delta / P.past) { // lbfgs.hpp:326-329
+    ls = count;
+    decided = true;
   } else {
-    step = sm.scal[1];
-    k = 1;
-  }
-  __syncthreads();
-
-  while (!done) {
-    // ---- start of an outer iteration: xp = x, gp = g, line-search setup (lbfgs.hpp:559-574, 290-309)
-    double finit = fx;
-    double dginit = 0.0;
-    if (w0) {
-      double acc = 0.0;
-      for (int e = lane; e < n; e += 64) {
-        sm.xp[e] = sm.x[e];
-        double gv = sm.g[e];
-        sm.gp[e] = gv;
-        acc += gv * sm.d[e];
-      }
-      acc = wave_sum(acc);
-      if (lane == 0) sm.scal[2] = acc;
-    }
-    __syncthreads();
-    dginit = sm.scal[2];
-    int ls = 0;
-    bool ls_fail = false;
-    if (!(step > 0.0)) {
-      ls = -1006; // LBFGSERR_INVALIDPARAMETERS
-      ls_fail = true;
-    } else if (0.0 < dginit) {
-      ls = -1005; // LBFGSERR_INCREASEGRADIENT
-      ls_fail = true;
-    }
-    const double dgtest = P.f_dec_coeff * dginit;
-    const double dstest = P.s_curv_coeff * dginit;
-    int count = 0;
-    bool brackt = false, touched = false;
-    double mu = 0.0, nu = P.max_step;
-    double stp = step;
-
-    // ---- line search (lbfgs.hpp:312-389)
-    while (!ls_fail) {
-      for (int e = tid; e < n; e += T) sm.x[e] = sm.xp[e] + stp * sm.d[e];
-      __syncthreads();
-      fx = block_eval<SUR>(D, b, sm, sm.x, sm.g);
-      ++count;
-      ++evals;
-      if (isinf(fx) || isnan(fx)) {
-        ls = -1012; // LBFGSERR_INVALID_FUNCVAL
-        break;
-      }
-      if (P.past > 0 && fabs(finit - fx) / (fabs(finit) + 1.0) < P.delta / P.past) { // lbfgs.hpp:326-329
-        ls = count;
-        break;
-      }
-      if (fx > finit + stp * dgtest) {
-        nu = stp;
-        brackt = true;
+    double mu = sm.st[sMU], nu = sm.st[sNU];
+    bool brackt = sm.ist[iBRACKT] != 0;
+    if (fx > finit + stp * sm.st[sDGTEST]) {
+      nu = stp;
+      brackt = true;
+    } else {
+      double gs = wave_dot<LV>(sm.g, sm.d, n, lane);
+      if (gs < sm.st[sDSTEST]) {
+        mu = stp;
       } else {
-        if (w0) {
-          double acc = 0.0;
-          for (int e = lane; e < n; e += 64) acc += sm.g[e] * sm.d[e];
-          acc = wave_sum(acc);
-          if (lane == 0) sm.scal[3] = acc;
-        }
-        __syncthreads();
-        double gs = sm.scal[3];
-        __syncthreads();
-        if (gs < dstest) {
-          mu = stp;
-        } else {
-          ls = count;
-          break;
-        }
+        ls = count;
+        decided = true;
       }
+    }
+    if (!decided) {
       if (P.max_linesearch <= count) {
         ls = -1009; // LBFGSERR_MAXIMUMLINESEARCH
-        break;
-      }
-      if (brackt && (nu - mu) < P.machine_prec * nu) {
+        decided = true;
+      } else if (brackt && (nu - mu) < P.machine_prec * nu) {
         ls = -1007; // LBFGSERR_WIDTHTOOSMALL
-        break;
-      }
-      if (brackt) stp = 0.5 * (mu + nu);
-      else stp *= 2.0;
-      if (stp < P.min_step) {
-        ls = -1011; // LBFGSERR_MINIMUMSTEP
-        break;
-      }
-      if (stp > P.max_step) {
-        if (touched) {
-          ls = -1010; // LBFGSERR_MAXIMUMSTEP
-          break;
+        decided = true;
+      } else {
+        if (brackt) stp = 0.5 * (mu + nu);
+        else stp *= 2.0;
+        if (stp < P.min_step) {
+          ls = -1011; // LBFGSERR_MINIMUMSTEP
+          decided = true;
+        } else if (stp > P.max_step) {
+          if (sm.ist[iTOUCHED]) {
+            ls = -1010; // LBFGSERR_MAXIMUMSTEP
+            decided = true;
+          } else {
+            if (lane == 0) sm.ist[iTOUCHED] = 1;
+            stp = P.max_step;
+          }
         }
-        touched = true;
-        stp = P.max_step;
       }
     }
-    step = stp;
+    if (lane == 0) {
+      sm.st[sMU] = mu;
+      sm.st[sNU] = nu;
+      sm.ist[iBRACKT] = brackt ? 1 : 0;
+      sm.st[sSTP] = stp;
+    }
+    if (!decided) { // next trial point
+      for (int e = lane; e < n; e += 64) sm.x[e] = sm.xp[e] + stp * sm.d[e];
+      if (lane == 0) sm.ist[iACTION] = kActEval;
+      pr.tick(kPLS);
+      return;
+    }
+  }
+  // the search ended; `step` takes the last trial step (lbfgs.hpp:574 passes it by reference)
+  if (lane == 0) sm.st[sSTEP] = stp;
+  if (ls < 0) { // revert x and g, keep fx (lbfgs.hpp:604-611)
+    for (int e = lane; e < n; e += 64) {
+      sm.x[e] = sm.xp[e];
+      sm.g[e] = sm.gp[e];
+    }
+    if (lane == 0) {
+      sm.ist[iRET] = ls;
+      sm.ist[iACTION] = kActDone;
+    }
+    return;
+  }
 
-    if (ls < 0) { // revert x and g, keep fx (lbfgs.hpp:604-611)
-      for (int e = tid; e < n; e += T) {
-        sm.x[e] = sm.xp[e];
-        sm.g[e] = sm.gp[e];
-      }
-      ret = ls;
-      break;
+  // ---- convergence / stopping tests (lbfgs.hpp:628-666)
+  int k = sm.ist[iK];
+  {
+    double gmax = 0.0, xmax = 0.0;
+    for (int e = lane; e < n; e += 64) {
+      gmax = fmax(gmax, fabs(sm.g[e]));
+      xmax = fmax(xmax, fabs(sm.x[e]));
     }
-
-    // ---- convergence / stopping tests (lbfgs.hpp:628-666)
-    if (w0) {
-      double gmax = 0.0, xmax = 0.0;
-      for (int e = lane; e < n; e += 64) {
-        gmax = fmax(gmax, fabs(sm.g[e]));
-        xmax = fmax(xmax, fabs(sm.x[e]));
-      }
-      gmax = wave_max(gmax);
-      xmax = wave_max(xmax);
-      if (lane == 0) sm.flag[1] = (gmax / fmax(1.0, xmax) < P.g_epsilon) ? 1 : 0;
-    }
-    __syncthreads();
-    if (sm.flag[1]) {
+    gmax = wave_max<LV>(gmax);
+    xmax = wave_max<LV>(xmax);
+    const int kGoOn = 12345;
+    int ret = kGoOn;
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
       ret = 0; // LBFGS_CONVERGENCE
-      break;
-    }
-    if (0 < P.past) {
-      if (P.past <= k) {
-        double rate = fabs(pf[k % P.past] - fx) / fmax(1.0, fabs(fx));
-        if (rate < P.delta) {
-          ret = 1; // LBFGS_STOP
-          break;
+    } else {
+      if (0 < P.past) {
+        int slot = k % P.past;
+        if (P.past <= k) {
+          double rate = fabs(sm.st[sPF0 + slot] - fx) / fmax(1.0, fabs(fx));
+          if (rate < P.delta) ret = 1; // LBFGS_STOP
         }
+        if (ret == kGoOn && lane == 0) sm.st[sPF0 + slot] = fx;
       }
-      pf[k % P.past] = fx;
+      if (ret == kGoOn && P.max_iterations != 0 && P.max_iterations <= k) ret = -1008; // LBFGSERR_MAXIMUMITERATION
     }
-    if (P.max_iterations != 0 && P.max_iterations <= k) {
-      ret = -1008; // LBFGSERR_MAXIMUMITERATION
-      break;
+    if (ret != kGoOn) {
+      if (lane == 0) {
+        sm.ist[iRET] = ret;
+        sm.ist[iACTION] = kActDone;
+      }
+      return;
     }
-    ++k;
+  }
+  ++k;
+  if (lane == 0) sm.ist[iK] = k;
+  pr.tick(kPLS);
 
-    // ---- history update + two-loop recursion on wave 0 (lbfgs.hpp:676-740)
-    if (w0) {
-      double *sc = hS + (size_t)end * L.npad, *yc = hY + (size_t)end * L.npad;
-      double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
-      for (int e = lane; e < n; e += 64) {
-        double sv = sm.x[e] - sm.xp[e];
-        double yv = sm.g[e] - sm.gp[e];
-        sc[e] = sv;
-        yc[e] = yv;
-        ys += yv * sv;
-        yy += yv * yv;
-        ss += sv * sv;
-        double gpv = sm.gp[e];
-        gpgp += gpv * gpv;
-        sm.d[e] = -sm.g[e];
-      }
-      ys = wave_sum(ys);
-      yy = wave_sum(yy);
-      ss = wave_sum(ss);
-      gpgp = wave_sum(gpgp);
-      if (lane == 0) sm.ys[end] = ys;
-      double cau = ss * sqrt(gpgp) * P.cautious_factor;
-      int nb = bound, ne = end;
-      if (ys > cau) {
-        ++nb;
-        nb = m < nb ? m : nb;
-        ne = (end + 1) % m;
-        // make this wave's own global stores visible to its own loads below
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
+  // ---- history update + two-loop recursion (lbfgs.hpp:676-740)
+  double *hS = D.histS + (size_t)b * m * npad;
+  double *hY = D.histY + (size_t)b * m * npad;
+  const int end = sm.ist[iEND];
+  int bound = sm.ist[iBOUND];
+  {
+    double *sc = hS + (size_t)end * npad, *yc = hY + (size_t)end * npad;
+    double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
+    for (int e = lane; e < n; e += 64) {
+      double sv = sm.x[e] - sm.xp[e];
+      double yv = sm.g[e] - sm.gp[e];
+      sc[e] = sv;
+      yc[e] = yv;
+      ys += yv * sv;
+      yy += yv * yv;
+      ss += sv * sv;
+      double gpv = sm.gp[e];
+      gpgp += gpv * gpv;
+      sm.d[e] = -sm.g[e];
+    }
+    ys = wave_sum<LV>(ys);
+    yy = wave_sum<LV>(yy);
+    ss = wave_sum<LV>(ss);
+    gpgp = wave_sum<LV>(gpgp);
+    if (lane == 0) {
+      sm.ys[end] = ys;
+      sm.rinv[end] = 1.0 / ys;
+    }
+    double cau = ss * sqrt(gpgp) * P.cautious_factor;
+    pr.tick(kPHIST);
+    if (ys > cau) {
+      ++bound;
+      bound = m < bound ? m : bound;
+      int ne = end + 1 == m ? 0 : end + 1;
+      if (n <= 64) {
+        // the newest column was written by these same lanes: program order makes it visible to them
+        double dreg = lane < n ? sm.d[lane] : 0.0;
+        dreg = two_loop_lane<LV, 8>(sm, hS, hY, npad, n, m, bound, ne, ys, yy, lane, dreg);
+        if (lane < n) sm.d[lane] = dreg;
+      } else {
         int j = ne;
-        for (int i = 0; i < nb; ++i) {
-          j = (j + m - 1) % m;
-          const double *sj = hS + (size_t)j * L.npad, *yj = hY + (size_t)j * L.npad;
+        for (int i = 0; i < bound; ++i) {
+          j = j == 0 ? m - 1 : j - 1;
+          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += sj[e] * sm.d[e];
-          acc = wave_sum(acc);
-          double ysj = (j == end) ? ys : sm.ys[j];
-          double a = acc / ysj;
+          acc = wave_sum<LV>(acc);
+          double a = acc / sm.ys[j];
           if (lane == 0) sm.alpha[j] = a;
           double na = -a;
           for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[e];
         }
         double sc0 = ys / yy;
         for (int e = lane; e < n; e += 64) sm.d[e] *= sc0;
-        for (int i = 0; i < nb; ++i) {
-          const double *sj = hS + (size_t)j * L.npad, *yj = hY + (size_t)j * L.npad;
+        for (int i = 0; i < bound; ++i) {
+          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += yj[e] * sm.d[e];
-          acc = wave_sum(acc);
-          double ysj = (j == end) ? ys : sm.ys[j];
-          double beta = acc / ysj;
+          acc = wave_sum<LV>(acc);
+          double beta = acc / sm.ys[j];
           double cf = sm.alpha[j] - beta;
           for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[e];
-          j = (j + 1) % m;
+          j = j == m - 1 ? 0 : j + 1;
         }
       }
       if (lane == 0) {
-        sm.flag[2] = nb;
-        sm.flag[3] = ne;
+        sm.ist[iEND] = ne;
+        sm.ist[iBOUND] = bound;
+        long long hs = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+        hs += bound;
+        sm.ist[iHISTLO] = (int)(hs & 0xffffffffLL);
+        sm.ist[iHISTHI] = (int)(hs >> 32);
       }
     }
-    __syncthreads();
-    {
-      int nb = sm.flag[2], ne = sm.flag[3];
-      if (ne != end) hist_sum += nb;
-      bound = nb;
-      end = ne;
+  }
+  if (lane == 0) sm.st[sSTEP] = 1.0; // lbfgs.hpp:743
+  pr.tick(kPLOOP);
+  // wave 0 wrote sSTEP / d through LDS; begin_iteration reads them back in program order
+  bool ok = begin_iteration<LV>(P, sm, n, lane);
+  if (lane == 0) sm.ist[iACTION] = ok ? kActEval : kActDone;
+  pr.tick(kPLS);
+}
+
+// ------------------------------------------------------------- the solver
+template <bool SUR, int LV, int MAXT>
+__global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict__ Dp, int mode) {
+  extern __shared__ double lds_raw[];
+  const DevBatch &D = *Dp;
+  const DevLayout &L = D.L;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int lane = tid & 63;
+  const int n = L.n;
+  Smem sm;
+  carve(sm, lds_raw, L, D.P.mem_size, T, D.ppt, D.op_in_lds != 0);
+  const long long tick0 = wall_clock64();
+  Prof pr;
+  pr.start(D.prof != nullptr && mode == kModeSolve);
+
+  // ---- one-time staging: decision vector, role tables, operators
+  const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
+  for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
+  for (int pt = tid; pt < L.Npts; pt += T) sm.ptinfo[pt] = (int)D.pt_piece[pt] | ((int)D.pt_j[pt] << 16);
+  for (int p = tid; p < L.Ntot; p += T) {
+    int sg = 0, p0 = 0, N = 0, pt0s = 0, sgl = 0, ooff = 0;
+    for (int s = 0, a = 0; s < L.M; s++) {
+      bool in = p >= L.seg_piece0[s];
+      sg = in ? s : sg;
+      p0 = in ? L.seg_piece0[s] : p0;
+      N = in ? L.piece_nums[s] : N;
+      pt0s = in ? L.seg_pt0[s] : pt0s;
+      sgl = in ? L.singuls[s] : sgl;
+      ooff = in ? a : ooff;
+      a += 6 * L.piece_nums[s] * (L.piece_nums[s] + 5);
     }
-    step = 1.0;
-    __syncthreads();
+    int lp = p - p0;
+    bool edge = (lp == 0 || lp == N - 1);
+    int *pc = sm.pcinfo + 8 * p;
+    // first constraint point of piece p: pieces of a segment are [Kd+1, K+1, ..., K+1, Kd+1] long
+    pc[0] = pt0s + (lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1));
+    pc[1] = edge ? L.Kd : L.K;
+    pc[2] = sg * 2 + (edge ? 1 : 0);
+    pc[3] = sg;
+    pc[4] = lp;
+    pc[5] = N;
+    pc[6] = sgl;
+    pc[7] = ooff;
+  }
+  for (int row = tid; row < L.rhs_tot; row += T) {
+    int sg = 0, r0 = 0, N = 0, x0 = 0;
+    for (int s = 0; s < L.M; s++) {
+      bool in = row >= L.seg_rhs0[s];
+      sg = in ? s : sg;
+      r0 = in ? L.seg_rhs0[s] : r0;
+      N = in ? L.piece_nums[s] : N;
+      x0 = in ? L.seg_x0[s] : x0;
+    }
+    int *ri = sm.rowinfo + 4 * row;
+    ri[0] = sg;
+    ri[1] = row - r0;
+    ri[2] = N;
+    ri[3] = x0;
+  }
+  if (D.op_in_lds) {
+    int off = 0;
+    for (int sg = 0; sg < L.M; sg++) {
+      int cnt = 6 * L.piece_nums[sg] * (L.piece_nums[sg] + 5);
+      for (int i = tid; i < cnt; i += T) {
+        sm.opM[off + i] = D.opM[sg][i];
+        sm.opMT[off + i] = D.opMT[sg][i];
+      }
+      off += cnt;
+    }
+  }
+  if (tid < iNUM) sm.ist[tid] = 0;
+  __syncthreads();
+
+  block_eval<SUR>(D, b, sm, sm.x, sm.g, pr);
+
+  if (mode == kModeEval) {
+    for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
+    if (tid == 0) D.f_out[b] = sm.st[sF];
+    return;
+  }
+  if (mode == kModeCoeffs) {
+    for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
+    for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[sg * 16 + 1];
+    return;
   }
 
-  __syncthreads();
+  // ---- lbfgs_optimize (lbfgs.hpp:440-751): wave 0 advances the solver state between evaluations
+  while (true) {
+    if (tid < 64) lbfgs_advance<LV>(D, sm, b, lane, pr);
+    __syncthreads();
+    if (sm.ist[iACTION] == kActDone) break;
+    block_eval<SUR>(D, b, sm, sm.x, sm.g, pr);
+  }
+
   for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
   if (tid == 0) {
+    const double fx = sm.st[sFX];
+    const int ret = sm.ist[iRET];
     D.f_out[b] = fx;
     D.status[b] = ret;
-    D.iters[b] = k;
-    D.evals[b] = evals;
-    D.hist_sum[b] = hist_sum;
+    D.iters[b] = sm.ist[iK];
+    D.evals[b] = sm.ist[iEVALS];
+    D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
     D.ticks[b] = wall_clock64() - tick0;
     // flag_success, traj_optimizer.cpp:176-201
     int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
-    if (fx >= P.fail_cost) ok = 0;
+    if (fx >= D.P.fail_cost) ok = 0;
     D.success[b] = ok;
+    if (pr.on) {
+      for (int i = 0; i < 12; i++) D.prof[(size_t)b * 12 + i] = pr.acc[i];
+    }
   }
 }
 
@@ -750,21 +1188,26 @@ hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------- host launchers
-hipError_t launch_solver(const DevBatch &D, int mode, int threads, hipStream_t stream) {
-  size_t lds = solver_lds_bytes(D.L, D.P, threads);
-  hipError_t e;
-  if (D.sur.S > 0) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solver_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solver_kernel<true>, dim3(D.B), dim3(threads), lds, stream, D, mode);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solver_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(solver_kernel<false>, dim3(D.B), dim3(threads), lds, stream, D, mode);
-  }
+template <bool SUR, int LV, int MAXT>
+static hipError_t launch_variant(const DevBatch *d_dev, int B, int mode, int threads, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solver_kernel<SUR, LV, MAXT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((solver_kernel<SUR, LV, MAXT>), dim3(B), dim3(threads), lds, stream, d_dev, mode);
   return hipGetLastError();
+}
+template <bool SUR>
+static hipError_t launch_lv(int n, const DevBatch *d_dev, int B, int mode, int threads, size_t lds, hipStream_t stream) {
+  if (n <= 16) return launch_variant<SUR, 4, 512>(d_dev, B, mode, threads, lds, stream);
+  if (n <= 32) return launch_variant<SUR, 5, 512>(d_dev, B, mode, threads, lds, stream);
+  return launch_variant<SUR, 6, 512>(d_dev, B, mode, threads, lds, stream);
+}
+
+// d_dev: device copy of the DevBatch `D` describes
+hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, hipStream_t stream) {
+  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.ppt, D.op_in_lds != 0);
+  if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, D.B, mode, threads, lds, stream);
+  return launch_lv<false>(D.L.n, d_dev, D.B, mode, threads, lds, stream);
 }
 
 } // namespace dftpav

@@ -593,8 +593,11 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   if (z_h0 < 1e-4 || (j == 0 && lp == 0) || (lp == N - 1 && j == K)) return; // traj_optimizer.cpp:550-553
 
   const int singul_ = in.singul;
-  const int dir = singul_ > 0 ? 0 : 1;
-  double max_vel = P.max_vel[dir], max_acc = P.max_acc[dir], max_cur = P.max_cur[dir];
+  // limits switch on the gear (traj_optimizer.cpp:448-457); selects keep the constants in scalar registers
+  const bool fwd = singul_ > 0;
+  double max_vel = fwd ? P.max_vel[0] : P.max_vel[1];
+  double max_acc = fwd ? P.max_acc[0] : P.max_acc[1];
+  double max_cur = fwd ? P.max_cur[0] : P.max_cur[1];
   double vel2_reci = 1.0 / (z_h0 * z_h0);
   double vel2_reci_e = 1.0 / (z_h0 * z_h0 + in.epis);
   double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);

@@ -20,7 +20,7 @@
  *     piece, instead of one running += over all points;
  *   - the three cost classes are summed into one running total per point;
  *   - dot products / norms of L-BFGS (Eigen-internal order in the reference,
- *     unpinned): 64-lane strided partials + xor butterfly 32,16,8,4,2,1;
+ *     unpinned): 64-lane strided partials + xor butterfly 1,2,4,8,16,32;
  *   - cos/sin/exp/log: the portable routines of traj_math.h (libm is not
  *     bit-reproducible across host and device).
  * The per-point mathematics is the shared header dftpav_amd/csrc/traj_math.h
@@ -83,10 +83,14 @@ inline int seg_of_piece(const DevLayout &L, int p) {
   return s;
 }
 
-// the kernel's wave_sum: lanes hold v[0..63]; v[i] += v[i ^ o] for o = 32..1
+// the kernel's wave_sum: lanes hold v[0..63]; v[i] += v[i ^ o] for o = 1, 2, 4, 8, 16, 32
+// (quad permutes, row_half_mirror, row_mirror, permlane16_swap, permlane32_swap)
+// The kernel folds only as many levels as the vector needs: 4 / 5 / 6 for n <= 16 / 32 / 64+.
+static thread_local int g_levels = 6;
+inline int levels_for(int n) { return n <= 16 ? 4 : (n <= 32 ? 5 : 6); }
 inline double butterfly_sum(double v[64]) {
   double t[64];
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = 1; o < (1 << g_levels); o <<= 1) {
     for (int i = 0; i < 64; i++) t[i] = v[i] + v[i ^ o];
     std::memcpy(v, t, sizeof(t));
   }
@@ -100,6 +104,12 @@ inline double wave_dot(const double *a, const double *b, int n) {
     for (int e = l; e < n; e += 64) acc += a[e] * b[e];
     v[l] = acc;
   }
+  return butterfly_sum(v);
+}
+// dot inside the two-loop recursion when n <= 64: one element per lane, no leading 0.0 +
+inline double lane_dot(const double *a, const double *b, int n) {
+  double v[64];
+  for (int l = 0; l < 64; l++) v[l] = l < n ? a[l] * b[l] : 0.0;
   return butterfly_sum(v);
 }
 inline double absmax(const double *a, int n) {
@@ -265,7 +275,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
     D.pGdT[p] = ag;
     D.pCost[p] = ac;
   }
-  // ---- E5
+  // ---- E5: four strided partial chains per output (rows q, q+4, ...), combined (p0+p1)+(p2+p3)
   for (int w = 0; w < 2 * L.rhs_tot; w++) {
     int row = w >> 1, d = w & 1;
     int sg = 0;
@@ -275,33 +285,51 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
     const double *MT = &D.opMT[sg][(size_t)col * 6 * N];
     const double *gc = &D.gdC[12 * L.seg_piece0[sg] + d];
     const double *tInv = &D.seg[sg * 16 + 8];
-    double acc = 0.0;
-    for (int p = 0; p < N; p++)
-      for (int k = 0; k < 6; k++) acc += MT[6 * p + k] * (gc[2 * (6 * p + k)] * tInv[k]);
-    D.adj[w] = acc;
+    double part[4];
+    for (int q = 0; q < 4; q++) {
+      double acc = 0.0;
+      for (int r = q; r < 6 * N; r += 4) acc += MT[r] * (gc[2 * r] * tInv[r % 6]);
+      part[q] = acc;
+    }
+    D.adj[w] = (part[0] + part[1]) + (part[2] + part[3]);
   }
-  for (int p = 0; p < L.Ntot; p++) {
-    int sg = seg_of_piece(L, p);
-    const double *tInv = &D.seg[sg * 16 + 8];
-    double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
-    const double *gc = &D.gdC[12 * p];
-    const double *bb = &D.b[12 * p];
-    double acc = 0.0;
-    for (int k = 0; k < 6; k++) acc += gdtInv[k] * (gc[2 * k] * bb[2 * k] + gc[2 * k + 1] * bb[2 * k + 1]);
-    D.pChain[p] = acc;
+  // per-piece chain-rule terms, then every per-segment sum as the kernel takes it: lane l holds
+  // 0.0 + the values of pieces l, l+64, ... of the segment, folded by the full 64-lane butterfly
+  std::vector<double> segsum(L.M * 8, 0.0);
+  {
+    const int saved = g_levels;
+    g_levels = 6;
+    for (int sg = 0; sg < L.M; sg++) {
+      const double *tInv = &D.seg[sg * 16 + 8];
+      double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
+      double lanes[5][64];
+      for (int l = 0; l < 64; l++) {
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+        for (int p = L.seg_piece0[sg] + l; p < L.seg_piece0[sg + 1]; p += 64) {
+          const double *gc = &D.gdC[12 * p];
+          const double *bb = &D.b[12 * p];
+          double acc = 0.0;
+          for (int k = 0; k < 6; k++) acc += gdtInv[k] * (gc[2 * k] * bb[2 * k] + gc[2 * k + 1] * bb[2 * k + 1]);
+          D.pChain[p] = acc;
+          v4 += acc;
+          v0 += D.pE[p];
+          v1 += D.pCost[p];
+          v2 += D.pGsm[p];
+          v3 += D.pGdT[p];
+        }
+        lanes[0][l] = v0; lanes[1][l] = v1; lanes[2][l] = v2; lanes[3][l] = v3; lanes[4][l] = v4;
+      }
+      for (int q = 0; q < 5; q++) segsum[sg * 8 + q] = butterfly_sum(lanes[q]);
+    }
+    g_levels = saved;
   }
   // ---- E6
   double f;
   {
     double sm_cost = 0.0, pen = 0.0, tc = 0.0;
     for (int sg = 0; sg < L.M; sg++) {
-      double en = 0.0, pc = 0.0;
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) {
-        en += D.pE[p];
-        pc += D.pCost[p];
-      }
-      sm_cost += en;
-      pen += pc;
+      sm_cost += segsum[sg * 8 + 0];
+      pen += segsum[sg * 8 + 1];
       tc += D.seg[sg * 16] * P.wei_time;
     }
     f = sm_cost + tc + pen;
@@ -324,8 +352,8 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
       const double *seg = &D.seg[sg * 16];
       double dt = seg[1];
       double gdT = 0.0;
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) gdT += D.pGsm[p];
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) gdT += D.pGdT[p];
+      gdT += segsum[sg * 8 + 2];
+      gdT += segsum[sg * 8 + 3];
       const double *ad = &D.adj[2 * L.seg_rhs0[sg]];
       double hv[2], tv[2];
       if (sg > 0) {
@@ -349,7 +377,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
       gdT += (iniS[sg * 6 + 4] * ad[2 * 2] + iniS[sg * 6 + 5] * ad[2 * 2 + 1]) * 2.0 * dt;
       gdT += tv[0] * ad[2 * (rt + 1)] + tv[1] * ad[2 * (rt + 1) + 1];
       gdT += (finS[sg * 6 + 4] * ad[2 * (rt + 2)] + finS[sg * 6 + 5] * ad[2 * (rt + 2) + 1]) * 2.0 * dt;
-      for (int p = L.seg_piece0[sg]; p < L.seg_piece0[sg + 1]; p++) gdT += D.pChain[p];
+      gdT += segsum[sg * 8 + 4];
       g[e] = (gdT / N + P.wei_time) * virtual_to_real_grad(x[e]);
     } else if (e < L.x_ang0) {
       int q = e - L.x_gear0;
@@ -473,6 +501,7 @@ extern "C" void oracle_dev_free(oracle_ctx *c) {
 }
 
 extern "C" double oracle_dev_eval(oracle_ctx *c, const double *x, double *g) {
+  g_levels = levels_for(static_cast<DevState *>(c->dev)->L.n);
   return dev_eval(c, *static_cast<DevState *>(c->dev), x, g);
 }
 
@@ -488,6 +517,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   DevState &D = *static_cast<DevState *>(c->dev);
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size;
+  g_levels = levels_for(n);
   std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), alpha_h(m, 0.0);
   std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
   double pf[8];
@@ -632,7 +662,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
         for (int i = 0; i < bound; ++i) {
           j = (j + m - 1) % m;
           const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-          double a = wave_dot(sj, d.data(), n) / ys_h[j];
+          double a = (n <= 64 ? lane_dot(sj, d.data(), n) : wave_dot(sj, d.data(), n)) / ys_h[j];
           alpha_h[j] = a;
           double na = -a;
           for (int e = 0; e < n; e++) d[e] += na * yj[e];
@@ -641,7 +671,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
         for (int e = 0; e < n; e++) d[e] *= sc0;
         for (int i = 0; i < bound; ++i) {
           const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-          double beta = wave_dot(yj, d.data(), n) / ys_h[j];
+          double beta = (n <= 64 ? lane_dot(yj, d.data(), n) : wave_dot(yj, d.data(), n)) / ys_h[j];
           double cf = alpha_h[j] - beta;
           for (int e = 0; e < n; e++) d[e] += cf * sj[e];
           j = (j + 1) % m;

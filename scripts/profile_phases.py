@@ -1,0 +1,34 @@
+"""Developer script: in-kernel phase breakdown of the solve kernel (shader clocks of thread 0)."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from dftpav_amd import capi, scenarios as sc
+
+NAMES = ["E1 rhs", "E2 coeffs", "E3+E4 samples", "E4 reduce", "E5 adjoint", "E6 assemble", "line search misc",
+         "history update", "two-loop", "-", "init", "-"]
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+p = capi.default_params()
+s = sc.baseline_config(cfg, B=B); s.apply_resolution(p)
+h = capi.Handle(p); h.set_surround(s.surround)
+bt = capi.Batch(h, s.layout, B); bt.upload(s)
+bt.solve_async(); bt.sync()
+ms0 = []
+for _ in range(3):
+    bt.solve_async(); bt.sync(); ms0.append(bt.last_solve_ms())
+bt.profile(True)
+bt.solve_async(); bt.sync(); ms1 = bt.last_solve_ms()
+r = bt.results()
+pr = bt.read_profile().astype(np.float64)
+tot = pr.sum(axis=1)
+print("cfg", cfg, "B", B, "kernel ms (no prof)", np.round(ms0, 3), "with prof", round(ms1, 3))
+print("iters mean/max", r["iters"].mean(), r["iters"].max(), "evals mean/max", r["evals"].mean(), r["evals"].max(),
+      "latency ms p50/max", np.median(r["latency_us"]) / 1e3, r["latency_us"].max() / 1e3)
+ghz = tot / (r["latency_us"] * 1e3)
+print("shader clock GHz (cycles/latency):", round(float(np.median(ghz)), 3))
+ev, it = r["evals"].astype(float), r["iters"].astype(float)
+for i, nm in enumerate(NAMES):
+    if nm == "-": continue
+    per = pr[:, i] / (ev if i < 6 else it)
+    print("%-18s %6.1f%%   %9.0f cycles per %s" % (nm, 100 * pr[:, i].sum() / tot.sum(), np.median(per), "eval" if i < 6 else "iter"))
+print("solves/s (kernel)", B / (np.mean(ms0) * 1e-3))
