@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -43,7 +44,7 @@ struct dftpav_batch {
   DevLayout L{};
   DevParams P{};
   int threads = 0;
-  bool op_in_lds = false;
+  bool op_in_lds = false, cor_in_lds = false;
   int ppt = 1;
   int NptsPad = 0;
   std::vector<double> x0_host;
@@ -53,7 +54,8 @@ struct dftpav_batch {
   double *d_x0 = nullptr, *d_iniS = nullptr, *d_finS = nullptr, *d_corridor = nullptr;
   int16_t *d_pt_piece = nullptr, *d_pt_j = nullptr;
   double *d_opM[kMaxSeg] = {nullptr}, *d_opMT[kMaxSeg] = {nullptr};
-  double *d_histS = nullptr, *d_histY = nullptr;
+  double *d_histS = nullptr, *d_histY = nullptr, *d_histST = nullptr, *d_histYT = nullptr, *d_histGc = nullptr,
+         *d_histGr = nullptr;
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
@@ -284,7 +286,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->h->device);
   (void)hipStreamSynchronize(b->h->stream);
-  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY,
+  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY, b->d_histST, b->d_histYT, b->d_histGc, b->d_histGr,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt};
   for (void *p : ptrs)
@@ -347,11 +349,28 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     return DFTPAV_E_UNSUPPORTED;
   }
   fill_dev_params(p, b->P);
-  b->threads = solver_threads(L);
-  b->ppt = solver_ppt(L, b->threads);
-  b->op_in_lds = solver_ops_in_lds(L, b->P, b->threads, b->ppt);
-  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds) + 64;
-  if (lds > 160 * 1024) {
+  // Residency plan.  Few trajectories (<= one per CU): latency shape, operators and the corridor
+  // staged in LDS.  Many: throughput shape, LDS kept small so that two workgroups share a CU.
+  {
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    bool throughput = B > n_cu;
+    if (const char *e = std::getenv("DFTPAV_MODE")) throughput = std::atoi(e) != 0; // 0 latency, 1 throughput
+    b->threads = solver_threads(L, throughput);
+    if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
+    b->ppt = solver_ppt(L, b->threads);
+    const size_t budget = throughput ? 78 * 1024 : 158 * 1024; // two workgroups per CU vs the whole LDS
+    b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, true, false) + 64 <= budget;
+    b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds, true) + 64 <= budget;
+    if (const char *e = std::getenv("DFTPAV_LDS")) { // bit 0 operators, bit 1 corridor
+      int v = std::atoi(e);
+      b->op_in_lds = (v & 1) != 0;
+      b->cor_in_lds = (v & 2) != 0;
+    }
+  }
+  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds, b->cor_in_lds) + 64;
+  if (lds > 160 * 1024 || b->threads < 64 || b->threads > 512 || b->threads % 64) {
     delete b;
     return DFTPAV_E_UNSUPPORTED;
   }
@@ -378,6 +397,17 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_pt_j, sizeof(int16_t) * L.Npts));
   BCHK(hipMalloc(&b->d_histS, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
   BCHK(hipMalloc(&b->d_histY, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMalloc(&b->d_histST, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
+  BCHK(hipMalloc(&b->d_histYT, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
+  BCHK(hipMalloc(&b->d_histGc, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
+  BCHK(hipMalloc(&b->d_histGr, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
+  // never-written slots are read (and discarded) by the unconditional block loads: keep them finite
+  BCHK(hipMemset(b->d_histS, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMemset(b->d_histY, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMemset(b->d_histST, 0, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
+  BCHK(hipMemset(b->d_histYT, 0, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
+  BCHK(hipMemset(b->d_histGc, 0, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
+  BCHK(hipMemset(b->d_histGr, 0, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
   BCHK(hipMalloc(&b->d_x_in, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_x_out, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_f, sizeof(double) * (size_t)B));
@@ -521,6 +551,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.pt_piece = b->d_pt_piece;
   D.pt_j = b->d_pt_j;
   D.op_in_lds = b->op_in_lds ? 1 : 0;
+  D.cor_in_lds = b->cor_in_lds ? 1 : 0;
   D.ppt = b->ppt;
   int off = 0;
   for (int i = 0; i < kMaxSeg; i++) {
@@ -540,6 +571,10 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.epis = b->epis;
   D.histS = b->d_histS;
   D.histY = b->d_histY;
+  D.histST = b->d_histST;
+  D.histYT = b->d_histYT;
+  D.histGc = b->d_histGc;
+  D.histGr = b->d_histGr;
   D.x_in = b->d_x_in;
   D.x_out = b->d_x_out;
   D.f_out = b->d_f;

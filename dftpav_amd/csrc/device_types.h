@@ -61,12 +61,15 @@ struct DevBatch {
   const double *opM[kMaxSeg];  // A_N^{-1} restricted to the N+5 non-zero RHS rows, [6N][N+5] row-major
   const double *opMT[kMaxSeg]; // its transpose [N+5][6N]
   int op_in_lds;               // operators are staged in LDS at kernel start
+  int cor_in_lds;              // the trajectory's half-planes are staged in LDS at kernel start
   int ppt;                     // constraint points per thread and chunk (chunk = ppt * blockDim)
   int op_off[kMaxSeg];         // offset (doubles) of each segment's operator inside the LDS copy
   DevSurround sur;
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
-  double *histS, *histY; // [B][mem][npad]
+  double *histS, *histY;   // [B][mem][npad]
+  double *histST, *histYT; // [B][64][mem] element-major copies (n <= 64)
+  double *histGc, *histGr; // [B][mem][32] in-block Gram entries s_j.y_i, by column and by row
   // in/out
   const double *x_in; // eval mode: [B][n]
   double *x_out;      // [B][n]
@@ -83,12 +86,10 @@ struct DevBatch {
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };
 
 // size in bytes of the dynamic LDS a launch needs
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds);
-// whether the MINCO operators fit next to the working set
-bool solver_ops_in_lds(const DevLayout &L, const DevParams &P, int threads, int ppt);
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds, bool cor_lds);
 // constraint points each thread handles per chunk
 int solver_ppt(const DevLayout &L, int threads);
-// picks the workgroup size for a layout
-int solver_threads(const DevLayout &L);
+// picks the workgroup size for a layout (throughput: more than one trajectory per CU)
+int solver_threads(const DevLayout &L, bool throughput);
 
 } // namespace dftpav

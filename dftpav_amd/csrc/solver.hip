@@ -51,6 +51,7 @@ struct Smem {
   double *st;     // [sNUM] scalar solver state
   double *segsum; // [M][8] per-segment sums: 0 jerk energy, 1 penalty cost, 2 d(jerk)/dT, 3 penalty gdT, 4 chain-rule gdT
   double *opM, *opMT; // operators of all segments back to back (only when D.op_in_lds)
+  double *cor;        // [4H][NptsPad] half-planes of this trajectory (only when D.cor_in_lds)
   int *ist;     // [iNUM]
   int *ptinfo;  // [Npts] piece | j<<16
   int *pcinfo;  // [Ntot][8] pt0, K, tab, segment, lp, N, singul, operator offset
@@ -67,7 +68,7 @@ __host__ __device__ inline int chunk_points(const DevLayout &L, int T, int ppt) 
   return c < L.Npts ? c : ((L.Npts + 63) / 64) * 64;
 }
 
-__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T, int ppt, bool op_lds) {
+__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T, int ppt, bool op_lds, bool cor_lds) {
   size_t n = 0;
   n += 5 * (size_t)L.npad;
   n += (size_t)L.M * 16;
@@ -81,28 +82,32 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   n += sNUM;
   n += (size_t)L.M * 8;
   if (op_lds) n += 2 * op_doubles(L);
+  if (cor_lds) n += (size_t)4 * L.H * (((size_t)L.Npts + 63) / 64 * 64);
   return n;
 }
 __host__ __device__ inline size_t smem_ints(const DevLayout &L) {
   return iNUM + (size_t)L.Npts + 8 * (size_t)L.Ntot + 4 * (size_t)L.rhs_tot;
 }
 
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds) {
-  return smem_doubles(L, P.mem_size, threads, ppt, op_lds) * sizeof(double) + smem_ints(L) * sizeof(int);
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds, bool cor_lds) {
+  return smem_doubles(L, P.mem_size, threads, ppt, op_lds, cor_lds) * sizeof(double) + smem_ints(L) * sizeof(int);
 }
 
-bool solver_ops_in_lds(const DevLayout &L, const DevParams &P, int threads, int ppt) {
-  return solver_lds_bytes(L, P, threads, ppt, true) <= 100 * 1024;
-}
-
-int solver_threads(const DevLayout &L) {
-  // at most 8 waves (two per SIMD: the full 256-VGPR budget), two constraint points per thread
-  // when there are more points than that; never fewer threads than the reduction stages use
-  int T = ((L.Npts + 1) / 2 + kWave - 1) / kWave * kWave;
-  int need = 16 * L.Ntot; // 16 threads per piece
-  if (T < need) T = (need + kWave - 1) / kWave * kWave;
-  int need5 = ((8 * L.rhs_tot + 63) / 64) * 64 + 128; // adjoint stage: 4 lanes per output + two summing waves
-  if (T < need5) T = need5;
+int solver_threads(const DevLayout &L, bool throughput) {
+  // Every stage is a strided loop, so any multiple of 64 works; the choice trades latency of one
+  // solve against how many trajectories a CU holds (256 VGPRs per lane => 8 waves per CU).
+  //   latency    : two constraint points per thread, at most 8 waves (batches that leave CUs idle)
+  //   throughput : three waves per trajectory, two workgroups resident per CU
+  int T;
+  if (throughput) {
+    T = 192;
+    if (L.Npts <= 128) T = 128;
+  } else {
+    T = ((L.Npts + 1) / 2 + kWave - 1) / kWave * kWave;
+    int need = 16 * L.Ntot; // the reduction stages like 16 threads per piece
+    if (need > 512) need = 512;
+    if (T < need) T = (need + kWave - 1) / kWave * kWave;
+  }
   if (T < 128) T = 128;
   if (T > 512) T = 512;
   return T;
@@ -115,7 +120,7 @@ int solver_ppt(const DevLayout &L, int threads) {
   return ppt;
 }
 
-__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int ppt, bool op_lds) {
+__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int ppt, bool op_lds, bool cor_lds) {
   double *p = base;
   s.x = p; p += L.npad;
   s.xp = p; p += L.npad;
@@ -146,6 +151,8 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
     s.opMT = p + nop;
     p += 2 * nop;
   }
+  s.cor = p;
+  if (cor_lds) p += (size_t)4 * L.H * ((L.Npts + 63) / 64 * 64);
   s.ist = reinterpret_cast<int *>(p);
   s.ptinfo = s.ist + iNUM;
   s.pcinfo = s.ptinfo + L.Npts;
@@ -184,7 +191,7 @@ __device__ inline void swap32(double v, double &x, double &y) {
   y = __hiloint2double(b[1], a[1]);
 }
 template <int LV>
-__device__ inline double wave_sum(double v) {
+__device__ inline double wave_sum_raw(double v) {
   double x, y;
   v += mov_dpp<0xB1>(v);  // quad_perm [1,0,3,2]
   v += mov_dpp<0x4E>(v);  // quad_perm [2,3,0,1]
@@ -201,7 +208,7 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 template <int LV>
-__device__ inline double wave_max(double v) {
+__device__ inline double wave_max_raw(double v) {
   double x, y;
   v = fmax(v, mov_dpp<0xB1>(v));
   v = fmax(v, mov_dpp<0x4E>(v));
@@ -216,6 +223,23 @@ __device__ inline double wave_max(double v) {
     v = fmax(x, y);
   }
   return v;
+}
+
+// The trimmed butterflies leave lanes beyond 2^LV with partial results; every use in the solver
+// logic wants one value for the whole wave (the lanes also take branches on it), so lane 0's
+// result is broadcast.
+__device__ inline double first_lane_f64(double v) {
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int LV>
+__device__ inline double wave_sum(double v) {
+  return first_lane_f64(wave_sum_raw<LV>(v));
+}
+template <int LV>
+__device__ inline double wave_max(double v) {
+  return first_lane_f64(wave_max_raw<LV>(v));
 }
 
 // a / b from the correctly rounded reciprocal y = 1/b (Markstein): q0 = a*y,
@@ -434,7 +458,10 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
         in.t_now = D.t_now;
         const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad + pt;
-        if (L.H <= 4) {
+        if (D.cor_in_lds) {
+          GlobalPlanes pl{sm.cor + pt, (size_t)((Npts + 63) / 64 * 64)};
+          sample_point_math<SUR>(P, D.sur, in, pl, o);
+        } else if (L.H <= 4) {
           double cor[16]; // all half-plane loads issued up front, consumed after the state evaluation
 #pragma unroll
           for (int k = 0; k < 16; k++) cor[k] = (k < 4 * L.H) ? cb[(size_t)k * D.NptsPad] : 0.0;
@@ -680,76 +707,149 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
 // no divergent region, so the loads stay in flight instead of being waited on
 // at a branch join; slot indices advance with wrap-around (no integer division).
 typedef const double __attribute__((address_space(1))) *gptr_t; // global (not flat) loads: vmcnt only
+typedef double __attribute__((address_space(1))) *gwptr_t;
 
-template <int LV, int PF>
-__device__ __forceinline__ double two_loop_lane(const Smem &sm, const double *hS_, const double *hY_, int npad, int n, int m,
-                                                int nb, int ne, double ys_new, double yy_new, int lane, double dreg) {
-  gptr_t hS = (gptr_t)hS_;
-  gptr_t hY = (gptr_t)hY_;
+__device__ inline double readlane_f64(double v, int srclane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
+// Per-trajectory L-BFGS history in global memory (lm_s, lm_y of lbfgs.hpp:512-513 plus what the
+// blocked recursion needs):
+//   S, Y   [m][npad]  row per slot           -> axpy passes, lanes over elements
+//   ST, YT [64][m]    element-major          -> block dot products, lanes over slots
+//   Gc     [m][32]    Gc[i][j&31] = s_j.y_i for the slots j below i in i's 32-block (read by lanes j)
+//   Gr     [m][32]    Gr[j][i&31] = s_j.y_i, the same numbers laid out for lanes i above j
+struct Hist {
+  gwptr_t S, Y, ST, YT, Gc, Gr;
+};
+__device__ inline Hist hist_of(const DevBatch &D, int b, int m, int npad) {
+  Hist h;
+  h.S = (gwptr_t)(D.histS + (size_t)b * m * npad);
+  h.Y = (gwptr_t)(D.histY + (size_t)b * m * npad);
+  h.ST = (gwptr_t)(D.histST + (size_t)b * 64 * m);
+  h.YT = (gwptr_t)(D.histYT + (size_t)b * 64 * m);
+  h.Gc = (gwptr_t)(D.histGc + (size_t)b * m * 32);
+  h.Gr = (gwptr_t)(D.histGr + (size_t)b * m * 32);
+  return h;
+}
+
+// acc = sum_e col[e*m] * v[e], e ascending from 0.0 (one lane per history slot).  The column is
+// fetched 16 elements at a time into registers before any of them is consumed, so the loads of a
+// batch overlap instead of each being waited on by the dependent add chain.
+__device__ __forceinline__ double column_dot(gwptr_t col, int m, const double *v, int n) {
+  double acc = 0.0;
+  for (int e0 = 0; e0 < n; e0 += 16) {
+    double cv[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      int e = e0 + u < n ? e0 + u : n - 1;
+      cv[u] = col[(size_t)e * m];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (e0 + u < n) acc += cv[u] * v[e0 + u];
+  }
+  return acc;
+}
+
+// Two-loop recursion (lbfgs.hpp:716-739) for n <= 64 in blocks of 32 history slots.
+// Within a block, s_j . q_current is formed as s_j . q_blockstart (one lane per slot, sequential
+// over the elements) minus alpha_i (s_j . y_i) for the newer slots i of the block, using the
+// in-block Gram entries written when slot i was stored; the direction itself then receives the
+// reference's axpys in the reference's order.  The dependent chain per slot is
+// {3-instruction exact division, v_readlane broadcast, multiply, subtract} instead of
+// {multiply, 5-level cross-lane reduction, division, multiply, add}.  The second loop mirrors it
+// with y_j . r.  oracle/dftpav_oracle_dev.cpp::blocked_two_loop is the same program on the host.
+template <int LV>
+__device__ __forceinline__ double two_loop_blocked(const Smem &sm, const Hist &H, int npad, int n, int m, int nb, int ne,
+                                                   double ys_new, double yy_new, int lane, double dreg) {
   const bool act = lane < n;
   const int ln = act ? lane : 0;
-  // raw loaded values stay untouched in the ring until their step (the lane mask is applied at
-  // the point of use), so nothing forces a wait on a load right after it was issued
-  double sreg[PF], yreg[PF], vys[PF], vri[PF], val[PF];
-  // ---- first loop: newest -> oldest (slot ne-1, ne-2, ...)
-  int jl = ne; // slot the ring was last loaded for
+  const int l32 = lane & 31;
+  nb = __builtin_amdgcn_readfirstlane(nb);
+  ne = __builtin_amdgcn_readfirstlane(ne);
+  // ---- first loop: newest -> oldest, one segment [seg_lo, cur) per 32-block
+  int remaining = nb, cur = ne == 0 ? m : ne;
+  while (remaining > 0) {
+    const int lo = ((cur - 1) >> 5) << 5;
+    const int seg_lo = cur - remaining > lo ? cur - remaining : lo;
+    const int la = seg_lo - lo, lb = cur - 1 - lo; // local slot range of the segment
+    // every load of the block is issued here, before anything consumes one: in-block Gram columns
+    // (lanes <-> slots), the y rows of the axpy pass (lanes <-> elements), then the element-major
+    // columns of the dot products
+    double g[32], row[32];
 #pragma unroll
-  for (int q = 0; q < PF; q++) {
-    jl = jl == 0 ? m - 1 : jl - 1;
-    sreg[q] = hS[(size_t)jl * npad + ln];
-    yreg[q] = hY[(size_t)jl * npad + ln];
-    vys[q] = sm.ys[jl];
-    vri[q] = sm.rinv[jl];
-  }
-  int j = ne;
-  for (int i0 = 0; i0 < nb; i0 += PF) {
+    for (int i = 0; i < 32; i++) g[i] = H.Gc[(size_t)(lo + i) * 32 + l32];
 #pragma unroll
-    for (int q = 0; q < PF; q++) {
-      if (i0 + q < nb) {
-        j = j == 0 ? m - 1 : j - 1;
-        double sv = act ? sreg[q] : 0.0, yv = act ? yreg[q] : 0.0;
-        double acc = wave_sum<LV>(sv * dreg);
-        double a = div_by_rcp(acc, vys[q], vri[q]); // lm_s.col(j).dot(d) / lm_ys(j)
-        if (lane == 0) sm.alpha[j] = a;
-        double na = -a;
-        dreg += na * yv;
-        jl = jl == 0 ? m - 1 : jl - 1;
-        sreg[q] = hS[(size_t)jl * npad + ln];
-        yreg[q] = hY[(size_t)jl * npad + ln];
-        vys[q] = sm.ys[jl];
-        vri[q] = sm.rinv[jl];
+    for (int i = 0; i < 32; i++) row[i] = H.Y[(size_t)(lo + i) * npad + ln];
+    const double ysl = sm.ys[lo + l32], ril = sm.rinv[lo + l32];
+    if (act) sm.d[lane] = dreg; // the direction at block start, for broadcast reads
+    double acc = column_dot(H.ST + lo + l32, m, sm.d, n);
+    double myalpha = 0.0;
+#pragma unroll
+    for (int i = 31; i >= 0; i--) {
+      if (i >= la && i <= lb) {
+        double a = div_by_rcp(acc, ysl, ril); // lm_s.col(j).dot(d) / lm_ys(j)
+        double ai = readlane_f64(a, i);
+        myalpha = lane == i ? a : myalpha;
+        double t = ai * g[i];
+        acc = (lane >= la && lane < i) ? acc - t : acc;
       }
     }
+    if (lane >= la && lane <= lb) sm.alpha[lo + lane] = myalpha;
+    // the axpys of the reference, d += (-alpha_i) y_i, newest first
+#pragma unroll
+    for (int i = 31; i >= 0; i--) {
+      if (i >= la && i <= lb) {
+        double na = -readlane_f64(myalpha, i);
+        dreg = act ? dreg + na * row[i] : dreg;
+      }
+    }
+    remaining -= cur - seg_lo;
+    cur = seg_lo == 0 ? m : seg_lo;
   }
   dreg *= ys_new / yy_new;
-  // ---- second loop: oldest -> newest, starting at the slot the first loop ended on
-  jl = j;
+  // ---- second loop: oldest -> newest, one segment [cur, seg_hi) per 32-block
+  remaining = nb;
+  cur = ne - nb;
+  if (cur < 0) cur += m;
+  while (remaining > 0) {
+    const int lo = (cur >> 5) << 5;
+    const int hi = lo + 32 < m ? lo + 32 : m;
+    const int seg_hi = cur + remaining < hi ? cur + remaining : hi;
+    const int la = cur - lo, lb = seg_hi - 1 - lo;
+    double g[32], row[32];
 #pragma unroll
-  for (int q = 0; q < PF; q++) {
-    sreg[q] = hS[(size_t)jl * npad + ln];
-    yreg[q] = hY[(size_t)jl * npad + ln];
-    vys[q] = sm.ys[jl];
-    vri[q] = sm.rinv[jl];
-    val[q] = sm.alpha[jl];
-    jl = jl == m - 1 ? 0 : jl + 1;
-  }
-  for (int i0 = 0; i0 < nb; i0 += PF) {
+    for (int i = 0; i < 32; i++) g[i] = H.Gr[(size_t)(lo + i) * 32 + l32];
 #pragma unroll
-    for (int q = 0; q < PF; q++) {
-      if (i0 + q < nb) {
-        double sv = act ? sreg[q] : 0.0, yv = act ? yreg[q] : 0.0;
-        double acc = wave_sum<LV>(yv * dreg);
-        double beta = div_by_rcp(acc, vys[q], vri[q]); // lm_y.col(j).dot(d) / lm_ys(j)
-        double cf = val[q] - beta;
-        dreg += cf * sv;
-        sreg[q] = hS[(size_t)jl * npad + ln];
-        yreg[q] = hY[(size_t)jl * npad + ln];
-        vys[q] = sm.ys[jl];
-        vri[q] = sm.rinv[jl];
-        val[q] = sm.alpha[jl];
-        jl = jl == m - 1 ? 0 : jl + 1;
+    for (int i = 0; i < 32; i++) row[i] = H.S[(size_t)(lo + i) * npad + ln];
+    const double ysl = sm.ys[lo + l32], ril = sm.rinv[lo + l32];
+    const double myalpha = sm.alpha[lo + l32];
+    if (act) sm.d[lane] = dreg;
+    double acc = column_dot(H.YT + lo + l32, m, sm.d, n);
+    double mycf = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      if (i >= la && i <= lb) {
+        double beta = div_by_rcp(acc, ysl, ril); // lm_y.col(j).dot(d) / lm_ys(j)
+        double cf = myalpha - beta;
+        double ci = readlane_f64(cf, i);
+        mycf = lane == i ? cf : mycf;
+        double t = ci * g[i];
+        acc = (lane > i && lane <= lb) ? acc + t : acc;
       }
     }
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      if (i >= la && i <= lb) {
+        double cf = readlane_f64(mycf, i);
+        dreg = act ? dreg + cf * row[i] : dreg;
+      }
+    }
+    remaining -= seg_hi - cur;
+    cur = seg_hi == m ? 0 : seg_hi;
   }
   return dreg;
 }
@@ -973,18 +1073,21 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
   pr.tick(kPLS);
 
   // ---- history update + two-loop recursion (lbfgs.hpp:676-740)
-  double *hS = D.histS + (size_t)b * m * npad;
-  double *hY = D.histY + (size_t)b * m * npad;
+  const Hist H = hist_of(D, b, m, npad);
   const int end = sm.ist[iEND];
   int bound = sm.ist[iBOUND];
   {
-    double *sc = hS + (size_t)end * npad, *yc = hY + (size_t)end * npad;
     double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
     for (int e = lane; e < n; e += 64) {
       double sv = sm.x[e] - sm.xp[e];
       double yv = sm.g[e] - sm.gp[e];
-      sc[e] = sv;
-      yc[e] = yv;
+      H.S[(size_t)end * npad + e] = sv;
+      H.Y[(size_t)end * npad + e] = yv;
+      if (n <= 64) {
+        H.ST[(size_t)e * m + end] = sv;
+        H.YT[(size_t)e * m + end] = yv;
+        sm.xp[e] = yv; // xp is dead until the next iteration starts: broadcast copy of y for the Gram entries
+      }
       ys += yv * sv;
       yy += yv * yv;
       ss += sv * sv;
@@ -1007,15 +1110,25 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       bound = m < bound ? m : bound;
       int ne = end + 1 == m ? 0 : end + 1;
       if (n <= 64) {
-        // the newest column was written by these same lanes: program order makes it visible to them
+        // in-block Gram entries of the new slot: s_j . y_new for the slots j below it in its 32-block
+        {
+          const int lo = (end >> 5) << 5, il = end - lo;
+          const int l32 = lane & 31;
+          double acc = column_dot(H.ST + lo + l32, m, sm.xp, n);
+          if (lane < il) {
+            H.Gc[(size_t)end * 32 + lane] = acc;
+            H.Gr[(size_t)(lo + lane) * 32 + il] = acc;
+          }
+        }
+        // columns written above by these same lanes are read back below in program order
         double dreg = lane < n ? sm.d[lane] : 0.0;
-        dreg = two_loop_lane<LV, 8>(sm, hS, hY, npad, n, m, bound, ne, ys, yy, lane, dreg);
+        dreg = two_loop_blocked<LV>(sm, H, npad, n, m, bound, ne, ys, yy, lane, dreg);
         if (lane < n) sm.d[lane] = dreg;
       } else {
         int j = ne;
         for (int i = 0; i < bound; ++i) {
           j = j == 0 ? m - 1 : j - 1;
-          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
+          gptr_t sj = H.S + (size_t)j * npad, yj = H.Y + (size_t)j * npad;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += sj[e] * sm.d[e];
           acc = wave_sum<LV>(acc);
@@ -1027,7 +1140,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         double sc0 = ys / yy;
         for (int e = lane; e < n; e += 64) sm.d[e] *= sc0;
         for (int i = 0; i < bound; ++i) {
-          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
+          gptr_t sj = H.S + (size_t)j * npad, yj = H.Y + (size_t)j * npad;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += yj[e] * sm.d[e];
           acc = wave_sum<LV>(acc);
@@ -1066,7 +1179,7 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   const int lane = tid & 63;
   const int n = L.n;
   Smem sm;
-  carve(sm, lds_raw, L, D.P.mem_size, T, D.ppt, D.op_in_lds != 0);
+  carve(sm, lds_raw, L, D.P.mem_size, T, D.ppt, D.op_in_lds != 0, D.cor_in_lds != 0);
   const long long tick0 = wall_clock64();
   Prof pr;
   pr.start(D.prof != nullptr && mode == kModeSolve);
@@ -1125,6 +1238,12 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
       }
       off += cnt;
     }
+  }
+  if (D.cor_in_lds) { // the only read of the corridor from HBM: it stays in LDS for the whole solve
+    const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad;
+    const int pitch = (L.Npts + 63) / 64 * 64;
+    for (int k = 0; k < 4 * L.H; k++)
+      for (int pt = tid; pt < L.Npts; pt += T) sm.cor[k * pitch + pt] = cb[(size_t)k * D.NptsPad + pt];
   }
   if (tid < iNUM) sm.ist[tid] = 0;
   __syncthreads();
@@ -1205,7 +1324,7 @@ static hipError_t launch_lv(int n, const DevBatch *d_dev, int B, int mode, int t
 
 // d_dev: device copy of the DevBatch `D` describes
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, hipStream_t stream) {
-  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.ppt, D.op_in_lds != 0);
+  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.ppt, D.op_in_lds != 0, D.cor_in_lds != 0);
   if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, D.B, mode, threads, lds, stream);
   return launch_lv<false>(D.L.n, d_dev, D.B, mode, threads, lds, stream);
 }

@@ -569,10 +569,9 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double beta0[6] = {1.0, s1, s2, s3, s4, s5};
   double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
   double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
-  double beta3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
   double alpha = 1.0 / K * j;
   const double *cc = in.cc;
-  double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0}, dddsigma[2] = {0, 0};
+  double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0};
   for (int k = 0; k < 6; k++) {
     double c0 = cc[2 * k], c1 = cc[2 * k + 1];
     sigma[0] += c0 * beta0[k];
@@ -581,16 +580,15 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     dsigma[1] += c1 * beta1[k];
     ddsigma[0] += c0 * beta2[k];
     ddsigma[1] += c1 * beta2[k];
-    dddsigma[0] += c0 * beta3[k];
-    dddsigma[1] += c1 * beta3[k];
   }
   double omg = (j == 0 || j == K) ? 0.5 : 1.0;
   double z_h0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
   double z_h1 = ddsigma[0] * dsigma[0] + ddsigma[1] * dsigma[1];
-  double z_h2 = dddsigma[0] * dsigma[0] + dddsigma[1] * dsigma[1];
   double z_h3 = ddsigma[1] * dsigma[0] + (-ddsigma[0]) * dsigma[1];
-  double z1 = dddsigma[1] * dsigma[0] + (-dddsigma[0]) * dsigma[1];
   if (z_h0 < 1e-4 || (j == 0 && lp == 0) || (lp == N - 1 && j == K)) return; // traj_optimizer.cpp:550-553
+  // sigma''' (traj_optimizer.cpp:508,519) only enters the gradients of the acceleration and curvature
+  // penalties; its value does not depend on when it is evaluated, so it is formed only where one is active
+  const double beta3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
 
   const int singul_ = in.singul;
   // limits switch on the gear (traj_optimizer.cpp:448-457); selects keep the constants in scalar registers
@@ -599,7 +597,9 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double max_acc = fwd ? P.max_acc[0] : P.max_acc[1];
   double max_cur = fwd ? P.max_cur[0] : P.max_cur[1];
   double vel2_reci = 1.0 / (z_h0 * z_h0);
-  double vel2_reci_e = 1.0 / (z_h0 * z_h0 + in.epis);
+  // z^2 + 0.0 == z^2 exactly, so with help_eps == 0 (the live value, traj_manager.cpp:610) the second
+  // reciprocal is the first one
+  double vel2_reci_e = in.epis == 0.0 ? vel2_reci : 1.0 / (z_h0 * z_h0 + in.epis);
   double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);
   z_h0 = 1.0 / z_h0;
   double z_h4 = z_h1 * vel2_reci;
@@ -620,23 +620,33 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double A[2] = {0, 0}, Bv[2] = {0, 0}, Cv[2] = {0, 0}, gdT = 0.0, cost = 0.0;
 
   // ---- safe corridor, traj_optimizer.cpp:592-622 (5 footprint entries, vertex 0 repeated)
+  // The body point of a vertex does not depend on the half-plane, and entry 4 of vec_le_ is entry 0
+  // again (traj_optimizer.cpp:1772-1773): the four distinct body points are formed once and the
+  // contribution of vertex 0 is accumulated a second time, in the order of the reference.
+  double Rle[4][2], bpt[4][2];
+  for (int v = 0; v < 4; v++) {
+    const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
+    Rle[v][0] = ego_R[0] * le0 + ego_R[1] * le1;
+    Rle[v][1] = ego_R[2] * le0 + ego_R[3] * le1;
+    bpt[v][0] = sigma[0] + Rle[v][0];
+    bpt[v][1] = sigma[1] + Rle[v][1];
+  }
   for (int k = 0; k < in.H; k++) {
     double on0, on1, q0, q1;
     plane(k, on0, on1, q0, q1);
-    for (int v = 0; v < 5; v++) {
-      const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
-      double Rle[2] = {ego_R[0] * le0 + ego_R[1] * le1, ego_R[2] * le0 + ego_R[3] * le1};
-      double bpt[2] = {sigma[0] + Rle[0], sigma[1] + Rle[1]};
-      double violaPos = on0 * (bpt[0] - q0) + on1 * (bpt[1] - q1);
+    for (int vv = 0; vv < 5; vv++) {
+      const int v = vv == 4 ? 0 : vv;
+      double violaPos = on0 * (bpt[v][0] - q0) + on1 * (bpt[v][1] - q1);
       if (violaPos > 0) {
+        const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
         double pena, penaD;
         smoothed_l1(violaPos, pena, penaD);
         double tl[4] = {le0, -le1, le1, le0};
         double Mm[4];
-        Mm[0] = singul_ * tl[0] * z_h0 - Rle[0] * dsigma[0] * vel2_reci;
-        Mm[1] = singul_ * tl[1] * z_h0 - Rle[0] * dsigma[1] * vel2_reci;
-        Mm[2] = singul_ * tl[2] * z_h0 - Rle[1] * dsigma[0] * vel2_reci;
-        Mm[3] = singul_ * tl[3] * z_h0 - Rle[1] * dsigma[1] * vel2_reci;
+        Mm[0] = singul_ * tl[0] * z_h0 - Rle[v][0] * dsigma[0] * vel2_reci;
+        Mm[1] = singul_ * tl[1] * z_h0 - Rle[v][0] * dsigma[1] * vel2_reci;
+        Mm[2] = singul_ * tl[2] * z_h0 - Rle[v][1] * dsigma[0] * vel2_reci;
+        Mm[3] = singul_ * tl[3] * z_h0 - Rle[v][1] * dsigma[1] * vel2_reci;
         double w[2] = {dsigma[0] + (R_dot[0] * le0 + R_dot[1] * le1), dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1)};
         double gradViolaPt = (alpha * on0) * w[0] + (alpha * on1) * w[1];
         double sc = omg * step * P.wei_obs * penaD;
@@ -677,6 +687,12 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     smoothed_l1(violaAcc, pena, penaD);
     double u0 = z_h4 * ddsigma[0] - z_h4 * z_h4 * dsigma[0];
     double u1 = z_h4 * ddsigma[1] - z_h4 * z_h4 * dsigma[1];
+    double ddd0 = 0.0, ddd1 = 0.0;
+    for (int k = 0; k < 6; k++) {
+      ddd0 += cc[2 * k] * beta3[k];
+      ddd1 += cc[2 * k + 1] * beta3[k];
+    }
+    double z_h2 = ddd0 * dsigma[0] + ddd1 * dsigma[1];
     double sqn = ddsigma[0] * ddsigma[0] + ddsigma[1] * ddsigma[1];
     double gradViolaAt = 2.0 * alpha * (z_h4 * (sqn + z_h2) - z_h4 * z_h4 * z_h1);
     double sc = omg * step * P.wei_feas * penaD;
@@ -693,6 +709,12 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     double ku1 = vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1];
     double kw0 = -(vel3_2_reci_e * dsigma[1]);
     double kw1 = vel3_2_reci_e * dsigma[0];
+    double ddd0 = 0.0, ddd1 = 0.0;
+    for (int k = 0; k < 6; k++) {
+      ddd0 += cc[2 * k] * beta3[k];
+      ddd1 += cc[2 * k + 1] * beta3[k];
+    }
+    double z1 = ddd1 * dsigma[0] + (-ddd0) * dsigma[1];
     double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
     if (violaCurL > 0.0) {
       double pena, penaD;
