@@ -54,8 +54,7 @@ struct dftpav_batch {
   double *d_x0 = nullptr, *d_iniS = nullptr, *d_finS = nullptr, *d_corridor = nullptr;
   int16_t *d_pt_piece = nullptr, *d_pt_j = nullptr;
   double *d_opM[kMaxSeg] = {nullptr}, *d_opMT[kMaxSeg] = {nullptr};
-  double *d_histS = nullptr, *d_histY = nullptr, *d_histST = nullptr, *d_histYT = nullptr, *d_histGc = nullptr,
-         *d_histGr = nullptr;
+  double *d_histS = nullptr, *d_histY = nullptr;
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
@@ -286,7 +285,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->h->device);
   (void)hipStreamSynchronize(b->h->stream);
-  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY, b->d_histST, b->d_histYT, b->d_histGc, b->d_histGr,
+  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt};
   for (void *p : ptrs)
@@ -397,17 +396,9 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_pt_j, sizeof(int16_t) * L.Npts));
   BCHK(hipMalloc(&b->d_histS, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
   BCHK(hipMalloc(&b->d_histY, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
-  BCHK(hipMalloc(&b->d_histST, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
-  BCHK(hipMalloc(&b->d_histYT, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
-  BCHK(hipMalloc(&b->d_histGc, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
-  BCHK(hipMalloc(&b->d_histGr, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
-  // never-written slots are read (and discarded) by the unconditional block loads: keep them finite
+  // never-written slots are read (and discarded) by the unconditional prefetch loads: keep them finite
   BCHK(hipMemset(b->d_histS, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
   BCHK(hipMemset(b->d_histY, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
-  BCHK(hipMemset(b->d_histST, 0, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
-  BCHK(hipMemset(b->d_histYT, 0, sizeof(double) * (size_t)B * 64 * b->P.mem_size));
-  BCHK(hipMemset(b->d_histGc, 0, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
-  BCHK(hipMemset(b->d_histGr, 0, sizeof(double) * (size_t)B * 32 * b->P.mem_size));
   BCHK(hipMalloc(&b->d_x_in, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_x_out, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_f, sizeof(double) * (size_t)B));
@@ -571,10 +562,6 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.epis = b->epis;
   D.histS = b->d_histS;
   D.histY = b->d_histY;
-  D.histST = b->d_histST;
-  D.histYT = b->d_histYT;
-  D.histGc = b->d_histGc;
-  D.histGr = b->d_histGr;
   D.x_in = b->d_x_in;
   D.x_out = b->d_x_out;
   D.f_out = b->d_f;

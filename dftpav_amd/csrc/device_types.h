@@ -67,9 +67,7 @@ struct DevBatch {
   DevSurround sur;
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
-  double *histS, *histY;   // [B][mem][npad]
-  double *histST, *histYT; // [B][64][mem] element-major copies (n <= 64)
-  double *histGc, *histGr; // [B][mem][32] in-block Gram entries s_j.y_i, by column and by row
+  double *histS, *histY; // [B][mem][npad]
   // in/out
   const double *x_in; // eval mode: [B][n]
   double *x_out;      // [B][n]

@@ -709,147 +709,90 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
 typedef const double __attribute__((address_space(1))) *gptr_t; // global (not flat) loads: vmcnt only
 typedef double __attribute__((address_space(1))) *gwptr_t;
 
-__device__ inline double readlane_f64(double v, int srclane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-  return __hiloint2double(hi, lo);
-}
-
-// Per-trajectory L-BFGS history in global memory (lm_s, lm_y of lbfgs.hpp:512-513 plus what the
-// blocked recursion needs):
-//   S, Y   [m][npad]  row per slot           -> axpy passes, lanes over elements
-//   ST, YT [64][m]    element-major          -> block dot products, lanes over slots
-//   Gc     [m][32]    Gc[i][j&31] = s_j.y_i for the slots j below i in i's 32-block (read by lanes j)
-//   Gr     [m][32]    Gr[j][i&31] = s_j.y_i, the same numbers laid out for lanes i above j
-struct Hist {
-  gwptr_t S, Y, ST, YT, Gc, Gr;
+// one block of PB consecutive history steps held in registers
+template <int PB>
+struct HistBlock {
+  double s[PB], y[PB], ys[PB], ri[PB], al[PB];
 };
-__device__ inline Hist hist_of(const DevBatch &D, int b, int m, int npad) {
-  Hist h;
-  h.S = (gwptr_t)(D.histS + (size_t)b * m * npad);
-  h.Y = (gwptr_t)(D.histY + (size_t)b * m * npad);
-  h.ST = (gwptr_t)(D.histST + (size_t)b * 64 * m);
-  h.YT = (gwptr_t)(D.histYT + (size_t)b * 64 * m);
-  h.Gc = (gwptr_t)(D.histGc + (size_t)b * m * 32);
-  h.Gr = (gwptr_t)(D.histGr + (size_t)b * m * 32);
-  return h;
-}
-
-// acc = sum_e col[e*m] * v[e], e ascending from 0.0 (one lane per history slot).  The column is
-// fetched 16 elements at a time into registers before any of them is consumed, so the loads of a
-// batch overlap instead of each being waited on by the dependent add chain.
-__device__ __forceinline__ double column_dot(gwptr_t col, int m, const double *v, int n) {
-  double acc = 0.0;
-  for (int e0 = 0; e0 < n; e0 += 16) {
-    double cv[16];
+// loads the PB slots starting at `jl` walking downwards (DIR = -1) or upwards (DIR = +1) with wrap-around;
+// unconditional loads from always-valid addresses, nothing consumes them here
+template <int PB, int DIR, bool ALPHA>
+__device__ __forceinline__ void load_block(HistBlock<PB> &R, const Smem &sm, gptr_t hS, gptr_t hY, int npad, int m, int ln, int &jl) {
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      int e = e0 + u < n ? e0 + u : n - 1;
-      cv[u] = col[(size_t)e * m];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (e0 + u < n) acc += cv[u] * v[e0 + u];
+  for (int q = 0; q < PB; q++) {
+    if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
+    R.s[q] = hS[(size_t)jl * npad + ln];
+    R.y[q] = hY[(size_t)jl * npad + ln];
+    R.ys[q] = sm.ys[jl];
+    R.ri[q] = sm.rinv[jl];
+    if (ALPHA) R.al[q] = sm.alpha[jl];
+    if (DIR > 0) jl = jl == m - 1 ? 0 : jl + 1;
   }
-  return acc;
+}
+template <int LV, int PB>
+__device__ __forceinline__ void first_loop_block(const HistBlock<PB> &R, const Smem &sm, int i0, int nb, int m, bool act,
+                                                 int lane, int &j, double &dreg) {
+#pragma unroll
+  for (int q = 0; q < PB; q++) {
+    if (i0 + q < nb) {
+      j = j == 0 ? m - 1 : j - 1;
+      double sv = act ? R.s[q] : 0.0, yv = act ? R.y[q] : 0.0;
+      double acc = wave_sum_raw<LV>(sv * dreg);
+      double a = div_by_rcp(acc, R.ys[q], R.ri[q]); // lm_s.col(j).dot(d) / lm_ys(j)
+      if (lane == 0) sm.alpha[j] = a;
+      double na = -a;
+      dreg += na * yv;
+    }
+  }
+}
+template <int LV, int PB>
+__device__ __forceinline__ void second_loop_block(const HistBlock<PB> &R, int i0, int nb, bool act, double &dreg) {
+#pragma unroll
+  for (int q = 0; q < PB; q++) {
+    if (i0 + q < nb) {
+      double sv = act ? R.s[q] : 0.0, yv = act ? R.y[q] : 0.0;
+      double acc = wave_sum_raw<LV>(yv * dreg);
+      double beta = div_by_rcp(acc, R.ys[q], R.ri[q]); // lm_y.col(j).dot(d) / lm_ys(j)
+      double cf = R.al[q] - beta;
+      dreg += cf * sv;
+    }
+  }
 }
 
-// Two-loop recursion (lbfgs.hpp:716-739) for n <= 64 in blocks of 32 history slots.
-// Within a block, s_j . q_current is formed as s_j . q_blockstart (one lane per slot, sequential
-// over the elements) minus alpha_i (s_j . y_i) for the newer slots i of the block, using the
-// in-block Gram entries written when slot i was stored; the direction itself then receives the
-// reference's axpys in the reference's order.  The dependent chain per slot is
-// {3-instruction exact division, v_readlane broadcast, multiply, subtract} instead of
-// {multiply, 5-level cross-lane reduction, division, multiply, add}.  The second loop mirrors it
-// with y_j . r.  oracle/dftpav_oracle_dev.cpp::blocked_two_loop is the same program on the host.
-template <int LV>
-__device__ __forceinline__ double two_loop_blocked(const Smem &sm, const Hist &H, int npad, int n, int m, int nb, int ne,
-                                                   double ys_new, double yy_new, int lane, double dreg) {
+// Two-loop recursion (lbfgs.hpp:716-739) for n <= 64: one element of the direction per lane, the
+// reference's sequence of dot / divide / axpy steps.  History columns (global memory: they live in
+// L2 / Infinity Cache), 1/ys and alpha (LDS) are double-buffered in registers in blocks of PB
+// steps: the loads of block k+1 are issued before block k is reduced, so their latency hides
+// behind ~PB dependent reductions and no wait is ever placed right after a load.  Only lanes
+// below 2^LV take part (the trimmed butterfly leaves the others with partial sums that are
+// never used: their direction element is masked).
+template <int LV, int PB>
+__device__ __forceinline__ double two_loop_lane(const Smem &sm, const double *hS_, const double *hY_, int npad, int n, int m,
+                                                int nb, int ne, double ys_new, double yy_new, int lane, double dreg) {
+  gptr_t hS = (gptr_t)hS_;
+  gptr_t hY = (gptr_t)hY_;
   const bool act = lane < n;
   const int ln = act ? lane : 0;
-  const int l32 = lane & 31;
   nb = __builtin_amdgcn_readfirstlane(nb);
-  ne = __builtin_amdgcn_readfirstlane(ne);
-  // ---- first loop: newest -> oldest, one segment [seg_lo, cur) per 32-block
-  int remaining = nb, cur = ne == 0 ? m : ne;
-  while (remaining > 0) {
-    const int lo = ((cur - 1) >> 5) << 5;
-    const int seg_lo = cur - remaining > lo ? cur - remaining : lo;
-    const int la = seg_lo - lo, lb = cur - 1 - lo; // local slot range of the segment
-    // every load of the block is issued here, before anything consumes one: in-block Gram columns
-    // (lanes <-> slots), the y rows of the axpy pass (lanes <-> elements), then the element-major
-    // columns of the dot products
-    double g[32], row[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) g[i] = H.Gc[(size_t)(lo + i) * 32 + l32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) row[i] = H.Y[(size_t)(lo + i) * npad + ln];
-    const double ysl = sm.ys[lo + l32], ril = sm.rinv[lo + l32];
-    if (act) sm.d[lane] = dreg; // the direction at block start, for broadcast reads
-    double acc = column_dot(H.ST + lo + l32, m, sm.d, n);
-    double myalpha = 0.0;
-#pragma unroll
-    for (int i = 31; i >= 0; i--) {
-      if (i >= la && i <= lb) {
-        double a = div_by_rcp(acc, ysl, ril); // lm_s.col(j).dot(d) / lm_ys(j)
-        double ai = readlane_f64(a, i);
-        myalpha = lane == i ? a : myalpha;
-        double t = ai * g[i];
-        acc = (lane >= la && lane < i) ? acc - t : acc;
-      }
-    }
-    if (lane >= la && lane <= lb) sm.alpha[lo + lane] = myalpha;
-    // the axpys of the reference, d += (-alpha_i) y_i, newest first
-#pragma unroll
-    for (int i = 31; i >= 0; i--) {
-      if (i >= la && i <= lb) {
-        double na = -readlane_f64(myalpha, i);
-        dreg = act ? dreg + na * row[i] : dreg;
-      }
-    }
-    remaining -= cur - seg_lo;
-    cur = seg_lo == 0 ? m : seg_lo;
+  HistBlock<PB> A, B;
+  // ---- first loop: newest -> oldest (slots ne-1, ne-2, ...)
+  int jl = ne, j = ne;
+  load_block<PB, -1, false>(A, sm, hS, hY, npad, m, ln, jl);
+  for (int i0 = 0; i0 < nb; i0 += 2 * PB) {
+    load_block<PB, -1, false>(B, sm, hS, hY, npad, m, ln, jl);
+    first_loop_block<LV, PB>(A, sm, i0, nb, m, act, lane, j, dreg);
+    load_block<PB, -1, false>(A, sm, hS, hY, npad, m, ln, jl);
+    first_loop_block<LV, PB>(B, sm, i0 + PB, nb, m, act, lane, j, dreg);
   }
   dreg *= ys_new / yy_new;
-  // ---- second loop: oldest -> newest, one segment [cur, seg_hi) per 32-block
-  remaining = nb;
-  cur = ne - nb;
-  if (cur < 0) cur += m;
-  while (remaining > 0) {
-    const int lo = (cur >> 5) << 5;
-    const int hi = lo + 32 < m ? lo + 32 : m;
-    const int seg_hi = cur + remaining < hi ? cur + remaining : hi;
-    const int la = cur - lo, lb = seg_hi - 1 - lo;
-    double g[32], row[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) g[i] = H.Gr[(size_t)(lo + i) * 32 + l32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) row[i] = H.S[(size_t)(lo + i) * npad + ln];
-    const double ysl = sm.ys[lo + l32], ril = sm.rinv[lo + l32];
-    const double myalpha = sm.alpha[lo + l32];
-    if (act) sm.d[lane] = dreg;
-    double acc = column_dot(H.YT + lo + l32, m, sm.d, n);
-    double mycf = 0.0;
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      if (i >= la && i <= lb) {
-        double beta = div_by_rcp(acc, ysl, ril); // lm_y.col(j).dot(d) / lm_ys(j)
-        double cf = myalpha - beta;
-        double ci = readlane_f64(cf, i);
-        mycf = lane == i ? cf : mycf;
-        double t = ci * g[i];
-        acc = (lane > i && lane <= lb) ? acc + t : acc;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      if (i >= la && i <= lb) {
-        double cf = readlane_f64(mycf, i);
-        dreg = act ? dreg + cf * row[i] : dreg;
-      }
-    }
-    remaining -= seg_hi - cur;
-    cur = seg_hi == m ? 0 : seg_hi;
+  // ---- second loop: oldest -> newest, starting at the slot the first loop ended on
+  jl = j;
+  load_block<PB, +1, true>(A, sm, hS, hY, npad, m, ln, jl);
+  for (int i0 = 0; i0 < nb; i0 += 2 * PB) {
+    load_block<PB, +1, true>(B, sm, hS, hY, npad, m, ln, jl);
+    second_loop_block<LV, PB>(A, i0, nb, act, dreg);
+    load_block<PB, +1, true>(A, sm, hS, hY, npad, m, ln, jl);
+    second_loop_block<LV, PB>(B, i0 + PB, nb, act, dreg);
   }
   return dreg;
 }
@@ -1073,21 +1016,18 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
   pr.tick(kPLS);
 
   // ---- history update + two-loop recursion (lbfgs.hpp:676-740)
-  const Hist H = hist_of(D, b, m, npad);
+  double *hS = D.histS + (size_t)b * m * npad;
+  double *hY = D.histY + (size_t)b * m * npad;
   const int end = sm.ist[iEND];
   int bound = sm.ist[iBOUND];
   {
+    double *sc = hS + (size_t)end * npad, *yc = hY + (size_t)end * npad;
     double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
     for (int e = lane; e < n; e += 64) {
       double sv = sm.x[e] - sm.xp[e];
       double yv = sm.g[e] - sm.gp[e];
-      H.S[(size_t)end * npad + e] = sv;
-      H.Y[(size_t)end * npad + e] = yv;
-      if (n <= 64) {
-        H.ST[(size_t)e * m + end] = sv;
-        H.YT[(size_t)e * m + end] = yv;
-        sm.xp[e] = yv; // xp is dead until the next iteration starts: broadcast copy of y for the Gram entries
-      }
+      sc[e] = sv;
+      yc[e] = yv;
       ys += yv * sv;
       yy += yv * yv;
       ss += sv * sv;
@@ -1110,25 +1050,15 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       bound = m < bound ? m : bound;
       int ne = end + 1 == m ? 0 : end + 1;
       if (n <= 64) {
-        // in-block Gram entries of the new slot: s_j . y_new for the slots j below it in its 32-block
-        {
-          const int lo = (end >> 5) << 5, il = end - lo;
-          const int l32 = lane & 31;
-          double acc = column_dot(H.ST + lo + l32, m, sm.xp, n);
-          if (lane < il) {
-            H.Gc[(size_t)end * 32 + lane] = acc;
-            H.Gr[(size_t)(lo + lane) * 32 + il] = acc;
-          }
-        }
-        // columns written above by these same lanes are read back below in program order
+        // the newest column was written by these same lanes: program order makes it visible to them
         double dreg = lane < n ? sm.d[lane] : 0.0;
-        dreg = two_loop_blocked<LV>(sm, H, npad, n, m, bound, ne, ys, yy, lane, dreg);
+        dreg = two_loop_lane<LV, 8>(sm, hS, hY, npad, n, m, bound, ne, ys, yy, lane, dreg);
         if (lane < n) sm.d[lane] = dreg;
       } else {
         int j = ne;
         for (int i = 0; i < bound; ++i) {
           j = j == 0 ? m - 1 : j - 1;
-          gptr_t sj = H.S + (size_t)j * npad, yj = H.Y + (size_t)j * npad;
+          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += sj[e] * sm.d[e];
           acc = wave_sum<LV>(acc);
@@ -1140,7 +1070,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         double sc0 = ys / yy;
         for (int e = lane; e < n; e += 64) sm.d[e] *= sc0;
         for (int i = 0; i < bound; ++i) {
-          gptr_t sj = H.S + (size_t)j * npad, yj = H.Y + (size_t)j * npad;
+          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += yj[e] * sm.d[e];
           acc = wave_sum<LV>(acc);

@@ -21,13 +21,6 @@
  *   - the three cost classes are summed into one running total per point;
  *   - dot products / norms of L-BFGS (Eigen-internal order in the reference,
  *     unpinned): 64-lane strided partials + xor butterfly 1,2,4,8,16,32;
- *   - two-loop recursion (lbfgs.hpp:716-739) for n <= 64: processed in blocks of 32 history
- *     slots.  Inside a block s_j . q_current is formed as s_j . q_blockstart minus the updates
- *     of the newer slots of the block, alpha_i (s_j . y_i), with the in-block Gram entries
- *     s_j . y_i computed once when slot i is written; q itself receives exactly the reference's
- *     sequence of axpys (deferred to the end of the block).  Same for the second loop with
- *     y_j . r.  Algebraically the reference's recursion; it turns 2 x bound dependent
- *     dot-reduce-divide-axpy steps into short per-block chains;
  *   - cos/sin/exp/log: the portable routines of traj_math.h (libm is not
  *     bit-reproducible across host and device).
  * The per-point mathematics is the shared header dftpav_amd/csrc/traj_math.h
@@ -518,67 +511,6 @@ extern "C" void oracle_dev_coeffs(const oracle_ctx *c, double *coeffs, double *p
   for (int sg = 0; sg < D.L.M; sg++) piece_dt[sg] = D.seg[sg * 16 + 1];
 }
 
-// ---- blocked two-loop recursion (n <= 64), the kernel's order
-// sequential dot from 0.0 over e = 0..n-1 (one lane per history slot in the kernel)
-static inline double seq_dot(const double *a, const double *b, int n) {
-  double acc = 0.0;
-  for (int e = 0; e < n; e++) acc += a[e] * b[e];
-  return acc;
-}
-// G(j,i) = s_j . y_i for slots j < i of the same 32-block is kept at Gc[i*32 + (j & 31)]
-static void blocked_two_loop(int n, int m, int bound, int ne, const double *hS, const double *hY, const double *ys_h,
-                             double *alpha_h, const double *Gc, double ys, double yy, double *d) {
-  // ---- first loop: newest -> oldest, one segment per 32-block
-  int remaining = bound, cur = ne == 0 ? m : ne; // segment = slots [seg_lo, cur)
-  std::vector<double> acc(32);
-  while (remaining > 0) {
-    int blk = (cur - 1) >> 5, lo = blk * 32;
-    int seg_lo = cur - remaining > lo ? cur - remaining : lo;
-    for (int j = seg_lo; j < cur; j++) acc[j - lo] = seq_dot(hS + (size_t)j * n, d, n);
-    for (int i = cur - 1; i >= seg_lo; i--) {
-      double a = acc[i - lo] / ys_h[i];
-      alpha_h[i] = a;
-      for (int j = seg_lo; j < i; j++) {
-        double t = a * Gc[(size_t)i * 32 + (j - lo)];
-        acc[j - lo] = acc[j - lo] - t;
-      }
-    }
-    for (int i = cur - 1; i >= seg_lo; i--) {
-      double na = -alpha_h[i];
-      const double *yi = hY + (size_t)i * n;
-      for (int e = 0; e < n; e++) d[e] += na * yi[e];
-    }
-    remaining -= cur - seg_lo;
-    cur = seg_lo == 0 ? m : seg_lo;
-  }
-  double sc0 = ys / yy;
-  for (int e = 0; e < n; e++) d[e] *= sc0;
-  // ---- second loop: oldest -> newest
-  remaining = bound;
-  cur = ((ne - bound) % m + m) % m; // oldest slot
-  while (remaining > 0) {
-    int blk = cur >> 5, lo = blk * 32, hi = lo + 32 < m ? lo + 32 : m;
-    int seg_hi = cur + remaining < hi ? cur + remaining : hi; // segment = slots [cur, seg_hi)
-    for (int j = cur; j < seg_hi; j++) acc[j - lo] = seq_dot(hY + (size_t)j * n, d, n);
-    for (int i = cur; i < seg_hi; i++) {
-      double beta = acc[i - lo] / ys_h[i];
-      double cf = alpha_h[i] - beta;
-      alpha_h[i] = cf; // the slot's alpha is not needed again: keep alpha - beta for the axpy pass
-      for (int j = i + 1; j < seg_hi; j++) {
-        double t = cf * Gc[(size_t)j * 32 + (i - lo)];
-        acc[j - lo] = acc[j - lo] + t;
-      }
-    }
-    for (int i = cur; i < seg_hi; i++) {
-      double cf = alpha_h[i];
-      const double *si = hS + (size_t)i * n;
-      for (int e = 0; e < n; e++) d[e] += cf * si[e];
-    }
-    remaining -= seg_hi - cur;
-    cur = seg_hi == m ? 0 : seg_hi;
-  }
-}
-
 // lbfgs_optimize (lbfgs.hpp:440-751) + line_search_lewisoverton (lbfgs.hpp:276-390)
 // with the kernel's reduction order for every dot product.
 extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
@@ -587,7 +519,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   const int n = D.L.n, m = P.mem_size;
   g_levels = levels_for(n);
   std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), alpha_h(m, 0.0);
-  std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0), Gc((size_t)m * 32, 0.0);
+  std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
   double pf[8];
   int evals = 0, k = 0, end = 0, bound = 0, ret = 0;
   long long hist_sum = 0;
@@ -725,12 +657,6 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
       if (ys > cau) {
         ++bound;
         bound = m < bound ? m : bound;
-        if (n <= 64) {
-          // in-block Gram entries of the new slot: s_j . y_new for the slots j below it in its 32-block
-          for (int j = (end >> 5) * 32; j < end; j++) Gc[(size_t)end * 32 + (j & 31)] = seq_dot(&hS[(size_t)j * n], yc, n);
-          end = (end + 1) % m;
-          blocked_two_loop(n, m, bound, end, hS.data(), hY.data(), ys_h.data(), alpha_h.data(), Gc.data(), ys, yy, d.data());
-        } else {
         end = (end + 1) % m;
         int j = end;
         for (int i = 0; i < bound; ++i) {
@@ -749,7 +675,6 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           double cf = alpha_h[j] - beta;
           for (int e = 0; e < n; e++) d[e] += cf * sj[e];
           j = (j + 1) % m;
-        }
         }
         hist_sum += bound;
       }
