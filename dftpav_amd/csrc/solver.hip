@@ -97,10 +97,10 @@ int solver_threads(const DevLayout &L, bool throughput) {
   // Every stage is a strided loop, so any multiple of 64 works; the choice trades latency of one
   // solve against how many trajectories a CU holds (256 VGPRs per lane => 8 waves per CU).
   //   latency    : two constraint points per thread, at most 8 waves (batches that leave CUs idle)
-  //   throughput : three waves per trajectory, two workgroups resident per CU
+  //   throughput : four waves per trajectory, two workgroups resident per CU
   int T;
   if (throughput) {
-    T = 192;
+    T = 256; // measured best of {64,128,192,256} at 1024..4096 trajectories of 528 points
     if (L.Npts <= 128) T = 128;
   } else {
     T = ((L.Npts + 1) / 2 + kWave - 1) / kWave * kWave;
@@ -460,16 +460,17 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad + pt;
         if (D.cor_in_lds) {
           GlobalPlanes pl{sm.cor + pt, (size_t)((Npts + 63) / 64 * 64)};
-          sample_point_math<SUR>(P, D.sur, in, pl, o);
+          if (L.H <= 4) sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
+          else sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
         } else if (L.H <= 4) {
           double cor[16]; // all half-plane loads issued up front, consumed after the state evaluation
 #pragma unroll
           for (int k = 0; k < 16; k++) cor[k] = (k < 4 * L.H) ? cb[(size_t)k * D.NptsPad] : 0.0;
           RegPlanes pl{cor};
-          sample_point_math<SUR>(P, D.sur, in, pl, o);
+          sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
         } else {
           GlobalPlanes pl{cb, (size_t)D.NptsPad};
-          sample_point_math<SUR>(P, D.sur, in, pl, o);
+          sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
         }
       } else {
 #pragma unroll

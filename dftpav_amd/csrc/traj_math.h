@@ -557,7 +557,9 @@ struct SampleIn {
 // sigma'' (each penalty's dviol/dc is beta0 a^T + beta1 b^T + beta2 c^T, so
 // out = {a (2), b (2), c (2), gdT, cost}); the caller chains them onto the piece
 // coefficients.  `plane(k, n0, n1, q0, q1)` loads half-plane k of this point.
-template <bool SUR, class PlaneLoader>
+// HU > 0: the half-plane loop is unrolled HU times with a guard on in.H (keeps a register-resident
+// plane array statically indexed); HU == 0: plain runtime loop.
+template <bool SUR, int HU, class PlaneLoader>
 DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S, const SampleIn &in, PlaneLoader plane,
                                         double out[8]) {
   for (int k = 0; k < 8; k++) out[k] = 0.0;
@@ -631,7 +633,11 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     bpt[v][0] = sigma[0] + Rle[v][0];
     bpt[v][1] = sigma[1] + Rle[v][1];
   }
-  for (int k = 0; k < in.H; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k < (HU > 0 ? HU : in.H); k++) {
+    if (HU > 0 && k >= in.H) break;
     double on0, on1, q0, q1;
     plane(k, on0, on1, q0, q1);
     for (int vv = 0; vv < 5; vv++) {

@@ -242,8 +242,8 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
           in.t_now = c->t_now;
           HostPlanes pl{c->cfgHs + (size_t)pt * L.H * 4};
           double o[8];
-          if (D.S.S > 0) sample_point_math<true>(P, D.S, in, pl, o);
-          else sample_point_math<false>(P, D.S, in, pl, o);
+          if (D.S.S > 0) sample_point_math<true, 0>(P, D.S, in, pl, o);
+          else sample_point_math<false, 0>(P, D.S, in, pl, o);
           for (int k = 0; k < 8; k++) D.part[(size_t)k * NP + pt] = o[k];
         }
       }
