@@ -5,8 +5,12 @@ A "step" = one pass of the hot path over one resident batch: every rank launches
 persistent solve kernel on its shard (inputs already in HBM), packs {cost,status,iters}
 records on the device and — for N>1 — joins the single RCCL all-gather of SURVEY §8(e).
 
-Workload (config.workload): BASELINE.json configs[2] — 256 random-restart trajectories per GPU,
-16 MINCO pieces, 32 pts/piece (33 samples), 50 static obstacles; weak scaling (per-GPU batch fixed).
+Workload (config.workload): the BASELINE.json configs[2]/[3] problem — random-restart /
+multi-hypothesis trajectories of 16 MINCO pieces x 32 pts/piece (33 samples), 50 static
+obstacles, every trajectory with its own H=4 rectangle corridor — at 4096 trajectories per GPU
+(weak scaling: per-GPU batch fixed; the solver is latency-bound per trajectory, so throughput is
+quoted on a batch that fills the chip).  At N=1 the line also carries the exact configs[2] case
+(batch 256) and the configs[1] case (one gear-shift trajectory) under "batch256" / "single".
 """
 import argparse
 import json
@@ -38,10 +42,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--config", type=int, default=3, help="BASELINE config (1-based) used as the workload")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="trajectories timed on the host cores (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="trajectories timed on the host cores (-1 = 4 per core, 0 = skip)")
     ap.add_argument("--seed", type=int, default=20240)
+    ap.add_argument("--no-extras", action="store_true", help="skip the batch-256 / single-trajectory side runs (profiling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,9 +125,9 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: %s, %d trajectories/GPU x %d pieces x %d pts/piece, "
-                                   "50 static obstacles, H=4 rectangle corridor" %
-                                   (args.config - 1, scen.name, args.batch_per_gpu, lay.n_pieces, scen.K + 1),
+            "config": {"workload": "BASELINE configs[2]/[3] problem (%s): %d trajectories/GPU x %d pieces x %d pts/piece, "
+                                   "50 static obstacles, H=4 rectangle corridor per trajectory, fp64 bit-exact mode" %
+                                   (scen.name, args.batch_per_gpu, lay.n_pieces, scen.K + 1),
                        "global_batch": B_total, "pieces": lay.n_pieces, "pts_per_piece": scen.K + 1,
                        "n_vars": lay.n_vars, "parallelism": "batch-sharded x%d, 1 all-gather of 16B records" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -134,24 +140,45 @@ def main():
             "mean_hist_depth": float(r["hist_sum"].sum() / max(1, r["iters"].sum())),
             "success_rate": float(r["success"].mean()),
         }
+        if world == 1 and not args.no_extras:
+            # ---- the exact BASELINE configs[2] case (batch 256) and configs[1] (one gear-shift trajectory)
+            def side(cfg, B, reps):
+                p2 = capi.default_params()
+                s2 = sc.baseline_config(cfg, B=B, seed=args.seed)
+                s2.apply_resolution(p2)
+                h2 = capi.Handle(p2, device=local_rank)
+                b2 = capi.Batch(h2, s2.layout, B)
+                b2.upload(s2)
+                b2.solve_async(); b2.sync()
+                ms = []
+                for _ in range(reps):
+                    b2.solve_async(); b2.sync(); ms.append(b2.last_solve_ms())
+                r2 = b2.results()
+                b2.close(); h2.close()
+                return {"batch": B, "solves_per_s": B / (float(np.mean(ms)) * 1e-3), "kernel_ms": float(np.mean(ms)),
+                        "p50_ms_per_solve": float(np.median(r2["latency_us"])) * 1e-3, "mean_iters": float(r2["iters"].mean())}
+            out["batch256"] = side(3, 256, 3)
+            out["single"] = side(2, 1, 5)
         # ---- reference CPU path beside it (rank 0, N=1 only): the oracle's literal restatement on the host cores
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample != 0:
             from oracle import pyoracle as po
             po.build()
-            ns = min(args.cpu_sample, shard.B)
-            sub = shard.subset(np.arange(ns))
             cores = os.cpu_count() or 1
+            ns = args.cpu_sample if args.cpu_sample > 0 else min(4 * cores, 1024)
+            sub = shard.subset(np.arange(ns) % shard.B)
             tc = time.perf_counter()
             rc = po.solve_batch(params, sub, nthreads=cores, order=0)
             wall = time.perf_counter() - tc
-            rd = po.solve_batch(params, sub.subset(np.arange(min(ns, 32))), nthreads=cores, order=1)
-            match = bool(np.array_equal(rd["final_cost"], r["final_cost"][:len(rd["final_cost"])]))
+            nd = min(32, shard.B)
+            rd = po.solve_batch(params, shard.subset(np.arange(nd)), nthreads=cores, order=1)
+            match = bool(np.array_equal(rd["final_cost"], r["final_cost"][:nd]) and np.array_equal(rd["x"], r["x"][:nd]))
             out["cpu_baseline"] = {"value": ns / wall, "unit": "solves/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d trajectories of the same batch, literal-order oracle, "
-                                             "OpenMP over trajectories" % ns,
-                                   "p50_ms_per_solve_1thread": float(np.median(rc["seconds"])) * 1e3,
+                                   "sample": "%d trajectories of the same batch (4 per core), literal-order oracle "
+                                             "(fp64 restatement of traj_optimizer.cpp/lbfgs.hpp), OpenMP over "
+                                             "trajectories, %.1f core-seconds" % (ns, float(rc["seconds"].sum())),
+                                   "p50_ms_per_solve_per_thread": float(np.median(rc["seconds"])) * 1e3,
                                    "mean_iters": float(rc["iters"].mean())}
-            out["parity"] = {"device_order_oracle_bit_exact_on_first_32": match}
+            out["parity"] = {"device_order_oracle_bit_exact_on_first_%d" % nd: match}
         print(json.dumps(out), flush=True)
     bt.close()
     h.close()

@@ -1,0 +1,39 @@
+"""Turns the rocprofv3 CSVs under gpurun_out/ into the tracked summaries under profiles/.
+
+  python scripts/summarize_profiles.py r01
+reads  gpurun_out/prof_<tag>/*/*_kernel_stats.csv          (rocprofv3 --kernel-trace --stats)
+       gpurun_out/pmc_fetch_<tag>/*/*_counter_collection.csv (rocprofv3 --pmc FETCH_SIZE)
+       gpurun_out/pmc_write_<tag>/*/*_counter_collection.csv (rocprofv3 --pmc WRITE_SIZE)
+writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, profiles/pmc_latest.json
+"""
+import csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles"); os.makedirs(out, exist_ok=True)
+ks = glob.glob(os.path.join(root, "gpurun_out", "prof_%s" % tag, "*", "*_kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(out, "%s_kernel_stats.csv" % tag))
+def counter(kind):
+    fs = glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (kind, tag), "*", "*_counter_collection.csv"))
+    vals = []
+    for r in csv.DictReader(open(fs[0])):
+        if "solver_kernel" in r["Kernel_Name"]:
+            vals.append((int(r["Grid_Size"]), int(r["Workgroup_Size"]), float(r["Counter_Value"])))
+    return vals
+fetch, write = counter("fetch"), counter("write")
+# the dominant launch is the one with the largest grid
+gmax = max(g for g, _, _ in fetch)
+f = [v for g, _, v in fetch if g == gmax]; w = [v for g, _, v in write if g == gmax]
+wg = [t for g, t, _ in fetch if g == gmax][0]
+fetch_kb, write_kb = sum(f) / len(f), sum(w) / len(w)
+# MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-B read
+# requests at 64 B, so it is doubled before it is compared with a byte count (calibrated for 16 B/lane
+# streams; our loads are 8 B/lane, so the doubled figure is an upper bound, the raw one a lower bound)
+rec = {"tag": tag, "kernel": "solver_kernel", "trajectories_per_launch": gmax // wg, "workgroup": wg,
+       "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+       "hbm_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024.0,
+       "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+       "launches_averaged": len(f)}
+json.dump(rec, open(os.path.join(out, "%s_pmc.json" % tag), "w"), indent=1)
+json.dump(rec, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
+print(json.dumps(rec))
