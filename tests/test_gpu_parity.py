@@ -200,3 +200,65 @@ def test_reference_class_interface(hiplib):
     # size mismatch -> False, as traj_optimizer.cpp:44-48
     assert opt.OptimizeTrajectory(ini, fin, inner, s.init_Ts[0], [polys[0][:-1], polys[1]], list(lay.singuls)) is False
     assert opt.OptimizeTrajectory(ini, fin, inner, [0.05, 8.0], polys, list(lay.singuls)) is False
+
+
+def test_more_than_64_variables_generic_path(hiplib, oracle):
+    """n = 79 decision variables: vectors span two elements per lane, the two-loop recursion takes the
+    strided (n > 64) path, six butterfly levels."""
+    p = hiplib.default_params()
+    s = sc.make_scenario([40], [1], 4, 6, 2, seed=9, n_obs=10, name="forty_pieces")
+    s.apply_resolution(p)
+    assert s.layout.n_vars == 79
+    p.lbfgs_max_iterations = 60  # keep the CPU side short; MAXIMUMITERATION counts as success (traj_optimizer.cpp:179)
+    h, bt = _batch(hiplib, s, p)
+    f, g = bt.eval(bt.x0())
+    for b in range(2):
+        fd, gd = oracle.OracleProblem(p, s, b, order=1).eval(bt.x0()[b])
+        assert f[b] == fd and np.array_equal(g[b], gd)
+    r = bt.solve()
+    ro = oracle.solve_batch(p, s, nthreads=2, order=1)
+    assert np.array_equal(r["final_cost"], ro["final_cost"]) and np.array_equal(r["x"], ro["x"])
+    assert np.array_equal(r["iters"], ro["iters"]) and np.array_equal(r["status"], ro["status"])
+    bt.close()
+    h.close()
+
+
+def test_six_half_planes_per_point(hiplib, oracle):
+    """hPoly matrices with more than four columns (the reference takes any 4xH, traj_optimizer.cpp:600)."""
+    p = hiplib.default_params()
+    base = sc.baseline_config(1, B=2)
+    base.apply_resolution(p)
+    cor = np.zeros((2, base.n_points, 6, 4))
+    cor[:, :, :4] = base.corridor
+    # two extra planes: the first two pulled 0.2 m inwards (so that they are the active ones), un-normalised normals
+    cor[:, :, 4:] = base.corridor[:, :, :2]
+    cor[:, :, 4:, 2:] -= 0.2 * base.corridor[:, :, :2, :2]
+    cor[:, :, 4:, :2] *= 3.0
+    lay = type(base.layout)(base.layout.piece_nums, base.layout.singuls, H=6)
+    s = sc.Scenario("six_planes", lay, base.K, base.Kd, 2, base.ini_states, base.fin_states, base.inner_pts,
+                    base.init_Ts, np.ascontiguousarray(cor))
+    h, bt = _batch(hiplib, s, p)
+    x = bt.x0() + np.random.default_rng(3).normal(0, 0.3, bt.x0().shape)
+    f, g = bt.eval(x)
+    for b in range(2):
+        fd, gd = oracle.OracleProblem(p, s, b, order=1).eval(x[b])
+        fl, gl = oracle.OracleProblem(p, s, b, order=0).eval(x[b])
+        assert f[b] == fd and np.array_equal(g[b], gd)
+        assert abs(f[b] - fl) <= 1e-11 * abs(fl)
+    r = bt.solve()
+    ro = oracle.solve_batch(p, s, nthreads=2, order=1)
+    assert np.array_equal(r["final_cost"], ro["final_cost"]) and np.array_equal(r["iters"], ro["iters"])
+    bt.close()
+    h.close()
+
+
+def test_cpp_host_mirror_runs(hiplib):
+    """The C++ PolyTrajOptimizer mirror (dftpav_amd/csrc/host) against the C-ABI on a real device."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "dftpav_amd", "csrc", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    out = subprocess.run([os.path.join(host, "host_example")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OptimizeTrajectory -> 1" in out.stdout and "short corridor -> 0" in out.stdout
