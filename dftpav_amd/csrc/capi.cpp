@@ -354,12 +354,14 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     int n_cu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    bool throughput = B > n_cu;
-    if (const char *e = std::getenv("DFTPAV_MODE")) throughput = std::atoi(e) != 0; // 0 latency, 1 throughput
-    b->threads = solver_threads(L, throughput);
+    int shape = B <= n_cu ? 0 : (B <= 2 * n_cu ? 1 : 2);
+    if (const char *e = std::getenv("DFTPAV_MODE")) shape = std::atoi(e); // 0 latency, 1 two per CU, 2 four per CU
+    b->threads = solver_threads(L, shape);
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
-    b->ppt = solver_ppt(L, b->threads);
-    const size_t budget = throughput ? 78 * 1024 : 158 * 1024; // two workgroups per CU vs the whole LDS
+    b->ppt = solver_ppt(L, b->threads, shape);
+    if (const char *e = std::getenv("DFTPAV_PPT")) b->ppt = std::atoi(e) > 0 ? std::atoi(e) : b->ppt;
+    // LDS budget per workgroup: the whole CU, half of it, a quarter of it
+    const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : 38 * 1024);
     b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, true, false) + 64 <= budget;
     b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds, true) + 64 <= budget;
     if (const char *e = std::getenv("DFTPAV_LDS")) { // bit 0 operators, bit 1 corridor

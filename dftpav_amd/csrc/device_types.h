@@ -86,8 +86,8 @@ enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };
 // size in bytes of the dynamic LDS a launch needs
 size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds, bool cor_lds);
 // constraint points each thread handles per chunk
-int solver_ppt(const DevLayout &L, int threads);
-// picks the workgroup size for a layout (throughput: more than one trajectory per CU)
-int solver_threads(const DevLayout &L, bool throughput);
+int solver_ppt(const DevLayout &L, int threads, int shape);
+// picks the workgroup size for a layout; shape 0/1/2 = at most one / two / more trajectories per CU
+int solver_threads(const DevLayout &L, int shape);
 
 } // namespace dftpav

@@ -93,14 +93,18 @@ size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int
   return smem_doubles(L, P.mem_size, threads, ppt, op_lds, cor_lds) * sizeof(double) + smem_ints(L) * sizeof(int);
 }
 
-int solver_threads(const DevLayout &L, bool throughput) {
-  // Every stage is a strided loop, so any multiple of 64 works; the choice trades latency of one
-  // solve against how many trajectories a CU holds (256 VGPRs per lane => 8 waves per CU).
-  //   latency    : two constraint points per thread, at most 8 waves (batches that leave CUs idle)
-  //   throughput : four waves per trajectory, two workgroups resident per CU
+int solver_threads(const DevLayout &L, int shape) {
+  // Every stage is a strided loop, so any multiple of 64 works; the choice trades the latency of one
+  // solve against how many trajectories a CU holds (256 VGPRs per lane => 8 waves per CU).  Measured on
+  // 528-point problems (scripts/profile_phases.py):
+  //   shape 0, <= 1 trajectory per CU : two constraint points per thread, up to 8 waves
+  //   shape 1, <= 2 per CU            : 4 waves, two workgroups resident per CU
+  //   shape 2, more                   : 2 waves, four workgroups resident per CU
   int T;
-  if (throughput) {
-    T = 256; // measured best of {64,128,192,256} at 1024..4096 trajectories of 528 points
+  if (shape == 2) {
+    T = 128;
+  } else if (shape == 1) {
+    T = 256;
     if (L.Npts <= 128) T = 128;
   } else {
     T = ((L.Npts + 1) / 2 + kWave - 1) / kWave * kWave;
@@ -113,8 +117,9 @@ int solver_threads(const DevLayout &L, bool throughput) {
   return T;
 }
 
-int solver_ppt(const DevLayout &L, int threads) {
+int solver_ppt(const DevLayout &L, int threads, int shape) {
   int ppt = (L.Npts + threads - 1) / threads;
+  if (shape == 2 && ppt > 2) ppt = 2; // small chunks keep the per-workgroup LDS under a quarter of the CU
   // keep the per-chunk partials (64 B per point) within ~48 KB of LDS
   while (ppt > 1 && (size_t)ppt * threads * 64 > 48 * 1024) --ppt;
   return ppt;
