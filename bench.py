@@ -62,13 +62,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- inputs: the whole job is generated from the seed on every rank, each keeps its shard
+    # ---- inputs: every rank generates its own shard from (seed, rank) — trajectories are independent,
+    # nothing is scattered; rank r owns global trajectories [r*B/G, (r+1)*B/G)
     B_total = args.batch_per_gpu * world
     params = capi.default_params()
-    scen = sc.baseline_config(args.config, B=B_total, seed=args.seed)
-    scen.apply_resolution(params)
     lo, hi = dd.shard_range(B_total, rank, world)
-    shard = scen.subset(np.arange(lo, hi))
+    shard = sc.baseline_config(args.config, B=hi - lo, seed=args.seed + 7919 * rank)
+    shard.apply_resolution(params)
+    scen = shard
     h = capi.Handle(params, device=local_rank)
     h.set_surround(shard.surround)
     bt = capi.Batch(h, shard.layout, shard.B)

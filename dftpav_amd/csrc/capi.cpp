@@ -54,7 +54,7 @@ struct dftpav_batch {
   double *d_x0 = nullptr, *d_iniS = nullptr, *d_finS = nullptr, *d_corridor = nullptr;
   int16_t *d_pt_piece = nullptr, *d_pt_j = nullptr;
   double *d_opM[kMaxSeg] = {nullptr}, *d_opMT[kMaxSeg] = {nullptr};
-  double *d_histS = nullptr, *d_histY = nullptr;
+  double *d_histS = nullptr, *d_histY = nullptr, *d_histU = nullptr, *d_histV = nullptr;
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
@@ -285,7 +285,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->h->device);
   (void)hipStreamSynchronize(b->h->stream);
-  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY,
+  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY, b->d_histU, b->d_histV,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt};
   for (void *p : ptrs)
@@ -401,6 +401,10 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   // never-written slots are read (and discarded) by the unconditional prefetch loads: keep them finite
   BCHK(hipMemset(b->d_histS, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
   BCHK(hipMemset(b->d_histY, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMalloc(&b->d_histU, sizeof(double) * (size_t)B * b->P.mem_size * 8));
+  BCHK(hipMalloc(&b->d_histV, sizeof(double) * (size_t)B * b->P.mem_size * 8));
+  BCHK(hipMemset(b->d_histU, 0, sizeof(double) * (size_t)B * b->P.mem_size * 8));
+  BCHK(hipMemset(b->d_histV, 0, sizeof(double) * (size_t)B * b->P.mem_size * 8));
   BCHK(hipMalloc(&b->d_x_in, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_x_out, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_f, sizeof(double) * (size_t)B));
@@ -564,6 +568,8 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.epis = b->epis;
   D.histS = b->d_histS;
   D.histY = b->d_histY;
+  D.histU = b->d_histU;
+  D.histV = b->d_histV;
   D.x_in = b->d_x_in;
   D.x_out = b->d_x_out;
   D.f_out = b->d_f;
@@ -707,3 +713,4 @@ extern "C" int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout,
   dftpav_batch_destroy(b);
   return rc;
 }
+

@@ -68,6 +68,9 @@ struct DevBatch {
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
   double *histS, *histY; // [B][mem][npad]
+  // products of neighbouring stored pairs, [B][mem][8] (solver.hip, two_loop_lane):
+  //   histU[j][d] = s_j . y_(the d+1-th pair after j),  histV[j][d] = y_j . s_(the d+1-th pair before j)
+  double *histU, *histV;
   // in/out
   const double *x_in; // eval mode: [B][n]
   double *x_out;      // [B][n]

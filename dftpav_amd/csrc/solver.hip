@@ -715,90 +715,219 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
 typedef const double __attribute__((address_space(1))) *gptr_t; // global (not flat) loads: vmcnt only
 typedef double __attribute__((address_space(1))) *gwptr_t;
 
-// one block of PB consecutive history steps held in registers
-template <int PB>
-struct HistBlock {
-  double s[PB], y[PB], ys[PB], ri[PB], al[PB];
-};
-// loads the PB slots starting at `jl` walking downwards (DIR = -1) or upwards (DIR = +1) with wrap-around;
-// unconditional loads from always-valid addresses, nothing consumes them here
-template <int PB, int DIR, bool ALPHA>
-__device__ __forceinline__ void load_block(HistBlock<PB> &R, const Smem &sm, gptr_t hS, gptr_t hY, int npad, int m, int ln, int &jl) {
-#pragma unroll
-  for (int q = 0; q < PB; q++) {
-    if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
-    R.s[q] = hS[(size_t)jl * npad + ln];
-    R.y[q] = hY[(size_t)jl * npad + ln];
-    R.ys[q] = sm.ys[jl];
-    R.ri[q] = sm.rinv[jl];
-    if (ALPHA) R.al[q] = sm.alpha[jl];
-    if (DIR > 0) jl = jl == m - 1 ? 0 : jl + 1;
-  }
+// ------------------------------------------- two-loop recursion, n <= 64
+// One element of the direction per lane.  The reference's step (lbfgs.hpp:722-726)
+//     alpha_t = s_t.d / ys_t ;  d -= alpha_t y_t
+// is a chain of ~25 dependent instructions (lane multiply, cross-lane reduction, divide, axpy).  It
+// is run in blocks of kLoopBlock stored pairs: the block's dot products are all taken against d as
+// it stands at the start of the block (independent reductions, they overlap in the pipeline), and
+// what the block's earlier steps would have removed from d is restored from the stored products of
+// neighbouring pairs,   s_t.(d - sum_u alpha_u y_u) = s_t.d - sum_u alpha_u (s_t.y_u),
+// so only one multiply-add and the division of a step wait for the previous step.  histU / histV
+// hold s_j.y_k for the kLoopBlock-1 pairs on either side of a pair; they are written once, when the
+// newer pair of the two is stored (lbfgs_advance).  oracle/dftpav_oracle_dev.cpp replays the same
+// sequence.
+constexpr int kLoopBlock = 8;
+__device__ inline double readlane_f64(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
 }
-template <int LV, int PB>
-__device__ __forceinline__ void first_loop_block(const HistBlock<PB> &R, const Smem &sm, int i0, int nb, int m, bool act,
-                                                 int lane, int &j, double &dreg) {
-#pragma unroll
-  for (int q = 0; q < PB; q++) {
-    if (i0 + q < nb) {
-      j = j == 0 ? m - 1 : j - 1;
-      double sv = act ? R.s[q] : 0.0, yv = act ? R.y[q] : 0.0;
-      double acc = wave_sum_raw<LV>(sv * dreg);
-      double a = div_by_rcp(acc, R.ys[q], R.ri[q]); // lm_s.col(j).dot(d) / lm_ys(j)
-      if (lane == 0) sm.alpha[j] = a;
-      double na = -a;
-      dreg += na * yv;
-    }
-  }
+// Cross-lane instructions are the expensive ones here (a DPP move or v_readlane costs ~10 cycles of
+// issue against ~4 for an fp64 FMA, scripts/ubench.hip), so the block's eight reductions share their
+// butterflies: at distance 1 a lane keeps the four sums whose index bit 0 matches its own and hands
+// the other four to its partner, at distance 2 it keeps two, at distance 4 one -- 7 exchanged values
+// instead of 24 -- and the remaining distances fold that one value as before.  The pairs added at
+// every distance are exactly those of wave_sum_raw (fp addition is commutative), so every sum has the
+// bits of lane_dot in the oracle.  Lane l ends up holding the total of step step_of_lane(l); the
+// mirrors used at distance 4 and 8 complement the lower lane bits, which the index map absorbs.
+__device__ inline int step_of_lane(int l) {
+  const int b0 = l & 1, b1 = (l >> 1) & 1, b2 = (l >> 2) & 1, b3 = (l >> 3) & 1;
+  return ((b2 ^ b3) << 2) | ((b1 ^ b2) << 1) | (b0 ^ b2);
 }
-template <int LV, int PB>
-__device__ __forceinline__ void second_loop_block(const HistBlock<PB> &R, int i0, int nb, bool act, double &dreg) {
+__host__ __device__ constexpr int lane_of_step(int u) { // a lane (< 8) holding step u
+  return (((u >> 2) & 1) << 2) | ((((u >> 1) ^ (u >> 2)) & 1) << 1) | ((u ^ (u >> 2)) & 1);
+}
+template <int LV>
+__device__ __forceinline__ double wave_sum8_transposed(const double (&v)[kLoopBlock], int lane) {
+  asm volatile("" : "+v"(lane)); // keeps the three masks local (see first_loop_block)
+  const bool k0 = ((lane ^ (lane >> 2)) & 1) != 0;        // bit 0 of my step
+  const bool k1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0; // bit 1
+  const bool k2 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0; // bit 2
+  double w[4], z[2];
 #pragma unroll
-  for (int q = 0; q < PB; q++) {
-    if (i0 + q < nb) {
-      double sv = act ? R.s[q] : 0.0, yv = act ? R.y[q] : 0.0;
-      double acc = wave_sum_raw<LV>(yv * dreg);
-      double beta = div_by_rcp(acc, R.ys[q], R.ri[q]); // lm_y.col(j).dot(d) / lm_ys(j)
-      double cf = R.al[q] - beta;
-      dreg += cf * sv;
-    }
+  for (int k = 0; k < 4; k++) {
+    const double keep = k0 ? v[2 * k + 1] : v[2 * k], send = k0 ? v[2 * k] : v[2 * k + 1];
+    w[k] = keep + mov_dpp<0xB1>(send); // quad_perm [1,0,3,2]
   }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double keep = k1 ? w[2 * k + 1] : w[2 * k], send = k1 ? w[2 * k] : w[2 * k + 1];
+    z[k] = keep + mov_dpp<0x4E>(send); // quad_perm [2,3,0,1]
+  }
+  double r;
+  {
+    const double keep = k2 ? z[1] : z[0], send = k2 ? z[0] : z[1];
+    r = keep + mov_dpp<0x141>(send); // row_half_mirror
+  }
+  r += mov_dpp<0x140>(r); // row_mirror
+  double x, y;
+  if (LV >= 5) {
+    swap16(r, x, y);
+    r = x + y;
+  }
+  if (LV >= 6) {
+    swap32(r, x, y);
+    r = x + y;
+  }
+  return r;
 }
 
-// Two-loop recursion (lbfgs.hpp:716-739) for n <= 64: one element of the direction per lane, the
-// reference's sequence of dot / divide / axpy steps.  History columns (global memory: they live in
-// L2 / Infinity Cache), 1/ys and alpha (LDS) are double-buffered in registers in blocks of PB
-// steps: the loads of block k+1 are issued before block k is reduced, so their latency hides
-// behind ~PB dependent reductions and no wait is ever placed right after a load.  Only lanes
-// below 2^LV take part (the trimmed butterfly leaves the others with partial sums that are
-// never used: their direction element is masked).
-template <int LV, int PB>
-__device__ __forceinline__ double two_loop_lane(const Smem &sm, const double *hS_, const double *hY_, int npad, int n, int m,
-                                                int nb, int ne, double ys_new, double yy_new, int lane, double dreg) {
-  gptr_t hS = (gptr_t)hS_;
-  gptr_t hY = (gptr_t)hY_;
+// one block of kLoopBlock consecutive steps: the history columns in registers; the per-step scalars
+// live in the lanes that own the step (step_of_lane): ys, 1/ys and the products with the block's
+// earlier steps, coef[u] = s_step . y_u (first loop) or y_step . s_u (second loop)
+struct HistBlock {
+  double s[kLoopBlock], y[kLoopBlock];
+  double coef[kLoopBlock - 1];
+  double ys, ri;
+  double al[kLoopBlock]; // second loop: alpha of every step of the block (uniform)
+};
+// loads the block whose first step sits in slot `jl`, walking downwards (DIR = -1) or upwards (+1)
+// with wrap-around; unconditional loads from always-valid addresses, nothing consumes them here
+template <int DIR, bool LOOP2>
+__device__ __forceinline__ void load_block(HistBlock &R, const Smem &sm, gptr_t hS, gptr_t hY, gptr_t hB, int npad, int m, int ln,
+                                           int lane, int &jl) {
+  const int st = step_of_lane(lane);
+  int js = jl + DIR * st; // |offset| < kLoopBlock <= m
+  js = js < 0 ? js + m : (js >= m ? js - m : js);
+#pragma unroll
+  for (int u = 0; u < kLoopBlock - 1; u++) R.coef[u] = hB[(size_t)js * 8 + (st > u ? st - u - 1 : 0)];
+  R.ys = sm.ys[js];
+  R.ri = sm.rinv[js];
+#pragma unroll
+  for (int q = 0; q < kLoopBlock; q++) {
+    R.s[q] = hS[(size_t)jl * npad + ln];
+    R.y[q] = hY[(size_t)jl * npad + ln];
+    if (LOOP2) R.al[q] = sm.alpha[jl];
+    if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
+    else jl = jl == m - 1 ? 0 : jl + 1;
+  }
+}
+// Makes every loaded register of the block a use: the wait for the block's loads lands here, before the
+// next block's loads are issued, so it can only be a wait for this block (the compiler's counter for
+// outstanding loads is conservative around the loop back edge and would otherwise wait for both).
+__device__ __forceinline__ void pin_block(HistBlock &R) {
+#pragma unroll
+  for (int q = 0; q < kLoopBlock; q++) {
+    asm volatile("" : "+v"(R.s[q]));
+    asm volatile("" : "+v"(R.y[q]));
+  }
+#pragma unroll
+  for (int u = 0; u < kLoopBlock - 1; u++) asm volatile("" : "+v"(R.coef[u]));
+}
+template <int LV, bool FULL>
+__device__ __forceinline__ void first_loop_block(const HistBlock &R, const Smem &sm, int i0, int nb, int m, bool act, int lane,
+                                                 int &j, double &dreg) {
+  double v[kLoopBlock];
+#pragma unroll
+  for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.s[q] : 0.0) * dreg; // lm_s.col(j).dot(d), steps past nb unused
+  double acc = wave_sum8_transposed<LV>(v, lane);
+  // (the lane masks below are recomputed from `st` where they are used: kept live across the loop they
+  // would be spilled and every reload is a cross-lane read)
+  int st = step_of_lane(lane);
+  asm volatile("" : "+v"(st));
+#pragma unroll
+  for (int u = 0; u < kLoopBlock; u++) {
+    if (FULL || i0 + u < nb) { // uniform
+      const double t = div_by_rcp(acc, R.ys, R.ri);             // ... / lm_ys(j): only the owner's quotient is used
+      const double au = readlane_f64(t, lane_of_step(u));       // alpha of step u for everybody
+      if (u < kLoopBlock - 1) {
+        const double nacc = __builtin_fma(-au, R.coef[u], acc);
+        acc = st > u ? nacc : acc;
+      }
+      dreg = __builtin_fma(-au, act ? R.y[u] : 0.0, dreg);
+    }
+  }
+  // lanes 0..7 own one step each; their sum stopped changing at their own step, so its quotient is their alpha
+  const double mine = div_by_rcp(acc, R.ys, R.ri);
+  int js = j - st;
+  js = js < 0 ? js + m : js;
+  if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[js] = mine;
+  const int done = FULL ? kLoopBlock : nb - i0;
+  j -= done;
+  j = j < 0 ? j + m : j;
+}
+template <int LV, bool FULL>
+__device__ __forceinline__ void second_loop_block(const HistBlock &R, int i0, int nb, bool act, int lane, double &dreg) {
+  double v[kLoopBlock];
+#pragma unroll
+  for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.y[q] : 0.0) * dreg; // lm_y.col(j).dot(d), steps past nb unused
+  double acc = wave_sum8_transposed<LV>(v, lane);
+  int st = step_of_lane(lane);
+  asm volatile("" : "+v"(st));
+#pragma unroll
+  for (int u = 0; u < kLoopBlock; u++) {
+    if (FULL || i0 + u < nb) { // uniform
+      const double t = div_by_rcp(acc, R.ys, R.ri);
+      const double bu = readlane_f64(t, lane_of_step(u)); // beta of step u
+      if (u < kLoopBlock - 1) {
+        double nacc = __builtin_fma(R.al[u], R.coef[u], acc);
+        nacc = __builtin_fma(-bu, R.coef[u], nacc);
+        acc = st > u ? nacc : acc;
+      }
+      dreg = __builtin_fma(R.al[u] - bu, act ? R.s[u] : 0.0, dreg);
+    }
+  }
+}
+template <int LV>
+__device__ __forceinline__ void first_loop_step(const HistBlock &R, const Smem &sm, int i0, int nb, int m, bool act, int lane,
+                                                int &j, double &dreg) {
+  if (i0 + kLoopBlock <= nb) first_loop_block<LV, true>(R, sm, i0, nb, m, act, lane, j, dreg);
+  else if (i0 < nb) first_loop_block<LV, false>(R, sm, i0, nb, m, act, lane, j, dreg);
+}
+template <int LV>
+__device__ __forceinline__ void second_loop_step(const HistBlock &R, int i0, int nb, bool act, int lane, double &dreg) {
+  if (i0 + kLoopBlock <= nb) second_loop_block<LV, true>(R, i0, nb, act, lane, dreg);
+  else if (i0 < nb) second_loop_block<LV, false>(R, i0, nb, act, lane, dreg);
+}
+
+// History columns (global memory: they live in L2 / Infinity Cache) are double-buffered in registers:
+// the loads of block k+1 are in flight while block k is reduced, and no wait is
+// ever placed right after a load.  Only lanes below 2^LV take part (the trimmed butterfly leaves the
+// others with partial sums that are never used: their direction element is masked).
+template <int LV>
+__device__ __forceinline__ double two_loop_lane(const Smem &sm, const double *hS_, const double *hY_, const double *hU_,
+                                                const double *hV_, int npad, int n, int m, int nb, int ne, double ys_new,
+                                                double yy_new, int lane, double dreg) {
+  gptr_t hS = (gptr_t)hS_, hY = (gptr_t)hY_, hU = (gptr_t)hU_, hV = (gptr_t)hV_;
   const bool act = lane < n;
   const int ln = act ? lane : 0;
   nb = __builtin_amdgcn_readfirstlane(nb);
-  HistBlock<PB> A, B;
+  constexpr int PB = kLoopBlock;
+  HistBlock A, B;
   // ---- first loop: newest -> oldest (slots ne-1, ne-2, ...)
-  int jl = ne, j = ne;
-  load_block<PB, -1, false>(A, sm, hS, hY, npad, m, ln, jl);
+  int j = ne == 0 ? m - 1 : ne - 1; // slot of the next step
+  int jl = j;
+  load_block<-1, false>(A, sm, hS, hY, hU, npad, m, ln, lane, jl);
   for (int i0 = 0; i0 < nb; i0 += 2 * PB) {
-    load_block<PB, -1, false>(B, sm, hS, hY, npad, m, ln, jl);
-    first_loop_block<LV, PB>(A, sm, i0, nb, m, act, lane, j, dreg);
-    load_block<PB, -1, false>(A, sm, hS, hY, npad, m, ln, jl);
-    first_loop_block<LV, PB>(B, sm, i0 + PB, nb, m, act, lane, j, dreg);
+    pin_block(A);
+    load_block<-1, false>(B, sm, hS, hY, hU, npad, m, ln, lane, jl);
+    first_loop_step<LV>(A, sm, i0, nb, m, act, lane, j, dreg);
+    pin_block(B);
+    load_block<-1, false>(A, sm, hS, hY, hU, npad, m, ln, lane, jl);
+    first_loop_step<LV>(B, sm, i0 + PB, nb, m, act, lane, j, dreg);
   }
   dreg *= ys_new / yy_new;
-  // ---- second loop: oldest -> newest, starting at the slot the first loop ended on
-  jl = j;
-  load_block<PB, +1, true>(A, sm, hS, hY, npad, m, ln, jl);
+  // ---- second loop: oldest -> newest, starting one past the slot the first loop ended on
+  jl = j == m - 1 ? 0 : j + 1;
+  load_block<+1, true>(A, sm, hS, hY, hV, npad, m, ln, lane, jl);
   for (int i0 = 0; i0 < nb; i0 += 2 * PB) {
-    load_block<PB, +1, true>(B, sm, hS, hY, npad, m, ln, jl);
-    second_loop_block<LV, PB>(A, i0, nb, act, dreg);
-    load_block<PB, +1, true>(A, sm, hS, hY, npad, m, ln, jl);
-    second_loop_block<LV, PB>(B, i0 + PB, nb, act, dreg);
+    pin_block(A);
+    load_block<+1, true>(B, sm, hS, hY, hV, npad, m, ln, lane, jl);
+    second_loop_step<LV>(A, i0, nb, act, lane, dreg);
+    pin_block(B);
+    load_block<+1, true>(A, sm, hS, hY, hV, npad, m, ln, lane, jl);
+    second_loop_step<LV>(B, i0 + PB, nb, act, lane, dreg);
   }
   return dreg;
 }
@@ -1028,10 +1157,11 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
   int bound = sm.ist[iBOUND];
   {
     double *sc = hS + (size_t)end * npad, *yc = hY + (size_t)end * npad;
-    double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0;
+    double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0, ylane = 0.0;
     for (int e = lane; e < n; e += 64) {
       double sv = sm.x[e] - sm.xp[e];
       double yv = sm.g[e] - sm.gp[e];
+      ylane = yv; // n <= 64: this lane's only element
       sc[e] = sv;
       yc[e] = yv;
       ys += yv * sv;
@@ -1055,10 +1185,37 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       ++bound;
       bound = m < bound ? m : bound;
       int ne = end + 1 == m ? 0 : end + 1;
-      if (n <= 64) {
+      if (n <= 64 && m >= kLoopBlock) {
+        // products of the new y with the s of the kLoopBlock-1 pairs before it (histU / histV)
+        double *hU = D.histU + (size_t)b * m * 8, *hV = D.histV + (size_t)b * m * 8;
+        {
+          const bool act = lane < n;
+          const int ln = act ? lane : 0;
+          const int nold = bound - 1 < kLoopBlock - 1 ? bound - 1 : kLoopBlock - 1;
+          double sv[kLoopBlock - 1];
+          int o = end;
+#pragma unroll
+          for (int dd = 0; dd < kLoopBlock - 1; dd++) {
+            o = o == 0 ? m - 1 : o - 1;
+            sv[dd] = ((gptr_t)hS)[(size_t)o * npad + ln];
+          }
+          o = end;
+#pragma unroll
+          for (int dd = 0; dd < kLoopBlock - 1; dd++) {
+            o = o == 0 ? m - 1 : o - 1;
+            if (dd < nold) {
+              double v = wave_sum_raw<LV>((act ? sv[dd] : 0.0) * ylane);
+              if (lane == 0) {
+                hU[(size_t)o * 8 + dd] = v;
+                hV[(size_t)end * 8 + dd] = v;
+              }
+            }
+          }
+          __threadfence_block(); // lane 0 wrote them, every lane of this wave reads them below
+        }
         // the newest column was written by these same lanes: program order makes it visible to them
         double dreg = lane < n ? sm.d[lane] : 0.0;
-        dreg = two_loop_lane<LV, 8>(sm, hS, hY, npad, n, m, bound, ne, ys, yy, lane, dreg);
+        dreg = two_loop_lane<LV>(sm, hS, hY, hU, hV, npad, n, m, bound, ne, ys, yy, lane, dreg);
         if (lane < n) sm.d[lane] = dreg;
       } else {
         int j = ne;

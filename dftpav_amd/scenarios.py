@@ -337,7 +337,7 @@ def make_scenario(piece_nums, singuls, K, Kd, B, seed, n_hyp=None, n_obs=50, wit
     M = len(piece_nums)
     layout = LayoutSpec(piece_nums, singuls, H=4)
     if n_hyp is None:
-        n_hyp = max(1, B // 16)
+        n_hyp = min(max(1, B // 16), 128)
     n_hyp = min(n_hyp, B)
     rng = _rng(seed)
     hyps = []

@@ -27,6 +27,7 @@
  * (the oracle may include product headers, never the reverse); orchestration,
  * reductions and the L-BFGS driver below are written independently of the kernel.
  */
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -513,6 +514,9 @@ extern "C" void oracle_dev_coeffs(const oracle_ctx *c, double *coeffs, double *p
 
 // lbfgs_optimize (lbfgs.hpp:440-751) + line_search_lewisoverton (lbfgs.hpp:276-390)
 // with the kernel's reduction order for every dot product.
+static const int kLoopBlock = 8; // stored pairs per block of the two-loop recursion (solver.hip)
+static const int kBand = kLoopBlock - 1;
+
 extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   DevState &D = *static_cast<DevState *>(c->dev);
   const DevParams &P = D.P;
@@ -520,6 +524,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   g_levels = levels_for(n);
   std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), alpha_h(m, 0.0);
   std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
+  std::vector<double> hU((size_t)m * 8, 0.0), hV((size_t)m * 8, 0.0); // products with the kBand neighbouring pairs
   double pf[8];
   int evals = 0, k = 0, end = 0, bound = 0, ret = 0;
   long long hist_sum = 0;
@@ -658,23 +663,79 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
         ++bound;
         bound = m < bound ? m : bound;
         end = (end + 1) % m;
-        int j = end;
-        for (int i = 0; i < bound; ++i) {
-          j = (j + m - 1) % m;
-          const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-          double a = (n <= 64 ? lane_dot(sj, d.data(), n) : wave_dot(sj, d.data(), n)) / ys_h[j];
-          alpha_h[j] = a;
-          double na = -a;
-          for (int e = 0; e < n; e++) d[e] += na * yj[e];
-        }
-        double sc0 = ys / yy;
-        for (int e = 0; e < n; e++) d[e] *= sc0;
-        for (int i = 0; i < bound; ++i) {
-          const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-          double beta = (n <= 64 ? lane_dot(yj, d.data(), n) : wave_dot(yj, d.data(), n)) / ys_h[j];
-          double cf = alpha_h[j] - beta;
-          for (int e = 0; e < n; e++) d[e] += cf * sj[e];
-          j = (j + 1) % m;
+        if (n <= 64) {
+          // Two-loop recursion (lbfgs.hpp:716-739) in blocks of kLoopBlock stored pairs, as the kernel runs
+          // it: the kLoopBlock dot products of a block are taken against the direction as it stands at the
+          // start of the block, and the effect of the block's earlier steps on a later dot product is
+          // restored from the stored products s_j.y_k of neighbouring pairs,
+          //     s_t.(d - sum_u alpha_u y_u) = s_t.d - sum_u alpha_u (s_t.y_u),
+          // so that only one multiply-add and the division of a step depend on the previous step.
+          const int cs = (end + m - 1) % m; // slot of the pair just stored
+          for (int dd = 0; dd < kBand && dd < bound - 1; dd++) { // products of the new y with the kBand pairs before it
+            const int o = (cs + m - 1 - dd) % m;
+            const double v = lane_dot(&hS[(size_t)o * n], yc, n);
+            hU[(size_t)o * 8 + dd] = v;  // s_o . y_(dd+1 pairs after o)
+            hV[(size_t)cs * 8 + dd] = v; // y_cs . s_(dd+1 pairs before cs)
+          }
+          auto nth_older = [&](int t) { return (cs - t % m + m) % m; }; // slot of the t-th pair before the newest
+          double al[kLoopBlock], dt[kLoopBlock];
+          for (int t0 = 0; t0 < bound; t0 += kLoopBlock) { // first loop, newest -> oldest
+            const int cnt = std::min(kLoopBlock, bound - t0);
+            for (int q = 0; q < cnt; q++) dt[q] = lane_dot(&hS[(size_t)nth_older(t0 + q) * n], d.data(), n);
+            for (int q = 0; q < cnt; q++) {
+              const int j = nth_older(t0 + q);
+              double acc = dt[q];
+              for (int u = 0; u < q; u++) acc = __builtin_fma(-al[u], hU[(size_t)j * 8 + (q - u - 1)], acc);
+              al[q] = acc / ys_h[j];
+              alpha_h[j] = al[q];
+            }
+            for (int q = 0; q < cnt; q++) {
+              const double *yj = &hY[(size_t)nth_older(t0 + q) * n];
+              for (int e = 0; e < n; e++) d[e] = __builtin_fma(-al[q], yj[e], d[e]);
+            }
+          }
+          const double sc0 = ys / yy;
+          for (int e = 0; e < n; e++) d[e] *= sc0;
+          double be[kLoopBlock];
+          for (int v0 = 0; v0 < bound; v0 += kLoopBlock) { // second loop, oldest -> newest
+            const int cnt = std::min(kLoopBlock, bound - v0);
+            for (int q = 0; q < cnt; q++) dt[q] = lane_dot(&hY[(size_t)nth_older(bound - 1 - (v0 + q)) * n], d.data(), n);
+            for (int q = 0; q < cnt; q++) {
+              const int j = nth_older(bound - 1 - (v0 + q));
+              double acc = dt[q];
+              for (int u = 0; u < q; u++) {
+                const double vv = hV[(size_t)j * 8 + (q - u - 1)];
+                acc = __builtin_fma(al[u], vv, acc);
+                acc = __builtin_fma(-be[u], vv, acc);
+              }
+              be[q] = acc / ys_h[j];
+              al[q] = alpha_h[j];
+            }
+            for (int q = 0; q < cnt; q++) {
+              const double cf = al[q] - be[q];
+              const double *sj = &hS[(size_t)nth_older(bound - 1 - (v0 + q)) * n];
+              for (int e = 0; e < n; e++) d[e] = __builtin_fma(cf, sj[e], d[e]);
+            }
+          }
+        } else {
+          int j = end;
+          for (int i = 0; i < bound; ++i) {
+            j = (j + m - 1) % m;
+            const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
+            double a = (n <= 64 ? lane_dot(sj, d.data(), n) : wave_dot(sj, d.data(), n)) / ys_h[j];
+            alpha_h[j] = a;
+            double na = -a;
+            for (int e = 0; e < n; e++) d[e] += na * yj[e];
+          }
+          double sc0 = ys / yy;
+          for (int e = 0; e < n; e++) d[e] *= sc0;
+          for (int i = 0; i < bound; ++i) {
+            const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
+            double beta = (n <= 64 ? lane_dot(yj, d.data(), n) : wave_dot(yj, d.data(), n)) / ys_h[j];
+            double cf = alpha_h[j] - beta;
+            for (int e = 0; e < n; e++) d[e] += cf * sj[e];
+            j = (j + 1) % m;
+          }
         }
         hist_sum += bound;
       }

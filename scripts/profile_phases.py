@@ -31,4 +31,7 @@ for i, nm in enumerate(NAMES):
     if nm == "-": continue
     per = pr[:, i] / (ev if i < 6 else it)
     print("%-18s %6.1f%%   %9.0f cycles per %s" % (nm, 100 * pr[:, i].sum() / tot.sum(), np.median(per), "eval" if i < 6 else "iter"))
+hs = r["hist_sum"].astype(float)
+print("two-loop cycles per history step (2 per entry per iteration):", round(float(np.median(pr[:, 8] / (2 * hs))), 1),
+      " mean depth", round(float((hs / it).mean()), 1))
 print("solves/s (kernel)", B / (np.mean(ms0) * 1e-3))
