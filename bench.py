@@ -134,6 +134,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "solver_kernel", "kernel_ms": kms,
+                         "launches_per_step": 2 if shard.B >= 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count else 1,
                          "algorithmic_bytes_per_launch": float(ebytes.sum())},
             "p50_ms_per_solve": float(np.median(r["latency_us"])) * 1e-3,
             "p95_ms_per_solve": float(np.percentile(r["latency_us"], 95)) * 1e-3,

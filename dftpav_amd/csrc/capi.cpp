@@ -21,7 +21,8 @@
 #include "traj_math.h"
 
 namespace dftpav {
-hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, hipStream_t stream);
+hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
+                         hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
@@ -45,6 +46,16 @@ struct dftpav_batch {
   DevParams P{};
   int threads = 0;
   bool op_in_lds = false, cor_in_lds = false;
+  // time-sliced scheduling (batches larger than the device holds at once): the queue launch runs in the
+  // shape above, the stragglers it hands over finish in the latency shape below
+  bool sched = false;
+  int slots = 0, slice = 0, hand_over = 0;
+  int threads2 = 0, ppt2 = 0;
+  bool op_in_lds2 = false, cor_in_lds2 = false;
+  int *d_queue = nullptr, *d_stragglers = nullptr, *d_sflag = nullptr, *d_iota = nullptr;
+  unsigned *d_qctl = nullptr;
+  double *d_state = nullptr;
+  DevBatch *d_dev2 = nullptr;
   int ppt = 1;
   int NptsPad = 0;
   std::vector<double> x0_host;
@@ -287,7 +298,8 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   (void)hipStreamSynchronize(b->h->stream);
   void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY, b->d_histU, b->d_histV,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
-                  b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt};
+                  b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
+                  b->d_queue, b->d_stragglers, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < kMaxSeg; i++) {
@@ -369,6 +381,25 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
       b->op_in_lds = (v & 1) != 0;
       b->cor_in_lds = (v & 2) != 0;
     }
+    // More trajectories than resident workgroups: solve lengths differ several-fold, and a launch of one
+    // workgroup per trajectory ends with a long tail of half-empty CUs.  Instead `slots` persistent
+    // workgroups take trajectories from a queue, run them `slice` iterations at a time and put the
+    // unfinished ones back, so all trajectories advance together; when no more than `hand_over` are left
+    // they are finished by a second launch in the latency shape (one wide workgroup per CU).
+    const int per_cu = shape == 0 ? 1 : (shape == 1 ? 2 : 4);
+    b->slots = n_cu * per_cu;
+    b->slice = 48;
+    b->hand_over = n_cu;
+    if (const char *e = std::getenv("DFTPAV_SLOTS")) b->slots = std::atoi(e);
+    if (const char *e = std::getenv("DFTPAV_SLICE")) b->slice = std::atoi(e);
+    if (const char *e = std::getenv("DFTPAV_HANDOVER")) b->hand_over = std::atoi(e);
+    b->sched = B >= b->slots && b->slots > 0 && b->slice > 0;
+    if (const char *e = std::getenv("DFTPAV_SCHED")) b->sched = std::atoi(e) != 0 && b->slots > 0 && b->slice > 0;
+    if (b->hand_over > B) b->hand_over = B;
+    b->threads2 = solver_threads(L, 0);
+    b->ppt2 = solver_ppt(L, b->threads2, 0);
+    b->op_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->ppt2, true, false) + 64 <= 158 * 1024;
+    b->cor_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->ppt2, b->op_in_lds2, true) + 64 <= 158 * 1024;
   }
   size_t lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds, b->cor_in_lds) + 64;
   if (lds > 160 * 1024 || b->threads < 64 || b->threads > 512 || b->threads % 64) {
@@ -417,6 +448,24 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_ticks, sizeof(long long) * (size_t)B));
   BCHK(hipMalloc(&b->d_prof, sizeof(long long) * (size_t)B * 12));
   BCHK(hipMalloc(&b->d_dev, sizeof(DevBatch)));
+  BCHK(hipMalloc(&b->d_dev2, sizeof(DevBatch)));
+  if (b->sched) {
+    const size_t stride = (size_t)solver_state_doubles(L, b->P);
+    BCHK(hipMalloc(&b->d_queue, sizeof(int) * (size_t)B));
+    BCHK(hipMalloc(&b->d_stragglers, sizeof(int) * (size_t)B));
+    BCHK(hipMalloc(&b->d_sflag, sizeof(int) * (size_t)B));
+    BCHK(hipMalloc(&b->d_iota, sizeof(int) * (size_t)B));
+    BCHK(hipMalloc(&b->d_qctl, sizeof(unsigned) * 16)); // [0..7] live counters, [8..15] their initial values
+    {
+      // queue = all trajectories: {head 0, published B, reserved B, unfinished B, stragglers 0}
+      const unsigned ctl0[8] = {0u, (unsigned)B, (unsigned)B, (unsigned)B, 0u, 0u, 0u, 0u};
+      BCHK(hipMemcpy(b->d_qctl + 8, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+    }
+    BCHK(hipMalloc(&b->d_state, sizeof(double) * stride * (size_t)B));
+    std::vector<int> iota(B);
+    for (int i = 0; i < B; i++) iota[i] = i;
+    BCHK(hipMemcpy(b->d_iota, iota.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice));
+  }
   BCHK(hipMalloc(&b->d_coef, sizeof(double) * (size_t)B * 12 * L.Ntot));
   BCHK(hipMalloc(&b->d_dt, sizeof(double) * (size_t)B * M));
   BCHK(hipEventCreate(&b->ev0));
@@ -570,6 +619,12 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.histY = b->d_histY;
   D.histU = b->d_histU;
   D.histV = b->d_histV;
+  D.queue = b->d_queue;
+  D.qctl = b->d_qctl;
+  D.stragglers = b->d_stragglers;
+  D.state = b->d_state;
+  D.sflag = b->d_sflag;
+  D.state_stride = solver_state_doubles(b->L, b->P);
   D.x_in = b->d_x_in;
   D.x_out = b->d_x_out;
   D.f_out = b->d_f;
@@ -593,7 +648,12 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
   int version = h->sur_version * 4 + (b->prof_on ? 1 : 0) + (b->uploaded ? 2 : 0);
   if (version != b->dev_version) {
     HIPCHK(h, hipMemcpyAsync(b->d_dev, &D, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream)); // D lives on this stack frame
+    DevBatch D2 = D; // the same batch in the latency shape (follow-up launch of a scheduled solve)
+    D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
+    D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
+    D2.ppt = b->ppt2;
+    HIPCHK(h, hipMemcpyAsync(b->d_dev2, &D2, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // D, D2 live on this stack frame
     b->dev_version = version;
   }
   return DFTPAV_OK;
@@ -620,7 +680,7 @@ extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, do
   HIPCHK(h, hipMemcpyAsync(b->d_x_in, x, sizeof(double) * nb, hipMemcpyHostToDevice, h->stream));
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeEval, b->threads, h->stream));
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeEval, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
   if (f) HIPCHK(h, hipMemcpyAsync(f, b->d_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, h->stream));
   if (g) HIPCHK(h, hipMemcpyAsync(g, b->d_g, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -634,7 +694,23 @@ extern "C" int dftpav_batch_solve_async(dftpav_batch *b) {
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, h->stream));
+  if (!b->sched) {
+    HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  } else {
+    // queue = all trajectories, flags cleared, counters reset: device-to-device, nothing waits on the host
+    HIPCHK(h, hipMemcpyAsync(b->d_queue, b->d_iota, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(b->d_sflag, 0, sizeof(int) * (size_t)b->B, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->d_qctl, b->d_qctl + 8, sizeof(unsigned) * 8, hipMemcpyDeviceToDevice, h->stream));
+    const int grid = b->slots < b->B ? b->slots : b->B;
+    HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, grid, SchedArgs{1, b->slice, b->hand_over}, h->stream));
+    if (b->hand_over > 0) {
+      DevBatch D2 = D;
+      D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
+      D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
+      D2.ppt = b->ppt2;
+      HIPCHK(h, launch_solver(D2, b->d_dev2, kModeSolve, b->threads2, b->hand_over, SchedArgs{2, 0, 0}, h->stream));
+    }
+  }
   HIPCHK(h, hipEventRecord(b->ev1, h->stream));
   b->timed = true;
   return DFTPAV_OK;
@@ -694,7 +770,7 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
   HIPCHK(h, hipSetDevice(h->device));
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, h->stream));
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (coeffs)
     HIPCHK(h, hipMemcpy(coeffs, b->d_coef, sizeof(double) * (size_t)b->B * 12 * b->L.Ntot, hipMemcpyDeviceToHost));

@@ -71,6 +71,13 @@ struct DevBatch {
   // products of neighbouring stored pairs, [B][mem][8] (solver.hip, two_loop_lane):
   //   histU[j][d] = s_j . y_(the d+1-th pair after j),  histV[j][d] = y_j . s_(the d+1-th pair before j)
   double *histU, *histV;
+  // time-sliced scheduling of batches larger than the device holds at once (solver.hip, solver_kernel)
+  int *queue;          // [B] ring of trajectories waiting for a workgroup
+  unsigned *qctl;      // [0] head  [1] published tail  [2] reserved tail  [3] unfinished  [4] number of stragglers
+  int *stragglers;     // [B] trajectories handed to the follow-up launch
+  double *state;       // [B][state_stride] solver state of a suspended trajectory
+  int *sflag;          // [B] 0 fresh, 1 suspended (state valid), 2 finished
+  int state_stride;
   // in/out
   const double *x_in; // eval mode: [B][n]
   double *x_out;      // [B][n]
@@ -85,6 +92,16 @@ struct DevBatch {
 };
 
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };
+
+// how a solve launch picks its trajectories
+struct SchedArgs {
+  int source;     // 0: workgroup i solves trajectory i   1: pops from DevBatch::queue until it is empty
+                  // 2: workgroup i resumes DevBatch::stragglers[i] (i < qctl[4])
+  int slice;      // iterations after which an unfinished trajectory is suspended (source 1; 0 = never)
+  int hand_over;  // source 1: once this few trajectories are unfinished, suspended ones go to `stragglers`
+};
+// doubles of solver state per suspended trajectory
+inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { return 5 * L.npad + 24 + 8 + 2 * P.mem_size; }
 
 // size in bytes of the dynamic LDS a launch needs
 size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds, bool cor_lds);

@@ -35,7 +35,7 @@ namespace dftpav {
 // ------------------------------------------------------------------ LDS carve
 // scalar L-BFGS state kept in Smem::st (doubles) and Smem::ist (ints)
 enum { sFX = 0, sFINIT, sDGINIT, sDGTEST, sDSTEST, sMU, sNU, sSTP, sSTEP, sF, sPF0 /* .. sPF0+7 */, sNUM = 24 };
-enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iNUM = 16 };
+enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iCUR, iNUM = 16 };
 enum { kActEval = 0, kActDone = 1 };
 
 struct Smem {
@@ -1262,24 +1262,75 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
 }
 
 // ------------------------------------------------------------- the solver
+// Work queue of a time-sliced launch (SchedArgs::source == 1): a ring of trajectory ids, popped and
+// pushed by thread 0 of a workgroup.  Everything a suspended trajectory owns (its state record, the
+// L-BFGS history) is written before the push and read after the pop, with device-scope fences in
+// between: the next slice may run on another XCD, behind another L2.
+__device__ inline int queue_pop(unsigned *ctl, const int *ring, int cap) {
+  while (true) {
+    unsigned h = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned t = __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (h >= t) return -1;
+    if (atomicCAS(&ctl[0], h, h + 1) == h) {
+      int id = __hip_atomic_load(&ring[h % (unsigned)cap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      return id;
+    }
+  }
+}
+__device__ inline void queue_push(unsigned *ctl, int *ring, int cap, int id) {
+  __threadfence();
+  unsigned t = atomicAdd(&ctl[2], 1u);
+  __hip_atomic_store(&ring[t % (unsigned)cap], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (atomicCAS(&ctl[1], t, t + 1) != t) { // publish in reservation order
+  }
+}
+
+// solver state of one trajectory <-> its record in DevBatch::state (everything lbfgs_advance keeps in LDS)
+__device__ inline void state_io(const DevBatch &D, const Smem &sm, int b, int tid, int T, bool save) {
+  const int npad = D.L.npad, m = D.P.mem_size;
+  double *rec = D.state + (size_t)b * D.state_stride;
+  double *vecs[5] = {sm.x, sm.xp, sm.g, sm.gp, sm.d};
+  for (int w = tid; w < 5 * npad; w += T) {
+    int a = w / npad, e = w - a * npad;
+    if (save) rec[w] = vecs[a][e];
+    else vecs[a][e] = rec[w];
+  }
+  double *r2 = rec + 5 * npad;
+  for (int w = tid; w < sNUM; w += T) {
+    if (save) r2[w] = sm.st[w];
+    else sm.st[w] = r2[w];
+  }
+  int *ri = reinterpret_cast<int *>(r2 + 24);
+  for (int w = tid; w < iNUM; w += T) {
+    if (save) ri[w] = sm.ist[w];
+    else sm.ist[w] = ri[w];
+  }
+  double *r3 = r2 + 24 + 8;
+  for (int w = tid; w < m; w += T) {
+    if (save) {
+      r3[w] = sm.ys[w];
+      r3[m + w] = sm.rinv[w];
+    } else {
+      sm.ys[w] = r3[w];
+      sm.rinv[w] = r3[m + w];
+    }
+  }
+}
+
 template <bool SUR, int LV, int MAXT>
-__global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict__ Dp, int mode) {
+__global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict__ Dp, int mode, SchedArgs sched) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
   const DevLayout &L = D.L;
-  const int b = blockIdx.x;
   const int tid = threadIdx.x, T = blockDim.x;
   const int lane = tid & 63;
   const int n = L.n;
   Smem sm;
   carve(sm, lds_raw, L, D.P.mem_size, T, D.ppt, D.op_in_lds != 0, D.cor_in_lds != 0);
-  const long long tick0 = wall_clock64();
   Prof pr;
-  pr.start(D.prof != nullptr && mode == kModeSolve);
 
-  // ---- one-time staging: decision vector, role tables, operators
-  const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
-  for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
+  // ---- one-time staging: role tables and operators (the same for every trajectory of the batch)
   for (int pt = tid; pt < L.Npts; pt += T) sm.ptinfo[pt] = (int)D.pt_piece[pt] | ((int)D.pt_j[pt] << 16);
   for (int p = tid; p < L.Ntot; p += T) {
     int sg = 0, p0 = 0, N = 0, pt0s = 0, sgl = 0, ooff = 0;
@@ -1332,53 +1383,121 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
       off += cnt;
     }
   }
-  if (D.cor_in_lds) { // the only read of the corridor from HBM: it stays in LDS for the whole solve
-    const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad;
-    const int pitch = (L.Npts + 63) / 64 * 64;
-    for (int k = 0; k < 4 * L.H; k++)
-      for (int pt = tid; pt < L.Npts; pt += T) sm.cor[k * pitch + pt] = cb[(size_t)k * D.NptsPad + pt];
-  }
-  if (tid < iNUM) sm.ist[tid] = 0;
-  __syncthreads();
 
-  block_eval<SUR>(D, b, sm, sm.x, sm.g, pr);
-
-  if (mode == kModeEval) {
-    for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
-    if (tid == 0) D.f_out[b] = sm.st[sF];
-    return;
-  }
-  if (mode == kModeCoeffs) {
-    for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
-    for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[sg * 16 + 1];
-    return;
-  }
-
-  // ---- lbfgs_optimize (lbfgs.hpp:440-751): wave 0 advances the solver state between evaluations
-  while (true) {
-    if (tid < 64) lbfgs_advance<LV>(D, sm, b, lane, pr);
-    __syncthreads();
-    if (sm.ist[iACTION] == kActDone) break;
-    block_eval<SUR>(D, b, sm, sm.x, sm.g, pr);
-  }
-
-  for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
-  if (tid == 0) {
-    const double fx = sm.st[sFX];
-    const int ret = sm.ist[iRET];
-    D.f_out[b] = fx;
-    D.status[b] = ret;
-    D.iters[b] = sm.ist[iK];
-    D.evals[b] = sm.ist[iEVALS];
-    D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
-    D.ticks[b] = wall_clock64() - tick0;
-    // flag_success, traj_optimizer.cpp:176-201
-    int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
-    if (fx >= D.P.fail_cost) ok = 0;
-    D.success[b] = ok;
-    if (pr.on) {
-      for (int i = 0; i < 12; i++) D.prof[(size_t)b * 12 + i] = pr.acc[i];
+  // ---- one trajectory (or one slice of one) per pass
+  for (int pass = 0;; pass++) {
+    __syncthreads(); // the previous pass is done with LDS
+    if (tid == 0) {
+      int id = -1;
+      if (mode != kModeSolve || sched.source == 0) {
+        id = pass == 0 ? (int)blockIdx.x : -1;
+      } else if (sched.source == 1) {
+        id = queue_pop(D.qctl, D.queue, D.B);
+      } else if (pass == 0) {
+        unsigned cnt = __hip_atomic_load(&D.qctl[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x < cnt) {
+          id = D.stragglers[blockIdx.x];
+          __threadfence();
+        }
+      }
+      sm.ist[iCUR] = id;
     }
+    __syncthreads();
+    const int b = sm.ist[iCUR];
+    if (b < 0) break;
+    const long long tick0 = wall_clock64();
+    pr.start(D.prof != nullptr && mode == kModeSolve);
+    const bool resume = mode == kModeSolve && sched.source != 0 && D.sflag[b] == 1;
+    __syncthreads(); // everybody has read iCUR before the state is restored over it
+
+    // ---- per-trajectory staging: decision vector (or the suspended state) and half-planes
+    if (resume) {
+      state_io(D, sm, b, tid, T, false);
+    } else {
+      const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
+      for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
+      if (tid < iNUM) sm.ist[tid] = 0;
+    }
+    if (D.cor_in_lds) { // the only read of the corridor from HBM: it stays in LDS for the whole pass
+      const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad;
+      const int pitch = (L.Npts + 63) / 64 * 64;
+      for (int k = 0; k < 4 * L.H; k++)
+        for (int pt = tid; pt < L.Npts; pt += T) sm.cor[k * pitch + pt] = cb[(size_t)k * D.NptsPad + pt];
+    }
+    __syncthreads();
+    const int k_start = sm.ist[iK];
+
+    block_eval<SUR>(D, b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
+
+    if (mode == kModeEval) {
+      for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
+      if (tid == 0) D.f_out[b] = sm.st[sF];
+      return;
+    }
+    if (mode == kModeCoeffs) {
+      for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
+      for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[sg * 16 + 1];
+      return;
+    }
+
+    // ---- lbfgs_optimize (lbfgs.hpp:440-751): wave 0 advances the solver state between evaluations
+    bool finished = true;
+    while (true) {
+      if (tid < 64) lbfgs_advance<LV>(D, sm, b, lane, pr);
+      __syncthreads();
+      if (sm.ist[iACTION] == kActDone) break;
+      if (sched.source == 1 && sched.slice > 0 && sm.ist[iK] - k_start >= sched.slice) { // uniform
+        finished = false;
+        break;
+      }
+      block_eval<SUR>(D, b, sm, sm.x, sm.g, pr);
+    }
+
+    const long long spent = wall_clock64() - tick0;
+    if (finished) {
+      for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
+      if (tid == 0) {
+        const double fx = sm.st[sFX];
+        const int ret = sm.ist[iRET];
+        D.f_out[b] = fx;
+        D.status[b] = ret;
+        D.iters[b] = sm.ist[iK];
+        D.evals[b] = sm.ist[iEVALS];
+        D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+        D.ticks[b] = (resume ? D.ticks[b] : 0) + spent; // time in service
+        // flag_success, traj_optimizer.cpp:176-201
+        int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
+        if (fx >= D.P.fail_cost) ok = 0;
+        D.success[b] = ok;
+        if (pr.on) {
+          for (int i = 0; i < 12; i++) D.prof[(size_t)b * 12 + i] = (resume ? D.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
+        }
+        if (sched.source != 0) {
+          D.sflag[b] = 2;
+          atomicSub(&D.qctl[3], 1u);
+        }
+      }
+    } else {
+      state_io(D, sm, b, tid, T, true);
+      __syncthreads(); // all of the record is written (and fenced by thread 0 below) before the id is handed on
+      if (tid == 0) {
+        D.ticks[b] = (resume ? D.ticks[b] : 0) + spent;
+        if (pr.on) {
+          for (int i = 0; i < 12; i++) D.prof[(size_t)b * 12 + i] = (resume ? D.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
+        }
+        D.sflag[b] = 1;
+        unsigned left = __hip_atomic_load(&D.qctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left <= (unsigned)sched.hand_over) {
+          __threadfence();
+          unsigned slot = atomicAdd(&D.qctl[4], 1u);
+          D.stragglers[slot] = b;
+          __threadfence();
+        } else {
+          queue_push(D.qctl, D.queue, D.B, b);
+        }
+      }
+    }
+    if (mode != kModeSolve || sched.source != 1) break;
   }
 }
 
@@ -1401,25 +1520,26 @@ hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream) {
 
 // ------------------------------------------------------------- host launchers
 template <bool SUR, int LV, int MAXT>
-static hipError_t launch_variant(const DevBatch *d_dev, int B, int mode, int threads, size_t lds, hipStream_t stream) {
+static hipError_t launch_variant(const DevBatch *d_dev, int grid, int mode, int threads, size_t lds, SchedArgs sched, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solver_kernel<SUR, LV, MAXT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((solver_kernel<SUR, LV, MAXT>), dim3(B), dim3(threads), lds, stream, d_dev, mode);
+  hipLaunchKernelGGL((solver_kernel<SUR, LV, MAXT>), dim3(grid), dim3(threads), lds, stream, d_dev, mode, sched);
   return hipGetLastError();
 }
 template <bool SUR>
-static hipError_t launch_lv(int n, const DevBatch *d_dev, int B, int mode, int threads, size_t lds, hipStream_t stream) {
-  if (n <= 16) return launch_variant<SUR, 4, 512>(d_dev, B, mode, threads, lds, stream);
-  if (n <= 32) return launch_variant<SUR, 5, 512>(d_dev, B, mode, threads, lds, stream);
-  return launch_variant<SUR, 6, 512>(d_dev, B, mode, threads, lds, stream);
+static hipError_t launch_lv(int n, const DevBatch *d_dev, int grid, int mode, int threads, size_t lds, SchedArgs sched, hipStream_t stream) {
+  if (n <= 16) return launch_variant<SUR, 4, 512>(d_dev, grid, mode, threads, lds, sched, stream);
+  if (n <= 32) return launch_variant<SUR, 5, 512>(d_dev, grid, mode, threads, lds, sched, stream);
+  return launch_variant<SUR, 6, 512>(d_dev, grid, mode, threads, lds, sched, stream);
 }
 
-// d_dev: device copy of the DevBatch `D` describes
-hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, hipStream_t stream) {
+// d_dev: device copy of the DevBatch `D` describes; grid: workgroups to launch (D.B unless the launch is scheduled)
+hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
+                         hipStream_t stream) {
   size_t lds = solver_lds_bytes(D.L, D.P, threads, D.ppt, D.op_in_lds != 0, D.cor_in_lds != 0);
-  if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, D.B, mode, threads, lds, stream);
-  return launch_lv<false>(D.L.n, d_dev, D.B, mode, threads, lds, stream);
+  if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
+  return launch_lv<false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
 }
 
 } // namespace dftpav

@@ -1,0 +1,30 @@
+"""Developer script: throughput of the time-sliced schedule vs the plain launch (run through gpurun)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from dftpav_amd import capi, scenarios as sc
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+p = capi.default_params()
+s = sc.baseline_config(3, B=B); s.apply_resolution(p)
+ref = None
+for tag, env in [("plain", {"DFTPAV_SCHED": "0"}),
+                 ("queue s48 h256", {"DFTPAV_SCHED": "1"}),
+                 ("queue s24 h256", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "24"}),
+                 ("queue s96 h256", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "96"}),
+                 ("queue s48 h512", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "512"}),
+                 ("queue s48 h128", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "128"}),
+                 ("queue s48 h0", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "0"})]:
+    for k in ("DFTPAV_SCHED", "DFTPAV_SLICE", "DFTPAV_HANDOVER", "DFTPAV_SLOTS"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    h = capi.Handle(p); bt = capi.Batch(h, s.layout, B); bt.upload(s)
+    bt.solve_async(); bt.sync()
+    ms = []
+    for _ in range(3):
+        bt.solve_async(); bt.sync(); ms.append(bt.last_solve_ms())
+    r = bt.results()
+    if ref is None: ref = r
+    same = all(np.array_equal(r[k], ref[k]) for k in ("final_cost", "x", "iters", "evals", "status"))
+    print("%-16s kernel ms %s  solves/s %8.0f  identical to plain: %s" % (tag, np.round(ms, 1), B / (np.mean(ms) * 1e-3), same), flush=True)
+    bt.close(); h.close()

@@ -21,19 +21,31 @@ def counter(kind):
             vals.append((int(r["Grid_Size"]), int(r["Workgroup_Size"]), float(r["Counter_Value"])))
     return vals
 fetch, write = counter("fetch"), counter("write")
-# the dominant launch is the one with the largest grid
+# One solve of a large batch is two launches of solver_kernel: the time-sliced launch (largest grid) and the
+# straggler launch that follows it; "per launch" below means per solve, i.e. both of them together.
 gmax = max(g for g, _, _ in fetch)
-f = [v for g, _, v in fetch if g == gmax]; w = [v for g, _, v in write if g == gmax]
+steps = sum(1 for g, _, _ in fetch if g == gmax)
 wg = [t for g, t, _ in fetch if g == gmax][0]
-fetch_kb, write_kb = sum(f) / len(f), sum(w) / len(w)
+fetch_kb, write_kb = sum(v for _, _, v in fetch) / steps, sum(v for _, _, v in write) / steps
+f = [0] * steps
 # MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts 128-B read
 # requests at 64 B, so it is doubled before it is compared with a byte count (calibrated for 16 B/lane
 # streams; our loads are 8 B/lane, so the doubled figure is an upper bound, the raw one a lower bound)
-rec = {"tag": tag, "kernel": "solver_kernel", "trajectories_per_launch": gmax // wg, "workgroup": wg,
+kstat = {}
+if ks:
+    for r in csv.DictReader(open(ks[0])):
+        if "solver_kernel" in r["Name"]:
+            launches_per_solve = len(set(g for g, _, _ in fetch))
+            solves = max(1, int(r["Calls"]) // launches_per_solve)
+            kstat = {"rocprof_calls": int(r["Calls"]), "rocprof_launches_per_solve": launches_per_solve,
+                     "rocprof_total_ms": float(r["TotalDurationNs"]) * 1e-6,
+                     "rocprof_solver_ms_per_solve": float(r["TotalDurationNs"]) * 1e-6 / solves}
+rec = {"tag": tag, "kernel": "solver_kernel", "solves_profiled": steps, "workgroups_time_sliced_launch": gmax // wg, "workgroup": wg,
        "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
        "hbm_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024.0,
        "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
        "launches_averaged": len(f)}
+rec.update(kstat)
 json.dump(rec, open(os.path.join(out, "%s_pmc.json" % tag), "w"), indent=1)
 json.dump(rec, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(rec))

@@ -78,6 +78,31 @@ def test_solve_matches_oracle(hiplib, oracle, cfg, B):
     h.close()
 
 
+@pytest.mark.parametrize("cfg,B,slots,slice_,hand_over", [(3, 48, 8, 7, 3), (3, 48, 5, 40, 0), (5, 6, 2, 9, 1), (2, 12, 4, 1, 12)])
+def test_time_sliced_schedule_is_bit_identical(hiplib, oracle, monkeypatch, cfg, B, slots, slice_, hand_over):
+    """Batches larger than the device holds at once are solved by persistent workgroups that suspend and resume
+    trajectories (solver.hip, SchedArgs): forced here on small batches, it must not change one bit."""
+    monkeypatch.setenv("DFTPAV_SCHED", "1")
+    monkeypatch.setenv("DFTPAV_SLOTS", str(slots))
+    monkeypatch.setenv("DFTPAV_SLICE", str(slice_))
+    monkeypatch.setenv("DFTPAV_HANDOVER", str(hand_over))
+    p = hiplib.default_params()
+    s = sc.baseline_config(cfg, B=B)
+    s.apply_resolution(p)
+    h, bt = _batch(hiplib, s, p)
+    ro = oracle.solve_batch(p, s, nthreads=8, order=1)
+    for rep in range(2):  # the second solve reuses queue, flags and state records
+        r = bt.solve()
+        assert np.array_equal(r["final_cost"], ro["final_cost"])
+        assert np.array_equal(r["x"], ro["x"])
+        for k in ("status", "iters", "evals", "success"):
+            assert np.array_equal(r[k], ro[k]), k
+        assert np.array_equal(r["hist_sum"], ro["hist_sum"])
+        assert (r["latency_us"] > 0).all()
+    bt.close()
+    h.close()
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_golden_fixtures(hiplib, name):
     """Against the committed golden vectors (no oracle at run time)."""
