@@ -56,7 +56,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    distributed = world > 1
+    # DFTPAV_BENCH_FORCE_DIST=1: take the RCCL path (init, barrier, all-gather, max-reduce) at world size 1 too
+    distributed = world > 1 or os.environ.get("DFTPAV_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
