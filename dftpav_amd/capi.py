@@ -26,7 +26,7 @@ EXPORTS = [
     "dftpav_last_error", "dftpav_set_surround", "dftpav_batch_create", "dftpav_batch_destroy",
     "dftpav_batch_upload", "dftpav_batch_get_x0", "dftpav_batch_eval", "dftpav_batch_solve_async",
     "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
-    "dftpav_solve_batch", "dftpav_stream",
+    "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
 ]
 
 
@@ -120,6 +120,23 @@ class Handle:
         self._check(lib().dftpav_set_surround(self._h, C.byref(s)), "set_surround")
         self._sur_keep = surround_set
 
+    def set_grid_map(self, grid, resolution, origin):
+        """Obstacle map of the corridor generator: uint8 [size_y][size_x], 80 = occupied (dftpav_grid_map)."""
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        m = GridMap(g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution), float(origin[0]), float(origin[1]))
+        fn = lib().dftpav_set_grid_map
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(fn(self._h, C.byref(m)), "set_grid_map")
+
+    def corridor_rectangles(self, states):
+        """getRectangleConst on the device: states [n][3] (x, y, yaw) -> [n][4][4] columns (n_x, n_y, p_x, p_y)."""
+        st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((st.shape[0], 4, 4), dtype=np.float64)
+        fn = lib().dftpav_corridor_rectangles
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self._check(fn(self._h, st.ctypes.data_as(C.c_void_p), st.shape[0], out.ctypes.data_as(C.c_void_p)), "corridor_rectangles")
+        return out
+
     def close(self):
         if self._h:
             lib().dftpav_destroy(self._h)
@@ -130,6 +147,12 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+
+class GridMap(C.Structure):
+    """dftpav_grid_map (include/dftpav_hip.h)."""
+    _fields_ = [("cells", C.c_void_p), ("size_x", C.c_int), ("size_y", C.c_int), ("resolution", C.c_double),
+                ("origin_x", C.c_double), ("origin_y", C.c_double)]
 
 
 class Batch:

@@ -23,6 +23,9 @@
 namespace dftpav {
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
                          hipStream_t stream);
+hipError_t launch_corridor(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
+                           const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
+                           int n_dl, double *hpoly, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
@@ -37,6 +40,11 @@ struct dftpav_handle {
   int sur_version = 0; // bumped by dftpav_set_surround so batches refresh their device descriptor
   int *d_sur_off = nullptr;
   double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr;
+  // obstacle map of the corridor generator (device copy) and the table of sample offsets along a line
+  dftpav_grid_map map{};
+  unsigned char *d_cells = nullptr;
+  double *d_dl = nullptr;
+  int n_dl = 0;
 };
 
 struct dftpav_batch {
@@ -190,12 +198,69 @@ extern "C" void dftpav_destroy(dftpav_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   free_surround(h);
+  if (h->d_cells) (void)hipFree(h->d_cells);
+  if (h->d_dl) (void)hipFree(h->d_dl);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
 extern "C" const char *dftpav_last_error(const dftpav_handle *h) { return h ? h->err.c_str() : "null handle"; }
 extern "C" void *dftpav_stream(dftpav_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+extern "C" int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map) {
+  if (!h || !map || !map->cells || map->size_x <= 0 || map->size_y <= 0 || !(map->resolution > 0.0)) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->d_cells) (void)hipFree(h->d_cells);
+  if (h->d_dl) (void)hipFree(h->d_dl);
+  h->d_cells = nullptr;
+  h->d_dl = nullptr;
+  const size_t ncell = (size_t)map->size_x * map->size_y;
+  HIPCHK(h, hipMalloc(&h->d_cells, ncell));
+  HIPCHK(h, hipMemcpy(h->d_cells, map->cells, ncell, hipMemcpyHostToDevice));
+  h->map = *map;
+  h->map.cells = nullptr;
+  // sample offsets of CheckIfCollisionUsingLine (map_adapter.cpp:119): dl = 0, then dl += checkl; the longest
+  // segment is the far edge of a fully grown rectangle
+  const double checkl = map->resolution / 2.0;
+  const double longest = std::max(h->params.veh_length, h->params.veh_width) + 2.0 * (10.0 + map->resolution) + 1.0;
+  std::vector<double> dl;
+  for (double v = 0.0; v < longest; v += checkl) dl.push_back(v);
+  h->n_dl = (int)dl.size();
+  HIPCHK(h, hipMalloc(&h->d_dl, sizeof(double) * dl.size()));
+  HIPCHK(h, hipMemcpy(h->d_dl, dl.data(), sizeof(double) * dl.size(), hipMemcpyHostToDevice));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states, int n_states, double *hpoly) {
+  if (!h || !states || !hpoly || n_states < 0) return DFTPAV_E_INVALID;
+  if (!h->d_cells) return DFTPAV_E_INVALID; // no map
+  if (n_states == 0) return DFTPAV_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  double *d_states = nullptr, *d_hpoly = nullptr;
+  HIPCHK(h, hipMalloc(&d_states, sizeof(double) * 3 * (size_t)n_states));
+  if (hipMalloc(&d_hpoly, sizeof(double) * 16 * (size_t)n_states) != hipSuccess) {
+    (void)hipFree(d_states);
+    h->err = "hipMalloc";
+    return DFTPAV_E_HIP;
+  }
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  chk(hipMemcpyAsync(d_states, states, sizeof(double) * 3 * (size_t)n_states, hipMemcpyHostToDevice, h->stream));
+  if (rc == DFTPAV_OK)
+    chk(launch_corridor(h->d_cells, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, d_states,
+                        n_states, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, h->d_dl, h->n_dl, d_hpoly, h->stream));
+  if (rc == DFTPAV_OK) chk(hipMemcpyAsync(hpoly, d_hpoly, sizeof(double) * 16 * (size_t)n_states, hipMemcpyDeviceToHost, h->stream));
+  chk(hipStreamSynchronize(h->stream));
+  (void)hipFree(d_states);
+  (void)hipFree(d_hpoly);
+  return rc;
+}
 
 extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   if (!h) return DFTPAV_E_INVALID;

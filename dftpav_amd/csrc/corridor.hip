@@ -1,0 +1,135 @@
+// Rectangle safe-corridor generation on the device: the step that produces the
+// half-planes the solve path consumes.
+//
+//   TrajPlanner::getRectangleConst                 traj_planner/src/traj_manager.cpp:1213-1469
+//   TrajPlannerAdapter::CheckIfCollisionUsingLine  traj_planner/src/map_adapter.cpp:117-129
+//   GridMapND::CheckIfEqualUsingGlobalPosition     common/src/common/basics/semantics.cc:169-179,214-221
+//
+// One wavefront per state (x, y, yaw).  The growth of the rectangle is a sequential decision process
+// (side after side, one cell at a time, at most 4 x 34 steps), but every decision is "does any sample
+// of three line segments fall into an occupied cell": the lanes take the samples (64 per pass, the
+// long edge needs up to three passes) and one ballot answers it.  The sample offsets dl = 0, +checkl,
+// +checkl, ... are the reference's running sum, tabulated once on the host so that lane k sees
+// exactly the k-th value of that sum.  The map is byte work out of L2 (a 120 m x 120 m map at 0.3 m
+// is 160 KB); the kernel is bound by the ~400 dependent decisions per state, not by bandwidth.
+// fp64 throughout, no contraction: bit-identical to oracle/corridor_oracle.cpp in order 1.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "traj_math.h"
+
+namespace dftpav {
+
+struct CorridorArgs {
+  const unsigned char *cells;
+  int size_x, size_y;
+  double resolution, origin_x, origin_y;
+  const double *states; // [n][3]
+  int n;
+  double veh_width, veh_length, veh_dcr;
+  const double *dl; // running sum 0, checkl, checkl + checkl, ...
+  int n_dl;
+  double *hpoly; // [n][4][4]
+};
+
+__device__ inline bool cell_occupied(const CorridorArgs &A, double x, double y) {
+  const double cx = round((x - A.origin_x) / A.resolution), cy = round((y - A.origin_y) / A.resolution);
+  if (!(cx >= 0.0 && cx < (double)A.size_x && cy >= 0.0 && cy < (double)A.size_y)) return false;
+  return A.cells[(int)cx + A.size_x * (int)cy] == 80; // GridMapND::OCCUPIED
+}
+
+// map_adapter.cpp:117-129 for the whole wave: lane k tests the sample at dl[k], dl[k + 64], ...
+__device__ inline bool line_hits(const CorridorArgs &A, double p1x, double p1y, double p2x, double p2y, int lane) {
+  const double dx = p2x - p1x, dy = p2y - p1y;
+  const double norm = sqrt(dx * dx + dy * dy);
+  for (int base = 0; base < A.n_dl; base += 64) {
+    const int k = base + lane;
+    const double dl = k < A.n_dl ? A.dl[k] : norm;
+    const bool active = dl < norm;
+    if (__ballot(active) == 0) break;
+    bool hit = false;
+    if (active) hit = cell_occupied(A, dx * dl / norm + p1x, dy * dl / norm + p1y);
+    if (__ballot(hit) != 0) return true;
+  }
+  return cell_occupied(A, p2x, p2y); // uniform
+}
+
+__global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (i >= A.n) return;
+  const double rx = A.states[3 * i], ry = A.states[3 * i + 1], yaw = A.states[3 * i + 2];
+  const double c = p_cos(yaw), s = p_sin(yaw), ns = -s; // egoR = [c -s; s c], traj_manager.cpp:1233-1234
+  const double step = A.resolution * 1.0, limit = 10.0; // :1218-1219
+  const double dcr = A.veh_dcr;
+  double sx = rx, sy = ry, W = A.veh_width, L = A.veh_length; // sourcePt, sourceVp
+  double expand[4] = {0.0, 0.0, 0.0, 0.0};
+  int open = 0xF;
+  while (open) { // NotFinishTable.norm() > 0
+#pragma unroll
+    for (int side = 0; side < 4; side++) {
+      if (!(open & (1 << side))) continue;
+      double a1, b1, a2, b2, na1, nb1, na2, nb2; // body coordinates of point1, point2, newpoint1, newpoint2
+      if (side == 0) { // +dy, :1311-1315
+        a1 = L / 2.0 + dcr; b1 = W / 2.0; a2 = -L / 2.0 + dcr; b2 = W / 2.0;
+        na1 = L / 2.0 + dcr; nb1 = W / 2.0 + step; na2 = -L / 2.0 + dcr; nb2 = W / 2.0 + step;
+      } else if (side == 1) { // +dx, :1343-1347
+        a1 = L / 2.0 + dcr; b1 = -W / 2.0; a2 = L / 2.0 + dcr; b2 = W / 2.0;
+        na1 = step + L / 2.0 + dcr; nb1 = -W / 2.0; na2 = step + L / 2.0 + dcr; nb2 = W / 2.0;
+      } else if (side == 2) { // -dy, :1375-1379
+        a1 = -L / 2.0 + dcr; b1 = -W / 2.0; a2 = L / 2.0 + dcr; b2 = -W / 2.0;
+        na1 = -L / 2.0 + dcr; nb1 = -W / 2.0 - step; na2 = L / 2.0 + dcr; nb2 = -W / 2.0 - step;
+      } else { // -dx, :1407-1411
+        a1 = -L / 2.0 + dcr; b1 = W / 2.0; a2 = -L / 2.0 + dcr; b2 = -W / 2.0;
+        na1 = -L / 2.0 + dcr - step; nb1 = W / 2.0; na2 = -L / 2.0 + dcr - step; nb2 = -W / 2.0;
+      }
+      const double p1x = sx + (c * a1 + ns * b1), p1y = sy + (s * a1 + c * b1);
+      const double p2x = sx + (c * a2 + ns * b2), p2y = sy + (s * a2 + c * b2);
+      const double n1x = sx + (c * na1 + ns * nb1), n1y = sy + (s * na1 + c * nb1);
+      const double n2x = sx + (c * na2 + ns * nb2), n2y = sy + (s * na2 + c * nb2);
+      // point1 -> newpoint1 -> newpoint2 -> point2
+      if (line_hits(A, p1x, p1y, n1x, n1y, lane) || line_hits(A, n1x, n1y, n2x, n2y, lane) ||
+          line_hits(A, n2x, n2y, p2x, p2y, lane)) {
+        open &= ~(1 << side);
+        continue;
+      }
+      expand[side] += step;
+      if (expand[side] >= limit) { // the centre / size update is skipped on the closing step, :1332-1335
+        open &= ~(1 << side);
+        continue;
+      }
+      double ma, mb;
+      if (side == 0) { ma = 0.0; mb = step / 2.0; W = W + step; }
+      else if (side == 1) { ma = step / 2.0; mb = 0.0; L = L + step; }
+      else if (side == 2) { ma = 0.0; mb = -step / 2.0; W = W + step; }
+      else { ma = -step / 2.0; mb = 0.0; L = L + step; }
+      const double nx = sx + (c * ma + ns * mb), ny = sy + (s * ma + c * mb);
+      sx = nx;
+      sy = ny;
+    }
+  }
+  if (lane == 0) { // traj_manager.cpp:1442-1465: (normal; point) columns from the RAW pose and size
+    double *H = A.hpoly + 16 * (size_t)i;
+    const double W0 = A.veh_width, L0 = A.veh_length;
+    double a, b;
+    a = L0 / 2.0 + dcr + expand[1]; b = W0 / 2.0 + expand[0];
+    H[0] = -s; H[1] = c; H[2] = rx + (c * a + ns * b); H[3] = ry + (s * a + c * b);
+    a = L0 / 2.0 + dcr + expand[1]; b = -W0 / 2.0 - expand[2];
+    H[4] = c; H[5] = s; H[6] = rx + (c * a + ns * b); H[7] = ry + (s * a + c * b);
+    a = -L0 / 2.0 + dcr - expand[3]; b = -W0 / 2.0 - expand[2];
+    H[8] = s; H[9] = -c; H[10] = rx + (c * a + ns * b); H[11] = ry + (s * a + c * b);
+    a = -L0 / 2.0 + dcr - expand[3]; b = W0 / 2.0 + expand[0];
+    H[12] = -c; H[13] = -s; H[14] = rx + (c * a + ns * b); H[15] = ry + (s * a + c * b);
+  }
+}
+
+hipError_t launch_corridor(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
+                           const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
+                           int n_dl, double *hpoly, hipStream_t stream) {
+  CorridorArgs A{cells, size_x, size_y, resolution, origin_x, origin_y, states, n, veh_width, veh_length, veh_dcr, dl, n_dl, hpoly};
+  const int waves_per_block = 4;
+  hipLaunchKernelGGL(corridor_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block), 0, stream, A);
+  return hipGetLastError();
+}
+
+} // namespace dftpav

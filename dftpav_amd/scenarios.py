@@ -172,6 +172,21 @@ def sample_obstacles(rng, n_obs, paths_xyyaw, arena=60.0, centre=(0.0, 0.0), cle
     return np.array(out).reshape(-1, 3)
 
 
+def occupancy_grid(obstacles, arena=80.0, centre=(0.0, 0.0), resolution=MAP_RESL):
+    """The obstacle map getRectangleConst queries (GridMapND<uint8_t, 2>, semantics.h:351-358): a cell is
+    OCCUPIED (80) when its centre lies inside a disc, FREE (127) otherwise.  Returns (grid [size_y][size_x], origin):
+    cell (ix, iy) is centred at origin + (ix, iy) * resolution (semantics.cc:214-221)."""
+    n = int(round(arena / resolution)) + 1
+    origin = (centre[0] - arena / 2.0, centre[1] - arena / 2.0)
+    xs = origin[0] + np.arange(n) * resolution
+    ys = origin[1] + np.arange(n) * resolution
+    X, Y = np.meshgrid(xs, ys)
+    grid = np.full((n, n), 127, dtype=np.uint8)
+    for ox, oy, r in np.asarray(obstacles).reshape(-1, 3):
+        grid[(X - ox) ** 2 + (Y - oy) ** 2 <= r * r] = 80
+    return grid, origin
+
+
 def rectangle_corridor(px, py, yaw, obstacles, step=MAP_RESL, limit=LIMIT_BOUND):
     """One 4-plane rectangle per state (x, y, yaw): the growth rule of
     TrajPlanner::getRectangleConst (traj_manager.cpp:1296-1441) — sides
@@ -380,10 +395,12 @@ def make_scenario(piece_nums, singuls, K, Kd, B, seed, n_hyp=None, n_obs=50, wit
     corridor = np.zeros((B, npts, 4, 4))
     hyp_of = np.zeros(B, dtype=np.int32)
     cors = []
+    states = np.zeros((n_hyp, npts, 3))  # constraint-point poses, the statelist of getRectangleConst
     for h in range(n_hyp):
         px = np.concatenate([s["x"] for s in hyps[h]])
         py = np.concatenate([s["y"] for s in hyps[h]])
         yw = np.concatenate([s["yaw"] for s in hyps[h]])
+        states[h] = np.stack([px, py, yw], axis=1)
         cors.append(rectangle_corridor(px, py, yw, obstacles))
     for b in range(B):
         h = b % n_hyp
@@ -406,7 +423,7 @@ def make_scenario(piece_nums, singuls, K, Kd, B, seed, n_hyp=None, n_obs=50, wit
         corridor[b] = cors[h]
     sur = moving_obstacles() if with_moving else None
     return Scenario(name, layout, K, Kd, B, ini_states, fin_states, inner_pts, init_Ts, corridor, 0.0, 0.0, sur,
-                    meta=dict(seed=seed, n_hyp=n_hyp, obstacles=obstacles, hyp_of=hyp_of))
+                    meta=dict(seed=seed, n_hyp=n_hyp, obstacles=obstacles, hyp_of=hyp_of, states=states))
 
 
 def baseline_config(config, B=None, seed=20240, n_hyp=None):

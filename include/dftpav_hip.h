@@ -167,6 +167,27 @@ const char *dftpav_last_error(const dftpav_handle *h);
  * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied. */
 int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s);
 
+/* ---- safe-corridor generation, the step before the solve ----
+ * Replaces map_itf_->GetObstacleMap + the map queries of getRectangleConst
+ * (traj_manager.cpp:1216-1217, map_adapter.cpp:93-97, semantics.h:351-358):
+ * a GridMapND<uint8_t, 2>, cell (ix, iy) at cells[ix + size_x * iy], centred at
+ * origin + (ix, iy) * resolution, 80 = OCCUPIED.  The cells are copied. */
+typedef struct dftpav_grid_map {
+  const unsigned char *cells;
+  int size_x, size_y;
+  double resolution;
+  double origin_x, origin_y;
+} dftpav_grid_map;
+int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map);
+
+/* Replaces TrajPlanner::getRectangleConst (traj_manager.cpp:1213-1469): one
+ * vehicle-aligned rectangle per state (x, y, yaw), grown cell by cell on the
+ * map of dftpav_set_grid_map with the raw vehicle size of dftpav_params.
+ * hpoly: [n_states][4][4], per state the four columns (n_x, n_y, p_x, p_y) of
+ * hPoly (traj_manager.cpp:1442-1465) — the layout dftpav_batch_data.corridor
+ * takes for H = 4. */
+int dftpav_corridor_rectangles(dftpav_handle *h, const double *states, int n_states, double *hpoly);
+
 /* Device-resident batch of B trajectories with a common layout. */
 int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out);
 void dftpav_batch_destroy(dftpav_batch *b);

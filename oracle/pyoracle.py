@@ -231,3 +231,21 @@ def minco_generate(inner, dT, head, tail):
     J = lib().oracle_minco_generate(N, dptr(inner), dT, dptr(np.ascontiguousarray(head, dtype=np.float64)),
                                     dptr(np.ascontiguousarray(tail, dtype=np.float64)), dptr(c))
     return c, J
+
+
+def corridor_rectangles(grid, resolution, origin, states, veh=(1.90, 4.88, 1.015), order=0):
+    """getRectangleConst (traj_manager.cpp:1213-1469) on an occupancy grid.
+
+    grid: uint8 [size_y][size_x] (cell (ix, iy) at grid[iy, ix], 80 = occupied); states: [n][3] (x, y, yaw).
+    Returns [n][4][4]: per state the four columns (n_x, n_y, p_x, p_y) of hPoly."""
+    L = lib()
+    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((st.shape[0], 4, 4), dtype=np.float64)
+    fn = L.oracle_corridor_rectangles
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int,
+                   C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    fn(g.ctypes.data, g.shape[1], g.shape[0], float(resolution), float(origin[0]), float(origin[1]), st.ctypes.data,
+       st.shape[0], float(veh[0]), float(veh[1]), float(veh[2]), int(order), out.ctypes.data)
+    return out

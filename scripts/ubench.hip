@@ -186,6 +186,69 @@ __global__ void blockbench(double *out, long long *cyc, double seed, int mode) {
   if (lane == 0) cyc[mode] = t1 - t0;
   out[lane] = dreg;
 }
+// ---- issue cost of memory instructions in a burst (all L2 / LDS hits; one wave)
+typedef const double __attribute__((address_space(1))) *gptr_t;
+__global__ void membench(const double *buf, double *out, long long *cyc, int stride) {
+  __shared__ double lds[4096];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 4096; i += 64) lds[i] = buf[i];
+  __syncthreads();
+  gptr_t g = (gptr_t)buf;
+  double acc = 0.0;
+  long long t0, t1;
+  // 0: 16 global loads (64-bit VGPR address each), consumed after the burst
+  t0 = clock64();
+  for (int it = 0; it < 200; it++) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = g[(size_t)(i * stride + (it & 7)) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += v[i];
+  }
+  t1 = clock64();
+  if (lane == 0) cyc[0] = t1 - t0;
+  // 1: the same with scalar base + 32-bit lane offset written as inline asm (saddr form)
+  t0 = clock64();
+  for (int it = 0; it < 200; it++) {
+    double v[16];
+    const unsigned off = (unsigned)lane * 8u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const double *row = buf + (size_t)(i * stride + (it & 7)) * 64; // uniform
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v[i]) : "v"(off), "s"(row) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += v[i];
+  }
+  t1 = clock64();
+  if (lane == 0) cyc[1] = t1 - t0;
+  // 2: 16 LDS reads (one double per lane), consumed after the burst
+  t0 = clock64();
+  for (int it = 0; it < 200; it++) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = lds[((i * 5 + (it & 7)) * 64 + lane) & 4095];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += v[i];
+  }
+  t1 = clock64();
+  if (lane == 0) cyc[2] = t1 - t0;
+  // 3: 16 adds only (to subtract)
+  t0 = clock64();
+  for (int it = 0; it < 200; it++) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = acc * (i + it);
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc += v[i];
+  }
+  t1 = clock64();
+  if (lane == 0) cyc[3] = t1 - t0;
+  out[lane] = acc;
+}
 __global__ void chase(const int *next, int start, int steps, long long *cyc, int *sink) {
   int p = start;
   long long t0 = clock64();
@@ -230,6 +293,18 @@ int main() {
     printf("block: products + transposed 8-way sum          %7.1f cycles per block\n", h[0] / 500.0);
     printf("block: + lane-distributed solve                 %7.1f cycles per block\n", h[1] / 500.0);
     printf("block: + direction update                       %7.1f cycles per block\n", h[2] / 500.0);
+  }
+  {
+    double *buf, *out; long long *cyc;
+    hipMalloc(&buf, 8u << 20); hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 64);
+    hipMemset(buf, 0, 8u << 20);
+    for (int rep = 0; rep < 2; rep++) membench<<<1, 64>>>(buf, out, cyc, 4);
+    hipDeviceSynchronize();
+    long long h[4]; hipMemcpy(h, cyc, 32, hipMemcpyDeviceToHost);
+    printf("burst of 16 global loads (VGPR address) + 16 adds    %7.1f cycles per burst\n", h[0] / 200.0);
+    printf("burst of 16 global loads (saddr, inline asm) + adds  %7.1f cycles per burst\n", h[1] / 200.0);
+    printf("burst of 16 LDS reads + 16 adds                      %7.1f cycles per burst\n", h[2] / 200.0);
+    printf("16 muls + 16 adds                                    %7.1f cycles per burst\n", h[3] / 200.0);
   }
   run_chase(256 << 10, "global load chase, 256 KB (L2)");
   run_chase(16 << 20, "global load chase, 16 MB (MALL?)");

@@ -1,0 +1,85 @@
+"""CPU checks of the corridor-generation oracle (oracle/corridor_oracle.cpp): the
+restatement of TrajPlanner::getRectangleConst (traj_manager.cpp:1213-1469).  The reference holds no
+golden vectors for it (parity unpinned); the pins are properties of the algorithm."""
+import numpy as np
+import pytest
+
+from dftpav_amd import scenarios as sc
+
+RES = sc.MAP_RESL
+VEH_W, VEH_L, VEH_DCR = 1.90, 4.88, 1.015  # semantics.h:66-76
+
+
+def _offsets(H, states):
+    """distance of each edge from the pose along its outward normal, [n][4]"""
+    pose = states[:, None, :2]
+    return np.einsum("pki,pki->pk", H[:, :, :2], H[:, :, 2:] - pose)
+
+
+def _scene(seed=3):
+    rng = np.random.default_rng(seed)
+    obs = np.column_stack([rng.uniform(-25, 25, 40), rng.uniform(-25, 25, 40), rng.uniform(0.5, 1.5, 40)])
+    grid, origin = sc.occupancy_grid(obs, arena=80.0)
+    states = np.column_stack([rng.uniform(-20, 20, 200), rng.uniform(-20, 20, 200), rng.uniform(-np.pi, np.pi, 200)])
+    return grid, origin, states
+
+
+def test_empty_map_grows_every_side_to_the_limit(oracle):
+    grid = np.full((400, 400), 127, dtype=np.uint8)
+    states = np.array([[0.0, 0.0, 0.3], [5.0, -3.0, -2.0]])
+    H = oracle.corridor_rectangles(grid, RES, (-60.0, -60.0), states)
+    off = _offsets(H, states)
+    n_steps = int(np.ceil(10.0 / RES))  # a side closes on the step that reaches limitBound, traj_manager.cpp:1332
+    grown = n_steps * RES
+    want = np.array([VEH_W / 2 + grown, VEH_L / 2 + VEH_DCR + grown, VEH_W / 2 + grown, VEH_L / 2 - VEH_DCR + grown])
+    assert np.allclose(off, want[None, :], atol=1e-9)
+    # normals: +y, +x, -y, -x of the body frame (traj_manager.cpp:1444-1463), unit length
+    c, s = np.cos(states[:, 2]), np.sin(states[:, 2])
+    assert np.allclose(H[:, 0, :2], np.stack([-s, c], 1)) and np.allclose(H[:, 1, :2], np.stack([c, s], 1))
+    assert np.allclose(H[:, 2, :2], np.stack([s, -c], 1)) and np.allclose(H[:, 3, :2], np.stack([-c, -s], 1))
+
+
+def test_rectangle_contains_the_vehicle_and_stops_at_obstacles(oracle):
+    grid, origin, states = _scene()
+    H = oracle.corridor_rectangles(grid, RES, origin, states)
+    off = _offsets(H, states)
+    base = np.array([VEH_W / 2, VEH_L / 2 + VEH_DCR, VEH_W / 2, VEH_L / 2 - VEH_DCR])
+    assert (off >= base[None, :] - 1e-9).all()
+    # expansions are whole numbers of cells
+    k = (off - base[None, :]) / RES
+    assert np.allclose(k, np.round(k), atol=1e-6)
+    assert (off - base[None, :] <= 10.0 + RES).all() and (k < 34.5).any()  # some side is stopped by an obstacle
+    # no occupied cell centre lies strictly inside a rectangle that was grown from a collision-free pose:
+    # the strips that were accepted were sampled every half cell
+    ys, xs = np.nonzero(grid == 80)
+    occ = np.stack([origin[0] + xs * RES, origin[1] + ys * RES], 1)
+    for i in range(len(states)):
+        sd = np.einsum("oki,ki->ok", occ[:, None, :] - H[i][None, :, 2:], H[i][:, :2])  # signed distance to each edge
+        inside = (sd < -0.5 * RES).all(axis=1)
+        c, s = np.cos(states[i, 2]), np.sin(states[i, 2])
+        body = (occ - states[i, :2]) @ np.array([[c, -s], [s, c]])
+        in_vehicle = (np.abs(body[:, 0] - VEH_DCR) <= VEH_L / 2 + RES) & (np.abs(body[:, 1]) <= VEH_W / 2 + RES)
+        assert not (inside & ~in_vehicle).any(), i
+
+
+def test_portable_trig_order_agrees_with_libm_order(oracle):
+    grid, origin, states = _scene(7)
+    H0 = oracle.corridor_rectangles(grid, RES, origin, states, order=0)
+    H1 = oracle.corridor_rectangles(grid, RES, origin, states, order=1)
+    # same growth decisions except where an ulp of cos/sin moves a sample across a cell boundary
+    same = np.isclose(_offsets(H0, states), _offsets(H1, states), atol=1e-9).all(axis=1)
+    assert same.mean() > 0.98
+    assert np.abs(H0[same] - H1[same]).max() < 1e-12
+
+
+def test_matches_the_analytic_generator_on_most_points(oracle):
+    """scenarios.rectangle_corridor grows the same rectangle against the discs themselves."""
+    s = sc.baseline_config(3, B=16)
+    st = s.meta["states"][0]
+    c = (0.5 * (st[:, 0].min() + st[:, 0].max()), 0.5 * (st[:, 1].min() + st[:, 1].max()))
+    grid, origin = sc.occupancy_grid(s.meta["obstacles"], arena=120.0, centre=c)
+    H = oracle.corridor_rectangles(grid, RES, origin, st)
+    A = s.corridor[0]
+    assert np.abs(A[:, :, :2] - H[:, :, :2]).max() < 1e-12
+    diff = np.abs(_offsets(A, st) - _offsets(H, st))
+    assert np.median(diff) <= RES and (diff <= 2 * RES).mean() > 0.8

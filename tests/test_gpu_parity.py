@@ -287,3 +287,60 @@ def test_cpp_host_mirror_runs(hiplib):
     out = subprocess.run([os.path.join(host, "host_example")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OptimizeTrajectory -> 1" in out.stdout and "short corridor -> 0" in out.stdout
+
+
+def _corridor_scene(seed):
+    rng = np.random.default_rng(seed)
+    obs = np.column_stack([rng.uniform(-25, 25, 60), rng.uniform(-25, 25, 60), rng.uniform(0.5, 1.5, 60)])
+    grid, origin = sc.occupancy_grid(obs, arena=80.0)
+    states = np.column_stack([rng.uniform(-22, 22, 1500), rng.uniform(-22, 22, 1500), rng.uniform(-7.0, 7.0, 1500)])
+    return grid, origin, states
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_corridor_rectangles_match_oracle(hiplib, oracle, seed):
+    """§8(f)-1: getRectangleConst (traj_manager.cpp:1213-1469) on the device, bit-exact against the oracle's
+    device-order mode (portable cos/sin); the literal mode (libm) agrees except where an ulp of cos/sin moves a
+    line sample across a cell boundary."""
+    grid, origin, states = _corridor_scene(seed)
+    h = hiplib.Handle(hiplib.default_params())
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    H = h.corridor_rectangles(states)
+    H1 = oracle.corridor_rectangles(grid, sc.MAP_RESL, origin, states, order=1)
+    assert np.array_equal(H, H1)
+    H0 = oracle.corridor_rectangles(grid, sc.MAP_RESL, origin, states, order=0)
+    same = (np.abs(H - H0).max(axis=(1, 2)) < 1e-9)
+    assert same.mean() > 0.98
+    # edge cases: no states, a state outside the map (every sample out of range counts as free), an empty map
+    assert h.corridor_rectangles(np.zeros((0, 3))).shape == (0, 4, 4)
+    far = np.array([[500.0, -300.0, 0.7]])
+    assert np.array_equal(h.corridor_rectangles(far), oracle.corridor_rectangles(grid, sc.MAP_RESL, origin, far, order=1))
+    empty = np.full((50, 70), 127, dtype=np.uint8)
+    h.set_grid_map(empty, 0.25, (-3.0, -4.0))
+    st = states[:40]
+    assert np.array_equal(h.corridor_rectangles(st), oracle.corridor_rectangles(empty, 0.25, (-3.0, -4.0), st, order=1))
+    h.close()
+
+
+def test_generated_corridor_feeds_the_solver(hiplib, oracle):
+    """corridor generation -> solve, both on the device, against the same chain on the CPU oracle."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(3, B=8)
+    s.apply_resolution(p)
+    st = s.meta["states"]
+    c = (0.5 * (st[..., 0].min() + st[..., 0].max()), 0.5 * (st[..., 1].min() + st[..., 1].max()))
+    grid, origin = sc.occupancy_grid(s.meta["obstacles"], arena=120.0, centre=c)
+    h = hiplib.Handle(p)
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    Hd = h.corridor_rectangles(st.reshape(-1, 3)).reshape(st.shape[0], st.shape[1], 4, 4)
+    Ho = oracle.corridor_rectangles(grid, sc.MAP_RESL, origin, st.reshape(-1, 3), order=1).reshape(Hd.shape)
+    assert np.array_equal(Hd, Ho)
+    s.corridor = np.ascontiguousarray(Hd[s.meta["hyp_of"]])
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    r = bt.solve()
+    ro = oracle.solve_batch(p, s, nthreads=4, order=1)
+    assert np.array_equal(r["final_cost"], ro["final_cost"]) and np.array_equal(r["x"], ro["x"])
+    assert r["success"].all()
+    bt.close()
+    h.close()
