@@ -162,6 +162,24 @@ def main():
                         "p50_ms_per_solve": float(np.median(r2["latency_us"])) * 1e-3, "mean_iters": float(r2["iters"].mean())}
             out["batch256"] = side(3, 256, 3)
             out["single"] = side(2, 1, 5)
+            # ---- the step before the solve: rectangle corridors of the shard's hypotheses on the device
+            st = shard.meta["states"].reshape(-1, 3)
+            cen = (0.5 * (st[:, 0].min() + st[:, 0].max()), 0.5 * (st[:, 1].min() + st[:, 1].max()))
+            span = max(st[:, 0].max() - st[:, 0].min(), st[:, 1].max() - st[:, 1].min()) + 40.0
+            grid, origin = sc.occupancy_grid(shard.meta["obstacles"], arena=span, centre=cen)
+            h.set_grid_map(grid, sc.MAP_RESL, origin)
+            Hc = h.corridor_rectangles(st)
+            tcor = []
+            for _ in range(3):
+                t1 = time.perf_counter(); Hc = h.corridor_rectangles(st); tcor.append(time.perf_counter() - t1)
+            nchk = min(2000, len(st))
+            from oracle import pyoracle as po  # the checker, never the thing measured
+            po.build()
+            out["corridor"] = {"states": int(len(st)), "map_cells": [int(grid.shape[1]), int(grid.shape[0])],
+                               "kernel_ms": h.corridor_last_ms(), "rectangles_per_s": len(st) / (h.corridor_last_ms() * 1e-3),
+                               "rectangles_per_s_with_pcie": len(st) / min(tcor),
+                               "oracle_bit_exact_on_first_%d" % nchk: bool(np.array_equal(
+                                   Hc[:nchk], po.corridor_rectangles(grid, sc.MAP_RESL, origin, st[:nchk], order=1)))}
         # ---- reference CPU path beside it (rank 0, N=1 only): the oracle's literal restatement on the host cores
         if world == 1 and args.cpu_sample != 0:
             from oracle import pyoracle as po

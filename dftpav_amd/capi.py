@@ -27,6 +27,7 @@ EXPORTS = [
     "dftpav_batch_upload", "dftpav_batch_get_x0", "dftpav_batch_eval", "dftpav_batch_solve_async",
     "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
+    "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states",
 ]
 
 
@@ -137,6 +138,13 @@ class Handle:
         self._check(fn(self._h, st.ctypes.data_as(C.c_void_p), st.shape[0], out.ctypes.data_as(C.c_void_p)), "corridor_rectangles")
         return out
 
+    def corridor_last_ms(self):
+        ms = C.c_float(0.0)
+        fn = lib().dftpav_corridor_last_ms
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self._check(fn(self._h, C.byref(ms)), "corridor_last_ms")
+        return float(ms.value)
+
     def close(self):
         if self._h:
             lib().dftpav_destroy(self._h)
@@ -170,11 +178,23 @@ class Batch:
             self._b = None
             handle._check(rc, "batch_create")
 
-    def upload(self, scen_or_data):
+    def upload(self, scen_or_data, with_corridor=True):
+        """with_corridor=False: everything but the half-planes (they come from corridor_from_states)."""
         d = scen_or_data.batch_data() if hasattr(scen_or_data, "batch_data") else scen_or_data
         self._keep = scen_or_data
+        if not with_corridor:
+            d.corridor = None
         rc = lib().dftpav_batch_upload(self._b, C.byref(d))
         self.handle._check(rc, "batch_upload")
+
+    def corridor_from_states(self, states):
+        """getRectangleConst for every constraint point of every trajectory, on the device, straight into the
+        solver's layout: states [B][Npts][3] (x, y, yaw); needs Handle.set_grid_map."""
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        assert st.shape[0] == self.B and st.shape[-1] == 3
+        fn = lib().dftpav_batch_corridor_from_states
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        self.handle._check(fn(self._b, st.ctypes.data_as(C.c_void_p)), "batch_corridor_from_states")
 
     def x0(self):
         x = np.zeros((self.B, self.n))

@@ -23,9 +23,9 @@
 namespace dftpav {
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
                          hipStream_t stream);
-hipError_t launch_corridor(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
+hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
-                           int n_dl, double *hpoly, hipStream_t stream);
+                           int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
@@ -43,8 +43,11 @@ struct dftpav_handle {
   // obstacle map of the corridor generator (device copy) and the table of sample offsets along a line
   dftpav_grid_map map{};
   unsigned char *d_cells = nullptr;
+  unsigned *d_bits = nullptr; // one bit per cell, when the whole map fits in a quarter of the LDS
   double *d_dl = nullptr;
   int n_dl = 0;
+  hipEvent_t cev0 = nullptr, cev1 = nullptr; // around the last corridor kernel
+  bool ctimed = false;
 };
 
 struct dftpav_batch {
@@ -54,6 +57,7 @@ struct dftpav_batch {
   DevParams P{};
   int threads = 0;
   bool op_in_lds = false, cor_in_lds = false;
+  bool have_corridor = false; // set by dftpav_batch_upload (host corridor) or dftpav_batch_corridor_from_states
   // time-sliced scheduling (batches larger than the device holds at once): the queue launch runs in the
   // shape above, the stragglers it hands over finish in the latency shape below
   bool sched = false;
@@ -199,7 +203,10 @@ extern "C" void dftpav_destroy(dftpav_handle *h) {
   (void)hipSetDevice(h->device);
   free_surround(h);
   if (h->d_cells) (void)hipFree(h->d_cells);
+  if (h->d_bits) (void)hipFree(h->d_bits);
   if (h->d_dl) (void)hipFree(h->d_dl);
+  if (h->cev0) (void)hipEventDestroy(h->cev0);
+  if (h->cev1) (void)hipEventDestroy(h->cev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -212,14 +219,23 @@ extern "C" int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map)
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->d_cells) (void)hipFree(h->d_cells);
+  if (h->d_bits) (void)hipFree(h->d_bits);
   if (h->d_dl) (void)hipFree(h->d_dl);
   h->d_cells = nullptr;
+  h->d_bits = nullptr;
   h->d_dl = nullptr;
   const size_t ncell = (size_t)map->size_x * map->size_y;
   HIPCHK(h, hipMalloc(&h->d_cells, ncell));
   HIPCHK(h, hipMemcpy(h->d_cells, map->cells, ncell, hipMemcpyHostToDevice));
   h->map = *map;
   h->map.cells = nullptr;
+  if (ncell <= (size_t)8 * 40 * 1024) { // <= 40 KB of bits per workgroup: four workgroups per CU
+    std::vector<unsigned> bits((ncell + 31) / 32, 0u);
+    for (size_t i = 0; i < ncell; i++)
+      if (map->cells[i] == 80) bits[i >> 5] |= 1u << (i & 31);
+    HIPCHK(h, hipMalloc(&h->d_bits, sizeof(unsigned) * bits.size()));
+    HIPCHK(h, hipMemcpy(h->d_bits, bits.data(), sizeof(unsigned) * bits.size(), hipMemcpyHostToDevice));
+  }
   // sample offsets of CheckIfCollisionUsingLine (map_adapter.cpp:119): dl = 0, then dl += checkl; the longest
   // segment is the far edge of a fully grown rectangle
   const double checkl = map->resolution / 2.0;
@@ -229,21 +245,16 @@ extern "C" int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map)
   h->n_dl = (int)dl.size();
   HIPCHK(h, hipMalloc(&h->d_dl, sizeof(double) * dl.size()));
   HIPCHK(h, hipMemcpy(h->d_dl, dl.data(), sizeof(double) * dl.size(), hipMemcpyHostToDevice));
+  if (!h->cev0) HIPCHK(h, hipEventCreate(&h->cev0));
+  if (!h->cev1) HIPCHK(h, hipEventCreate(&h->cev1));
   return DFTPAV_OK;
 }
 
-extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states, int n_states, double *hpoly) {
-  if (!h || !states || !hpoly || n_states < 0) return DFTPAV_E_INVALID;
-  if (!h->d_cells) return DFTPAV_E_INVALID; // no map
-  if (n_states == 0) return DFTPAV_OK;
-  HIPCHK(h, hipSetDevice(h->device));
-  double *d_states = nullptr, *d_hpoly = nullptr;
+// uploads the states and runs the corridor kernel into `hpoly` (device, [n][16]) or into a batch's corridor
+static int run_corridor(dftpav_handle *h, const double *states, int n_states, double *d_hpoly, double *batch_cor, int Npts,
+                        int NptsPad) {
+  double *d_states = nullptr;
   HIPCHK(h, hipMalloc(&d_states, sizeof(double) * 3 * (size_t)n_states));
-  if (hipMalloc(&d_hpoly, sizeof(double) * 16 * (size_t)n_states) != hipSuccess) {
-    (void)hipFree(d_states);
-    h->err = "hipMalloc";
-    return DFTPAV_E_HIP;
-  }
   int rc = DFTPAV_OK;
   auto chk = [&](hipError_t e) {
     if (e != hipSuccess && rc == DFTPAV_OK) {
@@ -252,12 +263,37 @@ extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states
     }
   };
   chk(hipMemcpyAsync(d_states, states, sizeof(double) * 3 * (size_t)n_states, hipMemcpyHostToDevice, h->stream));
+  chk(hipEventRecord(h->cev0, h->stream));
   if (rc == DFTPAV_OK)
-    chk(launch_corridor(h->d_cells, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, d_states,
-                        n_states, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, h->d_dl, h->n_dl, d_hpoly, h->stream));
-  if (rc == DFTPAV_OK) chk(hipMemcpyAsync(hpoly, d_hpoly, sizeof(double) * 16 * (size_t)n_states, hipMemcpyDeviceToHost, h->stream));
+    chk(launch_corridor(h->d_cells, h->d_bits, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, d_states,
+                        n_states, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, h->d_dl, h->n_dl, d_hpoly,
+                        batch_cor, Npts, NptsPad, h->stream));
+  chk(hipEventRecord(h->cev1, h->stream));
   chk(hipStreamSynchronize(h->stream));
+  h->ctimed = rc == DFTPAV_OK;
   (void)hipFree(d_states);
+  return rc;
+}
+
+extern "C" int dftpav_corridor_last_ms(dftpav_handle *h, float *ms) {
+  if (!h || !ms || !h->ctimed) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventElapsedTime(ms, h->cev0, h->cev1));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states, int n_states, double *hpoly) {
+  if (!h || !states || !hpoly || n_states < 0) return DFTPAV_E_INVALID;
+  if (!h->d_cells) return DFTPAV_E_INVALID; // no map
+  if (n_states == 0) return DFTPAV_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  double *d_hpoly = nullptr;
+  HIPCHK(h, hipMalloc(&d_hpoly, sizeof(double) * 16 * (size_t)n_states));
+  int rc = run_corridor(h, states, n_states, d_hpoly, nullptr, 1, 1);
+  if (rc == DFTPAV_OK && hipMemcpy(hpoly, d_hpoly, sizeof(double) * 16 * (size_t)n_states, hipMemcpyDeviceToHost) != hipSuccess) {
+    h->err = "hipMemcpy";
+    rc = DFTPAV_E_HIP;
+  }
   (void)hipFree(d_hpoly);
   return rc;
 }
@@ -490,6 +526,7 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_iniS, sizeof(double) * (size_t)B * M * 6));
   BCHK(hipMalloc(&b->d_finS, sizeof(double) * (size_t)B * M * 6));
   BCHK(hipMalloc(&b->d_corridor, sizeof(double) * (size_t)B * L.H * 4 * b->NptsPad));
+  BCHK(hipMemset(b->d_corridor, 0, sizeof(double) * (size_t)B * L.H * 4 * b->NptsPad));
   BCHK(hipMalloc(&b->d_pt_piece, sizeof(int16_t) * L.Npts));
   BCHK(hipMalloc(&b->d_pt_j, sizeof(int16_t) * L.Npts));
   BCHK(hipMalloc(&b->d_histS, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
@@ -581,8 +618,7 @@ static void clamp_col(double *col, double lim) { // traj_optimizer.cpp:65-76
 }
 
 extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) {
-  if (!b || !d || !d->ini_states || !d->fin_states || !d->inner_pts || !d->init_Ts || !d->corridor)
-    return DFTPAV_E_INVALID;
+  if (!b || !d || !d->ini_states || !d->fin_states || !d->inner_pts || !d->init_Ts) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   const dftpav_params &p = h->params;
   const DevLayout &L = b->L;
@@ -621,8 +657,8 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   // corridor: private normalised copy (traj_optimizer.cpp:15,49-52), transposed to
   // [trajectory][plane*4+component][point] so that lanes (points) read contiguous doubles
   const size_t per = (size_t)L.H * 4 * b->NptsPad;
-  std::vector<double> cor((size_t)B * per, 0.0);
-  for (int t = 0; t < B; t++)
+  std::vector<double> cor(d->corridor ? (size_t)B * per : 0, 0.0);
+  for (int t = 0; t < B && d->corridor; t++)
     for (int pt = 0; pt < L.Npts; pt++)
       for (int k = 0; k < L.H; k++) {
         const double *col = d->corridor + (((size_t)t * L.Npts + pt) * L.H + k) * 4;
@@ -636,11 +672,26 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   HIPCHK(h, hipMemcpy(b->d_x0, b->x0_host.data(), sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(b->d_iniS, ini.data(), sizeof(double) * ini.size(), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(b->d_finS, fin.data(), sizeof(double) * fin.size(), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(b->d_corridor, cor.data(), sizeof(double) * cor.size(), hipMemcpyHostToDevice));
+  if (d->corridor) {
+    HIPCHK(h, hipMemcpy(b->d_corridor, cor.data(), sizeof(double) * cor.size(), hipMemcpyHostToDevice));
+    b->have_corridor = true;
+  }
   b->t_now = d->t_now;
   b->epis = d->help_eps;
   b->uploaded = true;
   return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states) {
+  if (!b || !states) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (!h->d_cells) return DFTPAV_E_INVALID;       // no map
+  if (b->L.H != 4) return DFTPAV_E_UNSUPPORTED;   // rectangles
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int rc = run_corridor(h, states, b->B * b->L.Npts, nullptr, b->d_corridor, b->L.Npts, b->NptsPad);
+  if (rc == DFTPAV_OK) b->have_corridor = true;
+  return rc;
 }
 
 extern "C" int dftpav_batch_get_x0(dftpav_batch *b, double *x0) {
@@ -738,7 +789,7 @@ extern "C" int dftpav_debug_profile(dftpav_batch *b, int enable, long long *out)
 }
 
 extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g) {
-  if (!b || !x || !b->uploaded) return DFTPAV_E_INVALID;
+  if (!b || !x || !b->uploaded || !b->have_corridor) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   const size_t nb = (size_t)b->B * b->L.n;
   HIPCHK(h, hipSetDevice(h->device));
@@ -753,7 +804,7 @@ extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, do
 }
 
 extern "C" int dftpav_batch_solve_async(dftpav_batch *b) {
-  if (!b || !b->uploaded) return DFTPAV_E_INVALID;
+  if (!b || !b->uploaded || !b->have_corridor) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
   DevBatch D;

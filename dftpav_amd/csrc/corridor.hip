@@ -22,40 +22,98 @@ namespace dftpav {
 
 struct CorridorArgs {
   const unsigned char *cells;
+  const unsigned *bits; // the same map, one bit per cell (set = OCCUPIED), or nullptr when it does not fit in LDS
   int size_x, size_y;
   double resolution, origin_x, origin_y;
+  double res_rcp; // 1.0 / resolution
   const double *states; // [n][3]
   int n;
   double veh_width, veh_length, veh_dcr;
   const double *dl; // running sum 0, checkl, checkl + checkl, ...
   int n_dl;
-  double *hpoly; // [n][4][4]
+  double *hpoly; // [n][4][4], or nullptr:
+  // the solve path's own layout, [trajectory][4 * plane + component][NptsPad] with unit normals
+  // (traj_optimizer.cpp:49-52), state i being point i % Npts of trajectory i / Npts
+  double *batch_cor;
+  int Npts, NptsPad;
 };
 
-__device__ inline bool cell_occupied(const CorridorArgs &A, double x, double y) {
-  const double cx = round((x - A.origin_x) / A.resolution), cy = round((y - A.origin_y) / A.resolution);
+// GridMapND::CheckIfEqualUsingGlobalPosition(p, OCCUPIED): coord = round((p - origin) / resolution), out of range
+// counts as free (semantics.cc:169-179, 214-221).  BITS: the map is the 1-bit-per-cell copy staged in LDS.
+// a / b from the correctly rounded reciprocal y = 1/b (Markstein): the correctly rounded quotient, the same
+// bits as a / b (checked on 2^31 pairs on gfx950, see solver.hip), in 3 instructions instead of ~14
+__device__ inline double div_by_rcp(double a, double b, double y) {
+  double q0 = a * y;
+  double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, y, q0);
+}
+template <bool BITS>
+__device__ inline bool cell_occupied(const CorridorArgs &A, const unsigned *bits, double x, double y) {
+  const double cx = round(div_by_rcp(x - A.origin_x, A.resolution, A.res_rcp));
+  const double cy = round(div_by_rcp(y - A.origin_y, A.resolution, A.res_rcp));
   if (!(cx >= 0.0 && cx < (double)A.size_x && cy >= 0.0 && cy < (double)A.size_y)) return false;
-  return A.cells[(int)cx + A.size_x * (int)cy] == 80; // GridMapND::OCCUPIED
+  const int idx = (int)cx + A.size_x * (int)cy;
+  if (BITS) return (bits[idx >> 5] >> (idx & 31)) & 1u;
+  return A.cells[idx] == 80; // GridMapND::OCCUPIED
 }
 
-// map_adapter.cpp:117-129 for the whole wave: lane k tests the sample at dl[k], dl[k + 64], ...
-__device__ inline bool line_hits(const CorridorArgs &A, double p1x, double p1y, double p2x, double p2y, int lane) {
-  const double dx = p2x - p1x, dy = p2y - p1y;
-  const double norm = sqrt(dx * dx + dy * dy);
-  for (int base = 0; base < A.n_dl; base += 64) {
-    const int k = base + lane;
-    const double dl = k < A.n_dl ? A.dl[k] : norm;
-    const bool active = dl < norm;
-    if (__ballot(active) == 0) break;
+// One growth step asks whether any sample of point1 -> newpoint1 -> newpoint2 -> point2 is occupied
+// (three CheckIfCollisionUsingLine calls, map_adapter.cpp:117-129: samples at dl = 0, checkl, 2 checkl, ... < length,
+// then the end point).  The answer is the OR over all samples, so they are taken together: the two short
+// segments (one cell long) and the three end points in the first pass, the long edge 64 samples per pass.
+template <bool BITS>
+__device__ inline bool strip_hits(const CorridorArgs &A, const unsigned *bits, double p1x, double p1y, double n1x, double n1y,
+                                  double n2x, double n2y, double p2x, double p2y, int lane) {
+  // ---- pass 0: lanes 0..15 segment point1->newpoint1, 16..31 segment newpoint2->point2 (sample k = lane & 15),
+  //              lanes 32, 33, 34 the end points newpoint1, newpoint2, point2
+  {
+    const bool second = (lane & 16) != 0;
+    const double ax = second ? n2x : p1x, ay = second ? n2y : p1y, bx = second ? p2x : n1x, by = second ? p2y : n1y;
+    const double dx = bx - ax, dy = by - ay;
+    const double norm = sqrt(dx * dx + dy * dy), nrcp = 1.0 / norm;
+    const int k = lane & 15;
     bool hit = false;
-    if (active) hit = cell_occupied(A, dx * dl / norm + p1x, dy * dl / norm + p1y);
+    if (lane < 32) {
+      const double dl = k < A.n_dl ? A.dl[k] : norm;
+      if (dl < norm)
+        hit = cell_occupied<BITS>(A, bits, div_by_rcp(dx * dl, norm, nrcp) + ax, div_by_rcp(dy * dl, norm, nrcp) + ay);
+    } else if (lane == 32) {
+      hit = cell_occupied<BITS>(A, bits, n1x, n1y);
+    } else if (lane == 33) {
+      hit = cell_occupied<BITS>(A, bits, n2x, n2y);
+    } else if (lane == 34) {
+      hit = cell_occupied<BITS>(A, bits, p2x, p2y);
+    }
     if (__ballot(hit) != 0) return true;
   }
-  return cell_occupied(A, p2x, p2y); // uniform
+  // ---- the long edge newpoint1 -> newpoint2 (a short segment is one cell = 2 checkl long, traj_manager.cpp:1218,
+  //      1316: it never has more than 3 samples, so pass 0 covered it)
+  {
+    const double dx = n2x - n1x, dy = n2y - n1y;
+    const double norm = sqrt(dx * dx + dy * dy), nrcp = 1.0 / norm;
+    for (int base = 0; base < A.n_dl; base += 64) {
+      const int k = base + lane;
+      const double dl = k < A.n_dl ? A.dl[k] : norm;
+      const bool active = dl < norm;
+      if (__ballot(active) == 0) break;
+      bool hit = false;
+      if (active)
+        hit = cell_occupied<BITS>(A, bits, div_by_rcp(dx * dl, norm, nrcp) + n1x, div_by_rcp(dy * dl, norm, nrcp) + n1y);
+      if (__ballot(hit) != 0) return true;
+    }
+  }
+  return false;
 }
 
+template <bool BITS>
 __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
+  extern __shared__ unsigned lds_bits[];
   const int lane = threadIdx.x & 63;
+  if (BITS) { // the whole map, one bit per cell
+    const int words = (A.size_x * A.size_y + 31) >> 5;
+    for (int w = threadIdx.x; w < words; w += blockDim.x) lds_bits[w] = A.bits[w];
+    __syncthreads();
+  }
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= A.n) return;
   const double rx = A.states[3 * i], ry = A.states[3 * i + 1], yaw = A.states[3 * i + 2];
@@ -87,9 +145,7 @@ __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
       const double p2x = sx + (c * a2 + ns * b2), p2y = sy + (s * a2 + c * b2);
       const double n1x = sx + (c * na1 + ns * nb1), n1y = sy + (s * na1 + c * nb1);
       const double n2x = sx + (c * na2 + ns * nb2), n2y = sy + (s * na2 + c * nb2);
-      // point1 -> newpoint1 -> newpoint2 -> point2
-      if (line_hits(A, p1x, p1y, n1x, n1y, lane) || line_hits(A, n1x, n1y, n2x, n2y, lane) ||
-          line_hits(A, n2x, n2y, p2x, p2y, lane)) {
+      if (strip_hits<BITS>(A, lds_bits, p1x, p1y, n1x, n1y, n2x, n2y, p2x, p2y, lane)) {
         open &= ~(1 << side);
         continue;
       }
@@ -109,7 +165,8 @@ __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
     }
   }
   if (lane == 0) { // traj_manager.cpp:1442-1465: (normal; point) columns from the RAW pose and size
-    double *H = A.hpoly + 16 * (size_t)i;
+    double Hl[16];
+    double *H = A.hpoly ? A.hpoly + 16 * (size_t)i : Hl;
     const double W0 = A.veh_width, L0 = A.veh_length;
     double a, b;
     a = L0 / 2.0 + dcr + expand[1]; b = W0 / 2.0 + expand[0];
@@ -120,15 +177,37 @@ __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
     H[8] = s; H[9] = -c; H[10] = rx + (c * a + ns * b); H[11] = ry + (s * a + c * b);
     a = -L0 / 2.0 + dcr - expand[3]; b = W0 / 2.0 + expand[0];
     H[12] = -c; H[13] = -s; H[14] = rx + (c * a + ns * b); H[15] = ry + (s * a + c * b);
+    if (!A.hpoly) { // what dftpav_batch_upload does with a host corridor: normalise, component-major
+      const int t = i / A.Npts, pt = i - t * A.Npts;
+      double *dst = A.batch_cor + (size_t)t * 16 * A.NptsPad + pt;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double nrm = sqrt(H[4 * k] * H[4 * k] + H[4 * k + 1] * H[4 * k + 1]);
+        dst[(size_t)(4 * k + 0) * A.NptsPad] = H[4 * k] / nrm;
+        dst[(size_t)(4 * k + 1) * A.NptsPad] = H[4 * k + 1] / nrm;
+        dst[(size_t)(4 * k + 2) * A.NptsPad] = H[4 * k + 2];
+        dst[(size_t)(4 * k + 3) * A.NptsPad] = H[4 * k + 3];
+      }
+    }
   }
 }
 
-hipError_t launch_corridor(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
+hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
-                           int n_dl, double *hpoly, hipStream_t stream) {
-  CorridorArgs A{cells, size_x, size_y, resolution, origin_x, origin_y, states, n, veh_width, veh_length, veh_dcr, dl, n_dl, hpoly};
+                           int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream) {
+  CorridorArgs A{cells, bits, size_x, size_y, resolution, origin_x, origin_y, 1.0 / resolution, states, n, veh_width, veh_length, veh_dcr, dl, n_dl,
+                 hpoly, batch_cor, Npts, NptsPad};
   const int waves_per_block = 4;
-  hipLaunchKernelGGL(corridor_kernel, dim3((n + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block), 0, stream, A);
+  const dim3 grid((n + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
+  if (bits) {
+    const size_t lds = (((size_t)size_x * size_y + 31) / 32) * sizeof(unsigned);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&corridor_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(corridor_kernel<true>, grid, block, lds, stream, A);
+  } else {
+    hipLaunchKernelGGL(corridor_kernel<false>, grid, block, 0, stream, A);
+  }
   return hipGetLastError();
 }
 

@@ -187,6 +187,8 @@ int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map);
  * hPoly (traj_manager.cpp:1442-1465) — the layout dftpav_batch_data.corridor
  * takes for H = 4. */
 int dftpav_corridor_rectangles(dftpav_handle *h, const double *states, int n_states, double *hpoly);
+/* Duration of the last corridor kernel on the device (HIP events), without the copies. */
+int dftpav_corridor_last_ms(dftpav_handle *h, float *ms);
 
 /* Device-resident batch of B trajectories with a common layout. */
 int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out);
@@ -198,6 +200,13 @@ void dftpav_batch_destroy(dftpav_batch *b);
 int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
 
 /* Decision vectors x0 packed by upload ([B][n], host copy). */
+/* RunMINCOParking's pair getRectangleConst(statelist) -> OptimizeTrajectory(..., hPoly_container, ...)
+ * (traj_manager.cpp:569-610) without the rectangles leaving the device: the
+ * corridor of every trajectory of the batch is generated from its constraint-
+ * point poses, states [B][Npts][3] (x, y, yaw), straight into the solver's own
+ * layout.  Use with dftpav_batch_upload(d) where d->corridor == NULL.  H must be 4. */
+int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states);
+
 int dftpav_batch_get_x0(dftpav_batch *b, double *x0);
 
 /* L1 cut (unit-test boundary) == PolyTrajOptimizer::costFunctionCallback

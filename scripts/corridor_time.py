@@ -17,5 +17,7 @@ t = []
 for _ in range(5):
     t0 = time.perf_counter(); H = h.corridor_rectangles(st); t.append(time.perf_counter() - t0)
 t0 = time.perf_counter(); Ho = po.corridor_rectangles(grid, sc.MAP_RESL, origin, st[:20000], order=1); tc = time.perf_counter() - t0
-print("states", len(st), "map", grid.shape, "GPU (incl. PCIe both ways) %.2f ms -> %.2f M rectangles/s" % (1e3 * min(t), len(st) / min(t) / 1e6),
+km = h.corridor_last_ms()
+print("states", len(st), "map", grid.shape, "kernel %.2f ms -> %.1f M rectangles/s;" % (km, len(st) / km / 1e3),
+      "GPU incl. PCIe both ways %.2f ms -> %.2f M rectangles/s" % (1e3 * min(t), len(st) / min(t) / 1e6),
       "| CPU oracle 1 thread %.1f k rectangles/s" % (20000 / tc / 1e3), "| bit-identical:", np.array_equal(H[:20000], Ho))

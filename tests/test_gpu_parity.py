@@ -342,5 +342,18 @@ def test_generated_corridor_feeds_the_solver(hiplib, oracle):
     ro = oracle.solve_batch(p, s, nthreads=4, order=1)
     assert np.array_equal(r["final_cost"], ro["final_cost"]) and np.array_equal(r["x"], ro["x"])
     assert r["success"].all()
+    # the same without the rectangles leaving the device (dftpav_batch_corridor_from_states)
+    b2 = hiplib.Batch(h, s.layout, s.B)
+    b2.upload(s, with_corridor=False)
+    with pytest.raises(hiplib.DftpavError):
+        b2.solve_async()  # no corridor yet
+    b2.corridor_from_states(st[s.meta["hyp_of"]])
+    assert h.corridor_last_ms() > 0.0
+    f1, g1 = bt.eval(bt.x0())
+    f2, g2 = b2.eval(b2.x0())
+    assert np.array_equal(f1, f2) and np.array_equal(g1, g2)
+    r2 = b2.solve()
+    assert np.array_equal(r2["final_cost"], r["final_cost"]) and np.array_equal(r2["x"], r["x"])
+    b2.close()
     bt.close()
     h.close()
