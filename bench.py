@@ -162,6 +162,7 @@ def main():
                         "p50_ms_per_solve": float(np.median(r2["latency_us"])) * 1e-3, "mean_iters": float(r2["iters"].mean())}
             out["batch256"] = side(3, 256, 3)
             out["single"] = side(2, 1, 5)
+            out["moving_obstacles_1024"] = side(5, 1024, 1)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
             # ---- the step before the solve: rectangle corridors of the shard's hypotheses on the device
             st = shard.meta["states"].reshape(-1, 3)
             cen = (0.5 * (st[:, 0].min() + st[:, 0].max()), 0.5 * (st[:, 1].min() + st[:, 1].max()))
@@ -199,6 +200,10 @@ def main():
                                              "trajectories, %.1f core-seconds" % (ns, float(rc["seconds"].sum())),
                                    "p50_ms_per_solve_per_thread": float(np.median(rc["seconds"])) * 1e3,
                                    "mean_iters": float(rc["iters"].mean())}
+            # how the reference runs it: one planner thread, the other cores idle
+            r1 = po.solve_batch(params, shard.subset(np.arange(16) * max(1, shard.B // 16) % shard.B + min(shard.B - 1, 17)), nthreads=1, order=0)
+            out["cpu_baseline"]["single_thread_p50_ms_per_solve"] = float(np.median(r1["seconds"])) * 1e3
+            out["cpu_baseline"]["single_thread_p95_ms_per_solve"] = float(np.percentile(r1["seconds"], 95)) * 1e3
             out["parity"] = {"device_order_oracle_bit_exact_on_first_%d" % nd: match}
         print(json.dumps(out), flush=True)
     bt.close()
