@@ -201,7 +201,7 @@ def main():
                                    "p50_ms_per_solve_per_thread": float(np.median(rc["seconds"])) * 1e3,
                                    "mean_iters": float(rc["iters"].mean())}
             # how the reference runs it: one planner thread, the other cores idle
-            r1 = po.solve_batch(params, shard.subset(np.arange(16) * max(1, shard.B // 16) % shard.B + min(shard.B - 1, 17)), nthreads=1, order=0)
+            r1 = po.solve_batch(params, shard.subset((np.arange(16) * max(1, shard.B // 16) + 17) % shard.B), nthreads=1, order=0)
             out["cpu_baseline"]["single_thread_p50_ms_per_solve"] = float(np.median(r1["seconds"])) * 1e3
             out["cpu_baseline"]["single_thread_p95_ms_per_solve"] = float(np.percentile(r1["seconds"], 95)) * 1e3
             out["parity"] = {"device_order_oracle_bit_exact_on_first_%d" % nd: match}
