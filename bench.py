@@ -173,6 +173,11 @@ def main():
             tcor = []
             for _ in range(3):
                 t1 = time.perf_counter(); Hc = h.corridor_rectangles(st); tcor.append(time.perf_counter() - t1)
+            # ---- the step after the solve: collision re-check of all solved trajectories of the shard
+            colv, firstv = bt.validate()
+            out["validate"] = {"trajectories": int(shard.B), "kernel_ms": h.corridor_last_ms(),
+                               "trajectories_per_s": shard.B / (h.corridor_last_ms() * 1e-3),
+                               "colliding": int(colv.sum())}
             nchk = min(2000, len(st))
             from oracle import pyoracle as po  # the checker, never the thing measured
             po.build()

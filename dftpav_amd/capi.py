@@ -27,7 +27,7 @@ EXPORTS = [
     "dftpav_batch_upload", "dftpav_batch_get_x0", "dftpav_batch_eval", "dftpav_batch_solve_async",
     "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
-    "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states",
+    "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
 ]
 
 
@@ -186,6 +186,17 @@ class Batch:
             d.corridor = None
         rc = lib().dftpav_batch_upload(self._b, C.byref(d))
         self.handle._check(rc, "batch_upload")
+
+    def validate(self, sample_dt=0.05, vertex_res=0.1):
+        """Collision re-check of the solved trajectories against the handle's grid map (CheckReplan,
+        traj_server_ros.cpp:385-397): returns (collision [B], first_sample [B])."""
+        col = np.zeros(self.B, dtype=np.int32)
+        first = np.zeros(self.B, dtype=np.int32)
+        fn = lib().dftpav_batch_validate
+        fn.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        self.handle._check(fn(self._b, float(sample_dt), float(vertex_res), col.ctypes.data_as(C.c_void_p),
+                              first.ctypes.data_as(C.c_void_p)), "batch_validate")
+        return col, first
 
     def corridor_from_states(self, states):
         """getRectangleConst for every constraint point of every trajectory, on the device, straight into the

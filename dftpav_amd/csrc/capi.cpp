@@ -26,6 +26,10 @@ hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int
 hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
                            int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream);
+hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
+                           const double *coeffs, const double *piece_dt, const DevLayout &L, int B, double veh_width,
+                           double veh_length, double veh_dcr, const double *t_tab, int n_t, double sample_dt, const double *v_tab,
+                           int n_v, int *collision, int *first_sample, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
@@ -892,6 +896,56 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
     HIPCHK(h, hipMemcpy(coeffs, b->d_coef, sizeof(double) * (size_t)b->B * 12 * b->L.Ntot, hipMemcpyDeviceToHost));
   if (piece_dt) HIPCHK(h, hipMemcpy(piece_dt, b->d_dt, sizeof(double) * (size_t)b->B * b->L.M, hipMemcpyDeviceToHost));
   return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double vertex_res, int *collision, int *first_sample) {
+  if (!b || !b->uploaded || !(sample_dt > 0.0) || !(vertex_res > 0.0)) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (!h->d_cells) return DFTPAV_E_INVALID; // no map
+  HIPCHK(h, hipSetDevice(h->device));
+  // coefficients and piece durations of the solutions, regenerated on the device from x (as dftpav_batch_coeffs)
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  // the two running sums of the reference, tabulated: sample times (traj_server_ros.cpp:387) and the spacing of the
+  // outline points (shapes.cc:128)
+  std::vector<double> tt, vv;
+  {
+    double t = 0.0;
+    for (int k = 0; k < 4096; k++, t += sample_dt) tt.push_back(t);
+    const double longest = std::max(h->params.veh_length, h->params.veh_width) + 1.0;
+    for (double dl = vertex_res; dl < longest; dl += vertex_res) vv.push_back(dl);
+    if (vv.empty()) vv.push_back(vertex_res);
+  }
+  double *d_t = nullptr, *d_v = nullptr;
+  int *d_col = nullptr, *d_first = nullptr;
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  chk(hipMalloc(&d_t, sizeof(double) * tt.size()));
+  chk(hipMalloc(&d_v, sizeof(double) * vv.size()));
+  chk(hipMalloc(&d_col, sizeof(int) * (size_t)b->B));
+  chk(hipMalloc(&d_first, sizeof(int) * (size_t)b->B));
+  if (rc == DFTPAV_OK) {
+    chk(hipMemcpyAsync(d_t, tt.data(), sizeof(double) * tt.size(), hipMemcpyHostToDevice, h->stream));
+    chk(hipMemcpyAsync(d_v, vv.data(), sizeof(double) * vv.size(), hipMemcpyHostToDevice, h->stream));
+    chk(hipEventRecord(h->cev0, h->stream));
+    chk(launch_validate(h->d_cells, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, b->d_coef,
+                        b->d_dt, b->L, b->B, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, d_t, (int)tt.size(),
+                        sample_dt, d_v, (int)vv.size(), d_col, d_first, h->stream));
+    chk(hipEventRecord(h->cev1, h->stream));
+    if (collision) chk(hipMemcpyAsync(collision, d_col, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToHost, h->stream));
+    if (first_sample) chk(hipMemcpyAsync(first_sample, d_first, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToHost, h->stream));
+    chk(hipStreamSynchronize(h->stream));
+    h->ctimed = rc == DFTPAV_OK;
+  }
+  for (void *p : {(void *)d_t, (void *)d_v, (void *)d_col, (void *)d_first})
+    if (p) (void)hipFree(p);
+  return rc;
 }
 
 extern "C" int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B, const dftpav_batch_data *d,

@@ -88,6 +88,66 @@ DFTPAV_HD inline double p_cos(double x) {
 }
 
 // exp after fdlibm e_exp.c (argument reduction by ln2, degree-5 rational core);
+
+// atan / atan2 after fdlibm's s_atan.c / e_atan2.c (argument reduction to [0, 7/16] by the four breakpoints,
+// odd degree-21 polynomial), range tests written as comparisons.  Used for the heading of an output
+// trajectory (Piece::getAngle, poly_traj_utils.hpp:237-244); inputs are finite.
+DFTPAV_HD inline double p_atan(double x) {
+  const double hi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
+                        1.57079632679489655800e+00};
+  const double lo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17,
+                        6.12323399573676603587e-17};
+  const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01, aT2 = 1.42857142725034663711e-01,
+               aT3 = -1.11111104054623557880e-01, aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
+               aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02, aT8 = 4.97687799461593236017e-02,
+               aT9 = -3.65315727442169155270e-02, aT10 = 1.62858201153657823623e-02;
+  const bool neg = x < 0.0;
+  double ax = neg ? -x : x;
+  if (ax >= 7.378697629483820646e19) return neg ? -(hi[3] + lo[3]) : hi[3] + lo[3]; // |x| >= 2^66
+  int id;
+  if (ax < 0.4375) {
+    if (ax < 1.862645149230957031e-09) return x; // |x| < 2^-29
+    id = -1;
+  } else if (ax < 1.1875) {
+    if (ax < 0.6875) {
+      id = 0;
+      ax = (2.0 * ax - 1.0) / (2.0 + ax);
+    } else {
+      id = 1;
+      ax = (ax - 1.0) / (ax + 1.0);
+    }
+  } else if (ax < 2.4375) {
+    id = 2;
+    ax = (ax - 1.5) / (1.0 + 1.5 * ax);
+  } else {
+    id = 3;
+    ax = -1.0 / ax;
+  }
+  const double z = ax * ax, w = z * z;
+  const double s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+  const double s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+  if (id < 0) {
+    const double r = ax - ax * (s1 + s2);
+    return neg ? -r : r;
+  }
+  const double r = hi[id] - ((ax * (s1 + s2) - lo[id]) - ax);
+  return neg ? -r : r;
+}
+DFTPAV_HD inline double p_atan2(double y, double x) {
+  const double pi = 3.1415926535897931160e+00, pi_lo = 1.2246467991473531772e-16, pi_o_2 = 1.5707963267948965580e+00;
+  if (x == 1.0) return p_atan(y);
+  const bool yneg = y < 0.0 || (y == 0.0 && 1.0 / y < 0.0), xneg = x < 0.0 || (x == 0.0 && 1.0 / x < 0.0);
+  if (y == 0.0) return xneg ? (yneg ? -pi : pi) : y;
+  if (x == 0.0) return yneg ? -pi_o_2 : pi_o_2;
+  const double ay = yneg ? -y : y, ax = xneg ? -x : x;
+  double z;
+  if (ay > ax * 1.152921504606846976e18) z = pi_o_2 + 0.5 * pi_lo;       // |y/x| > 2^60
+  else if (xneg && ay * 1.152921504606846976e18 < ax) z = 0.0;           // |y/x| < 2^-60, x < 0
+  else z = p_atan(ay / ax);
+  if (!xneg) return yneg ? -z : z;
+  return yneg ? (z - pi_lo) - pi : pi - (z - pi_lo);
+}
+
 // the range here is alpha*(d - d0) <= 0 with |arg| up to a few hundred.
 DFTPAV_HD inline double p_exp(double x) {
   const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,

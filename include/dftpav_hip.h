@@ -251,6 +251,18 @@ int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piece_dt);
  * on the handle's stream around the launch. */
 int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms);
 
+/* ---- validation of the result, the step after the solve ----
+ * Replaces the collision re-check of TrajPlannerServer::CheckReplan
+ * (traj_server_ros.cpp:385-397) for every trajectory of a solved batch: each
+ * segment is sampled at t = 0, sample_dt, ... < duration (0.05 in the
+ * reference), the vehicle outline at spacing vertex_res (0.1, shapes.h:201)
+ * is tested against the map of dftpav_set_grid_map
+ * (semantic_map_manager.cc:639-662).  collision[t] = 1 if any sample of
+ * trajectory t collides, first_sample[t] = index of the first such sample
+ * counted over the segments in order (-1 if none).  Either output may be NULL.
+ * dftpav_corridor_last_ms reports the kernel's duration afterwards. */
+int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double vertex_res, int *collision, int *first_sample);
+
 /* One-shot convenience == OptimizeTrajectory for B trajectories. */
 int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B,
                        const dftpav_batch_data *d, double *x, double *final_cost,

@@ -249,3 +249,28 @@ def corridor_rectangles(grid, resolution, origin, states, veh=(1.90, 4.88, 1.015
     fn(g.ctypes.data, g.shape[1], g.shape[0], float(resolution), float(origin[0]), float(origin[1]), st.ctypes.data,
        st.shape[0], float(veh[0]), float(veh[1]), float(veh[2]), int(order), out.ctypes.data)
     return out
+
+
+def validate_trajectories(grid, resolution, origin, coeffs, piece_dt, piece_nums, singuls, veh=(1.90, 4.88, 1.015),
+                          sample_dt=0.05, vertex_res=0.1, order=0):
+    """The collision re-check of CheckReplan (traj_server_ros.cpp:385-397) for B trajectories.
+
+    coeffs: [B][Ntot][6][2] (entry [k][d] = coefficient of s^k), piece_dt: [B][M].  Returns (collision [B], first_sample [B])."""
+    L = lib()
+    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    co = np.ascontiguousarray(coeffs, dtype=np.float64)
+    B = co.shape[0]
+    dt = np.ascontiguousarray(piece_dt, dtype=np.float64).reshape(B, -1)
+    pn = np.ascontiguousarray(piece_nums, dtype=np.int32)
+    sg = np.ascontiguousarray(singuls, dtype=np.int32)
+    col = np.zeros(B, dtype=np.int32)
+    first = np.zeros(B, dtype=np.int32)
+    fn = L.oracle_validate_trajectories
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                   C.c_void_p, C.c_void_p]
+    fn(g.ctypes.data, g.shape[1], g.shape[0], float(resolution), float(origin[0]), float(origin[1]), co.ctypes.data,
+       dt.ctypes.data, pn.ctypes.data, sg.ctypes.data, len(pn), B, float(veh[0]), float(veh[1]), float(veh[2]),
+       float(sample_dt), float(vertex_res), int(order), col.ctypes.data, first.ctypes.data)
+    return col, first

@@ -357,3 +357,48 @@ def test_generated_corridor_feeds_the_solver(hiplib, oracle):
     b2.close()
     bt.close()
     h.close()
+
+
+@pytest.mark.parametrize("cfg,B", [(3, 24), (2, 6)])
+def test_validation_matches_oracle(hiplib, oracle, cfg, B):
+    """§8(f)-2: the sampled collision re-check of CheckReplan (traj_server_ros.cpp:385-397) on the device against
+    the oracle's device-order mode, on the solved trajectories, on a clear map and on maps with obstacles dropped
+    onto the paths."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(cfg, B=B)
+    s.apply_resolution(p)
+    st = s.meta["states"]
+    c = (0.5 * (st[..., 0].min() + st[..., 0].max()), 0.5 * (st[..., 1].min() + st[..., 1].max()))
+    obs = s.meta["obstacles"]
+    grid, origin = sc.occupancy_grid(obs, arena=140.0, centre=c)
+    h, bt = _batch(hiplib, s, p)
+    bt.solve()
+    co, dts = bt.coeffs()
+    lay = s.layout
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    col, first = bt.validate()
+    oc, of = oracle.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, lay.piece_nums, lay.singuls, order=1)
+    assert np.array_equal(col, oc) and np.array_equal(first, of)
+    assert h.corridor_last_ms() > 0.0
+    # obstacles on the nominal paths: most trajectories must be flagged, with the same first sample
+    rng = np.random.default_rng(cfg)
+    extra = []
+    for hyp in range(st.shape[0]):
+        for k in rng.choice(st.shape[1], 3, replace=False):
+            extra.append([st[hyp, k, 0], st[hyp, k, 1], 0.8])
+    grid2, origin2 = sc.occupancy_grid(np.vstack([obs, np.array(extra)]), arena=140.0, centre=c)
+    h.set_grid_map(grid2, sc.MAP_RESL, origin2)
+    col2, first2 = bt.validate()
+    oc2, of2 = oracle.validate_trajectories(grid2, sc.MAP_RESL, origin2, co, dts, lay.piece_nums, lay.singuls, order=1)
+    assert np.array_equal(col2, oc2) and np.array_equal(first2, of2)
+    assert col2.mean() > 0.5 and (first2[col2 == 1] >= 0).all() and (first2[col2 == 0] == -1).all()
+    # the libm order agrees except where an ulp moves an outline point across a cell boundary
+    oc0, of0 = oracle.validate_trajectories(grid2, sc.MAP_RESL, origin2, co, dts, lay.piece_nums, lay.singuls, order=0)
+    assert (oc0 == col2).mean() > 0.9
+    # coarser sampling / spacing parameters
+    col3, first3 = bt.validate(sample_dt=0.21, vertex_res=0.37)
+    oc3, of3 = oracle.validate_trajectories(grid2, sc.MAP_RESL, origin2, co, dts, lay.piece_nums, lay.singuls,
+                                            sample_dt=0.21, vertex_res=0.37, order=1)
+    assert np.array_equal(col3, oc3) and np.array_equal(first3, of3)
+    bt.close()
+    h.close()
