@@ -28,6 +28,7 @@ EXPORTS = [
     "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
+    "dftpav_fit_surround", "dftpav_get_surround",
 ]
 
 
@@ -120,6 +121,30 @@ class Handle:
         s = surround_set.c_struct()
         self._check(lib().dftpav_set_surround(self._h, C.byref(s)), "set_surround")
         self._sur_keep = surround_set
+
+    def fit_surround(self, states):
+        """ConverSurroundTrajFromPoints + setSurroundTrajs on the device: states [S][n][7] (x, y, angle, velocity,
+        acceleration, curvature, time_stamp)."""
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        S, n = (st.shape[0], st.shape[1]) if st.size else (0, 0)
+        fn = lib().dftpav_fit_surround
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        self._check(fn(self._h, st.ctypes.data_as(C.c_void_p), S, n), "fit_surround")
+        self._sur_keep = None
+
+    def get_surround(self):
+        """The installed moving obstacles as dict(offsets, durations, coeffs [np][12], total, start)."""
+        fn = lib().dftpav_get_surround
+        fn.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        S, npc = C.c_int(0), C.c_int(0)
+        self._check(fn(self._h, C.byref(S), C.byref(npc), None, None, None, None, None), "get_surround")
+        out = dict(offsets=np.zeros(S.value + 1, dtype=np.int32), durations=np.zeros(npc.value), coeffs=np.zeros((npc.value, 12)),
+                   total=np.zeros(S.value), start=np.zeros(S.value))
+        if S.value:
+            self._check(fn(self._h, None, None, out["offsets"].ctypes.data_as(C.c_void_p), out["durations"].ctypes.data_as(C.c_void_p),
+                           out["coeffs"].ctypes.data_as(C.c_void_p), out["total"].ctypes.data_as(C.c_void_p),
+                           out["start"].ctypes.data_as(C.c_void_p)), "get_surround")
+        return out
 
     def set_grid_map(self, grid, resolution, origin):
         """Obstacle map of the corridor generator: uint8 [size_y][size_x], 80 = occupied (dftpav_grid_map)."""

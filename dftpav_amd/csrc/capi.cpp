@@ -26,6 +26,8 @@ hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int
 hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
                            int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream);
+hipError_t launch_fit(const double *states, int S, int n_states, const double *opM, double *dur, double *coef, double *total,
+                      double *start, hipStream_t stream);
 hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *coeffs, const double *piece_dt, const DevLayout &L, int B, double veh_width,
                            double veh_length, double veh_dcr, const double *t_tab, int n_t, double sample_dt, const double *v_tab,
@@ -41,6 +43,7 @@ struct dftpav_handle {
   std::string err;
   // moving obstacles (device copies)
   int S = 0;
+  int sur_pieces = 0; // pieces of all obstacles together
   int sur_version = 0; // bumped by dftpav_set_surround so batches refresh their device descriptor
   int *d_sur_off = nullptr;
   double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr;
@@ -200,6 +203,7 @@ static void free_surround(dftpav_handle *h) {
   h->d_sur_off = nullptr;
   h->d_sur_dur = h->d_sur_coef = h->d_sur_total = h->d_sur_start = nullptr;
   h->S = 0;
+  h->sur_pieces = 0;
 }
 
 extern "C" void dftpav_destroy(dftpav_handle *h) {
@@ -217,6 +221,72 @@ extern "C" void dftpav_destroy(dftpav_handle *h) {
 
 extern "C" const char *dftpav_last_error(const dftpav_handle *h) { return h ? h->err.c_str() : "null handle"; }
 extern "C" void *dftpav_stream(dftpav_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+static void minco_operator(int N, std::vector<double> &Mop, std::vector<double> &MopT);
+
+extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S, int n_states) {
+  if (!h || (S > 0 && !states) || S < 0 || (S > 0 && n_states < 3)) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  free_surround(h);
+  h->sur_version++;
+  if (S == 0) return DFTPAV_OK; // ConverSurroundTrajFromPoints returns without obstacles, traj_manager.cpp:750-752
+  const int N = n_states - 1, np = S * N;
+  std::vector<int> off(S + 1);
+  for (int i = 0; i <= S; i++) off[i] = i * N;
+  std::vector<double> Mop, MopT;
+  minco_operator(N, Mop, MopT);
+  double *d_states = nullptr, *d_op = nullptr;
+  HIPCHK(h, hipMalloc(&h->d_sur_off, sizeof(int) * (S + 1)));
+  HIPCHK(h, hipMalloc(&h->d_sur_dur, sizeof(double) * np));
+  HIPCHK(h, hipMalloc(&h->d_sur_coef, sizeof(double) * 12 * np));
+  HIPCHK(h, hipMalloc(&h->d_sur_total, sizeof(double) * S));
+  HIPCHK(h, hipMalloc(&h->d_sur_start, sizeof(double) * S));
+  HIPCHK(h, hipMalloc(&d_states, sizeof(double) * 7 * (size_t)S * n_states));
+  if (hipMalloc(&d_op, sizeof(double) * Mop.size()) != hipSuccess) {
+    (void)hipFree(d_states);
+    h->err = "hipMalloc";
+    return DFTPAV_E_HIP;
+  }
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  chk(hipMemcpyAsync(h->d_sur_off, off.data(), sizeof(int) * (S + 1), hipMemcpyHostToDevice, h->stream));
+  chk(hipMemcpyAsync(d_states, states, sizeof(double) * 7 * (size_t)S * n_states, hipMemcpyHostToDevice, h->stream));
+  chk(hipMemcpyAsync(d_op, Mop.data(), sizeof(double) * Mop.size(), hipMemcpyHostToDevice, h->stream));
+  if (rc == DFTPAV_OK)
+    chk(launch_fit(d_states, S, n_states, d_op, h->d_sur_dur, h->d_sur_coef, h->d_sur_total, h->d_sur_start, h->stream));
+  chk(hipStreamSynchronize(h->stream)); // off / Mop live on this stack frame
+  (void)hipFree(d_states);
+  (void)hipFree(d_op);
+  if (rc == DFTPAV_OK) {
+    h->S = S;
+    h->sur_pieces = np;
+  } else {
+    free_surround(h);
+  }
+  return rc;
+}
+
+extern "C" int dftpav_get_surround(dftpav_handle *h, int *S, int *n_pieces, int *piece_offsets, double *durations, double *coeffs,
+                                   double *total_duration, double *start_time) {
+  if (!h) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (S) *S = h->S;
+  if (n_pieces) *n_pieces = h->sur_pieces;
+  if (h->S == 0) return DFTPAV_OK;
+  if (piece_offsets) HIPCHK(h, hipMemcpy(piece_offsets, h->d_sur_off, sizeof(int) * (h->S + 1), hipMemcpyDeviceToHost));
+  if (durations) HIPCHK(h, hipMemcpy(durations, h->d_sur_dur, sizeof(double) * h->sur_pieces, hipMemcpyDeviceToHost));
+  if (coeffs) HIPCHK(h, hipMemcpy(coeffs, h->d_sur_coef, sizeof(double) * 12 * h->sur_pieces, hipMemcpyDeviceToHost));
+  if (total_duration) HIPCHK(h, hipMemcpy(total_duration, h->d_sur_total, sizeof(double) * h->S, hipMemcpyDeviceToHost));
+  if (start_time) HIPCHK(h, hipMemcpy(start_time, h->d_sur_start, sizeof(double) * h->S, hipMemcpyDeviceToHost));
+  return DFTPAV_OK;
+}
 
 extern "C" int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map) {
   if (!h || !map || !map->cells || map->size_x <= 0 || map->size_y <= 0 || !(map->resolution > 0.0)) return DFTPAV_E_INVALID;
@@ -321,6 +391,7 @@ extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   HIPCHK(h, hipMemcpy(h->d_sur_coef, s->coeffs, sizeof(double) * 12 * np, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_sur_total, s->total_duration, sizeof(double) * S, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_sur_start, s->start_time, sizeof(double) * S, hipMemcpyHostToDevice));
+  h->sur_pieces = np;
   h->S = S;
   return DFTPAV_OK;
 }

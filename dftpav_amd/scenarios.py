@@ -303,6 +303,25 @@ DYNAMIC_OBS_YAML = [
 ]
 
 
+def predicted_states(pre_time=30.0, deltatime=1.0, cars=DYNAMIC_OBS_YAML, start_time=0.0):
+    """The predicted state sequences ConverSurroundTrajFromPoints receives (traj_manager.cpp:743): scripted circle
+    cars (parking_moving_obstacles.cc:41-57).  [S][n][7] = x, y, angle, velocity, acceleration, curvature, time_stamp."""
+    out = []
+    for (cx, cy, vel, rad, yaw0) in cars:
+        omg = vel / rad
+        ts = np.arange(0.0, pre_time + 1e-9, deltatime)
+        ang = yaw0 + ts * omg
+        st = np.zeros((len(ts), 7))
+        st[:, 0] = rad * np.cos(ang) + cx
+        st[:, 1] = rad * np.sin(ang) + cy
+        st[:, 2] = ang + np.pi / 2
+        st[:, 3] = vel
+        st[:, 5] = 1.0 / rad
+        st[:, 6] = start_time + ts
+        out.append(st)
+    return np.array(out)
+
+
 def moving_obstacles(pre_time=30.0, deltatime=1.0, cars=DYNAMIC_OBS_YAML, start_time=0.0):
     """Scripted circle cars (parking_moving_obstacles.cc:41-57) predicted
     `pre_time` s at `deltatime` steps and fitted as TrajPlanner::

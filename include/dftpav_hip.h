@@ -167,6 +167,20 @@ const char *dftpav_last_error(const dftpav_handle *h);
  * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied. */
 int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s);
 
+/* ---- moving-obstacle trajectory fitting ----
+ * Replaces TrajPlanner::ConverSurroundTrajFromPoints (traj_manager.cpp:743-789,
+ * with state_to_flat_output :139-158) followed by setSurroundTrajs: S predicted
+ * state sequences, states [S][n_states][7] = (x, y, angle, velocity,
+ * acceleration, curvature, time_stamp) per state, are each fitted on the device
+ * with a uniform-time minimum-jerk trajectory of n_states - 1 pieces and
+ * installed as the handle's moving obstacles (S == 0 clears them). */
+int dftpav_fit_surround(dftpav_handle *h, const double *states, int S, int n_states);
+/* Reads back the installed moving obstacles in the layout of dftpav_surround
+ * (any pointer may be NULL; call once with the arrays NULL to get S and the
+ * total number of pieces). */
+int dftpav_get_surround(dftpav_handle *h, int *S, int *n_pieces, int *piece_offsets, double *durations, double *coeffs,
+                        double *total_duration, double *start_time);
+
 /* ---- safe-corridor generation, the step before the solve ----
  * Replaces map_itf_->GetObstacleMap + the map queries of getRectangleConst
  * (traj_manager.cpp:1216-1217, map_adapter.cpp:93-97, semantics.h:351-358):

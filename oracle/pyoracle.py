@@ -274,3 +274,18 @@ def validate_trajectories(grid, resolution, origin, coeffs, piece_dt, piece_nums
        dt.ctypes.data, pn.ctypes.data, sg.ctypes.data, len(pn), B, float(veh[0]), float(veh[1]), float(veh[2]),
        float(sample_dt), float(vertex_res), int(order), col.ctypes.data, first.ctypes.data)
     return col, first
+
+
+def fit_surround(states, order=0):
+    """ConverSurroundTrajFromPoints (traj_manager.cpp:743-789): states [S][n][7] (x, y, angle, velocity, acceleration,
+    curvature, time_stamp) -> dict(durations [S][n-1], coeffs [S][n-1][12], total [S], start [S])."""
+    L = lib()
+    st = np.ascontiguousarray(states, dtype=np.float64)
+    S, n = st.shape[0], st.shape[1]
+    out = dict(durations=np.zeros((S, n - 1)), coeffs=np.zeros((S, n - 1, 12)), total=np.zeros(S), start=np.zeros(S))
+    fn = L.oracle_fit_surround
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(st.ctypes.data, S, n, int(order), out["durations"].ctypes.data, out["coeffs"].ctypes.data, out["total"].ctypes.data,
+       out["start"].ctypes.data)
+    return out

@@ -402,3 +402,54 @@ def test_validation_matches_oracle(hiplib, oracle, cfg, B):
     assert np.array_equal(col3, oc3) and np.array_equal(first3, of3)
     bt.close()
     h.close()
+
+
+def test_fit_surround_matches_oracle_and_feeds_the_solver(hiplib, oracle):
+    """§8(f)-4: ConverSurroundTrajFromPoints (traj_manager.cpp:743-789) on the device: bit-exact against the oracle's
+    device-order mode, and the fitted obstacles drive the moving-obstacle penalty exactly as uploaded ones do."""
+    st = sc.predicted_states()
+    h = hiplib.Handle(hiplib.default_params())
+    h.fit_surround(st)
+    got = h.get_surround()
+    want = oracle.fit_surround(st, order=1)
+    S, n = st.shape[0], st.shape[1]
+    assert np.array_equal(got["offsets"], np.arange(S + 1) * (n - 1))
+    assert np.array_equal(got["coeffs"].reshape(want["coeffs"].shape), want["coeffs"])
+    assert np.array_equal(got["durations"].reshape(S, n - 1), want["durations"])
+    assert np.array_equal(got["total"], want["total"]) and np.array_equal(got["start"], want["start"])
+    lit = oracle.fit_surround(st, order=0)
+    assert np.abs(lit["coeffs"] - want["coeffs"]).max() < 1e-9
+    # other sizes: 3 states (two pieces), many obstacles, uneven time stamps, a stationary first state
+    rng = np.random.default_rng(5)
+    st2 = sc.predicted_states(pre_time=9.0, deltatime=0.75, cars=[(rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(1, 6),
+                                                                   rng.uniform(5, 20), rng.uniform(-3, 3)) for _ in range(37)])
+    st2[:, :, 6] += rng.uniform(0, 0.01, st2.shape[:2]).cumsum(axis=1)
+    st2[3, 0, 3] = 0.0
+    for sub in (st2, st2[:, :3]):
+        h.fit_surround(sub)
+        g2, w2 = h.get_surround(), oracle.fit_surround(sub, order=1)
+        assert np.array_equal(g2["coeffs"].reshape(w2["coeffs"].shape), w2["coeffs"])
+        assert np.array_equal(g2["total"], w2["total"])
+    h.fit_surround(np.zeros((0, 0, 7)))
+    assert h.get_surround()["total"].size == 0
+    # cfg 5 with obstacles fitted on the device == cfg 5 with the same fit uploaded through dftpav_set_surround
+    p = hiplib.default_params()
+    s = sc.baseline_config(5, B=2)
+    s.apply_resolution(p)
+    h2 = hiplib.Handle(p)
+    h2.fit_surround(st)
+    bt = hiplib.Batch(h2, s.layout, s.B)
+    bt.upload(s)
+    f_dev, g_dev = bt.eval(bt.x0())
+    from dftpav_amd.pods import SurroundSet
+    ss = SurroundSet(got["offsets"], got["durations"], got["coeffs"], got["total"], got["start"])
+    h3 = hiplib.Handle(p)
+    h3.set_surround(ss)
+    b3 = hiplib.Batch(h3, s.layout, s.B)
+    b3.upload(s)
+    f_up, g_up = b3.eval(b3.x0())
+    assert np.array_equal(f_dev, f_up) and np.array_equal(g_dev, g_up)
+    for x in (bt, b3):
+        x.close()
+    for x in (h, h2, h3):
+        x.close()
