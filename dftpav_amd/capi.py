@@ -28,7 +28,7 @@ EXPORTS = [
     "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
-    "dftpav_fit_surround", "dftpav_get_surround",
+    "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
 ]
 
 
@@ -121,6 +121,26 @@ class Handle:
         s = surround_set.c_struct()
         self._check(lib().dftpav_set_surround(self._h, C.byref(s)), "set_surround")
         self._sur_keep = surround_set
+
+    def frontend_resample(self, paths, path_len, start_states, end_states, start_ctrl, fparams=None, **caps):
+        """getKinoNode (from SampleTraj on) + the resampling of RunMINCOParking on the device; returns the dict of padded
+        arrays of pods.FrontendOut."""
+        from .pods import FrontendParams, FrontendOut
+        P = np.ascontiguousarray(paths, dtype=np.float64)
+        n_hyp, max_path = P.shape[0], P.shape[1]
+        pl = np.ascontiguousarray(path_len, dtype=np.int32)
+        ss = np.ascontiguousarray(start_states, dtype=np.float64)
+        es = np.ascontiguousarray(end_states, dtype=np.float64)
+        sc_ = np.ascontiguousarray(start_ctrl, dtype=np.float64)
+        fp = fparams if fparams is not None else FrontendParams.default()
+        out = FrontendOut(n_hyp, **caps)
+        fn = lib().dftpav_frontend_resample
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                       C.c_void_p]
+        self._check(fn(self._h, C.byref(fp), P.ctypes.data_as(C.c_void_p), pl.ctypes.data_as(C.c_void_p), max_path,
+                       ss.ctypes.data_as(C.c_void_p), es.ctypes.data_as(C.c_void_p), sc_.ctypes.data_as(C.c_void_p), n_hyp,
+                       C.byref(out.c)), "frontend_resample")
+        return out.arrays()
 
     def fit_surround(self, states):
         """ConverSurroundTrajFromPoints + setSurroundTrajs on the device: states [S][n][7] (x, y, angle, velocity,

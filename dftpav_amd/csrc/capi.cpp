@@ -26,6 +26,9 @@ hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int
 hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
                            int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream);
+hipError_t launch_frontend(const dftpav_frontend_params &fp, const double *paths, const int *path_len, int max_path,
+                           const double *start_states, const double *end_states, const double *start_ctrl, int n_hyp,
+                           const dftpav_frontend_out &out, hipStream_t stream);
 hipError_t launch_fit(const double *states, int S, int n_states, const double *opM, double *dur, double *coef, double *total,
                       double *start, hipStream_t stream);
 hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
@@ -223,6 +226,72 @@ extern "C" const char *dftpav_last_error(const dftpav_handle *h) { return h ? h-
 extern "C" void *dftpav_stream(dftpav_handle *h) { return h ? (void *)h->stream : nullptr; }
 
 static void minco_operator(int N, std::vector<double> &Mop, std::vector<double> &MopT);
+
+extern "C" int dftpav_frontend_resample(dftpav_handle *h, const dftpav_frontend_params *fp, const double *paths, const int *path_len,
+                                        int max_path, const double *start_states, const double *end_states,
+                                        const double *start_ctrl, int n_hyp, const dftpav_frontend_out *out) {
+  if (!h || !fp || !paths || !path_len || !start_states || !end_states || !start_ctrl || !out || n_hyp < 0 || max_path < 2)
+    return DFTPAV_E_INVALID;
+  if (out->max_seg < 1 || out->max_seg > 16 || out->max_pieces < 2 || out->max_states < 1) return DFTPAV_E_UNSUPPORTED;
+  if (fp->traj_res < 1 || fp->dense_traj_res < 1 || !(fp->piece_duration > 0.0)) return DFTPAV_E_INVALID;
+  for (int i = 0; i < n_hyp; i++)
+    if (path_len[i] < 2 || path_len[i] > max_path) return DFTPAV_E_INVALID;
+  if (n_hyp == 0) return DFTPAV_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t nh = (size_t)n_hyp, MS = (size_t)out->max_seg, MP = (size_t)out->max_pieces, MST = (size_t)out->max_states;
+  struct Buf {
+    void **dev;
+    const void *src; // host input (nullptr for outputs)
+    void *dst;       // host output
+    size_t bytes;
+  };
+  double *d_paths = nullptr, *d_ss = nullptr, *d_es = nullptr, *d_sc = nullptr;
+  int *d_len = nullptr;
+  dftpav_frontend_out D = *out; // device pointers below
+  D.n_seg = nullptr; D.singul = nullptr; D.piece_nums = nullptr; D.piece_dt = nullptr; D.ini_states = nullptr;
+  D.fin_states = nullptr; D.inner_pts = nullptr; D.n_states = nullptr; D.states = nullptr;
+  Buf bufs[] = {
+      {(void **)&d_paths, paths, nullptr, sizeof(double) * nh * max_path * 3},
+      {(void **)&d_len, path_len, nullptr, sizeof(int) * nh},
+      {(void **)&d_ss, start_states, nullptr, sizeof(double) * nh * 4},
+      {(void **)&d_es, end_states, nullptr, sizeof(double) * nh * 4},
+      {(void **)&d_sc, start_ctrl, nullptr, sizeof(double) * nh * 2},
+      {(void **)&D.n_seg, nullptr, out->n_seg, sizeof(int) * nh},
+      {(void **)&D.singul, nullptr, out->singul, sizeof(int) * nh * MS},
+      {(void **)&D.piece_nums, nullptr, out->piece_nums, sizeof(int) * nh * MS},
+      {(void **)&D.piece_dt, nullptr, out->piece_dt, sizeof(double) * nh * MS},
+      {(void **)&D.ini_states, nullptr, out->ini_states, sizeof(double) * nh * MS * 6},
+      {(void **)&D.fin_states, nullptr, out->fin_states, sizeof(double) * nh * MS * 6},
+      {(void **)&D.inner_pts, nullptr, out->inner_pts, sizeof(double) * nh * MS * (MP - 1) * 2},
+      {(void **)&D.n_states, nullptr, out->n_states, sizeof(int) * nh * MS},
+      {(void **)&D.states, nullptr, out->states, sizeof(double) * nh * MS * MST * 3},
+  };
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  for (Buf &b : bufs) {
+    if (!b.src && !b.dst) {
+      rc = DFTPAV_E_INVALID;
+      break;
+    }
+    chk(hipMalloc(b.dev, b.bytes));
+    if (rc != DFTPAV_OK) break;
+    if (b.src) chk(hipMemcpyAsync(*b.dev, b.src, b.bytes, hipMemcpyHostToDevice, h->stream));
+    else chk(hipMemsetAsync(*b.dev, 0, b.bytes, h->stream));
+  }
+  if (rc == DFTPAV_OK) chk(launch_frontend(*fp, d_paths, d_len, max_path, d_ss, d_es, d_sc, n_hyp, D, h->stream));
+  if (rc == DFTPAV_OK)
+    for (Buf &b : bufs)
+      if (b.dst) chk(hipMemcpyAsync(b.dst, *b.dev, b.bytes, hipMemcpyDeviceToHost, h->stream));
+  chk(hipStreamSynchronize(h->stream));
+  for (Buf &b : bufs)
+    if (*b.dev) (void)hipFree(*b.dev);
+  return rc;
+}
 
 extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S, int n_states) {
   if (!h || (S > 0 && !states) || S < 0 || (S > 0 && n_states < 3)) return DFTPAV_E_INVALID;

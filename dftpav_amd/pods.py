@@ -162,3 +162,43 @@ class LayoutSpec:
         l.singuls = iptr(self.singuls)
         l.H = self.H
         return l
+
+
+class FrontendParams(C.Structure):
+    """dftpav_frontend_params (include/dftpav_hip.h), defaults of minco_config.pb.txt:66-67,76-80."""
+    _fields_ = [("max_forward_vel", C.c_double), ("max_forward_acc", C.c_double), ("max_backward_vel", C.c_double),
+                ("max_backward_acc", C.c_double), ("non_siguav", C.c_double), ("wheel_base", C.c_double),
+                ("piece_duration", C.c_double), ("traj_res", C.c_int), ("dense_traj_res", C.c_int)]
+
+    @classmethod
+    def default(cls, K=16, Kd=32):
+        return cls(5.0, 8.0, 2.0, 4.0, 0.2, 2.85, 1.0, K, Kd)
+
+
+class FrontendOutC(C.Structure):
+    _fields_ = [("max_seg", C.c_int), ("max_pieces", C.c_int), ("max_states", C.c_int), ("n_seg", C.c_void_p),
+                ("singul", C.c_void_p), ("piece_nums", C.c_void_p), ("piece_dt", C.c_void_p), ("ini_states", C.c_void_p),
+                ("fin_states", C.c_void_p), ("inner_pts", C.c_void_p), ("n_states", C.c_void_p), ("states", C.c_void_p)]
+
+
+class FrontendOut:
+    """Owner of the padded output arrays of dftpav_frontend_resample."""
+
+    def __init__(self, n_hyp, max_seg=8, max_pieces=64, max_states=2304):
+        self.n_seg = np.zeros(n_hyp, dtype=np.int32)
+        self.singul = np.zeros((n_hyp, max_seg), dtype=np.int32)
+        self.piece_nums = np.zeros((n_hyp, max_seg), dtype=np.int32)
+        self.piece_dt = np.zeros((n_hyp, max_seg))
+        self.ini_states = np.zeros((n_hyp, max_seg, 6))
+        self.fin_states = np.zeros((n_hyp, max_seg, 6))
+        self.inner_pts = np.zeros((n_hyp, max_seg, max_pieces - 1, 2))
+        self.n_states = np.zeros((n_hyp, max_seg), dtype=np.int32)
+        self.states = np.zeros((n_hyp, max_seg, max_states, 3))
+        self.c = FrontendOutC(max_seg, max_pieces, max_states, *[a.ctypes.data for a in (
+            self.n_seg, self.singul, self.piece_nums, self.piece_dt, self.ini_states, self.fin_states, self.inner_pts,
+            self.n_states, self.states)])
+
+    def arrays(self):
+        return dict(n_seg=self.n_seg, singul=self.singul, piece_nums=self.piece_nums, piece_dt=self.piece_dt,
+                    ini_states=self.ini_states, fin_states=self.fin_states, inner_pts=self.inner_pts, n_states=self.n_states,
+                    states=self.states)

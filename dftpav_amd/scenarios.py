@@ -353,6 +353,41 @@ def moving_obstacles(pre_time=30.0, deltatime=1.0, cars=DYNAMIC_OBS_YAML, start_
     return SurroundSet(np.array(offs), np.concatenate(durs), np.concatenate(coeffs), np.array(tot), np.array(st))
 
 
+def searched_paths(n_hyp, seed=0, gears=(1, -1), seg_duration=8.0, spacing=0.15, max_path=1024):
+    """Stand-ins for KinoAstar's SampleTraj (kino_astar.cpp:566-610): dense pose lists (x, y, yaw in (-pi, pi]) at
+    `spacing` metres along a kinematic-car path with the given gear sequence.  Returns paths [n_hyp][max_path][3],
+    path_len, start_states [n_hyp][4], end_states [n_hyp][4], start_ctrl [n_hyp][2]."""
+    paths = np.zeros((n_hyp, max_path, 3))
+    plen = np.zeros(n_hyp, dtype=np.int32)
+    ss, es, sc_ = np.zeros((n_hyp, 4)), np.zeros((n_hyp, 4)), np.zeros((n_hyp, 2))
+    for h in range(n_hyp):
+        rng = _rng(seed * 7919 + h)
+        pose = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi)])
+        pts = [pose.copy()]
+        v0 = rng.uniform(0.0, 1.5)
+        for gi, sg in enumerate(gears):
+            vs = v0 if gi == 0 else NON_SIGUAV
+            ev = _drive(rng, pose, sg, seg_duration, vs, NON_SIGUAV, 3.0 if sg > 0 else 1.5)
+            tt = np.linspace(0.0, seg_duration, 4001)
+            x, y, yaw, _, _, _ = ev(tt)
+            arc = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])
+            sa = np.arange(spacing, arc[-1], spacing)
+            xs, ys, yw = np.interp(sa, arc, x), np.interp(sa, arc, y), np.interp(sa, arc, yaw)
+            for k in range(len(sa)):
+                pts.append(np.array([xs[k], ys[k], yw[k]]))
+            pose = np.array([x[-1], y[-1], yaw[-1]])
+            pts.append(pose.copy())
+        P = np.array(pts)
+        P[:, 2] = np.arctan2(np.sin(P[:, 2]), np.cos(P[:, 2]))  # normalize_angle
+        n = min(len(P), max_path)
+        paths[h, :n] = P[:n]
+        plen[h] = n
+        ss[h] = [P[0, 0], P[0, 1], P[0, 2], gears[0] * v0]
+        es[h] = [P[n - 1, 0], P[n - 1, 1], P[n - 1, 2], gears[-1] * NON_SIGUAV]
+        sc_[h] = [rng.uniform(-0.3, 0.3), rng.uniform(-1.0, 1.0)]
+    return paths, plen, ss, es, sc_
+
+
 # --------------------------------------------------------------------------
 # scenario assembly
 # --------------------------------------------------------------------------

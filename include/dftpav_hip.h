@@ -167,6 +167,39 @@ const char *dftpav_last_error(const dftpav_handle *h);
  * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied. */
 int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s);
 
+/* ---- front-end resampling: from a searched path to the solver's arguments ----
+ * Replaces KinoAstar::getKinoNode from SampleTraj on (kino_astar.cpp:606-743:
+ * gear segmentation, trapezoid time allocation, flat boundary states) and the
+ * resampling of TrajPlanner::RunMINCOParking (traj_manager.cpp:531-568, through
+ * KinoAstar::evaluatePos, kino_astar.cpp:468-521) for n_hyp hypotheses. */
+typedef struct dftpav_frontend_params {
+  double max_forward_vel, max_forward_acc;   /* 5.0, 8.0  (minco_config.pb.txt:77-78) */
+  double max_backward_vel, max_backward_acc; /* 2.0, 4.0  (pb.txt:79-80) */
+  double non_siguav;                         /* 0.2       (kino_astar.h:207) */
+  double wheel_base;                         /* 2.85      (semantics.h:68) */
+  double piece_duration;                     /* 1.0       (pb.txt:76 traj_piece_duration) */
+  int traj_res, dense_traj_res;              /* samples per piece: inner pieces / first and last piece (pb.txt:66-67) */
+} dftpav_frontend_params;
+/* Caller-allocated outputs, padded: per hypothesis up to max_seg gear segments,
+ * per segment up to max_pieces pieces and max_states constraint-point poses. */
+typedef struct dftpav_frontend_out {
+  int max_seg, max_pieces, max_states;
+  int *n_seg;         /* [n_hyp]  segments found (may exceed max_seg: then only the first max_seg are written) */
+  int *singul;        /* [n_hyp][max_seg]  +1 forward / -1 reverse */
+  int *piece_nums;    /* [n_hyp][max_seg] */
+  double *piece_dt;   /* [n_hyp][max_seg]  timePerPiece; initTs = piece_dt * piece_nums */
+  double *ini_states; /* [n_hyp][max_seg][6]  col-major 2x3 flat state (p, v, a) */
+  double *fin_states; /* [n_hyp][max_seg][6] */
+  double *inner_pts;  /* [n_hyp][max_seg][max_pieces-1][2] */
+  int *n_states;      /* [n_hyp][max_seg]  poses produced (may exceed max_states: then only the first are written) */
+  double *states;     /* [n_hyp][max_seg][max_states][3]  statelist of getRectangleConst: (x, y, yaw) */
+} dftpav_frontend_out;
+/* paths: [n_hyp][max_path][3] poses (x, y, yaw in (-pi, pi]) of which path_len[h] >= 2 are used;
+ * start_states / end_states: [n_hyp][4] (x, y, yaw, v); start_ctrl: [n_hyp][2] (steer, acceleration). */
+int dftpav_frontend_resample(dftpav_handle *h, const dftpav_frontend_params *fp, const double *paths, const int *path_len,
+                             int max_path, const double *start_states, const double *end_states, const double *start_ctrl,
+                             int n_hyp, const dftpav_frontend_out *out);
+
 /* ---- moving-obstacle trajectory fitting ----
  * Replaces TrajPlanner::ConverSurroundTrajFromPoints (traj_manager.cpp:743-789,
  * with state_to_flat_output :139-158) followed by setSurroundTrajs: S predicted

@@ -289,3 +289,24 @@ def fit_surround(states, order=0):
     fn(st.ctypes.data, S, n, int(order), out["durations"].ctypes.data, out["coeffs"].ctypes.data, out["total"].ctypes.data,
        out["start"].ctypes.data)
     return out
+
+
+def frontend_resample(paths, path_len, start_states, end_states, start_ctrl, fparams=None, order=0, **caps):
+    """getKinoNode (from SampleTraj on) + the resampling of RunMINCOParking (kino_astar.cpp:606-795, traj_manager.cpp:531-568).
+    paths [n_hyp][max_path][3]; returns the dict of padded arrays of dftpav_amd.pods.FrontendOut."""
+    from dftpav_amd.pods import FrontendParams, FrontendOut
+    L = lib()
+    P = np.ascontiguousarray(paths, dtype=np.float64)
+    n_hyp, max_path = P.shape[0], P.shape[1]
+    pl = np.ascontiguousarray(path_len, dtype=np.int32)
+    ss = np.ascontiguousarray(start_states, dtype=np.float64)
+    es = np.ascontiguousarray(end_states, dtype=np.float64)
+    sc_ = np.ascontiguousarray(start_ctrl, dtype=np.float64)
+    fp = fparams if fparams is not None else FrontendParams.default()
+    out = FrontendOut(n_hyp, **caps)
+    fn = L.oracle_frontend_resample
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    fn(C.byref(fp), P.ctypes.data, pl.ctypes.data, max_path, ss.ctypes.data, es.ctypes.data, sc_.ctypes.data, n_hyp, int(order),
+       C.byref(out.c))
+    return out.arrays()

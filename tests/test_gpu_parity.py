@@ -453,3 +453,75 @@ def test_fit_surround_matches_oracle_and_feeds_the_solver(hiplib, oracle):
         x.close()
     for x in (h, h2, h3):
         x.close()
+
+
+@pytest.mark.parametrize("gears,K,Kd", [((1, -1), 16, 32), ((-1, 1, -1, 1), 32, 32), ((1,), 7, 11)])
+def test_frontend_resampling_matches_oracle(hiplib, oracle, gears, K, Kd):
+    """§8(f)-3: getKinoNode from SampleTraj on + the resampling of RunMINCOParking (kino_astar.cpp:606-795,
+    traj_manager.cpp:531-568) on the device, bit-exact against the oracle's device-order mode."""
+    from dftpav_amd.pods import FrontendParams
+    P, pl, ss, es, ct = sc.searched_paths(40, seed=len(gears) + K, gears=gears, seg_duration=6.0)
+    fp = FrontendParams.default(K=K, Kd=Kd)
+    h = hiplib.Handle(hiplib.default_params())
+    got = h.frontend_resample(P, pl, ss, es, ct, fp)
+    want = oracle.frontend_resample(P, pl, ss, es, ct, fp, order=1)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    assert (got["n_seg"] == len(gears)).all()
+    lit = oracle.frontend_resample(P, pl, ss, es, ct, fp, order=0)
+    assert np.array_equal(lit["piece_nums"], got["piece_nums"]) and np.abs(lit["states"] - got["states"]).max() < 1e-12
+    # capacity smaller than the number of gear changes: counts reported, nothing produced
+    small = h.frontend_resample(P, pl, ss, es, ct, fp, max_seg=max(1, len(gears) - 1))
+    ws = oracle.frontend_resample(P, pl, ss, es, ct, fp, order=1, max_seg=max(1, len(gears) - 1))
+    for k in ws:
+        assert np.array_equal(small[k], ws[k]), k
+    h.close()
+
+
+def test_frontend_to_validation_chain(hiplib, oracle):
+    """searched path -> resampling -> corridor -> solve -> validation, every stage on the device, against the
+    same chain on the CPU oracle (device-order modes)."""
+    from dftpav_amd.pods import FrontendParams, LayoutSpec
+    from dftpav_amd.scenarios import Scenario
+    nh = 6
+    P, pl, ss, es, ct = sc.searched_paths(nh, seed=4, gears=(1, -1), seg_duration=7.0)
+    fp = FrontendParams.default(K=16, Kd=32)
+    p = hiplib.default_params()
+    p.traj_resolution, p.des_traj_resolution = 16, 32
+    h = hiplib.Handle(p)
+    fe = h.frontend_resample(P, pl, ss, es, ct, fp)
+    assert np.array_equal(fe["piece_nums"], oracle.frontend_resample(P, pl, ss, es, ct, fp, order=1)["piece_nums"])
+    rng = np.random.default_rng(0)
+    obs = np.column_stack([rng.uniform(-40, 40, 60), rng.uniform(-40, 40, 60), rng.uniform(0.5, 1.5, 60)])
+    # keep the obstacles off the paths
+    d = np.hypot(obs[:, None, 0] - P[:, :, 0].reshape(1, -1), obs[:, None, 1] - P[:, :, 1].reshape(1, -1)).min(axis=1)
+    obs = obs[d > 5.0]
+    grid, origin = sc.occupancy_grid(obs, arena=120.0)
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    done = 0
+    for hyp in range(nh):  # hypotheses with the same layout could share a batch; here one batch each
+        M = int(fe["n_seg"][hyp])
+        pn = [int(x) for x in fe["piece_nums"][hyp, :M]]
+        lay = LayoutSpec(pn, [int(x) for x in fe["singul"][hyp, :M]], 4)
+        npts = lay.n_points(16, 32)
+        states = np.concatenate([fe["states"][hyp, i, :fe["n_states"][hyp, i]] for i in range(M)])
+        assert states.shape[0] == npts
+        inner = np.concatenate([fe["inner_pts"][hyp, i, :pn[i] - 1].reshape(-1) for i in range(M)])
+        s = Scenario("fe", lay, 16, 32, 1, fe["ini_states"][hyp:hyp + 1, :M].copy(), fe["fin_states"][hyp:hyp + 1, :M].copy(),
+                     inner[None].copy(), (fe["piece_dt"][hyp, :M] * fe["piece_nums"][hyp, :M])[None].copy(),
+                     np.zeros((1, npts, 4, 4)))
+        bt = hiplib.Batch(h, lay, 1)
+        bt.upload(s, with_corridor=False)
+        bt.corridor_from_states(states[None])
+        r = bt.solve()
+        s.corridor = oracle.corridor_rectangles(grid, sc.MAP_RESL, origin, states, order=1)[None]
+        ro = oracle.solve_batch(p, s, nthreads=1, order=1)
+        assert np.array_equal(r["final_cost"], ro["final_cost"]) and np.array_equal(r["x"], ro["x"])
+        col, first = bt.validate()
+        co, dts = bt.coeffs()
+        oc, of = oracle.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, lay.piece_nums, lay.singuls, order=1)
+        assert np.array_equal(col, oc) and np.array_equal(first, of)
+        done += int(r["success"][0])
+        bt.close()
+    assert done >= nh - 1
+    h.close()
