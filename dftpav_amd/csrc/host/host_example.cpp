@@ -4,6 +4,7 @@
 #include <cstdio>
 
 #include "poly_traj_optimizer.hpp"
+#include "traj_planner_steps.hpp"
 
 using namespace plan_manage;
 
@@ -43,5 +44,28 @@ int main() {
   polys[0].pop_back();
   bool bad = opt.OptimizeTrajectory(ini, fin, inner, Ts, polys, {1}, 0.0, 0.0);
   std::printf("short corridor -> %d (error %d)\n", (int)bad, opt.last_error());
-  return (ok && !bad) ? 0 : 1;
+  // ---- the steps around the solve, with the reference's member names
+  dftpav_handle *h = nullptr;
+  if (dftpav_create(&p, 0, &h) != DFTPAV_OK) return 1;
+  TrajPlannerSteps steps(h);
+  std::vector<unsigned char> cells(200 * 200, 127);
+  for (int iy = 0; iy < 200; iy++) cells[150 + 200 * iy] = 80; // a wall at x = 15
+  bool ok2 = steps.setObstacleMap(cells.data(), 200, 200, 0.3, -30.0, -30.0);
+  std::vector<std::array<double, 3>> path;
+  for (int i = 0; i <= 60; i++) path.push_back({0.15 * i, 0.0, 0.0}); // 9 m straight ahead
+  std::vector<FlatTrajData> flat;
+  dftpav_frontend_params fp{5.0, 8.0, 2.0, 4.0, 0.2, 2.85, 1.0, p.traj_resolution, p.des_traj_resolution};
+  ok2 = ok2 && steps.getKinoNode(path, {0, 0, 0, 0.5}, {9.0, 0, 0, 0.2}, {0, 0}, fp, flat);
+  ok2 = ok2 && flat.size() == 1 && steps.getRectangleConst(flat[0].states);
+  double front = 0.0;
+  if (ok2) front = steps.hPolys()[0](2, 1); // x of the front edge of the first rectangle: stops short of the wall
+  std::vector<std::vector<PredictedState>> sur(1);
+  for (int k = 0; k <= 10; k++) sur[0].push_back({-5.0 + 1.0 * k, 4.0, 0.0, 1.0, 0.0, 0.0, 1.0 * k});
+  ok2 = ok2 && steps.ConverSurroundTrajFromPoints(sur);
+  std::printf("getKinoNode -> %zu segment(s), %d pieces of %.3f s, %zu states; first rectangle's front edge at x = %.2f; "
+              "surround fit -> %d (error %d)\n",
+              flat.size(), ok2 ? flat[0].piece_nums : 0, ok2 ? flat[0].piece_duration : 0.0, ok2 ? flat[0].states.size() : (size_t)0,
+              front, (int)ok2, steps.last_error());
+  dftpav_destroy(h);
+  return (ok && !bad && ok2 && front < 15.0 && front > 3.0) ? 0 : 1;
 }

@@ -287,6 +287,8 @@ def test_cpp_host_mirror_runs(hiplib):
     out = subprocess.run([os.path.join(host, "host_example")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OptimizeTrajectory -> 1" in out.stdout and "short corridor -> 0" in out.stdout
+    # the TrajPlanner / KinoAstar steps around the solve (traj_planner_steps.hpp)
+    assert "getKinoNode -> 1 segment(s)" in out.stdout and "surround fit -> 1" in out.stdout
 
 
 def _corridor_scene(seed):
