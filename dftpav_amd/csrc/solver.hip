@@ -40,6 +40,7 @@ enum { kActEval = 0, kActDone = 1 };
 
 struct Smem {
   double *x, *xp, *g, *gp, *d;
+  double *bnd;  // [2][M][6] iniStates, finStates of the trajectory being solved
   double *seg;  // [M][16]  0:T 1:dt 2..7:t^k 8..13:t^-k
   double *spow; // [M][2][Kmax+1][6] powers of the accumulated sample offset (s1 += step, traj_optimizer.cpp:513)
   double *rhs;  // [rhs_tot][2]
@@ -71,6 +72,7 @@ __host__ __device__ inline int chunk_points(const DevLayout &L, int T, int ppt) 
 __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T, int ppt, bool op_lds, bool cor_lds) {
   size_t n = 0;
   n += 5 * (size_t)L.npad;
+  n += (size_t)L.M * 12;
   n += (size_t)L.M * 16;
   n += (size_t)L.M * 2 * (L.Kmax + 1) * 6;
   n += (size_t)L.rhs_tot * 2;
@@ -132,6 +134,7 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.g = p; p += L.npad;
   s.gp = p; p += L.npad;
   s.d = p; p += L.npad;
+  s.bnd = p; p += L.M * 12;
   s.seg = p; p += L.M * 16;
   s.spow = p; p += L.M * 2 * (L.Kmax + 1) * 6;
   s.rhs = p; p += L.rhs_tot * 2;
@@ -310,8 +313,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
   const DevParams &P = D.P;
   const int tid = threadIdx.x, T = blockDim.x;
   const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, rhs_tot = L.rhs_tot, Kmax1 = L.Kmax + 1;
-  const double *iniS = D.iniS + (size_t)b * M * 6;
-  const double *finS = D.finS + (size_t)b * M * 6;
+  const double *iniS = sm.bnd, *finS = sm.bnd + 6 * M; // boundary states of this trajectory, staged with x
 
   // ---- E1: segment durations, sample-offset power tables, MINCO right-hand sides
   {
@@ -1418,6 +1420,8 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
       for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
       if (tid < iNUM) sm.ist[tid] = 0;
     }
+    for (int w = tid; w < 12 * L.M; w += T)
+      sm.bnd[w] = w < 6 * L.M ? D.iniS[(size_t)b * L.M * 6 + w] : D.finS[(size_t)b * L.M * 6 + (w - 6 * L.M)];
     if (D.cor_in_lds) { // the only read of the corridor from HBM: it stays in LDS for the whole pass
       const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad;
       const int pitch = (L.Npts + 63) / 64 * 64;
