@@ -318,7 +318,9 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
   // ---- E1: segment durations, sample-offset power tables, MINCO right-hand sides
   {
     const int n_rhs = 2 * rhs_tot;
-    for (int w = tid; w < n_rhs + 3 * M; w += T) {
+    const int n_rhs_pad = (n_rhs + 63) & ~63; // the per-segment workers start on a wave of their own
+    for (int w = tid; w < n_rhs_pad + 3 * M; w += T) {
+      if (w >= n_rhs && w < n_rhs_pad) continue;
       if (w < n_rhs) {
         int row = w >> 1, d = w & 1;
         const int *ri = sm.rowinfo + 4 * row;
@@ -362,7 +364,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         }
         sm.rhs[w] = v;
       } else {
-        int q = w - n_rhs; // 3 workers per segment: 0 duration powers, 1/2 offset tables (K / Kd)
+        int q = w - n_rhs_pad; // 3 workers per segment: 0 duration powers, 1/2 offset tables (K / Kd)
         int sg = q / 3, role = q - 3 * sg;
         int N = 0;
         for (int s = 0; s < M; s++) N = (s == sg) ? L.piece_nums[s] : N;
