@@ -173,6 +173,7 @@ def main():
             tcor = []
             for _ in range(3):
                 t1 = time.perf_counter(); Hc = h.corridor_rectangles(st); tcor.append(time.perf_counter() - t1)
+            cor_ms = h.corridor_last_ms()
             # ---- the step after the solve: collision re-check of all solved trajectories of the shard
             colv, firstv = bt.validate()
             out["validate"] = {"trajectories": int(shard.B), "kernel_ms": h.corridor_last_ms(),
@@ -182,7 +183,7 @@ def main():
             from oracle import pyoracle as po  # the checker, never the thing measured
             po.build()
             out["corridor"] = {"states": int(len(st)), "map_cells": [int(grid.shape[1]), int(grid.shape[0])],
-                               "kernel_ms": h.corridor_last_ms(), "rectangles_per_s": len(st) / (h.corridor_last_ms() * 1e-3),
+                               "kernel_ms": cor_ms, "rectangles_per_s": len(st) / (cor_ms * 1e-3),
                                "rectangles_per_s_with_pcie": len(st) / min(tcor),
                                "oracle_bit_exact_on_first_%d" % nchk: bool(np.array_equal(
                                    Hc[:nchk], po.corridor_rectangles(grid, sc.MAP_RESL, origin, st[:nchk], order=1)))}
