@@ -29,6 +29,7 @@ EXPORTS = [
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
+    "dftpav_sample_restarts",
 ]
 
 
@@ -141,6 +142,22 @@ class Handle:
                        ss.ctypes.data_as(C.c_void_p), es.ctypes.data_as(C.c_void_p), sc_.ctypes.data_as(C.c_void_p), n_hyp,
                        C.byref(out.c)), "frontend_resample")
         return out.arrays()
+
+    def sample_restarts(self, inner, durs, n_restarts, sigma=0.3, lo=0.8, hi=1.25, seed=0):
+        """Seeded restarts of hypotheses on the device: inner [n_hyp][n_inner], durs [n_hyp][M] ->
+        (inner [n_hyp * n_restarts][n_inner], durs [n_hyp * n_restarts][M])."""
+        a = np.ascontiguousarray(inner, dtype=np.float64)
+        d = np.ascontiguousarray(durs, dtype=np.float64)
+        n_hyp, n_inner, M = a.shape[0], a.shape[1], d.shape[1]
+        oi = np.zeros((n_hyp * n_restarts, n_inner))
+        od = np.zeros((n_hyp * n_restarts, M))
+        fn = lib().dftpav_sample_restarts
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                       C.c_ulonglong, C.c_void_p, C.c_void_p]
+        self._check(fn(self._h, a.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), n_hyp, n_restarts, n_inner, M,
+                       float(sigma), float(lo), float(hi), int(seed), oi.ctypes.data_as(C.c_void_p),
+                       od.ctypes.data_as(C.c_void_p)), "sample_restarts")
+        return oi, od
 
     def fit_surround(self, states):
         """ConverSurroundTrajFromPoints + setSurroundTrajs on the device: states [S][n][7] (x, y, angle, velocity,

@@ -29,6 +29,8 @@ hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int
 hipError_t launch_frontend(const dftpav_frontend_params &fp, const double *paths, const int *path_len, int max_path,
                            const double *start_states, const double *end_states, const double *start_ctrl, int n_hyp,
                            const dftpav_frontend_out &out, hipStream_t stream);
+hipError_t launch_restarts(const double *inner, const double *durs, int n_hyp, int n_restarts, int n_inner, int M, double sigma,
+                           double lo, double hi, unsigned long long seed, double *out_inner, double *out_durs, hipStream_t stream);
 hipError_t launch_fit(const double *states, int S, int n_states, const double *opM, double *dur, double *coef, double *total,
                       double *start, hipStream_t stream);
 hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
@@ -226,6 +228,40 @@ extern "C" const char *dftpav_last_error(const dftpav_handle *h) { return h ? h-
 extern "C" void *dftpav_stream(dftpav_handle *h) { return h ? (void *)h->stream : nullptr; }
 
 static void minco_operator(int N, std::vector<double> &Mop, std::vector<double> &MopT);
+
+extern "C" int dftpav_sample_restarts(dftpav_handle *h, const double *inner_pts, const double *durations, int n_hyp, int n_restarts,
+                                      int n_inner, int M, double sigma, double dur_lo, double dur_hi, unsigned long long seed,
+                                      double *out_inner_pts, double *out_durations) {
+  if (!h || !inner_pts || !durations || !out_inner_pts || !out_durations || n_hyp < 0 || n_restarts < 1 || n_inner < 0 ||
+      (n_inner & 1) || M < 1 || !(sigma >= 0.0) || !(dur_lo > 0.0) || !(dur_hi >= dur_lo))
+    return DFTPAV_E_INVALID;
+  if (n_hyp == 0) return DFTPAV_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = (size_t)n_hyp * n_restarts;
+  double *d_in = nullptr, *d_du = nullptr, *d_oi = nullptr, *d_od = nullptr;
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  chk(hipMalloc(&d_in, sizeof(double) * std::max<size_t>(1, (size_t)n_hyp * n_inner)));
+  chk(hipMalloc(&d_du, sizeof(double) * (size_t)n_hyp * M));
+  chk(hipMalloc(&d_oi, sizeof(double) * std::max<size_t>(1, B * n_inner)));
+  chk(hipMalloc(&d_od, sizeof(double) * B * M));
+  if (rc == DFTPAV_OK) {
+    chk(hipMemcpyAsync(d_in, inner_pts, sizeof(double) * (size_t)n_hyp * n_inner, hipMemcpyHostToDevice, h->stream));
+    chk(hipMemcpyAsync(d_du, durations, sizeof(double) * (size_t)n_hyp * M, hipMemcpyHostToDevice, h->stream));
+    chk(launch_restarts(d_in, d_du, n_hyp, n_restarts, n_inner, M, sigma, dur_lo, dur_hi, seed, d_oi, d_od, h->stream));
+    chk(hipMemcpyAsync(out_inner_pts, d_oi, sizeof(double) * B * n_inner, hipMemcpyDeviceToHost, h->stream));
+    chk(hipMemcpyAsync(out_durations, d_od, sizeof(double) * B * M, hipMemcpyDeviceToHost, h->stream));
+    chk(hipStreamSynchronize(h->stream));
+  }
+  for (double *p : {d_in, d_du, d_oi, d_od})
+    if (p) (void)hipFree(p);
+  return rc;
+}
 
 extern "C" int dftpav_frontend_resample(dftpav_handle *h, const dftpav_frontend_params *fp, const double *paths, const int *path_len,
                                         int max_path, const double *start_states, const double *end_states,

@@ -200,6 +200,18 @@ int dftpav_frontend_resample(dftpav_handle *h, const dftpav_frontend_params *fp,
                              int max_path, const double *start_states, const double *end_states, const double *start_ctrl,
                              int n_hyp, const dftpav_frontend_out *out);
 
+/* ---- seeded restart sampler: the batch axis (SURVEY.md §8(d) "Restarts", §8(f)-3) ----
+ * No reference counterpart (the reference plans one trajectory per cycle).  Every
+ * hypothesis h (inner waypoints [n_inner] = x0, y0, x1, y1, ...; M segment
+ * durations) yields n_restarts trajectories, b = h * n_restarts + r: r == 0 is the
+ * hypothesis itself, r > 0 has its waypoints moved by N(0, sigma^2) per coordinate
+ * and every duration scaled by U[dur_lo, dur_hi].  The generator (SplitMix64
+ * streams keyed by (seed, h, r), Box-Muller) is defined in
+ * dftpav_amd/csrc/restart.hip; the same (seed, h, r) gives the same bits anywhere. */
+int dftpav_sample_restarts(dftpav_handle *h, const double *inner_pts, const double *durations, int n_hyp, int n_restarts,
+                           int n_inner, int M, double sigma, double dur_lo, double dur_hi, unsigned long long seed,
+                           double *out_inner_pts, double *out_durations);
+
 /* ---- moving-obstacle trajectory fitting ----
  * Replaces TrajPlanner::ConverSurroundTrajFromPoints (traj_manager.cpp:743-789,
  * with state_to_flat_output :139-158) followed by setSurroundTrajs: S predicted

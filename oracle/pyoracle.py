@@ -310,3 +310,21 @@ def frontend_resample(paths, path_len, start_states, end_states, start_ctrl, fpa
     fn(C.byref(fp), P.ctypes.data, pl.ctypes.data, max_path, ss.ctypes.data, es.ctypes.data, sc_.ctypes.data, n_hyp, int(order),
        C.byref(out.c))
     return out.arrays()
+
+
+def sample_restarts(inner, durs, n_restarts, sigma=0.3, lo=0.8, hi=1.25, seed=0):
+    """The restart sampler of dftpav_amd/csrc/restart.hip on the CPU: inner [n_hyp][n_inner], durs [n_hyp][M] ->
+    (inner [n_hyp * n_restarts][n_inner], durs [n_hyp * n_restarts][M]), trajectory b = hypothesis * n_restarts + restart."""
+    L = lib()
+    a = np.ascontiguousarray(inner, dtype=np.float64)
+    d = np.ascontiguousarray(durs, dtype=np.float64)
+    n_hyp, n_inner, M = a.shape[0], a.shape[1], d.shape[1]
+    oi = np.zeros((n_hyp * n_restarts, n_inner))
+    od = np.zeros((n_hyp * n_restarts, M))
+    fn = L.oracle_sample_restarts
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                   C.c_ulonglong, C.c_void_p, C.c_void_p]
+    fn(a.ctypes.data, d.ctypes.data, n_hyp, n_restarts, n_inner, M, float(sigma), float(lo), float(hi), int(seed),
+       oi.ctypes.data, od.ctypes.data)
+    return oi, od

@@ -527,3 +527,16 @@ def test_frontend_to_validation_chain(hiplib, oracle):
         bt.close()
     assert done >= nh - 1
     h.close()
+
+
+def test_restart_sampler_matches_oracle(hiplib, oracle):
+    """The seeded restart sampler (restart.hip; SURVEY §8(d) "Restarts"): bit-exact against its oracle."""
+    rng = np.random.default_rng(3)
+    h = hiplib.Handle(hiplib.default_params())
+    for n_hyp, n_inner, M, nr in ((7, 30, 1, 33), (3, 26, 3, 200), (1, 0, 2, 4)):
+        inner = rng.uniform(-10, 10, (n_hyp, n_inner))
+        durs = rng.uniform(5, 20, (n_hyp, M))
+        gi, gd = h.sample_restarts(inner, durs, nr, sigma=0.3, lo=0.8, hi=1.25, seed=2024)
+        oi, od = oracle.sample_restarts(inner, durs, nr, sigma=0.3, lo=0.8, hi=1.25, seed=2024)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    h.close()
