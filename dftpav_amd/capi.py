@@ -29,7 +29,7 @@ EXPORTS = [
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
-    "dftpav_sample_restarts",
+    "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses",
 ]
 
 
@@ -260,14 +260,14 @@ class Batch:
                               first.ctypes.data_as(C.c_void_p)), "batch_validate")
         return col, first
 
-    def corridor_from_states(self, states):
-        """getRectangleConst for every constraint point of every trajectory, on the device, straight into the
-        solver's layout: states [B][Npts][3] (x, y, yaw); needs Handle.set_grid_map."""
+    def corridor_from_states(self, states, n_restarts=1):
+        """getRectangleConst for every constraint point, on the device, straight into the solver's layout: states
+        [B / n_restarts][Npts][3] (x, y, yaw), the restarts of a hypothesis sharing its corridor; needs Handle.set_grid_map."""
         st = np.ascontiguousarray(states, dtype=np.float64)
-        assert st.shape[0] == self.B and st.shape[-1] == 3
-        fn = lib().dftpav_batch_corridor_from_states
-        fn.argtypes = [C.c_void_p, C.c_void_p]
-        self.handle._check(fn(self._b, st.ctypes.data_as(C.c_void_p)), "batch_corridor_from_states")
+        assert st.shape[0] * n_restarts == self.B and st.shape[-1] == 3
+        fn = lib().dftpav_batch_corridor_from_hypotheses
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.handle._check(fn(self._b, st.ctypes.data_as(C.c_void_p), int(n_restarts)), "batch_corridor_from_hypotheses")
 
     def x0(self):
         x = np.zeros((self.B, self.n))

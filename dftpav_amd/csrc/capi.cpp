@@ -25,7 +25,7 @@ hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int
                          hipStream_t stream);
 hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
-                           int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream);
+                           int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, int replicate, hipStream_t stream);
 hipError_t launch_frontend(const dftpav_frontend_params &fp, const double *paths, const int *path_len, int max_path,
                            const double *start_states, const double *end_states, const double *start_ctrl, int n_hyp,
                            const dftpav_frontend_out &out, hipStream_t stream);
@@ -431,7 +431,7 @@ extern "C" int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map)
 
 // uploads the states and runs the corridor kernel into `hpoly` (device, [n][16]) or into a batch's corridor
 static int run_corridor(dftpav_handle *h, const double *states, int n_states, double *d_hpoly, double *batch_cor, int Npts,
-                        int NptsPad) {
+                        int NptsPad, int replicate) {
   double *d_states = nullptr;
   HIPCHK(h, hipMalloc(&d_states, sizeof(double) * 3 * (size_t)n_states));
   int rc = DFTPAV_OK;
@@ -446,7 +446,7 @@ static int run_corridor(dftpav_handle *h, const double *states, int n_states, do
   if (rc == DFTPAV_OK)
     chk(launch_corridor(h->d_cells, h->d_bits, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, d_states,
                         n_states, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, h->d_dl, h->n_dl, d_hpoly,
-                        batch_cor, Npts, NptsPad, h->stream));
+                        batch_cor, Npts, NptsPad, replicate, h->stream));
   chk(hipEventRecord(h->cev1, h->stream));
   chk(hipStreamSynchronize(h->stream));
   h->ctimed = rc == DFTPAV_OK;
@@ -468,7 +468,7 @@ extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states
   HIPCHK(h, hipSetDevice(h->device));
   double *d_hpoly = nullptr;
   HIPCHK(h, hipMalloc(&d_hpoly, sizeof(double) * 16 * (size_t)n_states));
-  int rc = run_corridor(h, states, n_states, d_hpoly, nullptr, 1, 1);
+  int rc = run_corridor(h, states, n_states, d_hpoly, nullptr, 1, 1, 1);
   if (rc == DFTPAV_OK && hipMemcpy(hpoly, d_hpoly, sizeof(double) * 16 * (size_t)n_states, hipMemcpyDeviceToHost) != hipSuccess) {
     h->err = "hipMemcpy";
     rc = DFTPAV_E_HIP;
@@ -862,16 +862,19 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   return DFTPAV_OK;
 }
 
-extern "C" int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states) {
-  if (!b || !states) return DFTPAV_E_INVALID;
+extern "C" int dftpav_batch_corridor_from_hypotheses(dftpav_batch *b, const double *states, int n_restarts) {
+  if (!b || !states || n_restarts < 1 || b->B % n_restarts) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   if (!h->d_cells) return DFTPAV_E_INVALID;       // no map
   if (b->L.H != 4) return DFTPAV_E_UNSUPPORTED;   // rectangles
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  int rc = run_corridor(h, states, b->B * b->L.Npts, nullptr, b->d_corridor, b->L.Npts, b->NptsPad);
+  int rc = run_corridor(h, states, (b->B / n_restarts) * b->L.Npts, nullptr, b->d_corridor, b->L.Npts, b->NptsPad, n_restarts);
   if (rc == DFTPAV_OK) b->have_corridor = true;
   return rc;
+}
+extern "C" int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states) {
+  return dftpav_batch_corridor_from_hypotheses(b, states, 1);
 }
 
 extern "C" int dftpav_batch_get_x0(dftpav_batch *b, double *x0) {

@@ -36,6 +36,7 @@ struct CorridorArgs {
   // (traj_optimizer.cpp:49-52), state i being point i % Npts of trajectory i / Npts
   double *batch_cor;
   int Npts, NptsPad;
+  int replicate; // every trajectory i / Npts is written `replicate` times: trajectories t * replicate + r (restarts share a corridor)
 };
 
 // GridMapND::CheckIfEqualUsingGlobalPosition(p, OCCUPIED): coord = round((p - origin) / resolution), out of range
@@ -179,14 +180,16 @@ __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
     H[12] = -c; H[13] = -s; H[14] = rx + (c * a + ns * b); H[15] = ry + (s * a + c * b);
     if (!A.hpoly) { // what dftpav_batch_upload does with a host corridor: normalise, component-major
       const int t = i / A.Npts, pt = i - t * A.Npts;
-      double *dst = A.batch_cor + (size_t)t * 16 * A.NptsPad + pt;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const double nrm = sqrt(H[4 * k] * H[4 * k] + H[4 * k + 1] * H[4 * k + 1]);
-        dst[(size_t)(4 * k + 0) * A.NptsPad] = H[4 * k] / nrm;
-        dst[(size_t)(4 * k + 1) * A.NptsPad] = H[4 * k + 1] / nrm;
-        dst[(size_t)(4 * k + 2) * A.NptsPad] = H[4 * k + 2];
-        dst[(size_t)(4 * k + 3) * A.NptsPad] = H[4 * k + 3];
+        H[4 * k] = H[4 * k] / nrm;
+        H[4 * k + 1] = H[4 * k + 1] / nrm;
+      }
+      for (int r = 0; r < A.replicate; r++) {
+        double *dst = A.batch_cor + ((size_t)t * A.replicate + r) * 16 * A.NptsPad + pt;
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[(size_t)k * A.NptsPad] = H[k];
       }
     }
   }
@@ -194,9 +197,9 @@ __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
 
 hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                            const double *states, int n, double veh_width, double veh_length, double veh_dcr, const double *dl,
-                           int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, hipStream_t stream) {
+                           int n_dl, double *hpoly, double *batch_cor, int Npts, int NptsPad, int replicate, hipStream_t stream) {
   CorridorArgs A{cells, bits, size_x, size_y, resolution, origin_x, origin_y, 1.0 / resolution, states, n, veh_width, veh_length, veh_dcr, dl, n_dl,
-                 hpoly, batch_cor, Npts, NptsPad};
+                 hpoly, batch_cor, Npts, NptsPad, replicate};
   const int waves_per_block = 4;
   const dim3 grid((n + waves_per_block - 1) / waves_per_block), block(64 * waves_per_block);
   if (bits) {

@@ -265,6 +265,11 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  * point poses, states [B][Npts][3] (x, y, yaw), straight into the solver's own
  * layout.  Use with dftpav_batch_upload(d) where d->corridor == NULL.  H must be 4. */
 int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states);
+/* The same when the batch is n_restarts restarts of each hypothesis (trajectory
+ * t = hypothesis * n_restarts + restart, as dftpav_sample_restarts lays them out)
+ * and the restarts share their hypothesis' corridor, as the path they were
+ * sampled from does: states [B / n_restarts][Npts][3]. */
+int dftpav_batch_corridor_from_hypotheses(dftpav_batch *b, const double *states, int n_restarts);
 
 int dftpav_batch_get_x0(dftpav_batch *b, double *x0);
 

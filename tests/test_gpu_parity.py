@@ -356,6 +356,16 @@ def test_generated_corridor_feeds_the_solver(hiplib, oracle):
     assert np.array_equal(f1, f2) and np.array_equal(g1, g2)
     r2 = b2.solve()
     assert np.array_equal(r2["final_cost"], r["final_cost"]) and np.array_equal(r2["x"], r["x"])
+    # restarts sharing their hypothesis' corridor: one rectangle set per hypothesis, replicated on the device
+    order = np.argsort(s.meta["hyp_of"], kind="stable")  # trajectory = hypothesis * n_restarts + restart
+    nr = s.B // st.shape[0]
+    s3 = s.subset(order)
+    b3 = hiplib.Batch(h, s.layout, s.B)
+    b3.upload(s3, with_corridor=False)
+    b3.corridor_from_states(st, n_restarts=nr)
+    f3, g3 = b3.eval(b3.x0())
+    assert np.array_equal(f3, f1[order]) and np.array_equal(g3, g1[order])
+    b3.close()
     b2.close()
     bt.close()
     h.close()
