@@ -1078,7 +1078,7 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
 }
 
 extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double vertex_res, int *collision, int *first_sample) {
-  if (!b || !b->uploaded || !(sample_dt > 0.0) || !(vertex_res > 0.0)) return DFTPAV_E_INVALID;
+  if (!b || !b->uploaded || !b->timed || !(sample_dt > 0.0) || !(vertex_res > 0.0)) return DFTPAV_E_INVALID; // nothing solved yet
   dftpav_handle *h = b->h;
   if (!h->d_cells) return DFTPAV_E_INVALID; // no map
   HIPCHK(h, hipSetDevice(h->device));
