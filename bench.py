@@ -179,9 +179,20 @@ def main():
             out["validate"] = {"trajectories": int(shard.B), "kernel_ms": h.corridor_last_ms(),
                                "trajectories_per_s": shard.B / (h.corridor_last_ms() * 1e-3),
                                "colliding": int(colv.sum())}
-            nchk = min(2000, len(st))
             from oracle import pyoracle as po  # the checker, never the thing measured
             po.build()
+            # ---- the read-out of the result: GetState every 10 ms over every solved trajectory
+            cor, dts = bt.coeffs()
+            n_rd = int(float(np.max(np.sum(dts * shard.layout.piece_nums[None, :], axis=1))) / 0.01) + 2
+            rd, nv = bt.sample_states(sample_dt=0.01, n_samples=n_rd)
+            rd_ms = h.corridor_last_ms()
+            ord_, onv = po.sample_states(cor[:64], dts[:64], shard.layout.piece_nums, shard.layout.singuls, sample_dt=0.01,
+                                         n_samples=n_rd, wheel_base=params.veh_wheel_base, order=1)
+            out["readout"] = {"trajectories": int(shard.B), "samples_per_trajectory": n_rd, "kernel_ms": rd_ms,
+                              "states_per_s": float(nv.sum()) / (rd_ms * 1e-3), "written_GB_per_s": rd.nbytes / (rd_ms * 1e-3) / 1e9,
+                              "oracle_bit_exact_on_first_64": bool(np.array_equal(rd[:64], ord_) and np.array_equal(nv[:64], onv))}
+            del rd
+            nchk = min(2000, len(st))
             out["corridor"] = {"states": int(len(st)), "map_cells": [int(grid.shape[1]), int(grid.shape[0])],
                                "kernel_ms": cor_ms, "rectangles_per_s": len(st) / (cor_ms * 1e-3),
                                "rectangles_per_s_with_pcie": len(st) / min(tcor),

@@ -29,7 +29,8 @@ EXPORTS = [
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
-    "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses",
+    "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
+    "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
 ]
 
 
@@ -122,6 +123,20 @@ class Handle:
         s = surround_set.c_struct()
         self._check(lib().dftpav_set_surround(self._h, C.byref(s)), "set_surround")
         self._sur_keep = surround_set
+
+    def set_surround_wire(self, blobs):
+        """Installs serialised trajectories (wire_pack) as the moving obstacles; each blob becomes one obstacle."""
+        self._sur_keep = None
+        fn = lib().dftpav_set_surround_wire
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        S = len(blobs)
+        if S == 0:
+            self._check(fn(self._h, None, None, 0), "set_surround_wire")
+            return
+        keep = [C.create_string_buffer(bytes(bl), len(bl)) for bl in blobs]
+        ptrs = (C.c_void_p * S)(*[C.cast(k, C.c_void_p) for k in keep])
+        sizes = (C.c_size_t * S)(*[len(bl) for bl in blobs])
+        self._check(fn(self._h, ptrs, sizes, S), "set_surround_wire")
 
     def frontend_resample(self, paths, path_len, start_states, end_states, start_ctrl, fparams=None, **caps):
         """getKinoNode (from SampleTraj on) + the resampling of RunMINCOParking on the device; returns the dict of padded
@@ -260,6 +275,22 @@ class Batch:
                               first.ctypes.data_as(C.c_void_p)), "batch_validate")
         return col, first
 
+    def sample_states(self, t0=0.0, sample_dt=0.01, n_samples=None, filter_singularity=True):
+        """Trajectory::GetState over the grid t0 + k * sample_dt for every solved trajectory, played back as the
+        server does (traj_server_ros.cpp:244-259): returns (states [B][n_samples][8] = time_stamp, x, y, angle,
+        curvature, velocity, acceleration, steer; n_valid [B])."""
+        if n_samples is None:
+            _, dts = self.coeffs()
+            total = float(np.max(np.sum(dts * self.layout.piece_nums[None, :], axis=1)))
+            n_samples = int(np.ceil((total - t0) / sample_dt)) + 1
+        st = np.zeros((self.B, int(n_samples), 8))
+        nv = np.zeros(self.B, dtype=np.int32)
+        fn = lib().dftpav_batch_sample_states
+        fn.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.handle._check(fn(self._b, float(t0), float(sample_dt), int(n_samples), int(bool(filter_singularity)),
+                              st.ctypes.data_as(C.c_void_p), nv.ctypes.data_as(C.c_void_p)), "batch_sample_states")
+        return st, nv
+
     def corridor_from_states(self, states, n_restarts=1):
         """getRectangleConst for every constraint point, on the device, straight into the solver's layout: states
         [B / n_restarts][Npts][3] (x, y, yaw), the restarts of a hypothesis sharing its corridor; needs Handle.set_grid_map."""
@@ -340,3 +371,53 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+# ---- serialised trajectories ("DPTJ" v1, include/dftpav_hip.h): pure host code, no device needed
+def wire_size(piece_nums):
+    pn = np.ascontiguousarray(piece_nums, dtype=np.int32)
+    fn = lib().dftpav_wire_size
+    fn.restype = C.c_size_t
+    fn.argtypes = [C.c_int, C.c_void_p]
+    return int(fn(len(pn), pn.ctypes.data_as(C.c_void_p)))
+
+
+def wire_pack(layout, coeffs, piece_dt, drone_id=0, traj_id=0, start_time=0.0):
+    """One trajectory (coeffs [Ntot][6][2], piece_dt [M] as Batch.coeffs returns them per trajectory) -> bytes."""
+    co = np.ascontiguousarray(coeffs, dtype=np.float64)
+    dt = np.ascontiguousarray(piece_dt, dtype=np.float64)
+    assert co.shape == (layout.n_pieces, 6, 2) and dt.shape == (layout.M,)
+    cap = wire_size(layout.piece_nums)
+    buf = C.create_string_buffer(cap)
+    wr = C.c_size_t(0)
+    fn = lib().dftpav_wire_pack
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p]
+    ls = layout.c_struct()
+    rc = fn(C.byref(ls), co.ctypes.data_as(C.c_void_p), dt.ctypes.data_as(C.c_void_p), int(drone_id), int(traj_id),
+            float(start_time), buf, cap, C.byref(wr))
+    if rc != 0:
+        raise DftpavError(rc, "wire_pack")
+    return buf.raw[:wr.value]
+
+
+def wire_unpack(blob):
+    """bytes -> dict(drone_id, traj_id, start_time, singuls, piece_nums, seg_start, seg_duration, durations [np],
+    coeffs [np][12] in CoefficientMat order x5,y5,...,x0,y0)."""
+    blob = bytes(blob)
+    did, tid, M, npc = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    st = C.c_double(0.0)
+    fi = lib().dftpav_wire_info
+    fi.argtypes = [C.c_char_p, C.c_size_t] + [C.c_void_p] * 5
+    rc = fi(blob, len(blob), C.byref(did), C.byref(tid), C.byref(st), C.byref(M), C.byref(npc))
+    if rc != 0:
+        raise DftpavError(rc, "wire_info")
+    out = dict(drone_id=did.value, traj_id=tid.value, start_time=st.value, singuls=np.zeros(M.value, dtype=np.int32),
+               piece_nums=np.zeros(M.value, dtype=np.int32), seg_start=np.zeros(M.value), seg_duration=np.zeros(M.value),
+               durations=np.zeros(npc.value), coeffs=np.zeros((npc.value, 12)))
+    fu = lib().dftpav_wire_unpack
+    fu.argtypes = [C.c_char_p, C.c_size_t] + [C.c_void_p] * 6
+    rc = fu(blob, len(blob), *[out[k].ctypes.data_as(C.c_void_p)
+                               for k in ("singuls", "piece_nums", "seg_start", "seg_duration", "durations", "coeffs")])
+    if rc != 0:
+        raise DftpavError(rc, "wire_unpack")
+    return out

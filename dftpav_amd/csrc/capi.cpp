@@ -37,6 +37,8 @@ hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, d
                            const double *coeffs, const double *piece_dt, const DevLayout &L, int B, double veh_width,
                            double veh_length, double veh_dcr, const double *t_tab, int n_t, double sample_dt, const double *v_tab,
                            int n_v, int *collision, int *first_sample, hipStream_t stream);
+hipError_t launch_states(const double *coeffs, const double *piece_dt, const DevLayout &L, int B, double wheel_base, double t0,
+                         double sample_dt, int n_samples, int filter, double *states, int *n_valid, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 }
 using namespace dftpav;
@@ -1125,6 +1127,191 @@ extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double v
   for (void *p : {(void *)d_t, (void *)d_v, (void *)d_col, (void *)d_first})
     if (p) (void)hipFree(p);
   return rc;
+}
+
+extern "C" int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sample_dt, int n_samples, int filter_singularity,
+                                          double *states, int *n_valid) {
+  if (!b || !b->uploaded || !b->timed || !(sample_dt > 0.0) || n_samples <= 0 || !states) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  double *d_states = nullptr;
+  int *d_valid = nullptr;
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  if (!h->cev0) chk(hipEventCreate(&h->cev0));
+  if (!h->cev1) chk(hipEventCreate(&h->cev1));
+  const size_t nst = (size_t)b->B * (size_t)n_samples * 8;
+  chk(hipMalloc(&d_states, sizeof(double) * nst));
+  chk(hipMalloc(&d_valid, sizeof(int) * (size_t)b->B));
+  if (rc == DFTPAV_OK) {
+    chk(hipEventRecord(h->cev0, h->stream));
+    chk(launch_states(b->d_coef, b->d_dt, b->L, b->B, h->params.veh_wheel_base, t0, sample_dt, n_samples, filter_singularity != 0,
+                      d_states, d_valid, h->stream));
+    chk(hipEventRecord(h->cev1, h->stream));
+    chk(hipMemcpyAsync(states, d_states, sizeof(double) * nst, hipMemcpyDeviceToHost, h->stream));
+    if (n_valid) chk(hipMemcpyAsync(n_valid, d_valid, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToHost, h->stream));
+    chk(hipStreamSynchronize(h->stream));
+    h->ctimed = rc == DFTPAV_OK;
+  }
+  if (d_states) (void)hipFree(d_states);
+  if (d_valid) (void)hipFree(d_valid);
+  return rc;
+}
+
+// ------------------------------------------------- serialised trajectories (include/dftpav_hip.h, "DPTJ" v1)
+namespace {
+constexpr size_t kWireHeader = 32, kWireSegment = 24, kWirePiece = 104;
+template <class T> inline void put(unsigned char *&p, T v) {
+  std::memcpy(p, &v, sizeof(T));
+  p += sizeof(T);
+}
+template <class T> inline T get(const unsigned char *&p) {
+  T v;
+  std::memcpy(&v, p, sizeof(T));
+  p += sizeof(T);
+  return v;
+}
+} // namespace
+
+extern "C" size_t dftpav_wire_size(int n_segments, const int *piece_nums) {
+  if (n_segments <= 0 || n_segments > kMaxSeg || !piece_nums) return 0;
+  size_t n = kWireHeader;
+  for (int i = 0; i < n_segments; i++) {
+    if (piece_nums[i] <= 0) return 0;
+    n += kWireSegment + kWirePiece * (size_t)piece_nums[i];
+  }
+  return n;
+}
+
+extern "C" int dftpav_wire_pack(const dftpav_layout *layout, const double *coeffs, const double *piece_dt, int drone_id,
+                                int traj_id, double start_time, void *buf, size_t capacity, size_t *written) {
+  if (!layout || !coeffs || !piece_dt || !buf) return DFTPAV_E_INVALID;
+  const size_t need = dftpav_wire_size(layout->M, layout->piece_nums);
+  if (need == 0 || capacity < need) return DFTPAV_E_INVALID;
+  unsigned char *p = (unsigned char *)buf;
+  std::memcpy(p, "DPTJ", 4);
+  p += 4;
+  put<unsigned short>(p, 1);
+  put<unsigned char>(p, 5);
+  put<unsigned char>(p, 2);
+  put<int>(p, drone_id);
+  put<int>(p, traj_id);
+  put<int>(p, layout->M);
+  put<int>(p, 0);
+  put<double>(p, start_time);
+  double world = start_time; // addSingulTraj: each segment starts where the previous one ended
+  int piece = 0;
+  for (int i = 0; i < layout->M; i++) {
+    const int N = layout->piece_nums[i];
+    double dur = 0.0; // getTotalDuration: piece durations summed in order
+    for (int q = 0; q < N; q++) dur += piece_dt[i];
+    put<int>(p, layout->singuls ? layout->singuls[i] : 1);
+    put<int>(p, N);
+    put<double>(p, world);
+    put<double>(p, dur);
+    world = world + dur;
+    for (int q = 0; q < N; q++, piece++) {
+      put<double>(p, piece_dt[i]);
+      const double *c = coeffs + (size_t)piece * 12; // [k][d], k = power
+      for (int k = 5; k >= 0; k--) {                   // column 0 of CoefficientMat multiplies t^5
+        put<double>(p, c[2 * k]);
+        put<double>(p, c[2 * k + 1]);
+      }
+    }
+  }
+  if (written) *written = need;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_wire_info(const void *buf, size_t size, int *drone_id, int *traj_id, double *start_time, int *n_segments,
+                                int *n_pieces) {
+  if (!buf || size < kWireHeader) return DFTPAV_E_INVALID;
+  const unsigned char *p = (const unsigned char *)buf;
+  if (std::memcmp(p, "DPTJ", 4) != 0) return DFTPAV_E_INVALID;
+  p += 4;
+  if (get<unsigned short>(p) != 1 || get<unsigned char>(p) != 5 || get<unsigned char>(p) != 2) return DFTPAV_E_INVALID;
+  const int did = get<int>(p), tid = get<int>(p), M = get<int>(p);
+  (void)get<int>(p);
+  const double st = get<double>(p);
+  if (M <= 0 || M > kMaxSeg) return DFTPAV_E_INVALID;
+  size_t off = kWireHeader;
+  int pieces = 0;
+  for (int i = 0; i < M; i++) {
+    if (size < off + kWireSegment) return DFTPAV_E_INVALID;
+    const unsigned char *q = (const unsigned char *)buf + off;
+    const int sg = get<int>(q), N = get<int>(q);
+    if ((sg != 1 && sg != -1) || N <= 0 || N > 4096) return DFTPAV_E_INVALID;
+    off += kWireSegment + kWirePiece * (size_t)N;
+    pieces += N;
+  }
+  if (size < off) return DFTPAV_E_INVALID;
+  if (drone_id) *drone_id = did;
+  if (traj_id) *traj_id = tid;
+  if (start_time) *start_time = st;
+  if (n_segments) *n_segments = M;
+  if (n_pieces) *n_pieces = pieces;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_wire_unpack(const void *buf, size_t size, int *singuls, int *piece_nums, double *seg_start,
+                                  double *seg_duration, double *durations, double *coeffs) {
+  int M = 0;
+  if (int rc = dftpav_wire_info(buf, size, nullptr, nullptr, nullptr, &M, nullptr)) return rc;
+  const unsigned char *p = (const unsigned char *)buf + kWireHeader;
+  int piece = 0;
+  for (int i = 0; i < M; i++) {
+    const int sg = get<int>(p), N = get<int>(p);
+    const double st = get<double>(p), du = get<double>(p);
+    if (singuls) singuls[i] = sg;
+    if (piece_nums) piece_nums[i] = N;
+    if (seg_start) seg_start[i] = st;
+    if (seg_duration) seg_duration[i] = du;
+    for (int q = 0; q < N; q++, piece++) {
+      const double d = get<double>(p);
+      if (durations) durations[piece] = d;
+      for (int k = 0; k < 12; k++) {
+        const double c = get<double>(p);
+        if (coeffs) coeffs[(size_t)piece * 12 + k] = c;
+      }
+    }
+  }
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_set_surround_wire(dftpav_handle *h, const void *const *bufs, const size_t *sizes, int S) {
+  if (!h) return DFTPAV_E_INVALID;
+  if (S <= 0) return dftpav_set_surround(h, nullptr);
+  if (!bufs || !sizes) return DFTPAV_E_INVALID;
+  std::vector<int> off(1, 0);
+  std::vector<double> dur, coef, total, start;
+  for (int s = 0; s < S; s++) {
+    int M = 0, np = 0;
+    double st = 0.0;
+    if (int rc = dftpav_wire_info(bufs[s], sizes[s], nullptr, nullptr, &st, &M, &np)) return rc;
+    std::vector<int> sg(M), pn(M);
+    const size_t at = dur.size();
+    dur.resize(at + np);
+    coef.resize((at + np) * 12);
+    if (int rc = dftpav_wire_unpack(bufs[s], sizes[s], sg.data(), pn.data(), nullptr, nullptr, dur.data() + at, coef.data() + at * 12))
+      return rc;
+    for (int i = 0; i < M; i++)
+      if (sg[i] != 1) return DFTPAV_E_INVALID; // the obstacle model is forward-only (traj_manager.cpp:726,775)
+    double tot = 0.0; // LocalTrajData::duration = Trajectory::getTotalDuration of the joined pieces
+    for (int q = 0; q < np; q++) tot += dur[at + q];
+    off.push_back((int)(at + np));
+    total.push_back(tot);
+    start.push_back(st);
+  }
+  dftpav_surround sur{S, off.data(), dur.data(), coef.data(), total.data(), start.data()};
+  return dftpav_set_surround(h, &sur);
 }
 
 extern "C" int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B, const dftpav_batch_data *d,

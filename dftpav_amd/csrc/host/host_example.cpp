@@ -40,6 +40,28 @@ int main() {
   std::printf("OptimizeTrajectory -> %d, status %d, cost %.6f, %d iterations, %zu segments, dt %.4f\n", (int)ok,
               opt.last_status(), opt.last_cost(), opt.last_iterations(), opt.getMinJerkOptPtr()->size(),
               ok ? (*opt.getMinJerkOptPtr())[0].getDt() : 0.0);
+  // ---- the read-out of the plan the way the server publishes it, and the plan as bytes
+  bool ok3 = ok;
+  if (ok) {
+    TrajPlannerSteps out(opt.handle());
+    std::vector<std::vector<State>> st;
+    ok3 = out.GetStates(opt.solved_batch(), 1, 0.0, 0.01, 400, st);
+    const MinJerkOptView &mj = (*opt.getMinJerkOptPtr())[0];
+    const double total = mj.getDt() * N;
+    ok3 = ok3 && !st[0].empty() && st[0].size() <= 400 && st[0].front().x == 0.0 && st[0].front().velocity > 1.9;
+    std::vector<double> c((size_t)12 * N), dtp(1);
+    ok3 = ok3 && dftpav_batch_coeffs(opt.solved_batch(), c.data(), dtp.data()) == DFTPAV_OK;
+    const int pn[1] = {N}, sg[1] = {1};
+    dftpav_layout lay{1, pn, sg, 4};
+    std::vector<unsigned char> blob;
+    ok3 = ok3 && out.SerializeTraj(lay, c.data(), dtp.data(), 1, 1, 0.0, blob) && out.setSurroundTrajsFromWire({blob});
+    int S = 0, np = 0;
+    ok3 = ok3 && dftpav_get_surround(opt.handle(), &S, &np, nullptr, nullptr, nullptr, nullptr, nullptr) == DFTPAV_OK && S == 1 && np == N;
+    ok3 = ok3 && out.setSurroundTrajsFromWire({});
+    std::printf("GetStates -> %zu states over %.3f s, last x = %.3f, v = %.3f; plan serialised to %zu bytes and installed as an obstacle -> %d\n",
+                st.empty() ? (size_t)0 : st[0].size(), total, (st.empty() || st[0].empty()) ? 0.0 : st[0].back().x,
+                (st.empty() || st[0].empty()) ? 0.0 : st[0].back().velocity, blob.size(), (int)ok3);
+  }
   // a size error is reported the reference's way: false, no throw (traj_optimizer.cpp:44-48)
   polys[0].pop_back();
   bool bad = opt.OptimizeTrajectory(ini, fin, inner, Ts, polys, {1}, 0.0, 0.0);
@@ -67,5 +89,5 @@ int main() {
               flat.size(), ok2 ? flat[0].piece_nums : 0, ok2 ? flat[0].piece_duration : 0.0, ok2 ? flat[0].states.size() : (size_t)0,
               front, (int)ok2, steps.last_error());
   dftpav_destroy(h);
-  return (ok && !bad && ok2 && front < 15.0 && front > 3.0) ? 0 : 1;
+  return (ok && !bad && ok2 && ok3 && front < 15.0 && front > 3.0) ? 0 : 1;
 }

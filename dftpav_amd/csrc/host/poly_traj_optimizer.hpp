@@ -74,6 +74,7 @@ class PolyTrajOptimizer {
  public:
   PolyTrajOptimizer() { dftpav_default_params(&params_); }
   ~PolyTrajOptimizer() {
+    drop_batch();
     if (h_) dftpav_destroy(h_);
   }
   PolyTrajOptimizer(const PolyTrajOptimizer &) = delete;
@@ -82,6 +83,7 @@ class PolyTrajOptimizer {
   // traj_optimizer.h:100 — the ros::NodeHandle only served debug publishers
   void setParam(const dftpav_params &p) {
     params_ = p;
+    drop_batch();
     if (h_) {
       dftpav_destroy(h_);
       h_ = nullptr;
@@ -97,6 +99,10 @@ class PolyTrajOptimizer {
   double last_cost() const { return cost_; }
   int last_iterations() const { return iters_; }
   int last_error() const { return err_; } // DFTPAV_E_* of the last call (0 if it reached the solver)
+  // the solved problem stays on the device until the next call, for the steps that consume it there
+  // (TrajPlannerSteps::CheckCollision / GetStates); NULL before the first successful upload
+  dftpav_batch *solved_batch() const { return batch_; }
+  dftpav_handle *handle() const { return h_; }
 
   // traj_optimizer.h:118-120
   bool OptimizeTrajectory(const std::vector<Mat> &iniStates, const std::vector<Mat> &finStates,
@@ -104,6 +110,7 @@ class PolyTrajOptimizer {
                           std::vector<std::vector<Mat>> &hPoly_container, std::vector<int> singuls, double now,
                           double help_eps) {
     err_ = DFTPAV_OK;
+    drop_batch();
     const int M = (int)initInnerPts.size();
     if ((int)initTs.size() != M || M < 1) return fail(DFTPAV_E_INVALID); // traj_optimizer.cpp:26-29
     for (double T : initTs)
@@ -182,8 +189,11 @@ class PolyTrajOptimizer {
         o += piece_nums[i];
       }
     }
-    dftpav_batch_destroy(b);
-    if (rc != DFTPAV_OK) return fail(rc);
+    if (rc != DFTPAV_OK) {
+      dftpav_batch_destroy(b);
+      return fail(rc);
+    }
+    batch_ = b;
     return success != 0;
   }
 
@@ -192,6 +202,11 @@ class PolyTrajOptimizer {
     err_ = code;
     return false;
   }
+  void drop_batch() {
+    if (batch_) dftpav_batch_destroy(batch_);
+    batch_ = nullptr;
+  }
+  dftpav_batch *batch_ = nullptr;
   dftpav_params params_;
   dftpav_handle *h_ = nullptr;
   const SurroundSet *surround_ = nullptr;

@@ -10,7 +10,10 @@
 //   TrajPlanner::getRectangleConst(statelist)       MGR:1213-1469      getRectangleConst(statelist) -> hPolys_
 //   TrajPlanner::ConverSurroundTrajFromPoints(...)  MGR:743-789        ConverSurroundTrajFromPoints(sur_trajs) (installs them)
 //   collision part of CheckReplan                   SRV:385-397        CheckCollision(batch) -> per trajectory bool
-// (MGR = traj_planner/src/traj_manager.cpp, KA = traj_planner/src/kino_astar.cpp, SRV = traj_planner/src/traj_server_ros.cpp)
+//   Trajectory::GetState as PublishData plays it    PTU:378-406,       GetStates(batch, t0, dt, n) -> common::State rows per trajectory
+//     back, FilterSingularityState                  SRV:244-259,335-356
+//   LocalTrajData as bytes (PolyTraj.msg, unused)   msg/PolyTraj.msg   SerializeTraj(...) / setSurroundTrajsFromWire(blobs)
+// (PTU = plan_utils/poly_traj_utils.hpp, MGR = traj_planner/src/traj_manager.cpp, KA = traj_planner/src/kino_astar.cpp, SRV = traj_planner/src/traj_server_ros.cpp)
 #pragma once
 #include <array>
 #include <vector>
@@ -24,6 +27,11 @@ namespace plan_manage {
 // curvature, time_stamp
 struct PredictedState {
   double x, y, angle, velocity, acceleration, curvature, time_stamp;
+};
+
+// common::State as Trajectory::GetState fills it (poly_traj_utils.hpp:388-404) — one row of dftpav_batch_sample_states
+struct State {
+  double time_stamp, x, y, angle, curvature, velocity, acceleration, steer;
 };
 
 // plan_utils::FlatTrajData (traj_container.hpp) plus what RunMINCOParking derives from it per gear segment
@@ -114,6 +122,39 @@ class TrajPlannerSteps {
   bool CheckCollision(dftpav_batch *batch, int B, std::vector<int> &is_collision) {
     is_collision.assign(B, 0);
     return ok(dftpav_batch_validate(batch, 0.05, 0.1, is_collision.data(), nullptr));
+  }
+
+  // the states the server would publish for every trajectory of a solved batch at t0, t0 + dt, ...;
+  // states[t] holds the samples that fall inside trajectory t
+  bool GetStates(dftpav_batch *batch, int B, double t0, double dt, int n_samples, std::vector<std::vector<State>> &states,
+                 bool filter_singularity = true) {
+    static_assert(sizeof(State) == 8 * sizeof(double), "State is 8 packed doubles");
+    std::vector<State> flat((size_t)B * n_samples);
+    std::vector<int> valid(B, 0);
+    states.assign(B, {});
+    if (!ok(dftpav_batch_sample_states(batch, t0, dt, n_samples, filter_singularity ? 1 : 0, &flat[0].time_stamp, valid.data())))
+      return false;
+    for (int t = 0; t < B; t++) states[t].assign(flat.begin() + (size_t)t * n_samples, flat.begin() + (size_t)t * n_samples + valid[t]);
+    return true;
+  }
+
+  // one solved trajectory (its rows of dftpav_batch_coeffs) as a "DPTJ" blob
+  bool SerializeTraj(const dftpav_layout &layout, const double *coeffs, const double *piece_dt, int drone_id, int traj_id,
+                     double start_time, std::vector<unsigned char> &blob) {
+    blob.assign(dftpav_wire_size(layout.M, layout.piece_nums), 0);
+    size_t written = 0;
+    if (blob.empty()) return ok(DFTPAV_E_INVALID);
+    return ok(dftpav_wire_pack(&layout, coeffs, piece_dt, drone_id, traj_id, start_time, blob.data(), blob.size(), &written));
+  }
+  // setSurroundTrajs for obstacles that arrive serialised
+  bool setSurroundTrajsFromWire(const std::vector<std::vector<unsigned char>> &blobs) {
+    std::vector<const void *> ptr;
+    std::vector<size_t> len;
+    for (const auto &b : blobs) {
+      ptr.push_back(b.data());
+      len.push_back(b.size());
+    }
+    return ok(dftpav_set_surround_wire(h_, ptr.data(), len.data(), (int)blobs.size()));
   }
 
  private:

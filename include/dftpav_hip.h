@@ -21,6 +21,8 @@
 #ifndef DFTPAV_HIP_H
 #define DFTPAV_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -326,6 +328,56 @@ int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms);
  * counted over the segments in order (-1 if none).  Either output may be NULL.
  * dftpav_corridor_last_ms reports the kernel's duration afterwards. */
 int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double vertex_res, int *collision, int *first_sample);
+
+/* ---- read-out of the result: Trajectory::GetState over a time grid ----
+ * Replaces Trajectory::GetState (poly_traj_utils.hpp:378-406, with
+ * Piece::getStateExpPos :303-340) called the way the server plays a plan back
+ * (TrajPlannerServer::PublishData, traj_server_ros.cpp:244-259): the gear
+ * segments of a trajectory follow one another in time as
+ * TrajContainer::addSingulTraj chains them (traj_container.hpp:58-73,
+ * traj_manager.cpp:617-624; time 0 = start of the first segment), sample k
+ * carries the time stamp t0 + k * sample_dt and is read from the first segment
+ * whose end_time is not <= that time; past the last segment nothing is
+ * published.  states [B][n_samples][8] = {time_stamp, x, y, angle, curvature,
+ * velocity, acceleration, steer} (the fields of common::State the server
+ * publishes), rows past n_valid[t] are zero; n_valid [B] may be NULL.
+ * filter_singularity != 0 applies TrajPlannerServer::FilterSingularityState
+ * (traj_server_ros.cpp:335-356) along each trajectory, the history being the
+ * previous sample.  Needs a solved batch. */
+int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sample_dt, int n_samples, int filter_singularity,
+                               double *states, int *n_valid);
+
+/* ---- serialised form of a trajectory -----------------------
+ * The reference declares traj_planner/msg/PolyTraj.msg:1-9 (drone_id, traj_id,
+ * start_time, order, float32 coefficients, durations) and never uses it; plans
+ * and predicted obstacle motions travel as plan_utils::LocalTrajData
+ * (traj_container.hpp:28-38) inside one process.  This is the same content as
+ * bytes, in fp64 so that a trajectory survives the trip bit for bit
+ * (little-endian, every field naturally aligned):
+ *
+ *   header  (32 B)  char magic[4] = "DPTJ"; u16 version = 1; u8 order = 5; u8 dim = 2;
+ *                   i32 drone_id; i32 traj_id; i32 n_segments; i32 reserved = 0; f64 start_time
+ *   segment (24 B)  i32 singul; i32 n_pieces; f64 start_time; f64 duration   (LocalTrajData of one gear segment,
+ *                   start/duration as addSingulTraj computes them from header.start_time)
+ *   piece  (104 B)  f64 duration; f64 coeff[12]   CoefficientMat column-major, column 0 multiplies t^5:
+ *                   x5,y5, x4,y4, ... x0,y0 (poly_traj_utils.hpp:77-87, 993) — the layout of dftpav_surround.coeffs
+ *
+ * dftpav_wire_size: bytes of a trajectory with these segments (0 on bad input).
+ * dftpav_wire_pack: one trajectory from the arrays dftpav_batch_coeffs returns for it (coeffs [Ntot][6][2], piece_dt [M]).
+ * dftpav_wire_info: validates a blob, returns its header fields and the total piece count (any output may be NULL).
+ * dftpav_wire_unpack: singuls/piece_nums/seg_start/seg_duration [n_segments], durations [pieces], coeffs [pieces][12].
+ * dftpav_set_surround_wire: installs S blobs as the moving obstacles (== dftpav_set_surround; the segments of a
+ *   blob are joined into one obstacle trajectory that starts at the blob's start_time).  The reference builds its
+ *   obstacle model with getTraj(1) (traj_manager.cpp:726,775), so a blob with a reverse segment is refused.
+ * Pure host code except the last one. */
+size_t dftpav_wire_size(int n_segments, const int *piece_nums);
+int dftpav_wire_pack(const dftpav_layout *layout, const double *coeffs, const double *piece_dt, int drone_id, int traj_id,
+                     double start_time, void *buf, size_t capacity, size_t *written);
+int dftpav_wire_info(const void *buf, size_t size, int *drone_id, int *traj_id, double *start_time, int *n_segments,
+                     int *n_pieces);
+int dftpav_wire_unpack(const void *buf, size_t size, int *singuls, int *piece_nums, double *seg_start, double *seg_duration,
+                       double *durations, double *coeffs);
+int dftpav_set_surround_wire(dftpav_handle *h, const void *const *bufs, const size_t *sizes, int S);
 
 /* One-shot convenience == OptimizeTrajectory for B trajectories. */
 int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B,

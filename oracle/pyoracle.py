@@ -276,6 +276,27 @@ def validate_trajectories(grid, resolution, origin, coeffs, piece_dt, piece_nums
     return col, first
 
 
+def sample_states(coeffs, piece_dt, piece_nums, singuls, t0=0.0, sample_dt=0.01, n_samples=100, filter_singularity=True,
+                  wheel_base=2.85, order=0):
+    """Trajectory::GetState over a time grid, played back as the server does (states_oracle.cpp): returns
+    (states [B][n_samples][8], n_valid [B])."""
+    L = lib()
+    co = np.ascontiguousarray(coeffs, dtype=np.float64)
+    B = co.shape[0]
+    dt = np.ascontiguousarray(piece_dt, dtype=np.float64).reshape(B, -1)
+    pn = np.ascontiguousarray(piece_nums, dtype=np.int32)
+    sg = np.ascontiguousarray(singuls, dtype=np.int32)
+    st = np.zeros((B, int(n_samples), 8))
+    nv = np.zeros(B, dtype=np.int32)
+    fn = L.oracle_sample_states
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    fn(co.ctypes.data, dt.ctypes.data, pn.ctypes.data, sg.ctypes.data, len(pn), B, float(wheel_base), float(t0),
+       float(sample_dt), int(n_samples), int(bool(filter_singularity)), int(order), st.ctypes.data, nv.ctypes.data)
+    return st, nv
+
+
 def fit_surround(states, order=0):
     """ConverSurroundTrajFromPoints (traj_manager.cpp:743-789): states [S][n][7] (x, y, angle, velocity, acceleration,
     curvature, time_stamp) -> dict(durations [S][n-1], coeffs [S][n-1][12], total [S], start [S])."""

@@ -289,6 +289,8 @@ def test_cpp_host_mirror_runs(hiplib):
     assert "OptimizeTrajectory -> 1" in out.stdout and "short corridor -> 0" in out.stdout
     # the TrajPlanner / KinoAstar steps around the solve (traj_planner_steps.hpp)
     assert "getKinoNode -> 1 segment(s)" in out.stdout and "surround fit -> 1" in out.stdout
+    # the read-out (GetStates) and the plan as bytes, installed as an obstacle
+    assert "GetStates -> " in out.stdout and "installed as an obstacle -> 1" in out.stdout
 
 
 def _corridor_scene(seed):
@@ -550,3 +552,103 @@ def test_restart_sampler_matches_oracle(hiplib, oracle):
         oi, od = oracle.sample_restarts(inner, durs, nr, sigma=0.3, lo=0.8, hi=1.25, seed=2024)
         assert np.array_equal(gi, oi) and np.array_equal(gd, od)
     h.close()
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 6), (3, 16)])
+def test_state_sampling_matches_oracle(hiplib, oracle, cfg, B):
+    """§8(f)-2, the read-out half: Trajectory::GetState (poly_traj_utils.hpp:378-406) over a time grid for every
+    solved trajectory, with the server's playback rule and singularity filter (traj_server_ros.cpp:244-259, 335-356),
+    bit for bit against the oracle's device-order mode."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(cfg, B=B)
+    s.apply_resolution(p)
+    h, bt = _batch(hiplib, s, p)
+    bt.solve()
+    co, dts = bt.coeffs()
+    lay = s.layout
+    total = (dts * lay.piece_nums[None, :]).sum(axis=1)
+    for t0, dt, n, filt in [(0.0, 0.01, int(total.max() / 0.01) + 40, True), (0.0, 0.01, 300, False),
+                            (-0.3, 0.037, 600, True), (2.5, 0.2, 7, True)]:
+        st, nv = bt.sample_states(t0=t0, sample_dt=dt, n_samples=n, filter_singularity=filt)
+        so, no = oracle.sample_states(co, dts, lay.piece_nums, lay.singuls, t0=t0, sample_dt=dt, n_samples=n,
+                                      filter_singularity=filt, wheel_base=p.veh_wheel_base, order=1)
+        assert np.array_equal(nv, no)
+        assert np.array_equal(st, so)
+        sl, nl = oracle.sample_states(co, dts, lay.piece_nums, lay.singuls, t0=t0, sample_dt=dt, n_samples=n,
+                                      filter_singularity=filt, wheel_base=p.veh_wheel_base, order=0)
+        assert np.array_equal(nv, nl)
+        # the libm order differs by rounding only (headings compared on the circle; curvature amplifies 1 / v^3)
+        assert np.allclose(st[..., [0, 1, 2, 5]], sl[..., [0, 1, 2, 5]], rtol=1e-12, atol=1e-12)
+        assert np.abs(np.angle(np.exp(1j * (st[..., 3] - sl[..., 3])))).max() < 1e-9
+    # the first n_valid samples cover the plan, the rest is zero; the read-out starts at the initial state
+    st, nv = bt.sample_states(t0=0.0, sample_dt=0.01, n_samples=int(total.max() / 0.01) + 40)
+    for b in range(B):
+        assert abs(nv[b] * 0.01 - total[b]) <= 0.011
+        assert (st[b, nv[b]:] == 0.0).all()
+        assert np.allclose(st[b, 0, 1:3], s.ini_states[b, 0, :2], atol=1e-9)
+    assert h.corridor_last_ms() > 0.0
+    # limits the solve enforces softly, seen on the read-out
+    v = np.abs(st[..., 5])
+    assert v.max() < p.max_forward_vel * 1.1
+    bt.close()
+    h.close()
+
+
+def test_wire_round_trip_feeds_the_solver(hiplib, oracle):
+    """§8(f)-4: trajectories serialised as "DPTJ" blobs and installed as the moving obstacles are the obstacles the
+    scenario installs directly: same tables on the device, same solves bit for bit; a solved plan survives the
+    trip into another handle's obstacle set."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(5, B=3)
+    s.apply_resolution(p)
+    sur = s.surround
+    from dftpav_amd import capi, pods
+    blobs = []
+    for k in range(sur.S):
+        a, e = sur.piece_offsets[k], sur.piece_offsets[k + 1]
+        assert np.all(sur.durations[a:e] == sur.durations[a])
+        co = sur.coeffs[a:e].reshape(-1, 6, 2)[:, ::-1, :]  # CoefficientMat order -> [power][x/y]
+        lay1 = pods.LayoutSpec([e - a], [1])
+        blobs.append(capi.wire_pack(lay1, co, np.array([sur.durations[a]]), drone_id=k, traj_id=k + 1,
+                                    start_time=float(sur.start_time[k])))
+    h, bt = _batch(hiplib, s, p)
+    bt.solve()
+    ref = bt.results()
+    direct = h.get_surround()
+    bt.close()
+    h2 = hiplib.Handle(p)
+    h2.set_surround_wire(blobs)
+    got = h2.get_surround()
+    for key in ("offsets", "durations", "coeffs", "start"):
+        assert np.array_equal(direct[key], got[key]), key
+    run = np.array([np.cumsum(sur.durations[sur.piece_offsets[k]:sur.piece_offsets[k + 1]])[-1] for k in range(sur.S)])
+    assert np.array_equal(got["total"], run)  # Trajectory::getTotalDuration: running sum of the pieces
+    if np.array_equal(run, sur.total_duration):
+        bt2 = hiplib.Batch(h2, s.layout, s.B)
+        bt2.upload(s)
+        bt2.solve()
+        r2 = bt2.results()
+        assert np.array_equal(ref["final_cost"], r2["final_cost"]) and np.array_equal(ref["x"], r2["x"])
+        bt2.close()
+    # a reverse segment cannot be an obstacle of the reference's model
+    lay_r = pods.LayoutSpec([2], [-1])
+    bad = capi.wire_pack(lay_r, np.zeros((2, 6, 2)), np.array([1.0]))
+    with pytest.raises(hiplib.DftpavError):
+        h2.set_surround_wire([bad])
+    # a solved forward plan, serialised, becomes somebody else's obstacle
+    s3 = sc.baseline_config(3, B=2)
+    p3 = hiplib.default_params()
+    s3.apply_resolution(p3)
+    h3, bt3 = _batch(hiplib, s3, p3)
+    bt3.solve()
+    co3, dt3 = bt3.coeffs()
+    blob = capi.wire_pack(s3.layout, co3[1], dt3[1], drone_id=3, traj_id=9, start_time=1.25)
+    h2.set_surround_wire([blob])
+    g = h2.get_surround()
+    assert list(g["offsets"]) == [0, s3.layout.n_pieces] and g["start"][0] == 1.25
+    assert np.array_equal(g["coeffs"].reshape(-1, 6, 2)[:, ::-1, :], co3[1])
+    h2.set_surround_wire([])
+    assert len(h2.get_surround()["total"]) == 0
+    bt3.close()
+    h3.close()
+    h2.close()
