@@ -292,9 +292,11 @@ struct RegPlanes {
   }
 };
 // strided plane loader over the component-major corridor of one trajectory
-struct GlobalPlanes {
-  const double *base; // &corridor[b][0][pt]
-  size_t pitch;       // NptsPad
+// half-plane k of one constraint point; the pointer carries its address space so that the loads are
+// global_load / ds_read rather than flat_load (a generic pointer cannot tell the compiler which)
+template <class P> struct PitchedPlanes {
+  P base;       // &corridor[b][0][pt]
+  size_t pitch; // NptsPad
   __device__ inline void operator()(int k, double &n0, double &n1, double &q0, double &q1) const {
     n0 = base[(size_t)(4 * k + 0) * pitch];
     n1 = base[(size_t)(4 * k + 1) * pitch];
@@ -302,11 +304,72 @@ struct GlobalPlanes {
     q1 = base[(size_t)(4 * k + 3) * pitch];
   }
 };
+typedef const double __attribute__((address_space(1))) *cor_g_t;
+typedef const double __attribute__((address_space(3))) *cor_l_t;
+typedef PitchedPlanes<cor_g_t> GlobalPlanes;
+typedef PitchedPlanes<cor_l_t> LdsPlanes;
 
 // ----------------------------------------------------- cost + gradient
 // PolyTrajOptimizer::costFunctionCallback (traj_optimizer.cpp:206-350) for the
 // decision vector x (LDS) of trajectory b; writes g (LDS) and f (sm.st[sF]).
 // D is read through scalar loads (uniform); per-lane lookups go through the LDS tables.
+// Row of the dense MINCO operator times the right-hand side (E2) / column times the scaled gradient (E5).
+// All operator values of a chunk are requested back to back before the first one is used: at two waves per
+// SIMD nothing else hides an L2 (or LDS) round trip, so a loop that waits per element is a chain of them.
+// Out-of-range slots re-read the last valid element and are masked at use; the sums keep their order.
+typedef const double __attribute__((address_space(1))) *opg_t; // operator in global memory: global_load, vmcnt only
+constexpr int kOpChunk = 24;
+constexpr int kRedChunk = 11; // points per batch of the transposed reduction (a full piece of 33 = 3 batches)
+template <class P> __device__ __forceinline__ double op_row_dot(P Mrow, const double *rh, int ncol) {
+  double acc = 0.0;
+  for (int c0 = 0; c0 < ncol; c0 += kOpChunk) {
+    double mv[kOpChunk], rv[kOpChunk];
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int col = c0 + j < ncol ? c0 + j : ncol - 1;
+      mv[j] = Mrow[col];
+    }
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int col = c0 + j < ncol ? c0 + j : ncol - 1;
+      rv[j] = rh[2 * col];
+    }
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const double t = acc + mv[j] * rv[j];
+      acc = c0 + j < ncol ? t : acc;
+    }
+  }
+  return acc;
+}
+// lane q of a quad sums rows q, q + 4, q + 8, ... of one operator column against gc[2 r] * tInv[r mod 6]
+template <class P> __device__ __forceinline__ double op_col_dot(P MT, const double *gc, const double *tInv, int q, int nrow) {
+  double acc = 0.0;
+  for (int r0 = q; r0 < nrow; r0 += 4 * kOpChunk) {
+    double mv[kOpChunk], gv[kOpChunk], tv[kOpChunk];
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
+      mv[j] = MT[r];
+    }
+    int k = r0 % 6;
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
+      gv[j] = gc[2 * r];
+      tv[j] = tInv[k];
+      k += 4;
+      if (k >= 6) k -= 6;
+    }
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const double t = acc + mv[j] * (gv[j] * tv[j]);
+      acc = r0 + 4 * j < nrow ? t : acc;
+    }
+  }
+  return acc;
+}
+
 template <bool SUR>
 __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem &sm, const double *x, double *g, Prof &pr) {
   const DevLayout &L = D.L; // uniform accesses only (scalar loads)
@@ -407,20 +470,18 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
       int k = q >> 1, d = q & 1;
       const int *pc = sm.pcinfo + 8 * p;
       int sg = pc[3], lp = pc[4], N = pc[5];
-      const double *Mop;
-      if (D.op_in_lds) {
-        Mop = sm.opM + pc[7];
-      } else {
-        Mop = D.opM[0];
-        for (int s = 1; s < M; s++) Mop = (s == sg) ? D.opM[s] : Mop;
-      }
-      const double *Mrow = Mop + (size_t)(6 * lp + k) * (N + 5);
       int r0 = 0; // first RHS row of the segment
       for (int s = 0; s < M; s++) r0 = (s == sg) ? L.seg_rhs0[s] : r0;
       const double *rh = sm.rhs + 2 * r0 + d;
-      double acc = 0.0;
-#pragma unroll 8
-      for (int col = 0; col < N + 5; col++) acc += Mrow[col] * rh[2 * col];
+      const size_t roff = (size_t)(6 * lp + k) * (N + 5);
+      double acc;
+      if (D.op_in_lds) {
+        acc = op_row_dot(sm.opM + pc[7] + roff, rh, N + 5);
+      } else {
+        const double *Mop = D.opM[0];
+        for (int s = 1; s < M; s++) Mop = (s == sg) ? D.opM[s] : Mop;
+        acc = op_row_dot((opg_t)Mop + roff, rh, N + 5);
+      }
       sm.b[12 * p + q] = acc;
       sm.c[12 * p + q] = acc * sm.seg[sg * 16 + 8 + k];
     }
@@ -468,17 +529,19 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         in.t_now = D.t_now;
         const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad + pt;
         if (D.cor_in_lds) {
-          GlobalPlanes pl{sm.cor + pt, (size_t)((Npts + 63) / 64 * 64)};
+          LdsPlanes pl{(cor_l_t)(sm.cor + pt), (size_t)((Npts + 63) / 64 * 64)};
           if (L.H <= 4) sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
           else sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
         } else if (L.H <= 4) {
-          double cor[16]; // all half-plane loads issued up front, consumed after the state evaluation
+          double cor[16]; // all half-plane loads issued up front (unconditionally: rows past 4 H re-read row 0 and
+                          // are never used), consumed after the state evaluation
+          const cor_g_t cg = (cor_g_t)cb;
 #pragma unroll
-          for (int k = 0; k < 16; k++) cor[k] = (k < 4 * L.H) ? cb[(size_t)k * D.NptsPad] : 0.0;
+          for (int k = 0; k < 16; k++) cor[k] = cg[(size_t)(k < 4 * L.H ? k : 0) * D.NptsPad];
           RegPlanes pl{cor};
           sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
         } else {
-          GlobalPlanes pl{cb, (size_t)D.NptsPad};
+          GlobalPlanes pl{(cor_g_t)cb, (size_t)D.NptsPad};
           sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
         }
       } else {
@@ -511,11 +574,36 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         const int k1 = k >= 1 ? k - 1 : 0, k2 = k >= 2 ? k - 2 : 0;
         const double kd = (double)k, kkd = (double)(k * (k - 1));
         double acc = sm.gdC[12 * p + q]; // continue the chain that starts at the smoothness gradient
-#pragma unroll 4
-        for (int j = j0; j < j1; j++) {
-          const double *e = tab + 6 * j;
-          double b0 = e[k], b1 = kd * e[k1], b2 = kkd * e[k2];
-          acc += b0 * pa[j] + b1 * pb[j] + b2 * pc2[j];
+        // batches of kRedChunk points: every LDS read of a batch is issued before the first add (slots past j1
+        // re-read the last point and are masked), the chain itself stays in point order
+#ifdef E4R_EXP
+        if (E4R_EXP == 1) j1 = j0; // timing experiment: no reduction at all
+#endif
+        for (int jb = j0; jb < j1; jb += kRedChunk) {
+          double e0[kRedChunk], e1[kRedChunk], e2[kRedChunk], va[kRedChunk], vb[kRedChunk], vc[kRedChunk];
+#pragma unroll
+          for (int t = 0; t < kRedChunk; t++) {
+            const int j = jb + t < j1 ? jb + t : j1 - 1;
+            const double *e = tab + 6 * j;
+            e0[t] = e[k];
+            e1[t] = e[k1];
+            e2[t] = e[k2];
+            va[t] = pa[j];
+            vb[t] = pb[j];
+            vc[t] = pc2[j];
+          }
+#pragma unroll
+          for (int t = 0; t < kRedChunk; t++) {
+#if defined(E4R_EXP) && E4R_EXP == 2
+            const double nx = acc + ((e0[t] + va[t]) + (e1[t] + vb[t]) + (e2[t] + vc[t])); // loads + 6 adds
+#elif defined(E4R_EXP) && E4R_EXP == 3
+            const double nx = acc + e0[t] * va[t]; // a third of the loads
+#else
+            const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
+            const double nx = acc + (b0 * va[t] + b1 * vb[t] + b2 * vc[t]);
+#endif
+            acc = jb + t < j1 ? nx : acc;
+          }
         }
         sm.gdC[12 * p + q] = acc;
       } else {
@@ -552,22 +640,15 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
             ooff = (s == sg) ? a : ooff;
             a += 6 * L.piece_nums[s] * (L.piece_nums[s] + 5);
           }
-          const double *MTb;
-          if (D.op_in_lds) {
-            MTb = sm.opMT + ooff;
-          } else {
-            MTb = D.opMT[0];
-            for (int s = 1; s < M; s++) MTb = (s == sg) ? D.opMT[s] : MTb;
-          }
-          const double *MT = MTb + (size_t)col * 6 * N;
           const double *gc = sm.gdC + 12 * p0 + d;
           const double *tInv = sm.seg + sg * 16 + 8;
-          int k = q; // r mod 6, stepped without a division
-#pragma unroll 6
-          for (int r = q; r < 6 * N; r += 4) {
-            acc += MT[r] * (gc[2 * r] * tInv[k]);
-            k += 4;
-            if (k >= 6) k -= 6;
+          const size_t coff = (size_t)col * 6 * N;
+          if (D.op_in_lds) {
+            acc = op_col_dot(sm.opMT + ooff + coff, gc, tInv, q, 6 * N);
+          } else {
+            const double *MTb = D.opMT[0];
+            for (int s = 1; s < M; s++) MTb = (s == sg) ? D.opMT[s] : MTb;
+            acc = op_col_dot((opg_t)MTb + coff, gc, tInv, q, 6 * N);
           }
         }
         acc += mov_dpp<0xB1>(acc);
