@@ -69,6 +69,10 @@ __host__ __device__ inline int chunk_points(const DevLayout &L, int T, int ppt) 
   return c < L.Npts ? c : ((L.Npts + 63) / 64) * 64;
 }
 
+// row stride of the per-point partial buffer: the x and y rows of a quantity are read together by the
+// transposed reduction, so consecutive rows start 8 banks apart instead of on the same bank
+__host__ __device__ inline int part_stride(const DevLayout &L, int T, int ppt) { return chunk_points(L, T, ppt) + 4; }
+
 __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T, int ppt, bool op_lds, bool cor_lds) {
   size_t n = 0;
   n += 5 * (size_t)L.npad;
@@ -78,7 +82,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   n += (size_t)L.rhs_tot * 2;
   n += 3 * (size_t)L.Ntot * 12;
   n += (size_t)L.rhs_tot * 2;
-  n += 8 * (size_t)chunk_points(L, T, ppt);
+  n += 8 * (size_t)part_stride(L, T, ppt);
   n += 4 * (size_t)L.Ntot;
   n += 3 * (size_t)mem;
   n += sNUM;
@@ -142,7 +146,7 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.c = p; p += L.Ntot * 12;
   s.gdC = p; p += L.Ntot * 12;
   s.adj = p; p += L.rhs_tot * 2;
-  s.part = p; p += 8 * chunk_points(L, T, ppt);
+  s.part = p; p += 8 * part_stride(L, T, ppt);
   s.pE = p; p += L.Ntot;
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
@@ -502,6 +506,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
 
   // ---- E4: penalty integral over the constraint points (traj_optimizer.cpp:486-779), in chunks
   const int chunk = chunk_points(L, T, D.ppt);
+  const int pstride = part_stride(L, T, D.ppt);
   for (int base = 0; base < Npts; base += chunk) {
     for (int r = 0; r < D.ppt; r++) {
       int loc = tid + r * T;
@@ -549,7 +554,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         for (int k = 0; k < 8; k++) o[k] = 0.0;
       }
 #pragma unroll
-      for (int k = 0; k < 8; k++) sm.part[k * chunk + loc] = o[k];
+      for (int k = 0; k < 8; k++) sm.part[k * pstride + loc] = o[k];
     }
     __syncthreads();
     pr.tick(kPE3S);
@@ -565,49 +570,62 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
       if (j1 <= j0) continue;
       if (q < 12) {
         int k = q >> 1, d = q & 1;
-        const double *pa = sm.part + (0 + d) * chunk + (pt0 - base);
-        const double *pb = sm.part + (2 + d) * chunk + (pt0 - base);
-        const double *pc2 = sm.part + (4 + d) * chunk + (pt0 - base);
+        const double *pa = sm.part + (0 + d) * pstride + (pt0 - base);
+        const double *pb = sm.part + (2 + d) * pstride + (pt0 - base);
+        const double *pc2 = sm.part + (4 + d) * pstride + (pt0 - base);
         // beta0[k] = s^k, beta1[k] = k s^(k-1), beta2[k] = k(k-1) s^(k-2): the same products as
         // traj_optimizer.cpp:505-507 (x1.0 and x0.0 are exact), read from the power table without branching
         const double *tab = sm.spow + (size_t)pc[2] * Kmax1 * 6;
         const int k1 = k >= 1 ? k - 1 : 0, k2 = k >= 2 ? k - 2 : 0;
         const double kd = (double)k, kkd = (double)(k * (k - 1));
         double acc = sm.gdC[12 * p + q]; // continue the chain that starts at the smoothness gradient
-        // batches of kRedChunk points: every LDS read of a batch is issued before the first add (slots past j1
-        // re-read the last point and are masked), the chain itself stays in point order
-#ifdef E4R_EXP
-        if (E4R_EXP == 1) j1 = j0; // timing experiment: no reduction at all
-#endif
-        for (int jb = j0; jb < j1; jb += kRedChunk) {
+        // batches of kRedChunk points: every LDS read of a batch is issued before the first add, the chain itself
+        // stays in point order.  A full batch uses constant offsets from one address per array, which lets the
+        // compiler pair the reads (ds_read2_b64: the cost here is per LDS instruction, ~14 cycles each); the last,
+        // partial batch re-reads its last point in the unused slots and masks them.
+        typedef const double __attribute__((address_space(3))) *lds_t;
+        const lds_t ek = (lds_t)(tab + k), ek1 = (lds_t)(tab + k1), ek2 = (lds_t)(tab + k2);
+        const lds_t la = (lds_t)pa, lb = (lds_t)pb, lc = (lds_t)pc2;
+        int jb = j0;
+        for (; jb + kRedChunk <= j1; jb += kRedChunk) {
           double e0[kRedChunk], e1[kRedChunk], e2[kRedChunk], va[kRedChunk], vb[kRedChunk], vc[kRedChunk];
 #pragma unroll
           for (int t = 0; t < kRedChunk; t++) {
-            const int j = jb + t < j1 ? jb + t : j1 - 1;
-            const double *e = tab + 6 * j;
-            e0[t] = e[k];
-            e1[t] = e[k1];
-            e2[t] = e[k2];
-            va[t] = pa[j];
-            vb[t] = pb[j];
-            vc[t] = pc2[j];
+            e0[t] = ek[6 * (jb + t)];
+            e1[t] = ek1[6 * (jb + t)];
+            e2[t] = ek2[6 * (jb + t)];
+            va[t] = la[jb + t];
+            vb[t] = lb[jb + t];
+            vc[t] = lc[jb + t];
           }
 #pragma unroll
           for (int t = 0; t < kRedChunk; t++) {
-#if defined(E4R_EXP) && E4R_EXP == 2
-            const double nx = acc + ((e0[t] + va[t]) + (e1[t] + vb[t]) + (e2[t] + vc[t])); // loads + 6 adds
-#elif defined(E4R_EXP) && E4R_EXP == 3
-            const double nx = acc + e0[t] * va[t]; // a third of the loads
-#else
+            const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
+            acc += b0 * va[t] + b1 * vb[t] + b2 * vc[t];
+          }
+        }
+        if (jb < j1) {
+          double e0[kRedChunk], e1[kRedChunk], e2[kRedChunk], va[kRedChunk], vb[kRedChunk], vc[kRedChunk];
+#pragma unroll
+          for (int t = 0; t < kRedChunk - 1; t++) {
+            const int j = jb + t < j1 ? jb + t : j1 - 1;
+            e0[t] = ek[6 * j];
+            e1[t] = ek1[6 * j];
+            e2[t] = ek2[6 * j];
+            va[t] = la[j];
+            vb[t] = lb[j];
+            vc[t] = lc[j];
+          }
+#pragma unroll
+          for (int t = 0; t < kRedChunk - 1; t++) {
             const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
             const double nx = acc + (b0 * va[t] + b1 * vb[t] + b2 * vc[t]);
-#endif
             acc = jb + t < j1 ? nx : acc;
           }
         }
         sm.gdC[12 * p + q] = acc;
       } else {
-        const double *pv = sm.part + (q == 12 ? 6 : 7) * chunk + (pt0 - base);
+        const double *pv = sm.part + (q == 12 ? 6 : 7) * pstride + (pt0 - base);
         double acc = q == 12 ? sm.pGdT[p] : sm.pCost[p];
 #pragma unroll 8
         for (int j = j0; j < j1; j++) acc += pv[j];

@@ -47,7 +47,10 @@ bt.solve_async(); bt.sync()
 t0 = time.perf_counter(); bt.solve_async(); bt.sync(); t_solve = time.perf_counter() - t0
 r = bt.results()
 t0 = time.perf_counter(); col, first = bt.validate(); t_val = time.perf_counter() - t0; k_val = h.corridor_last_ms()
-tot = t_fe + t_rs + t_up + t_cor + t_solve + t_val
+bt.sample_states(sample_dt=0.1, n_samples=8)
+t0 = time.perf_counter(); st, nv = bt.sample_states(sample_dt=0.1, n_samples=int(rd.max() / 0.1) + 2); t_rd = time.perf_counter() - t0
+k_rd = h.corridor_last_ms()
+tot = t_fe + t_rs + t_up + t_cor + t_solve + t_val + t_rd
 print("hypotheses %d (of %d searched, %d pieces), restarts %d -> B = %d trajectories, %d obstacles, map %s" %
       (len(grp), n_hyp, N, n_restarts, B, len(obs), grid.shape))
 print("  resampling of %d paths        %8.2f ms" % (n_hyp, 1e3 * t_fe))
@@ -58,4 +61,6 @@ print("  corridor of every hypothesis    %8.2f ms  (kernel %.2f ms, %.1f M recta
 print("  solve                           %8.2f ms  (%.0f solves/s, success %.3f, mean iterations %.0f)" %
       (1e3 * t_solve, B / t_solve, r["success"].mean(), r["iters"].mean()))
 print("  collision re-check              %8.2f ms  (kernel %.2f ms), colliding %d" % (1e3 * t_val, k_val, int(col.sum())))
+print("  read-out every 0.1 s            %8.2f ms  (kernel %.3f ms, %d states, %.0f MB to the host)" %
+      (1e3 * t_rd, k_rd, int(nv.sum()), st.nbytes / 1e6))
 print("  whole cycle                     %8.2f ms  -> %.0f planned trajectories/s" % (1e3 * tot, B / tot))
