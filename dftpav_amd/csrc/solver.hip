@@ -340,7 +340,7 @@ template <class P> __device__ __forceinline__ double op_row_dot(P Mrow, const do
     }
 #pragma unroll
     for (int j = 0; j < kOpChunk; j++) {
-      const double t = acc + mv[j] * rv[j];
+      const double t = fma_(mv[j], rv[j], acc);
       acc = c0 + j < ncol ? t : acc;
     }
   }
@@ -367,7 +367,7 @@ template <class P> __device__ __forceinline__ double op_col_dot(P MT, const doub
     }
 #pragma unroll
     for (int j = 0; j < kOpChunk; j++) {
-      const double t = acc + mv[j] * (gv[j] * tv[j]);
+      const double t = fma_(mv[j], gv[j] * tv[j], acc);
       acc = r0 + 4 * j < nrow ? t : acc;
     }
   }
@@ -601,7 +601,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
 #pragma unroll
           for (int t = 0; t < kRedChunk; t++) {
             const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
-            acc += b0 * va[t] + b1 * vb[t] + b2 * vc[t];
+            acc += fma_(b2, vc[t], fma_(b1, vb[t], b0 * va[t]));
           }
         }
         if (jb < j1) {
@@ -619,7 +619,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
 #pragma unroll
           for (int t = 0; t < kRedChunk - 1; t++) {
             const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
-            const double nx = acc + (b0 * va[t] + b1 * vb[t] + b2 * vc[t]);
+            const double nx = acc + fma_(b2, vc[t], fma_(b1, vb[t], b0 * va[t]));
             acc = jb + t < j1 ? nx : acc;
           }
         }
@@ -895,10 +895,16 @@ struct HistBlock {
   double ys, ri;
   double al[kLoopBlock]; // second loop: alpha of every step of the block (uniform)
 };
+// the three LDS arrays the recursion touches, as pointers that carry their address space (the recursion is an
+// out-of-line function: a generic pointer would turn every access into a flat one)
+typedef double __attribute__((address_space(3))) *lds_rw_t;
+struct LoopLds {
+  lds_rw_t ys, rinv, alpha;
+};
 // loads the block whose first step sits in slot `jl`, walking downwards (DIR = -1) or upwards (+1)
 // with wrap-around; unconditional loads from always-valid addresses, nothing consumes them here
 template <int DIR, bool LOOP2>
-__device__ __forceinline__ void load_block(HistBlock &R, const Smem &sm, gptr_t hS, gptr_t hY, gptr_t hB, int npad, int m, int ln,
+__device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr_t hS, gptr_t hY, gptr_t hB, int npad, int m, int ln,
                                            int lane, int &jl) {
   const int st = step_of_lane(lane);
   int js = jl + DIR * st; // |offset| < kLoopBlock <= m
@@ -929,7 +935,7 @@ __device__ __forceinline__ void pin_block(HistBlock &R) {
   for (int u = 0; u < kLoopBlock - 1; u++) asm volatile("" : "+v"(R.coef[u]));
 }
 template <int LV, bool FULL>
-__device__ __forceinline__ void first_loop_block(const HistBlock &R, const Smem &sm, int i0, int nb, int m, bool act, int lane,
+__device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopLds &sm, int i0, int nb, int m, bool act, int lane,
                                                  int &j, double &dreg) {
   double v[kLoopBlock];
 #pragma unroll
@@ -983,7 +989,7 @@ __device__ __forceinline__ void second_loop_block(const HistBlock &R, int i0, in
   }
 }
 template <int LV>
-__device__ __forceinline__ void first_loop_step(const HistBlock &R, const Smem &sm, int i0, int nb, int m, bool act, int lane,
+__device__ __forceinline__ void first_loop_step(const HistBlock &R, const LoopLds &sm, int i0, int nb, int m, bool act, int lane,
                                                 int &j, double &dreg) {
   if (i0 + kLoopBlock <= nb) first_loop_block<LV, true>(R, sm, i0, nb, m, act, lane, j, dreg);
   else if (i0 < nb) first_loop_block<LV, false>(R, sm, i0, nb, m, act, lane, j, dreg);
@@ -998,11 +1004,28 @@ __device__ __forceinline__ void second_loop_step(const HistBlock &R, int i0, int
 // the loads of block k+1 are in flight while block k is reduced, and no wait is
 // ever placed right after a load.  Only lanes below 2^LV take part (the trimmed butterfly leaves the
 // others with partial sums that are never used: their direction element is masked).
+//
+// Out of line on purpose: inlined into the solve kernel the recursion shares one register allocation with
+// the per-point evaluation, and an unrelated edit there moved spills into this loop (290 -> 386 cycles per
+// history step).  As a function it is allocated on its own.  Arguments arrive in vector registers; the
+// uniform ones are moved to scalar registers on entry.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T uni_ptr(T p) {
+  unsigned long long a = (unsigned long long)p;
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return (T)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ lds_rw_t uni_lds(lds_rw_t p) {
+  return (lds_rw_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)p);
+}
 template <int LV>
-__device__ __forceinline__ double two_loop_lane(const Smem &sm, const double *hS_, const double *hY_, const double *hU_,
-                                                const double *hV_, int npad, int n, int m, int nb, int ne, double ys_new,
-                                                double yy_new, int lane, double dreg) {
-  gptr_t hS = (gptr_t)hS_, hY = (gptr_t)hY_, hU = (gptr_t)hU_, hV = (gptr_t)hV_;
+__device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_t l_rinv, lds_rw_t l_alpha, gptr_t hS, gptr_t hY,
+                                                          gptr_t hU, gptr_t hV, int npad, int n, int m, int nb, int ne,
+                                                          double ys_new, double yy_new, int lane, double dreg) {
+  const LoopLds sm{uni_lds(l_ys), uni_lds(l_rinv), uni_lds(l_alpha)};
+  hS = uni_ptr(hS); hY = uni_ptr(hY); hU = uni_ptr(hU); hV = uni_ptr(hV);
+  npad = uni(npad); n = uni(n); m = uni(m); ne = uni(ne);
   const bool act = lane < n;
   const int ln = act ? lane : 0;
   nb = __builtin_amdgcn_readfirstlane(nb);
@@ -1318,7 +1341,8 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         }
         // the newest column was written by these same lanes: program order makes it visible to them
         double dreg = lane < n ? sm.d[lane] : 0.0;
-        dreg = two_loop_lane<LV>(sm, hS, hY, hU, hV, npad, n, m, bound, ne, ys, yy, lane, dreg);
+        dreg = two_loop_lane<LV>((lds_rw_t)sm.ys, (lds_rw_t)sm.rinv, (lds_rw_t)sm.alpha, (gptr_t)hS, (gptr_t)hY, (gptr_t)hU,
+                                 (gptr_t)hV, npad, n, m, bound, ne, ys, yy, lane, dreg);
         if (lane < n) sm.d[lane] = dreg;
       } else {
         int j = ne;

@@ -1,8 +1,9 @@
 // traj_math.h — the per-constraint-point mathematics of the solve path, written
 // once for host and device.
 //
-// Everything here is straight-line fp64 arithmetic built from + - * / sqrt and
-// comparisons only (transcendentals are the portable routines below, not libm),
+// Everything here is straight-line fp64 arithmetic built from + - * / sqrt, explicit
+// fused multiply-adds (fma_) and comparisons only (transcendentals are the portable
+// routines below, not libm),
 // evaluated in the written left-to-right order with floating-point contraction
 // disabled (-ffp-contract=off on both compilers).  gfx950 and x86-64 then
 // produce the same bits (scripts/ieee_probe.hip: sqrt, /, 1/x, a*b+c identical
@@ -26,6 +27,12 @@
 #endif
 
 namespace dftpav {
+
+// Fused multiply-add with a single rounding, written out where it is wanted: v_fma_f64 on gfx950 and the
+// correctly rounded fma of the host (hardware or libm) — a defined IEEE operation with the same result
+// everywhere, unlike compiler contraction, which stays off.  The per-point evaluation is made of
+// multiply-add pairs; fusing them removes a quarter of its instructions and shortens every dependent chain.
+DFTPAV_HD inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ------------------------------------------------------------ portable math
 DFTPAV_HD inline double p_abs(double x) { return x < 0.0 ? -x : x; }
@@ -210,8 +217,8 @@ DFTPAV_HD inline void smoothed_l1(double x, double &f, double &df) {
   const double d2c = 3.0 * f3c;
   const double d3c = 4.0 * f4c;
   if (x < pe) {
-    f = (f4c * x + f3c) * x * x * x;
-    df = (d3c * x + d2c) * x * x;
+    f = fma_(f4c, x, f3c) * x * x * x;
+    df = fma_(d3c, x, d2c) * x * x;
   } else {
     f = x - half;
     df = 1.0;
@@ -636,17 +643,17 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0};
   for (int k = 0; k < 6; k++) {
     double c0 = cc[2 * k], c1 = cc[2 * k + 1];
-    sigma[0] += c0 * beta0[k];
-    sigma[1] += c1 * beta0[k];
-    dsigma[0] += c0 * beta1[k];
-    dsigma[1] += c1 * beta1[k];
-    ddsigma[0] += c0 * beta2[k];
-    ddsigma[1] += c1 * beta2[k];
+    sigma[0] = fma_(c0, beta0[k], sigma[0]);
+    sigma[1] = fma_(c1, beta0[k], sigma[1]);
+    dsigma[0] = fma_(c0, beta1[k], dsigma[0]);
+    dsigma[1] = fma_(c1, beta1[k], dsigma[1]);
+    ddsigma[0] = fma_(c0, beta2[k], ddsigma[0]);
+    ddsigma[1] = fma_(c1, beta2[k], ddsigma[1]);
   }
   double omg = (j == 0 || j == K) ? 0.5 : 1.0;
-  double z_h0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
-  double z_h1 = ddsigma[0] * dsigma[0] + ddsigma[1] * dsigma[1];
-  double z_h3 = ddsigma[1] * dsigma[0] + (-ddsigma[0]) * dsigma[1];
+  double z_h0 = sqrt(fma_(dsigma[0], dsigma[0], dsigma[1] * dsigma[1]));
+  double z_h1 = fma_(ddsigma[0], dsigma[0], ddsigma[1] * dsigma[1]);
+  double z_h3 = fma_(ddsigma[1], dsigma[0], (-ddsigma[0]) * dsigma[1]);
   if (z_h0 < 1e-4 || (j == 0 && lp == 0) || (lp == N - 1 && j == K)) return; // traj_optimizer.cpp:550-553
   // sigma''' (traj_optimizer.cpp:508,519) only enters the gradients of the acceleration and curvature
   // penalties; its value does not depend on when it is evaluated, so it is formed only where one is active
@@ -661,14 +668,14 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double vel2_reci = 1.0 / (z_h0 * z_h0);
   // z^2 + 0.0 == z^2 exactly, so with help_eps == 0 (the live value, traj_manager.cpp:610) the second
   // reciprocal is the first one
-  double vel2_reci_e = in.epis == 0.0 ? vel2_reci : 1.0 / (z_h0 * z_h0 + in.epis);
+  double vel2_reci_e = in.epis == 0.0 ? vel2_reci : 1.0 / fma_(z_h0, z_h0, in.epis);
   double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);
   z_h0 = 1.0 / z_h0;
   double z_h4 = z_h1 * vel2_reci;
-  double violaVel = 1.0 / vel2_reci - max_vel * max_vel;
+  double violaVel = fma_(-max_vel, max_vel, 1.0 / vel2_reci);
   double acc2 = z_h1 * z_h1 * vel2_reci;
   double cur = z_h3 * vel3_2_reci_e;
-  double violaAcc = acc2 - max_acc * max_acc;
+  double violaAcc = fma_(-max_acc, max_acc, acc2);
   double violaCurL = cur - max_cur;
   double violaCurR = -cur - max_cur;
   double ego_R[4] = {singul_ * dsigma[0] * z_h0, singul_ * -dsigma[1] * z_h0, singul_ * dsigma[1] * z_h0,
@@ -677,7 +684,7 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   {
     double ta[4] = {ddsigma[0], -ddsigma[1], ddsigma[1], ddsigma[0]};
     double tv[4] = {dsigma[0], -dsigma[1], dsigma[1], dsigma[0]};
-    for (int k = 0; k < 4; k++) R_dot[k] = singul_ * (ta[k] * z_h0 - tv[k] * vel2_reci * z_h0 * z_h1);
+    for (int k = 0; k < 4; k++) R_dot[k] = singul_ * fma_(ta[k], z_h0, -(tv[k] * vel2_reci * z_h0 * z_h1));
   }
   double A[2] = {0, 0}, Bv[2] = {0, 0}, Cv[2] = {0, 0}, gdT = 0.0, cost = 0.0;
 
@@ -688,8 +695,8 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double Rle[4][2], bpt[4][2];
   for (int v = 0; v < 4; v++) {
     const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
-    Rle[v][0] = ego_R[0] * le0 + ego_R[1] * le1;
-    Rle[v][1] = ego_R[2] * le0 + ego_R[3] * le1;
+    Rle[v][0] = fma_(ego_R[0], le0, ego_R[1] * le1);
+    Rle[v][1] = fma_(ego_R[2], le0, ego_R[3] * le1);
     bpt[v][0] = sigma[0] + Rle[v][0];
     bpt[v][1] = sigma[1] + Rle[v][1];
   }
@@ -702,26 +709,26 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     plane(k, on0, on1, q0, q1);
     for (int vv = 0; vv < 5; vv++) {
       const int v = vv == 4 ? 0 : vv;
-      double violaPos = on0 * (bpt[v][0] - q0) + on1 * (bpt[v][1] - q1);
+      double violaPos = fma_(on0, bpt[v][0] - q0, on1 * (bpt[v][1] - q1));
       if (violaPos > 0) {
         const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
         double pena, penaD;
         smoothed_l1(violaPos, pena, penaD);
         double tl[4] = {le0, -le1, le1, le0};
         double Mm[4];
-        Mm[0] = singul_ * tl[0] * z_h0 - Rle[v][0] * dsigma[0] * vel2_reci;
-        Mm[1] = singul_ * tl[1] * z_h0 - Rle[v][0] * dsigma[1] * vel2_reci;
-        Mm[2] = singul_ * tl[2] * z_h0 - Rle[v][1] * dsigma[0] * vel2_reci;
-        Mm[3] = singul_ * tl[3] * z_h0 - Rle[v][1] * dsigma[1] * vel2_reci;
-        double w[2] = {dsigma[0] + (R_dot[0] * le0 + R_dot[1] * le1), dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1)};
-        double gradViolaPt = (alpha * on0) * w[0] + (alpha * on1) * w[1];
+        Mm[0] = fma_(singul_ * tl[0], z_h0, -(Rle[v][0] * dsigma[0] * vel2_reci));
+        Mm[1] = fma_(singul_ * tl[1], z_h0, -(Rle[v][0] * dsigma[1] * vel2_reci));
+        Mm[2] = fma_(singul_ * tl[2], z_h0, -(Rle[v][1] * dsigma[0] * vel2_reci));
+        Mm[3] = fma_(singul_ * tl[3], z_h0, -(Rle[v][1] * dsigma[1] * vel2_reci));
+        double w[2] = {dsigma[0] + fma_(R_dot[0], le0, R_dot[1] * le1), dsigma[1] + fma_(R_dot[2], le0, R_dot[3] * le1)};
+        double gradViolaPt = fma_(alpha * on0, w[0], (alpha * on1) * w[1]);
         double sc = omg * step * P.wei_obs * penaD;
-        A[0] += sc * on0;
-        A[1] += sc * on1;
-        Bv[0] += sc * (on0 * Mm[0] + on1 * Mm[2]);
-        Bv[1] += sc * (on0 * Mm[1] + on1 * Mm[3]);
-        gdT += omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
-        cost += omg * step * P.wei_obs * pena;
+        A[0] = fma_(sc, on0, A[0]);
+        A[1] = fma_(sc, on1, A[1]);
+        Bv[0] = fma_(sc, fma_(on0, Mm[0], on1 * Mm[2]), Bv[0]);
+        Bv[1] = fma_(sc, fma_(on0, Mm[1], on1 * Mm[3]), Bv[1]);
+        gdT = fma_(omg * P.wei_obs, fma_(penaD * gradViolaPt, step, pena / K), gdT);
+        cost = fma_(omg * step * P.wei_obs, pena, cost);
       }
     }
   }
@@ -742,67 +749,67 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     smoothed_l1(violaVel, pena, penaD);
     double gradViolaVt = 2.0 * alpha * z_h1;
     double sc = omg * step * P.wei_feas * penaD;
-    Bv[0] += sc * (2.0 * dsigma[0]);
-    Bv[1] += sc * (2.0 * dsigma[1]);
-    gdT += omg * P.wei_feas * (penaD * gradViolaVt * step + pena / K);
-    cost += omg * step * P.wei_feas * pena;
+    Bv[0] = fma_(sc, 2.0 * dsigma[0], Bv[0]);
+    Bv[1] = fma_(sc, 2.0 * dsigma[1], Bv[1]);
+    gdT = fma_(omg * P.wei_feas, fma_(penaD * gradViolaVt, step, pena / K), gdT);
+    cost = fma_(omg * step * P.wei_feas, pena, cost);
   }
   // ---- longitudinal acceleration, traj_optimizer.cpp:655-665
   if (violaAcc > 0.0) {
     double pena, penaD;
     smoothed_l1(violaAcc, pena, penaD);
-    double u0 = z_h4 * ddsigma[0] - z_h4 * z_h4 * dsigma[0];
-    double u1 = z_h4 * ddsigma[1] - z_h4 * z_h4 * dsigma[1];
+    double u0 = fma_(z_h4, ddsigma[0], -(z_h4 * z_h4 * dsigma[0]));
+    double u1 = fma_(z_h4, ddsigma[1], -(z_h4 * z_h4 * dsigma[1]));
     double ddd0 = 0.0, ddd1 = 0.0;
     for (int k = 0; k < 6; k++) {
-      ddd0 += cc[2 * k] * beta3[k];
-      ddd1 += cc[2 * k + 1] * beta3[k];
+      ddd0 = fma_(cc[2 * k], beta3[k], ddd0);
+      ddd1 = fma_(cc[2 * k + 1], beta3[k], ddd1);
     }
-    double z_h2 = ddd0 * dsigma[0] + ddd1 * dsigma[1];
-    double sqn = ddsigma[0] * ddsigma[0] + ddsigma[1] * ddsigma[1];
-    double gradViolaAt = 2.0 * alpha * (z_h4 * (sqn + z_h2) - z_h4 * z_h4 * z_h1);
+    double z_h2 = fma_(ddd0, dsigma[0], ddd1 * dsigma[1]);
+    double sqn = fma_(ddsigma[0], ddsigma[0], ddsigma[1] * ddsigma[1]);
+    double gradViolaAt = 2.0 * alpha * fma_(z_h4, sqn + z_h2, -(z_h4 * z_h4 * z_h1));
     double sc = omg * step * P.wei_feas * penaD;
-    Bv[0] += sc * (2.0 * u0);
-    Bv[1] += sc * (2.0 * u1);
-    Cv[0] += sc * (2.0 * z_h4 * dsigma[0]);
-    Cv[1] += sc * (2.0 * z_h4 * dsigma[1]);
-    gdT += omg * P.wei_feas * (penaD * gradViolaAt * step + pena / K);
-    cost += omg * step * P.wei_feas * pena;
+    Bv[0] = fma_(sc, 2.0 * u0, Bv[0]);
+    Bv[1] = fma_(sc, 2.0 * u1, Bv[1]);
+    Cv[0] = fma_(sc, 2.0 * z_h4 * dsigma[0], Cv[0]);
+    Cv[1] = fma_(sc, 2.0 * z_h4 * dsigma[1], Cv[1]);
+    gdT = fma_(omg * P.wei_feas, fma_(penaD * gradViolaAt, step, pena / K), gdT);
+    cost = fma_(omg * step * P.wei_feas, pena, cost);
   }
   // ---- curvature, two one-sided penalties weighted x10, traj_optimizer.cpp:684-705
   if (violaCurL > 0.0 || violaCurR > 0.0) {
-    double ku0 = vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0];
-    double ku1 = vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1];
+    double ku0 = fma_(vel3_2_reci_e, ddsigma[1], -(3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0]));
+    double ku1 = fma_(vel3_2_reci_e, -ddsigma[0], -(3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1]));
     double kw0 = -(vel3_2_reci_e * dsigma[1]);
     double kw1 = vel3_2_reci_e * dsigma[0];
     double ddd0 = 0.0, ddd1 = 0.0;
     for (int k = 0; k < 6; k++) {
-      ddd0 += cc[2 * k] * beta3[k];
-      ddd1 += cc[2 * k + 1] * beta3[k];
+      ddd0 = fma_(cc[2 * k], beta3[k], ddd0);
+      ddd1 = fma_(cc[2 * k + 1], beta3[k], ddd1);
     }
-    double z1 = ddd1 * dsigma[0] + (-ddd0) * dsigma[1];
-    double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
+    double z1 = fma_(ddd1, dsigma[0], (-ddd0) * dsigma[1]);
+    double kt = alpha * vel3_2_reci_e * fma_(-(3 * vel2_reci_e * z_h3), z_h1, z1);
     if (violaCurL > 0.0) {
       double pena, penaD;
       smoothed_l1(violaCurL, pena, penaD);
       double sc = omg * step * P.wei_feas * 10.0 * penaD;
-      Bv[0] += sc * ku0;
-      Bv[1] += sc * ku1;
-      Cv[0] += sc * kw0;
-      Cv[1] += sc * kw1;
-      gdT += omg * P.wei_feas * 10.0 * (penaD * kt * step + pena / K);
-      cost += omg * step * P.wei_feas * 10.0 * pena;
+      Bv[0] = fma_(sc, ku0, Bv[0]);
+      Bv[1] = fma_(sc, ku1, Bv[1]);
+      Cv[0] = fma_(sc, kw0, Cv[0]);
+      Cv[1] = fma_(sc, kw1, Cv[1]);
+      gdT = fma_(omg * P.wei_feas * 10.0, fma_(penaD * kt, step, pena / K), gdT);
+      cost = fma_(omg * step * P.wei_feas * 10.0, pena, cost);
     }
     if (violaCurR > 0.0) {
       double pena, penaD;
       smoothed_l1(violaCurR, pena, penaD);
       double sc = omg * step * P.wei_feas * 10.0 * penaD;
-      Bv[0] += sc * -ku0;
-      Bv[1] += sc * -ku1;
-      Cv[0] += sc * -kw0;
-      Cv[1] += sc * -kw1;
-      gdT += omg * P.wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
-      cost += omg * step * P.wei_feas * 10.0 * pena;
+      Bv[0] = fma_(sc, -ku0, Bv[0]);
+      Bv[1] = fma_(sc, -ku1, Bv[1]);
+      Cv[0] = fma_(sc, -kw0, Cv[0]);
+      Cv[1] = fma_(sc, -kw1, Cv[1]);
+      gdT = fma_(omg * P.wei_feas * 10.0, fma_(penaD * (-kt), step, pena / K), gdT);
+      cost = fma_(omg * step * P.wei_feas * 10.0, pena, cost);
     }
   }
   out[0] = A[0]; out[1] = A[1];

@@ -202,7 +202,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
     const double *Mrow = &D.opM[sg][(size_t)lr * (N + 5)];
     const double *rh = &D.rhs[2 * L.seg_rhs0[sg] + d];
     double acc = 0.0;
-    for (int col = 0; col < N + 5; col++) acc += Mrow[col] * rh[2 * col];
+    for (int col = 0; col < N + 5; col++) acc = fma_(Mrow[col], rh[2 * col], acc);
     D.b[w] = acc;
     D.c[w] = acc * D.seg[sg * 16 + 8 + k];
   }
@@ -266,7 +266,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
       for (int j = 0; j <= K; j++) {
         double b0, b1, b2;
         beta_row(k, tab[j], b0, b1, b2);
-        acc += b0 * pa[j] + b1 * pb[j] + b2 * pc[j];
+        acc += fma_(b2, pc[j], fma_(b1, pb[j], b0 * pa[j]));
       }
       D.gdC[12 * p + q] = acc;
     }
@@ -289,7 +289,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
     double part[4];
     for (int q = 0; q < 4; q++) {
       double acc = 0.0;
-      for (int r = q; r < 6 * N; r += 4) acc += MT[r] * (gc[2 * r] * tInv[r % 6]);
+      for (int r = q; r < 6 * N; r += 4) acc = fma_(MT[r], gc[2 * r] * tInv[r % 6], acc);
       part[q] = acc;
     }
     D.adj[w] = (part[0] + part[1]) + (part[2] + part[3]);
