@@ -700,11 +700,75 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     bpt[v][0] = sigma[0] + Rle[v][0];
     bpt[v][1] = sigma[1] + Rle[v][1];
   }
+  if (HU > 0) {
+    // The 5 H tests first, collected in a bit mask (bit 5 k + vv, the order of the reference's nested loops),
+    // then one pass over the set bits: on the GPU a lane only spends time on its own violated half-planes --
+    // as nested loops every one of the 20 bodies ran for the whole wave if a single lane needed it.
+    double pn0[HU > 0 ? HU : 1], pn1[HU > 0 ? HU : 1], pq0[HU > 0 ? HU : 1], pq1[HU > 0 ? HU : 1];
+    unsigned active = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-  for (int k = 0; k < (HU > 0 ? HU : in.H); k++) {
-    if (HU > 0 && k >= in.H) break;
+    for (int k = 0; k < HU; k++) {
+      pn0[k] = pn1[k] = pq0[k] = pq1[k] = 0.0;
+      if (k < in.H) {
+        plane(k, pn0[k], pn1[k], pq0[k], pq1[k]);
+        for (int vv = 0; vv < 5; vv++) {
+          const int v = vv == 4 ? 0 : vv;
+          const double violaPos = fma_(pn0[k], bpt[v][0] - pq0[k], pn1[k] * (bpt[v][1] - pq1[k]));
+          if (violaPos > 0) active |= 1u << (5 * k + vv);
+        }
+      }
+    }
+    while (active) {
+      const int bit = __builtin_ctz(active);
+      active &= active - 1;
+      const int k = (bit * 13) >> 6; // bit / 5 for bit < 32
+      const int vv = bit - 5 * k;
+      const int v = vv == 4 ? 0 : vv;
+      double on0 = pn0[0], on1 = pn1[0], q0 = pq0[0], q1 = pq1[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int t = 1; t < HU; t++) {
+        on0 = k == t ? pn0[t] : on0;
+        on1 = k == t ? pn1[t] : on1;
+        q0 = k == t ? pq0[t] : q0;
+        q1 = k == t ? pq1[t] : q1;
+      }
+      double bp0 = bpt[0][0], bp1 = bpt[0][1], rl0 = Rle[0][0], rl1 = Rle[0][1], le0 = P.vec_le[0][0], le1 = P.vec_le[0][1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int t = 1; t < 4; t++) {
+        bp0 = v == t ? bpt[t][0] : bp0;
+        bp1 = v == t ? bpt[t][1] : bp1;
+        rl0 = v == t ? Rle[t][0] : rl0;
+        rl1 = v == t ? Rle[t][1] : rl1;
+        le0 = v == t ? P.vec_le[t][0] : le0;
+        le1 = v == t ? P.vec_le[t][1] : le1;
+      }
+      const double violaPos = fma_(on0, bp0 - q0, on1 * (bp1 - q1)); // the same expression as in the test: > 0 here
+      double pena, penaD;
+      smoothed_l1(violaPos, pena, penaD);
+      double tl[4] = {le0, -le1, le1, le0};
+      double Mm[4];
+      Mm[0] = fma_(singul_ * tl[0], z_h0, -(rl0 * dsigma[0] * vel2_reci));
+      Mm[1] = fma_(singul_ * tl[1], z_h0, -(rl0 * dsigma[1] * vel2_reci));
+      Mm[2] = fma_(singul_ * tl[2], z_h0, -(rl1 * dsigma[0] * vel2_reci));
+      Mm[3] = fma_(singul_ * tl[3], z_h0, -(rl1 * dsigma[1] * vel2_reci));
+      double w[2] = {dsigma[0] + fma_(R_dot[0], le0, R_dot[1] * le1), dsigma[1] + fma_(R_dot[2], le0, R_dot[3] * le1)};
+      double gradViolaPt = fma_(alpha * on0, w[0], (alpha * on1) * w[1]);
+      double sc = omg * step * P.wei_obs * penaD;
+      A[0] = fma_(sc, on0, A[0]);
+      A[1] = fma_(sc, on1, A[1]);
+      Bv[0] = fma_(sc, fma_(on0, Mm[0], on1 * Mm[2]), Bv[0]);
+      Bv[1] = fma_(sc, fma_(on0, Mm[1], on1 * Mm[3]), Bv[1]);
+      gdT = fma_(omg * P.wei_obs, fma_(penaD * gradViolaPt, step, pena / K), gdT);
+      cost = fma_(omg * step * P.wei_obs, pena, cost);
+    }
+  } else {
+  for (int k = 0; k < in.H; k++) {
     double on0, on1, q0, q1;
     plane(k, on0, on1, q0, q1);
     for (int vv = 0; vv < 5; vv++) {
@@ -729,6 +793,7 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
         Bv[1] = fma_(sc, fma_(on0, Mm[1], on1 * Mm[3]), Bv[1]);
         gdT = fma_(omg * P.wei_obs, fma_(penaD * gradViolaPt, step, pena / K), gdT);
         cost = fma_(omg * step * P.wei_obs, pena, cost);
+        }
       }
     }
   }
