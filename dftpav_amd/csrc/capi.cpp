@@ -579,7 +579,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->h->device);
   (void)hipStreamSynchronize(b->h->stream);
-  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histY, b->d_histU, b->d_histV,
+  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histU, b->d_histV,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
                   b->d_queue, b->d_stragglers, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2};
@@ -711,11 +711,11 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMemset(b->d_corridor, 0, sizeof(double) * (size_t)B * L.H * 4 * b->NptsPad));
   BCHK(hipMalloc(&b->d_pt_piece, sizeof(int16_t) * L.Npts));
   BCHK(hipMalloc(&b->d_pt_j, sizeof(int16_t) * L.Npts));
-  BCHK(hipMalloc(&b->d_histS, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
-  BCHK(hipMalloc(&b->d_histY, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  // s and y of a stored pair are interleaved element by element: one 16-byte load fetches both (solver.hip, load_block)
+  BCHK(hipMalloc(&b->d_histS, sizeof(double) * 2 * (size_t)B * b->P.mem_size * L.npad));
+  b->d_histY = b->d_histS + 1; // alias into the same allocation, never freed on its own
   // never-written slots are read (and discarded) by the unconditional prefetch loads: keep them finite
-  BCHK(hipMemset(b->d_histS, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
-  BCHK(hipMemset(b->d_histY, 0, sizeof(double) * (size_t)B * b->P.mem_size * L.npad));
+  BCHK(hipMemset(b->d_histS, 0, sizeof(double) * 2 * (size_t)B * b->P.mem_size * L.npad));
   BCHK(hipMalloc(&b->d_histU, sizeof(double) * (size_t)B * b->P.mem_size * 8));
   BCHK(hipMalloc(&b->d_histV, sizeof(double) * (size_t)B * b->P.mem_size * 8));
   BCHK(hipMemset(b->d_histU, 0, sizeof(double) * (size_t)B * b->P.mem_size * 8));

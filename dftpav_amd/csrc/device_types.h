@@ -67,7 +67,7 @@ struct DevBatch {
   DevSurround sur;
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
-  double *histS, *histY; // [B][mem][npad]
+  double *histS, *histY; // one buffer [B][mem][npad][2]: (s, y) interleaved per element, histY == histS + 1
   // products of neighbouring stored pairs, [B][mem][8] (solver.hip, two_loop_lane):
   //   histU[j][d] = s_j . y_(the d+1-th pair after j),  histV[j][d] = y_j . s_(the d+1-th pair before j)
   double *histU, *histV;

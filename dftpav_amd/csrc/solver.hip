@@ -915,8 +915,13 @@ __device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr
   R.ri = sm.rinv[js];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) {
-    R.s[q] = hS[(size_t)jl * npad + ln];
-    R.y[q] = hY[(size_t)jl * npad + ln];
+    {
+      // element e of pair j is the double2 (s, y) at [(j * npad + e)]: one 16-byte load instead of two 8-byte ones
+      typedef double __attribute__((ext_vector_type(2))) d2_t;
+      const d2_t sy = *(const d2_t __attribute__((address_space(1))) *)(hS + ((size_t)jl * npad + ln) * 2);
+      R.s[q] = sy.x;
+      R.y[q] = sy.y;
+    }
     if (LOOP2) R.al[q] = sm.alpha[jl];
     if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
     else jl = jl == m - 1 ? 0 : jl + 1;
@@ -1277,19 +1282,20 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
   pr.tick(kPLS);
 
   // ---- history update + two-loop recursion (lbfgs.hpp:676-740)
-  double *hS = D.histS + (size_t)b * m * npad;
-  double *hY = D.histY + (size_t)b * m * npad;
+  // s and y of a pair are interleaved element by element (histY == histS + 1, element stride 2)
+  double *hS = D.histS + (size_t)b * m * npad * 2;
+  double *hY = hS + 1;
   const int end = sm.ist[iEND];
   int bound = sm.ist[iBOUND];
   {
-    double *sc = hS + (size_t)end * npad, *yc = hY + (size_t)end * npad;
+    double *sc = hS + (size_t)end * npad * 2, *yc = hY + (size_t)end * npad * 2;
     double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0, ylane = 0.0;
     for (int e = lane; e < n; e += 64) {
       double sv = sm.x[e] - sm.xp[e];
       double yv = sm.g[e] - sm.gp[e];
       ylane = yv; // n <= 64: this lane's only element
-      sc[e] = sv;
-      yc[e] = yv;
+      sc[2 * e] = sv;
+      yc[2 * e] = yv;
       ys += yv * sv;
       yy += yv * yv;
       ss += sv * sv;
@@ -1323,7 +1329,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
 #pragma unroll
           for (int dd = 0; dd < kLoopBlock - 1; dd++) {
             o = o == 0 ? m - 1 : o - 1;
-            sv[dd] = ((gptr_t)hS)[(size_t)o * npad + ln];
+            sv[dd] = ((gptr_t)hS)[((size_t)o * npad + ln) * 2];
           }
           o = end;
 #pragma unroll
@@ -1348,25 +1354,25 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         int j = ne;
         for (int i = 0; i < bound; ++i) {
           j = j == 0 ? m - 1 : j - 1;
-          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
+          const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
           double acc = 0.0;
-          for (int e = lane; e < n; e += 64) acc += sj[e] * sm.d[e];
+          for (int e = lane; e < n; e += 64) acc += sj[2 * e] * sm.d[e];
           acc = wave_sum<LV>(acc);
           double a = acc / sm.ys[j];
           if (lane == 0) sm.alpha[j] = a;
           double na = -a;
-          for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[e];
+          for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[2 * e];
         }
         double sc0 = ys / yy;
         for (int e = lane; e < n; e += 64) sm.d[e] *= sc0;
         for (int i = 0; i < bound; ++i) {
-          const double *sj = hS + (size_t)j * npad, *yj = hY + (size_t)j * npad;
+          const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
           double acc = 0.0;
-          for (int e = lane; e < n; e += 64) acc += yj[e] * sm.d[e];
+          for (int e = lane; e < n; e += 64) acc += yj[2 * e] * sm.d[e];
           acc = wave_sum<LV>(acc);
           double beta = acc / sm.ys[j];
           double cf = sm.alpha[j] - beta;
-          for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[e];
+          for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[2 * e];
           j = j == m - 1 ? 0 : j + 1;
         }
       }

@@ -14,7 +14,10 @@ for tag, env in [("plain", {"DFTPAV_SCHED": "0"}),
                  ("queue s96 h256", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "96"}),
                  ("queue s48 h512", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "512"}),
                  ("queue s48 h128", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "128"}),
-                 ("queue s48 h0", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "0"})]:
+                 ("queue s48 h0", {"DFTPAV_SCHED": "1", "DFTPAV_HANDOVER": "0"}),
+                 ("queue s32 h384", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "32", "DFTPAV_HANDOVER": "384"}),
+                 ("queue s64 h192", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "64", "DFTPAV_HANDOVER": "192"}),
+                 ("queue s48 h256 768 slots", {"DFTPAV_SCHED": "1", "DFTPAV_SLOTS": "768"})]:
     for k in ("DFTPAV_SCHED", "DFTPAV_SLICE", "DFTPAV_HANDOVER", "DFTPAV_SLOTS"):
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -26,5 +29,5 @@ for tag, env in [("plain", {"DFTPAV_SCHED": "0"}),
     r = bt.results()
     if ref is None: ref = r
     same = all(np.array_equal(r[k], ref[k]) for k in ("final_cost", "x", "iters", "evals", "status"))
-    print("%-16s kernel ms %s  solves/s %8.0f  identical to plain: %s" % (tag, np.round(ms, 1), B / (np.mean(ms) * 1e-3), same), flush=True)
+    print("%-26s kernel ms %s  solves/s %8.0f  identical to plain: %s" % (tag, np.round(ms, 1), B / (np.mean(ms) * 1e-3), same), flush=True)
     bt.close(); h.close()
