@@ -1288,14 +1288,19 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
   const int end = sm.ist[iEND];
   int bound = sm.ist[iBOUND];
   {
-    double *sc = hS + (size_t)end * npad * 2, *yc = hY + (size_t)end * npad * 2;
+    double *sc = hS + (size_t)end * npad * 2;
     double ys = 0.0, yy = 0.0, ss = 0.0, gpgp = 0.0, ylane = 0.0;
     for (int e = lane; e < n; e += 64) {
       double sv = sm.x[e] - sm.xp[e];
       double yv = sm.g[e] - sm.gp[e];
       ylane = yv; // n <= 64: this lane's only element
-      sc[2 * e] = sv;
-      yc[2 * e] = yv;
+      {
+        typedef double __attribute__((ext_vector_type(2))) d2_t;
+        d2_t sy;
+        sy.x = sv;
+        sy.y = yv;
+        *reinterpret_cast<d2_t *>(sc + 2 * e) = sy; // the pair as one 16-byte store (yc == sc + 1)
+      }
       ys += yv * sv;
       yy += yv * yv;
       ss += sv * sv;
