@@ -30,7 +30,7 @@ EXPORTS = [
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
-    "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
+    "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
 ]
 
 
@@ -337,6 +337,18 @@ class Batch:
     def solve(self):
         self.solve_async()
         return self.results()
+
+    def solve_chained(self, prev=None):
+        """Throughput mode for a stream of equally shaped batches (dftpav_batch_solve_chained): this batch's last
+        trajectories stay suspended for the next chained solve, `prev`'s are taken over and finished here."""
+        fn = lib().dftpav_batch_solve_chained
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        self.handle._check(fn(self._b, prev._b if prev is not None else None), "solve_chained")
+
+    def finish(self):
+        fn = lib().dftpav_batch_finish
+        fn.argtypes = [C.c_void_p]
+        self.handle._check(fn(self._b), "finish")
 
     def profile(self, enable=True):
         """Debug: switch the in-kernel phase profiler (thread 0 shader-clock deltas) on or off."""

@@ -40,6 +40,7 @@ hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, d
 hipError_t launch_states(const double *coeffs, const double *piece_dt, const DevLayout &L, int B, double wheel_base, double t0,
                          double sample_dt, int n_samples, int filter, double *states, int *n_valid, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
+hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream);
 }
 using namespace dftpav;
 
@@ -78,7 +79,9 @@ struct dftpav_batch {
   int slots = 0, slice = 0, hand_over = 0;
   int threads2 = 0, ppt2 = 0;
   bool op_in_lds2 = false, cor_in_lds2 = false;
-  int *d_queue = nullptr, *d_stragglers = nullptr, *d_sflag = nullptr, *d_iota = nullptr;
+  int *d_queue = nullptr, *d_stragglers = nullptr, *d_stragglers2 = nullptr, *d_sflag = nullptr, *d_iota = nullptr;
+  int qcap = 0;
+  bool pending = false; // a chained solve left this batch's stragglers for the next chained solve (or dftpav_batch_finish)
   unsigned *d_qctl = nullptr;
   double *d_state = nullptr;
   DevBatch *d_dev2 = nullptr;
@@ -582,7 +585,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histU, b->d_histV,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
-                  b->d_queue, b->d_stragglers, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2};
+                  b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < kMaxSeg; i++) {
@@ -735,8 +738,10 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_dev2, sizeof(DevBatch)));
   if (b->sched) {
     const size_t stride = (size_t)solver_state_doubles(L, b->P);
-    BCHK(hipMalloc(&b->d_queue, sizeof(int) * (size_t)B));
+    b->qcap = 2 * B; // own trajectories + the stragglers adopted from a previous batch of the same size
+    BCHK(hipMalloc(&b->d_queue, sizeof(int) * (size_t)b->qcap));
     BCHK(hipMalloc(&b->d_stragglers, sizeof(int) * (size_t)B));
+    BCHK(hipMalloc(&b->d_stragglers2, sizeof(int) * (size_t)B));
     BCHK(hipMalloc(&b->d_sflag, sizeof(int) * (size_t)B));
     BCHK(hipMalloc(&b->d_iota, sizeof(int) * (size_t)B));
     BCHK(hipMalloc(&b->d_qctl, sizeof(unsigned) * 16)); // [0..7] live counters, [8..15] their initial values
@@ -923,6 +928,8 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.queue = b->d_queue;
   D.qctl = b->d_qctl;
   D.stragglers = b->d_stragglers;
+  D.stragglers2 = b->d_stragglers2;
+  D.qcap = b->qcap;
   D.state = b->d_state;
   D.sflag = b->d_sflag;
   D.state_stride = solver_state_doubles(b->L, b->P);
@@ -988,28 +995,75 @@ extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, do
   return DFTPAV_OK;
 }
 
-extern "C" int dftpav_batch_solve_async(dftpav_batch *b) {
-  if (!b || !b->uploaded || !b->have_corridor) return DFTPAV_E_INVALID;
+// the follow-up launch of a scheduled solve: the stragglers in the latency shape
+static int launch_stragglers(dftpav_batch *b, const DevBatch &D, int source) {
+  dftpav_handle *h = b->h;
+  DevBatch D2 = D;
+  D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
+  D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
+  D2.ppt = b->ppt2;
+  HIPCHK(h, launch_solver(D2, b->d_dev2, kModeSolve, b->threads2, b->hand_over, SchedArgs{source, 0, 0, nullptr}, h->stream));
+  return DFTPAV_OK;
+}
+
+// a chained solve left the stragglers of `b` suspended: finish them now (no-op otherwise)
+static int finish_pending(dftpav_batch *b) {
+  if (!b->pending) return DFTPAV_OK;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
+  if (b->hand_over > 0)
+    if (int rc = launch_stragglers(b, D, 2)) return rc;
+  HIPCHK(h, hipEventRecord(b->ev1, h->stream));
+  b->pending = false;
+  return DFTPAV_OK;
+}
+
+static bool chain_compatible(const dftpav_batch *a, const dftpav_batch *b) {
+  return a->h == b->h && a->sched && b->sched && a->B == b->B && a->threads == b->threads && a->ppt == b->ppt &&
+         a->op_in_lds == b->op_in_lds && a->cor_in_lds == b->cor_in_lds && a->threads2 == b->threads2 && a->ppt2 == b->ppt2 &&
+         a->hand_over == b->hand_over && a->hand_over > 0 && a->NptsPad == b->NptsPad && a->prof_on == b->prof_on &&
+         std::memcmp(&a->L, &b->L, sizeof(DevLayout)) == 0 && std::memcmp(&a->P, &b->P, sizeof(DevParams)) == 0 &&
+         a->t_now == b->t_now && a->epis == b->epis;
+}
+
+static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
+  if (!b || !b->uploaded || !b->have_corridor || prev == b) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  b->pending = false; // a new solve of this batch supersedes whatever it had suspended
+  if (prev && prev->pending && !(chained && chain_compatible(b, prev)))
+    if (int rc = finish_pending(prev)) return rc;
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
   if (!b->sched) {
-    HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+    HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, h->stream));
   } else {
     // queue = all trajectories, flags cleared, counters reset: device-to-device, nothing waits on the host
     HIPCHK(h, hipMemcpyAsync(b->d_queue, b->d_iota, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(b->d_sflag, 0, sizeof(int) * (size_t)b->B, h->stream));
     HIPCHK(h, hipMemcpyAsync(b->d_qctl, b->d_qctl + 8, sizeof(unsigned) * 8, hipMemcpyDeviceToDevice, h->stream));
     const int grid = b->slots < b->B ? b->slots : b->B;
-    HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, grid, SchedArgs{1, b->slice, b->hand_over}, h->stream));
-    if (b->hand_over > 0) {
-      DevBatch D2 = D;
-      D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
-      D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
-      D2.ppt = b->ppt2;
-      HIPCHK(h, launch_solver(D2, b->d_dev2, kModeSolve, b->threads2, b->hand_over, SchedArgs{2, 0, 0}, h->stream));
+    const bool adopt = chained && prev && prev->pending;
+    if (adopt) {
+      DevBatch Dprev;
+      if (int rc = sync_dev(prev, Dprev)) return rc;
+      HIPCHK(h, launch_adopt(D, Dprev, h->stream));
+      HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, grid, SchedArgs{1, b->slice, b->hand_over, prev->d_dev}, h->stream));
+      // whatever of the adopted trajectories met this batch's end game: finished in the latency shape (normally none:
+      // the workgroups of this launch leave at once)
+      if (int rc = launch_stragglers(prev, Dprev, 3)) return rc;
+      HIPCHK(h, hipEventRecord(prev->ev1, h->stream));
+      prev->pending = false;
+    } else {
+      HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, grid, SchedArgs{1, b->slice, b->hand_over, nullptr}, h->stream));
+    }
+    if (chained && b->hand_over > 0) {
+      b->pending = true;
+    } else if (b->hand_over > 0) {
+      if (int rc = launch_stragglers(b, D, 2)) return rc;
     }
   }
   HIPCHK(h, hipEventRecord(b->ev1, h->stream));
@@ -1017,9 +1071,19 @@ extern "C" int dftpav_batch_solve_async(dftpav_batch *b) {
   return DFTPAV_OK;
 }
 
+extern "C" int dftpav_batch_solve_async(dftpav_batch *b) { return solve_impl(b, nullptr, false); }
+
+extern "C" int dftpav_batch_solve_chained(dftpav_batch *b, dftpav_batch *prev) { return solve_impl(b, prev, true); }
+
+extern "C" int dftpav_batch_finish(dftpav_batch *b) {
+  if (!b) return DFTPAV_E_INVALID;
+  return finish_pending(b);
+}
+
 extern "C" int dftpav_batch_sync(dftpav_batch *b) {
   if (!b) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
+  if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFTPAV_OK;
@@ -1039,6 +1103,7 @@ extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_co
   if (!b) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   const int B = b->B;
+  if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (x) HIPCHK(h, hipMemcpy(x, b->d_x_out, sizeof(double) * (size_t)B * b->L.n, hipMemcpyDeviceToHost));
@@ -1059,6 +1124,7 @@ extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_co
 extern "C" int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst) {
   if (!b || !device_dst) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
+  if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
   DevBatch D = make_dev(b);
   HIPCHK(h, launch_pack(D, device_dst, h->stream));
@@ -1069,6 +1135,7 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
   if (!b || !b->uploaded) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
@@ -1085,6 +1152,7 @@ extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double v
   if (!h->d_cells) return DFTPAV_E_INVALID; // no map
   HIPCHK(h, hipSetDevice(h->device));
   // coefficients and piece durations of the solutions, regenerated on the device from x (as dftpav_batch_coeffs)
+  if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
@@ -1134,6 +1202,7 @@ extern "C" int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sam
   if (!b || !b->uploaded || !b->timed || !(sample_dt > 0.0) || n_samples <= 0 || !states) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));

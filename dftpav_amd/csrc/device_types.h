@@ -74,7 +74,9 @@ struct DevBatch {
   // time-sliced scheduling of batches larger than the device holds at once (solver.hip, solver_kernel)
   int *queue;          // [B] ring of trajectories waiting for a workgroup
   unsigned *qctl;      // [0] head  [1] published tail  [2] reserved tail  [3] unfinished  [4] number of stragglers
-  int *stragglers;     // [B] trajectories handed to the follow-up launch
+  int *stragglers;     // [B] trajectories handed to the follow-up launch (count in qctl[4])
+  int *stragglers2;    // [B] adopted trajectories a chained launch could not finish (count in qctl[5])
+  int qcap;            // entries of `queue` (B own trajectories + room for adopted ones)
   double *state;       // [B][state_stride] solver state of a suspended trajectory
   int *sflag;          // [B] 0 fresh, 1 suspended (state valid), 2 finished
   int state_stride;
@@ -94,11 +96,14 @@ struct DevBatch {
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };
 
 // how a solve launch picks its trajectories
+constexpr int kAltTag = 1 << 30; // queue entry of a trajectory that belongs to SchedArgs::alt, not to the launched batch
 struct SchedArgs {
   int source;     // 0: workgroup i solves trajectory i   1: pops from DevBatch::queue until it is empty
-                  // 2: workgroup i resumes DevBatch::stragglers[i] (i < qctl[4])
+                  // 2: workgroup i resumes DevBatch::stragglers[i] (i < qctl[4])   3: ... stragglers2[i] (i < qctl[5])
   int slice;      // iterations after which an unfinished trajectory is suspended (source 1; 0 = never)
   int hand_over;  // source 1: once this few trajectories are unfinished, suspended ones go to `stragglers`
+  const DevBatch *alt; // source 1, chained solves: descriptor of the previous batch, whose stragglers sit in
+                       // this batch's queue tagged with kAltTag (same layout, parameters and launch shape)
 };
 // doubles of solver state per suspended trajectory
 inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { return 5 * L.npad + 24 + 8 + 2 * P.mem_size; }

@@ -375,7 +375,9 @@ template <class P> __device__ __forceinline__ double op_col_dot(P MT, const doub
 }
 
 template <bool SUR>
-__device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem &sm, const double *x, double *g, Prof &pr) {
+__device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_b, const Smem &sm, const double *x, double *g,
+                                           Prof &pr) {
+  // cor_b: half-planes of this trajectory, &corridor[b][0][0] of the batch it belongs to
   const DevLayout &L = D.L; // uniform accesses only (scalar loads)
   const DevParams &P = D.P;
   const int tid = threadIdx.x, T = blockDim.x;
@@ -532,7 +534,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, int b, const Smem 
         in.trajid = sg;
         in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
         in.t_now = D.t_now;
-        const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad + pt;
+        const double *cb = cor_b + pt;
         if (D.cor_in_lds) {
           LdsPlanes pl{(cor_l_t)(sm.cor + pt), (size_t)((Npts + 63) / 64 * 64)};
           if (L.H <= 4) sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
@@ -1022,7 +1024,11 @@ template <class T> __device__ __forceinline__ T uni_ptr(T p) {
   return (T)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ lds_rw_t uni_lds(lds_rw_t p) {
+#if defined(__HIP_DEVICE_COMPILE__) // LDS pointers are 32 bits wide on the device
   return (lds_rw_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)p);
+#else
+  return p;
+#endif
 }
 template <int LV>
 __device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_t l_rinv, lds_rw_t l_alpha, gptr_t hS, gptr_t hY,
@@ -1114,7 +1120,9 @@ __device__ __forceinline__ bool begin_iteration(const DevParams &P, const Smem &
 // search of lbfgs.hpp:312-389 unrolled into it).  Runs on wave 0, every lane computing the same
 // scalars from LDS; sets iACTION to kActEval (a new trial x is in sm.x) or kActDone.
 template <int LV>
-__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, int b, int lane, Prof &pr) {
+__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, double *hS_b, double *hU_b, double *hV_b, int lane,
+                                              Prof &pr) {
+  // hS_b / hU_b / hV_b: this trajectory's history blocks inside the batch it belongs to
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
   const double f = sm.st[sF];
@@ -1283,7 +1291,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
 
   // ---- history update + two-loop recursion (lbfgs.hpp:676-740)
   // s and y of a pair are interleaved element by element (histY == histS + 1, element stride 2)
-  double *hS = D.histS + (size_t)b * m * npad * 2;
+  double *hS = hS_b;
   double *hY = hS + 1;
   const int end = sm.ist[iEND];
   int bound = sm.ist[iBOUND];
@@ -1324,7 +1332,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       int ne = end + 1 == m ? 0 : end + 1;
       if (n <= 64 && m >= kLoopBlock) {
         // products of the new y with the s of the kLoopBlock-1 pairs before it (histU / histV)
-        double *hU = D.histU + (size_t)b * m * 8, *hV = D.histV + (size_t)b * m * 8;
+        double *hU = hU_b, *hV = hV_b;
         {
           const bool act = lane < n;
           const int ln = act ? lane : 0;
@@ -1459,7 +1467,15 @@ __device__ inline void state_io(const DevBatch &D, const Smem &sm, int b, int ti
 template <bool SUR, int LV, int MAXT>
 __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict__ Dp, int mode, SchedArgs sched) {
   extern __shared__ double lds_raw[];
-  const DevBatch &D = *Dp;
+  // D0: the launched batch (queue, launch shape, role tables).  Inside a pass D is the batch the trajectory of
+  // that pass belongs to -- D0, or for an adopted straggler of a chained solve the previous batch (sched.alt),
+  // which has the same layout, parameters and shape by construction (dftpav_batch_solve_chained checks).
+  const DevBatch &D0 = *Dp;
+  if (mode == kModeSolve && sched.source >= 2) { // list launches: one workgroup per list entry, the rest leave at once
+    const unsigned cnt = __hip_atomic_load(&D0.qctl[sched.source == 2 ? 4 : 5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x >= cnt) return;
+  }
+  const DevBatch &D = D0; // prologue only; shadowed per pass below
   const DevLayout &L = D.L;
   const int tid = threadIdx.x, T = blockDim.x;
   const int lane = tid & 63;
@@ -1530,36 +1546,41 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
       if (mode != kModeSolve || sched.source == 0) {
         id = pass == 0 ? (int)blockIdx.x : -1;
       } else if (sched.source == 1) {
-        id = queue_pop(D.qctl, D.queue, D.B);
+        id = queue_pop(D0.qctl, D0.queue, D0.qcap);
       } else if (pass == 0) {
-        unsigned cnt = __hip_atomic_load(&D.qctl[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x < cnt) {
-          id = D.stragglers[blockIdx.x];
-          __threadfence();
-        }
+        id = (sched.source == 2 ? D0.stragglers : D0.stragglers2)[blockIdx.x]; // blockIdx.x < count, checked on entry
+        __threadfence();
       }
       sm.ist[iCUR] = id;
     }
     __syncthreads();
-    const int b = sm.ist[iCUR];
-    if (b < 0) break;
+    const int cur = sm.ist[iCUR];
+    if (cur < 0) break;
+    const bool adopted = (cur & kAltTag) != 0;
+    const int b = cur & (kAltTag - 1);
+    // Db: the batch this trajectory's buffers live in.  Everything else (layout, parameters, launch shape,
+    // operators) is read from D0 = D, whose loads the compiler may keep in scalar registers across passes.
+    const DevBatch &Db = adopted ? *sched.alt : D0;
+    const double *cor_b = Db.corridor + (size_t)b * L.H * 4 * D.NptsPad;
+    double *hS_b = Db.histS + (size_t)b * D.P.mem_size * L.npad * 2;
+    double *hU_b = Db.histU + (size_t)b * D.P.mem_size * 8, *hV_b = Db.histV + (size_t)b * D.P.mem_size * 8;
     const long long tick0 = wall_clock64();
-    pr.start(D.prof != nullptr && mode == kModeSolve);
-    const bool resume = mode == kModeSolve && sched.source != 0 && D.sflag[b] == 1;
+    pr.start(Db.prof != nullptr && mode == kModeSolve);
+    const bool resume = mode == kModeSolve && sched.source != 0 && Db.sflag[b] == 1;
     __syncthreads(); // everybody has read iCUR before the state is restored over it
 
     // ---- per-trajectory staging: decision vector (or the suspended state) and half-planes
     if (resume) {
-      state_io(D, sm, b, tid, T, false);
+      state_io(Db, sm, b, tid, T, false);
     } else {
-      const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
+      const double *xsrc = (mode == kModeSolve) ? Db.x0 : (mode == kModeEval ? Db.x_in : Db.x_out);
       for (int e = tid; e < n; e += T) sm.x[e] = xsrc[(size_t)b * n + e];
       if (tid < iNUM) sm.ist[tid] = 0;
     }
     for (int w = tid; w < 12 * L.M; w += T)
-      sm.bnd[w] = w < 6 * L.M ? D.iniS[(size_t)b * L.M * 6 + w] : D.finS[(size_t)b * L.M * 6 + (w - 6 * L.M)];
+      sm.bnd[w] = w < 6 * L.M ? Db.iniS[(size_t)b * L.M * 6 + w] : Db.finS[(size_t)b * L.M * 6 + (w - 6 * L.M)];
     if (D.cor_in_lds) { // the only read of the corridor from HBM: it stays in LDS for the whole pass
-      const double *cb = D.corridor + (size_t)b * L.H * 4 * D.NptsPad;
+      const double *cb = Db.corridor + (size_t)b * L.H * 4 * D.NptsPad;
       const int pitch = (L.Npts + 63) / 64 * 64;
       for (int k = 0; k < 4 * L.H; k++)
         for (int pt = tid; pt < L.Npts; pt += T) sm.cor[k * pitch + pt] = cb[(size_t)k * D.NptsPad + pt];
@@ -1567,78 +1588,104 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     __syncthreads();
     const int k_start = sm.ist[iK];
 
-    block_eval<SUR>(D, b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
+    block_eval<SUR>(D, cor_b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
 
     if (mode == kModeEval) {
-      for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
-      if (tid == 0) D.f_out[b] = sm.st[sF];
+      for (int e = tid; e < n; e += T) Db.g_out[(size_t)b * n + e] = sm.g[e];
+      if (tid == 0) Db.f_out[b] = sm.st[sF];
       return;
     }
     if (mode == kModeCoeffs) {
-      for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
-      for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[sg * 16 + 1];
+      for (int w = tid; w < 12 * L.Ntot; w += T) Db.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
+      for (int sg = tid; sg < L.M; sg += T) Db.dt_out[(size_t)b * L.M + sg] = sm.seg[sg * 16 + 1];
       return;
     }
 
     // ---- lbfgs_optimize (lbfgs.hpp:440-751): wave 0 advances the solver state between evaluations
     bool finished = true;
     while (true) {
-      if (tid < 64) lbfgs_advance<LV>(D, sm, b, lane, pr);
+      if (tid < 64) lbfgs_advance<LV>(D, sm, hS_b, hU_b, hV_b, lane, pr);
       __syncthreads();
       if (sm.ist[iACTION] == kActDone) break;
       if (sched.source == 1 && sched.slice > 0 && sm.ist[iK] - k_start >= sched.slice) { // uniform
         finished = false;
         break;
       }
-      block_eval<SUR>(D, b, sm, sm.x, sm.g, pr);
+      block_eval<SUR>(D, cor_b, sm, sm.x, sm.g, pr);
     }
 
     const long long spent = wall_clock64() - tick0;
     if (finished) {
-      for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
+      for (int e = tid; e < n; e += T) Db.x_out[(size_t)b * n + e] = sm.x[e];
       if (tid == 0) {
         const double fx = sm.st[sFX];
         const int ret = sm.ist[iRET];
-        D.f_out[b] = fx;
-        D.status[b] = ret;
-        D.iters[b] = sm.ist[iK];
-        D.evals[b] = sm.ist[iEVALS];
-        D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
-        D.ticks[b] = (resume ? D.ticks[b] : 0) + spent; // time in service
+        Db.f_out[b] = fx;
+        Db.status[b] = ret;
+        Db.iters[b] = sm.ist[iK];
+        Db.evals[b] = sm.ist[iEVALS];
+        Db.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+        Db.ticks[b] = (resume ? Db.ticks[b] : 0) + spent; // time in service
         // flag_success, traj_optimizer.cpp:176-201
         int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
         if (fx >= D.P.fail_cost) ok = 0;
-        D.success[b] = ok;
+        Db.success[b] = ok;
         if (pr.on) {
-          for (int i = 0; i < 12; i++) D.prof[(size_t)b * 12 + i] = (resume ? D.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
+          for (int i = 0; i < 12; i++) Db.prof[(size_t)b * 12 + i] = (resume ? Db.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
         }
         if (sched.source != 0) {
-          D.sflag[b] = 2;
-          atomicSub(&D.qctl[3], 1u);
+          Db.sflag[b] = 2;
+          atomicSub(&Db.qctl[3], 1u);
         }
       }
     } else {
-      state_io(D, sm, b, tid, T, true);
+      state_io(Db, sm, b, tid, T, true);
       __syncthreads(); // all of the record is written (and fenced by thread 0 below) before the id is handed on
       if (tid == 0) {
-        D.ticks[b] = (resume ? D.ticks[b] : 0) + spent;
+        Db.ticks[b] = (resume ? Db.ticks[b] : 0) + spent;
         if (pr.on) {
-          for (int i = 0; i < 12; i++) D.prof[(size_t)b * 12 + i] = (resume ? D.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
+          for (int i = 0; i < 12; i++) Db.prof[(size_t)b * 12 + i] = (resume ? Db.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
         }
-        D.sflag[b] = 1;
-        unsigned left = __hip_atomic_load(&D.qctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Db.sflag[b] = 1;
+        // the end game is decided by the launched batch's own unfinished count; an adopted trajectory caught by
+        // it goes to its own batch's second list (finished by a list launch of that batch right after this one)
+        unsigned left = __hip_atomic_load(&D0.qctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (left <= (unsigned)sched.hand_over) {
           __threadfence();
-          unsigned slot = atomicAdd(&D.qctl[4], 1u);
-          D.stragglers[slot] = b;
+          if (adopted) {
+            unsigned slot = atomicAdd(&Db.qctl[5], 1u);
+            Db.stragglers2[slot] = b;
+          } else {
+            unsigned slot = atomicAdd(&Db.qctl[4], 1u);
+            Db.stragglers[slot] = b;
+          }
           __threadfence();
         } else {
-          queue_push(D.qctl, D.queue, D.B, b);
+          queue_push(D0.qctl, D0.queue, D0.qcap, cur);
         }
       }
     }
     if (mode != kModeSolve || sched.source != 1) break;
   }
+}
+
+// Chained solves: the stragglers the previous batch's queue launch left behind join the queue of the next
+// batch (tagged), so that the long tail of one batch is worked off inside the full-occupancy phase of the next
+// instead of on a nearly empty device.  One workgroup; runs between the queue reset and the queue launch.
+__global__ void adopt_kernel(unsigned *ctl, int *queue, int qcap, unsigned *prev_ctl, const int *prev_list) {
+  const unsigned cnt = prev_ctl[4], tail = ctl[1];
+  for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) queue[(tail + i) % (unsigned)qcap] = prev_list[i] | kAltTag;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ctl[1] = tail + cnt;
+    ctl[2] = tail + cnt;
+    prev_ctl[4] = 0; // consumed
+    prev_ctl[5] = 0; // the second list starts empty
+  }
+}
+hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream) {
+  hipLaunchKernelGGL(adopt_kernel, dim3(1), dim3(256), 0, stream, D.qctl, D.queue, D.qcap, prev.qctl, prev.stragglers);
+  return hipGetLastError();
 }
 
 // {f64 cost, i32 status, i32 iters} records for the all-gather of SURVEY §8(e)

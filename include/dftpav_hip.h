@@ -302,6 +302,19 @@ int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *st
                          int *success, int *iters, int *evals, long long *hist_sum,
                          double *latency_us);
 
+/* Chained solves: throughput mode for a stream of equally shaped batches (restarts of successive planning
+ * cycles).  The iteration counts of a batch are heavy-tailed: when its queue launch is down to the last
+ * trajectories, a plain solve finishes them on a nearly empty device.  dftpav_batch_solve_chained(b, prev) starts
+ * b like dftpav_batch_solve_async but (1) leaves b's own last trajectories suspended and (2) takes over the ones
+ * `prev` left suspended, so that they are worked off inside b's full-occupancy phase.  Results are bit-identical
+ * to a plain solve.  `prev` is complete when this call's work is (stream order); b is complete after the next
+ * chained solve that names it as `prev`, or after dftpav_batch_finish(b) -- which dftpav_batch_sync / _results /
+ * _pack_results / _coeffs / _validate / _sample_states call by themselves.  b and prev must be different batches
+ * of the same handle with the same layout, size, parameters and plan; otherwise (or with prev == NULL, or for
+ * batches too small to be scheduled) the call degrades to finishing prev and solving b unchained. */
+int dftpav_batch_solve_chained(dftpav_batch *b, dftpav_batch *prev);
+int dftpav_batch_finish(dftpav_batch *b);
+
 /* Multi-GPU hand-off: packs one 16-byte record {f64 final_cost, i32 status, i32 iters}
  * per trajectory into caller-owned DEVICE memory (asynchronously, on the handle's
  * stream) — the send buffer of the single all-gather of SURVEY §8(e). */

@@ -652,3 +652,69 @@ def test_wire_round_trip_feeds_the_solver(hiplib, oracle):
     bt3.close()
     h3.close()
     h2.close()
+
+
+def test_chained_solves_are_bit_identical(hiplib, oracle, monkeypatch):
+    """Throughput mode (dftpav_batch_solve_chained): the stragglers of one batch are worked off inside the queue
+    launch of the next.  Three different batches of the same shape through the chain, small slot / slice / hand-over
+    settings so that every path runs (adoption, adopted trajectories caught by the next end game, a final finish):
+    every result equals the plain solve bit for bit, and the oracle on a sample."""
+    monkeypatch.setenv("DFTPAV_SCHED", "1")
+    monkeypatch.setenv("DFTPAV_SLOTS", "8")
+    monkeypatch.setenv("DFTPAV_SLICE", "9")
+    monkeypatch.setenv("DFTPAV_HANDOVER", "6")
+    p = hiplib.default_params()
+    B = 40
+    scen = [sc.baseline_config(3, B=B, seed=20240 + 31 * k) for k in range(3)]
+    for s in scen:
+        s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    plain = []
+    for s in scen:
+        bt = hiplib.Batch(h, s.layout, B)
+        bt.upload(s)
+        plain.append(bt.solve())
+        bt.close()
+    bts = []
+    for s in scen:
+        bt = hiplib.Batch(h, s.layout, B)
+        bt.upload(s)
+        bts.append(bt)
+    bts[0].solve_chained(None)
+    bts[1].solve_chained(bts[0])
+    r0 = bts[0].results()          # complete: its stragglers were finished inside batch 1's launches
+    bts[2].solve_chained(bts[1])
+    r1 = bts[1].results()
+    r2 = bts[2].results()          # results() finishes the pending stragglers of the last batch
+    for got, ref in zip((r0, r1, r2), plain):
+        for k in keys:
+            assert np.array_equal(got[k], ref[k]), k
+    # the chain again over the same objects (their queues and lists are reused), ending with an explicit finish
+    bts[0].solve_chained(bts[2])   # bts[2] is no longer pending: degrades to an unchained start of the chain
+    bts[1].solve_chained(bts[0])
+    bts[1].finish()
+    for got, ref in zip((bts[0].results(), bts[1].results()), plain[:2]):
+        for k in keys:
+            assert np.array_equal(got[k], ref[k]), k
+    # a reader on a pending batch finishes it by itself
+    bts[2].solve_chained(None)
+    co, dts = bts[2].coeffs()
+    assert np.array_equal(bts[2].results()["x"], plain[2]["x"]) and np.isfinite(co).all()
+    # and the oracle agrees with what came through the chain
+    ro = oracle.solve_batch(p, scen[1].subset(np.arange(6)), order=1)
+    assert np.array_equal(r1["final_cost"][:6], ro["final_cost"]) and np.array_equal(r1["x"][:6], ro["x"])
+    # incompatible partner (another size): prev is finished first, then a plain chained start
+    s4 = sc.baseline_config(3, B=24, seed=5)
+    s4.apply_resolution(p)
+    b4 = hiplib.Batch(h, s4.layout, 24)
+    b4.upload(s4)
+    bts[0].solve_chained(None)
+    b4.solve_chained(bts[0])
+    assert np.array_equal(bts[0].results()["final_cost"], plain[0]["final_cost"])
+    ref4 = hiplib.Batch(h, s4.layout, 24)
+    ref4.upload(s4)
+    assert np.array_equal(b4.results()["x"], ref4.solve()["x"])
+    for bt in bts + [b4, ref4]:
+        bt.close()
+    h.close()
