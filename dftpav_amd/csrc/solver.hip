@@ -64,6 +64,14 @@ __host__ __device__ inline size_t op_doubles(const DevLayout &L) {
   for (int i = 0; i < L.M; i++) n += (size_t)6 * L.piece_nums[i] * (L.piece_nums[i] + 5);
   return n;
 }
+// The LDS copy of the transposed operator pads its rows by kOpTPad doubles: the adjoint reads 8 columns at the
+// same row index per instruction, and 6 N doubles is a multiple of the bank period for N = 16 or 32 (8-way conflict).
+constexpr int kOpTPad = 4;
+__host__ __device__ inline size_t opT_lds_doubles(const DevLayout &L) {
+  size_t n = 0;
+  for (int i = 0; i < L.M; i++) n += (size_t)(6 * L.piece_nums[i] + kOpTPad) * (L.piece_nums[i] + 5);
+  return n;
+}
 __host__ __device__ inline int chunk_points(const DevLayout &L, int T, int ppt) {
   int c = T * ppt;
   return c < L.Npts ? c : ((L.Npts + 63) / 64) * 64;
@@ -87,7 +95,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   n += 3 * (size_t)mem;
   n += sNUM;
   n += (size_t)L.M * 8;
-  if (op_lds) n += 2 * op_doubles(L);
+  if (op_lds) n += op_doubles(L) + opT_lds_doubles(L);
   if (cor_lds) n += (size_t)4 * L.H * (((size_t)L.Npts + 63) / 64 * 64);
   return n;
 }
@@ -161,7 +169,7 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   if (op_lds) {
     size_t nop = op_doubles(L);
     s.opMT = p + nop;
-    p += 2 * nop;
+    p += nop + opT_lds_doubles(L);
   }
   s.cor = p;
   if (cor_lds) p += (size_t)4 * L.H * ((L.Npts + 63) / 64 * 64);
@@ -654,17 +662,17 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
           int row = o >> 1, d = o & 1;
           const int *ri = sm.rowinfo + 4 * row;
           int sg = ri[0], col = ri[1], N = ri[2];
-          int p0 = 0, ooff = 0;
+          int p0 = 0, ooff = 0; // ooff: offset of the segment's operator inside the padded LDS copy
           for (int s = 0, a = 0; s < M; s++) {
             p0 = (s == sg) ? L.seg_piece0[s] : p0;
             ooff = (s == sg) ? a : ooff;
-            a += 6 * L.piece_nums[s] * (L.piece_nums[s] + 5);
+            a += (6 * L.piece_nums[s] + kOpTPad) * (L.piece_nums[s] + 5);
           }
           const double *gc = sm.gdC + 12 * p0 + d;
           const double *tInv = sm.seg + sg * 16 + 8;
           const size_t coff = (size_t)col * 6 * N;
           if (D.op_in_lds) {
-            acc = op_col_dot(sm.opMT + ooff + coff, gc, tInv, q, 6 * N);
+            acc = op_col_dot(sm.opMT + ooff + (size_t)col * (6 * N + kOpTPad), gc, tInv, q, 6 * N);
           } else {
             const double *MTb = D.opMT[0];
             for (int s = 1; s < M; s++) MTb = (s == sg) ? D.opMT[s] : MTb;
@@ -1527,14 +1535,16 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     ri[3] = x0;
   }
   if (D.op_in_lds) {
-    int off = 0;
+    int off = 0, offT = 0;
     for (int sg = 0; sg < L.M; sg++) {
-      int cnt = 6 * L.piece_nums[sg] * (L.piece_nums[sg] + 5);
+      const int N = L.piece_nums[sg], cnt = 6 * N * (N + 5);
       for (int i = tid; i < cnt; i += T) {
         sm.opM[off + i] = D.opM[sg][i];
-        sm.opMT[off + i] = D.opMT[sg][i];
+        const int col = i / (6 * N), r = i - col * 6 * N;
+        sm.opMT[offT + col * (6 * N + kOpTPad) + r] = D.opMT[sg][i];
       }
       off += cnt;
+      offT += (6 * N + kOpTPad) * (N + 5);
     }
   }
 
