@@ -275,9 +275,11 @@ def main():
             tc = time.perf_counter()
             rc = po.solve_batch(params, sub, nthreads=cores, order=0)
             wall = time.perf_counter() - tc
-            nd = min(32, shard.B)
-            rd = po.solve_batch(params, shard.subset(np.arange(nd)), nthreads=cores, order=1)
-            match = bool(np.array_equal(rd["final_cost"], r["final_cost"][:nd]) and np.array_equal(rd["x"], r["x"][:nd]))
+            nd = min(max(32, cores), shard.B)  # one trajectory per core: about one solve time of wall clock
+            pick = (np.arange(nd) * max(1, shard.B // nd)) % shard.B  # strided through the batch (restarts of all hypotheses)
+            rd = po.solve_batch(params, shard.subset(pick), nthreads=cores, order=1)
+            match = bool(np.array_equal(rd["final_cost"], r["final_cost"][pick]) and np.array_equal(rd["x"], r["x"][pick]) and
+                         np.array_equal(rd["iters"], r["iters"][pick]))
             out["cpu_baseline"] = {"value": ns / wall, "unit": "solves/s", "cores": cores, "kind": "port",
                                    "sample": "%d trajectories of the same batch (4 per core), literal-order oracle "
                                              "(fp64 restatement of traj_optimizer.cpp/lbfgs.hpp), OpenMP over "
@@ -288,7 +290,7 @@ def main():
             r1 = po.solve_batch(params, shard.subset((np.arange(16) * max(1, shard.B // 16) + 17) % shard.B), nthreads=1, order=0)
             out["cpu_baseline"]["single_thread_p50_ms_per_solve"] = float(np.median(r1["seconds"])) * 1e3
             out["cpu_baseline"]["single_thread_p95_ms_per_solve"] = float(np.percentile(r1["seconds"], 95)) * 1e3
-            out["parity"] = {"device_order_oracle_bit_exact_on_first_%d" % nd: match}
+            out["parity"] = {"device_order_oracle_bit_exact_on_%d_sampled" % nd: match}
         print(json.dumps(out), flush=True)
     for b_ in bts:
         b_.close()
