@@ -207,6 +207,11 @@ def main():
                 b2.close(); h2.close()
                 return {"batch": B, "solves_per_s": B / (float(np.mean(ms)) * 1e-3), "kernel_ms": float(np.mean(ms)),
                         "p50_ms_per_solve": float(np.median(r2["latency_us"])) * 1e-3, "mean_iters": float(r2["iters"].mean())}
+            # the same batch as isolated solves (no chaining: its tail runs on a nearly empty device)
+            iso = []
+            for _ in range(3):
+                bt.solve_async(); bt.sync(); iso.append(bt.last_solve_ms())
+            out["isolated"] = {"batch": int(shard.B), "kernel_ms": float(np.mean(iso)), "solves_per_s": shard.B / (float(np.mean(iso)) * 1e-3)}
             out["batch256"] = side(3, 256, 3)
             # one gear-shift trajectory alone on the GPU: the solver is chaotic (an instance needs 90 or 340 iterations
             # depending on the last bit), so the latency is quoted as the median over 9 seeded instances, with the
