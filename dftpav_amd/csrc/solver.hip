@@ -570,6 +570,65 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
     pr.tick(kPE3S);
     // transposed reduction, 16 threads per piece: 12 chain (A,B,C) onto gdC, 2 more chain gdT and cost
     int lim = base + chunk < Npts ? base + chunk : Npts;
+    // Narrow workgroups (the throughput shape, 128 threads): 8 lanes per piece instead, lane k < 6 chaining both
+    // dimensions of row k -- the three powers of a point are read once for x and y (9 LDS reads per point and two
+    // outputs instead of 12), and 16 pieces fit one pass.  Every chain is the same sequence of additions as below.
+    if (T <= 128) {
+      for (int w = tid; w < 8 * Ntot; w += T) {
+        const int p = w >> 3, q = w & 7;
+        const int *pc = sm.pcinfo + 8 * p;
+        const int pt0 = pc[0], K = pc[1];
+        const int j0 = base > pt0 ? base - pt0 : 0;
+        const int j1 = (pt0 + K + 1 < lim ? pt0 + K + 1 : lim) - pt0; // exclusive
+        if (j1 <= j0) continue;
+        typedef const double __attribute__((address_space(3))) *lds_t;
+        if (q < 6) {
+          const int k = q;
+          const double *tab = sm.spow + (size_t)pc[2] * Kmax1 * 6;
+          const int k1 = k >= 1 ? k - 1 : 0, k2 = k >= 2 ? k - 2 : 0;
+          const double kd = (double)k, kkd = (double)(k * (k - 1));
+          const lds_t ek = (lds_t)(tab + k), ek1 = (lds_t)(tab + k1), ek2 = (lds_t)(tab + k2);
+          const lds_t a0 = (lds_t)(sm.part + 0 * pstride + (pt0 - base)), a1 = (lds_t)(sm.part + 1 * pstride + (pt0 - base));
+          const lds_t b0p = (lds_t)(sm.part + 2 * pstride + (pt0 - base)), b1p = (lds_t)(sm.part + 3 * pstride + (pt0 - base));
+          const lds_t c0 = (lds_t)(sm.part + 4 * pstride + (pt0 - base)), c1 = (lds_t)(sm.part + 5 * pstride + (pt0 - base));
+          double accx = sm.gdC[12 * p + 2 * k], accy = sm.gdC[12 * p + 2 * k + 1];
+          constexpr int RC = 8;
+          int jb = j0;
+          for (; jb + RC <= j1; jb += RC) {
+            double e0[RC], e1[RC], e2[RC], ax[RC], ay[RC], bx[RC], by[RC], cx[RC], cy[RC];
+#pragma unroll
+            for (int t = 0; t < RC; t++) {
+              e0[t] = ek[6 * (jb + t)];
+              e1[t] = ek1[6 * (jb + t)];
+              e2[t] = ek2[6 * (jb + t)];
+              ax[t] = a0[jb + t]; ay[t] = a1[jb + t];
+              bx[t] = b0p[jb + t]; by[t] = b1p[jb + t];
+              cx[t] = c0[jb + t]; cy[t] = c1[jb + t];
+            }
+#pragma unroll
+            for (int t = 0; t < RC; t++) {
+              const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
+              accx += fma_(b2, cx[t], fma_(b1, bx[t], b0 * ax[t]));
+              accy += fma_(b2, cy[t], fma_(b1, by[t], b0 * ay[t]));
+            }
+          }
+          for (; jb < j1; jb++) { // at most RC - 1 points
+            const double b0 = ek[6 * jb], b1 = kd * ek1[6 * jb], b2 = kkd * ek2[6 * jb];
+            accx += fma_(b2, c0[jb], fma_(b1, b0p[jb], b0 * a0[jb]));
+            accy += fma_(b2, c1[jb], fma_(b1, b1p[jb], b0 * a1[jb]));
+          }
+          sm.gdC[12 * p + 2 * k] = accx;
+          sm.gdC[12 * p + 2 * k + 1] = accy;
+        } else {
+          const double *pv = sm.part + q * pstride + (pt0 - base); // row 6: gdT, row 7: cost
+          double acc = q == 6 ? sm.pGdT[p] : sm.pCost[p];
+#pragma unroll 8
+          for (int j = j0; j < j1; j++) acc += pv[j];
+          if (q == 6) sm.pGdT[p] = acc;
+          else sm.pCost[p] = acc;
+        }
+      }
+    } else
     for (int w = tid; w < 16 * Ntot; w += T) {
       int p = w >> 4, q = w & 15;
       if (q >= 14) continue;
