@@ -354,6 +354,33 @@ template <class P> __device__ __forceinline__ double op_row_dot(P Mrow, const do
   }
   return acc;
 }
+// the same row against both dimensions of the right-hand side (rh[2 col], rh[2 col + 1]): the operator values
+// are fetched once for the two sums
+template <class P> __device__ __forceinline__ void op_row_dot2(P Mrow, const double *rh, int ncol, double &ax, double &ay) {
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int c0 = 0; c0 < ncol; c0 += kOpChunk) {
+    double mv[kOpChunk], r0[kOpChunk], r1[kOpChunk];
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int col = c0 + j < ncol ? c0 + j : ncol - 1;
+      mv[j] = Mrow[col];
+    }
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int col = c0 + j < ncol ? c0 + j : ncol - 1;
+      r0[j] = rh[2 * col];
+      r1[j] = rh[2 * col + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const double t0 = fma_(mv[j], r0[j], acc0), t1 = fma_(mv[j], r1[j], acc1);
+      acc0 = c0 + j < ncol ? t0 : acc0;
+      acc1 = c0 + j < ncol ? t1 : acc1;
+    }
+  }
+  ax = acc0;
+  ay = acc1;
+}
 // lane q of a quad sums rows q, q + 4, q + 8, ... of one operator column against gc[2 r] * tInv[r mod 6]
 template <class P> __device__ __forceinline__ double op_col_dot(P MT, const double *gc, const double *tInv, int q, int nrow) {
   double acc = 0.0;
@@ -477,7 +504,34 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
   pr.tick(kPE1);
 
   // ---- E2: b = A^{-1} rhs (dense operator), c = b * t^-k   (MinJerkOpt::generate, poly_traj_utils.hpp:979-984)
-  // 16 threads per piece, 12 of them active: (row k, dimension d)
+  // 16 threads per piece, 12 of them active: (row k, dimension d); narrow workgroups: 8 per piece, 6 active, a
+  // thread forms both dimensions of its row from one fetch of the operator values (one pass for 16 pieces)
+  if (T <= 128) {
+    for (int w = tid; w < 8 * Ntot; w += T) {
+      const int p = w >> 3, k = w & 7;
+      if (k < 6) {
+        const int *pc = sm.pcinfo + 8 * p;
+        const int sg = pc[3], lp = pc[4], N = pc[5];
+        int r0 = 0; // first RHS row of the segment
+        for (int s = 0; s < M; s++) r0 = (s == sg) ? L.seg_rhs0[s] : r0;
+        const double *rh = sm.rhs + 2 * r0;
+        const size_t roff = (size_t)(6 * lp + k) * (N + 5);
+        double ax, ay;
+        if (D.op_in_lds) {
+          op_row_dot2(sm.opM + pc[7] + roff, rh, N + 5, ax, ay);
+        } else {
+          const double *Mop = D.opM[0];
+          for (int s = 1; s < M; s++) Mop = (s == sg) ? D.opM[s] : Mop;
+          op_row_dot2((opg_t)Mop + roff, rh, N + 5, ax, ay);
+        }
+        const double tk = sm.seg[sg * 16 + 8 + k];
+        sm.b[12 * p + 2 * k] = ax;
+        sm.b[12 * p + 2 * k + 1] = ay;
+        sm.c[12 * p + 2 * k] = ax * tk;
+        sm.c[12 * p + 2 * k + 1] = ay * tk;
+      }
+    }
+  } else
   for (int w = tid; w < 16 * Ntot; w += T) {
     int p = w >> 4, q = w & 15;
     if (q < 12) {
