@@ -409,6 +409,38 @@ template <class P> __device__ __forceinline__ double op_col_dot(P MT, const doub
   return acc;
 }
 
+// the same column against both dimensions of the gradient (gc[2 r], gc[2 r + 1])
+template <class P>
+__device__ __forceinline__ void op_col_dot2(P MT, const double *gc, const double *tInv, int q, int nrow, double &ax, double &ay) {
+  double acc0 = 0.0, acc1 = 0.0;
+  for (int r0 = q; r0 < nrow; r0 += 4 * kOpChunk) {
+    double mv[kOpChunk], g0[kOpChunk], g1[kOpChunk], tv[kOpChunk];
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
+      mv[j] = MT[r];
+    }
+    int k = r0 % 6;
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
+      g0[j] = gc[2 * r];
+      g1[j] = gc[2 * r + 1];
+      tv[j] = tInv[k];
+      k += 4;
+      if (k >= 6) k -= 6;
+    }
+#pragma unroll
+    for (int j = 0; j < kOpChunk; j++) {
+      const double t0 = fma_(mv[j], g0[j] * tv[j], acc0), t1 = fma_(mv[j], g1[j] * tv[j], acc1);
+      acc0 = r0 + 4 * j < nrow ? t0 : acc0;
+      acc1 = r0 + 4 * j < nrow ? t1 : acc1;
+    }
+  }
+  ax = acc0;
+  ay = acc1;
+}
+
 template <bool SUR>
 __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_b, const Smem &sm, const double *x, double *g,
                                            Prof &pr) {
@@ -765,14 +797,17 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
   // next wave: chain-rule duration terms per piece, summed per segment by a 64-lane butterfly
   // next wave: the other per-piece quantities (jerk energy, penalty cost, gdT parts), same butterfly
   {
-    const int n_out = 2 * rhs_tot;
+    // narrow workgroups: a quad forms both dimensions of its row from one fetch of the operator column, which
+    // halves the quads (one pass of 128 threads for 21 rows) and leaves one light task per wave for the second pass
+    const bool both = T <= 128;
+    const int n_out = both ? rhs_tot : 2 * rhs_tot;
     const int span = ((4 * n_out + 63) >> 6) << 6; // whole waves: the quad butterfly needs all 4 lanes alive
     for (int w = tid; w < span + 128; w += T) {
       if (w < span) {
         int o = w >> 2, q = w & 3;
-        double acc = 0.0;
+        double acc = 0.0, acc2 = 0.0;
         if (o < n_out) {
-          int row = o >> 1, d = o & 1;
+          int row = both ? o : o >> 1, d = both ? 0 : o & 1;
           const int *ri = sm.rowinfo + 4 * row;
           int sg = ri[0], col = ri[1], N = ri[2];
           int p0 = 0, ooff = 0; // ooff: offset of the segment's operator inside the padded LDS copy
@@ -784,7 +819,15 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
           const double *gc = sm.gdC + 12 * p0 + d;
           const double *tInv = sm.seg + sg * 16 + 8;
           const size_t coff = (size_t)col * 6 * N;
-          if (D.op_in_lds) {
+          if (both) {
+            if (D.op_in_lds) {
+              op_col_dot2(sm.opMT + ooff + (size_t)col * (6 * N + kOpTPad), gc, tInv, q, 6 * N, acc, acc2);
+            } else {
+              const double *MTb = D.opMT[0];
+              for (int s = 1; s < M; s++) MTb = (s == sg) ? D.opMT[s] : MTb;
+              op_col_dot2((opg_t)MTb + coff, gc, tInv, q, 6 * N, acc, acc2);
+            }
+          } else if (D.op_in_lds) {
             acc = op_col_dot(sm.opMT + ooff + (size_t)col * (6 * N + kOpTPad), gc, tInv, q, 6 * N);
           } else {
             const double *MTb = D.opMT[0];
@@ -794,7 +837,16 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         }
         acc += mov_dpp<0xB1>(acc);
         acc += mov_dpp<0x4E>(acc);
-        if (o < n_out && q == 0) sm.adj[o] = acc;
+        if (both) {
+          acc2 += mov_dpp<0xB1>(acc2);
+          acc2 += mov_dpp<0x4E>(acc2);
+          if (o < n_out && q == 0) {
+            sm.adj[2 * o] = acc;
+            sm.adj[2 * o + 1] = acc2;
+          }
+        } else if (o < n_out && q == 0) {
+          sm.adj[o] = acc;
+        }
       } else if (w < span + 64) {
         int ln = w - span;
         for (int sg = 0; sg < M; sg++) {
