@@ -463,40 +463,25 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         int sg = ri[0], col = ri[1], N = ri[2];
         double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
         double dt = Tr / N;
-        double v;
-        if (col < 3) { // head p, v*dt, a*dt^2 (poly_traj_utils.hpp:969-971), junction override traj_optimizer.cpp:273-277
-          if (col == 0) {
-            v = sg > 0 ? x[L.x_gear0 + 2 * (sg - 1) + d] : iniS[sg * 6 + d];
-          } else if (col == 1) {
-            double hv;
-            if (sg > 0) {
-              double th = x[L.x_ang0 + sg - 1];
-              hv = d == 0 ? -P.non_sinv * p_cos(th) : -P.non_sinv * p_sin(th);
-            } else {
-              hv = iniS[sg * 6 + 2 + d];
-            }
-            v = hv * dt;
-          } else {
-            v = iniS[sg * 6 + 4 + d] * (dt * dt);
-          }
-        } else if (col < N + 2) {
-          v = x[ri[3] + 2 * (col - 3) + d]; // ri[3] = offset of the segment's waypoints inside x
-        } else { // tail, poly_traj_utils.hpp:975-977, junction override traj_optimizer.cpp:278-282
-          int k = col - (N + 2);
-          if (k == 0) {
-            v = sg < M - 1 ? x[L.x_gear0 + 2 * sg + d] : finS[sg * 6 + d];
-          } else if (k == 1) {
-            double tv;
-            if (sg < M - 1) {
-              double th = x[L.x_ang0 + sg];
-              tv = d == 0 ? P.non_sinv * p_cos(th) : P.non_sinv * p_sin(th);
-            } else {
-              tv = finS[sg * 6 + 2 + d];
-            }
-            v = tv * dt;
-          } else {
-            v = finS[sg * 6 + 4 + d] * (dt * dt);
-          }
+        // Every entry is one stored value (a waypoint or junction position from x, or a boundary state) times
+        // 1, dt or dt^2 (poly_traj_utils.hpp:968-977), so it is formed without branching: the lanes of a wave hold
+        // all kinds of rows and a branch per kind serialises them (each with its own LDS round trip).  x * 1.0 is x.
+        // Only the junction velocities of a gear shift (traj_optimizer.cpp:273-282) keep a branch: they need cos / sin.
+        const bool head = col < 3, tail = col >= N + 2;
+        const int k = head ? col : (tail ? col - (N + 2) : 0);
+        const bool junction = (head && sg > 0) || (tail && sg < M - 1);
+        const bool from_x = (!head && !tail) || (k == 0 && junction);
+        int ix = head ? L.x_gear0 + 2 * (sg - 1) + d : (tail ? L.x_gear0 + 2 * sg + d : ri[3] + 2 * (col - 3) + d);
+        ix = from_x ? ix : 0; // ri[3] = offset of the segment's waypoints inside x
+        const int ib = (tail ? 6 * M : 0) + sg * 6 + 2 * k + d; // sm.bnd: iniS of every segment, then finS
+        const double xv = x[ix], bv = sm.bnd[ib];
+        const double scale = k == 0 ? 1.0 : (k == 1 ? dt : dt * dt);
+        double v = (from_x ? xv : bv) * scale;
+        if (k == 1 && junction) {
+          const double th = x[L.x_ang0 + (head ? sg - 1 : sg)];
+          const double hv = head ? (d == 0 ? -P.non_sinv * p_cos(th) : -P.non_sinv * p_sin(th))
+                                 : (d == 0 ? P.non_sinv * p_cos(th) : P.non_sinv * p_sin(th));
+          v = hv * dt;
         }
         sm.rhs[w] = v;
       } else {

@@ -5,7 +5,7 @@ import numpy as np
 from dftpav_amd import capi, scenarios as sc
 
 NAMES = ["E1 rhs", "E2 coeffs", "E3+E4 samples", "E4 reduce", "E5 adjoint", "E6 assemble", "line search misc",
-         "history update", "two-loop", "-", "init", "-"]
+         "history update", "two-loop", "x (experiments)", "init", "misc (experiments)"]
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 p = capi.default_params()
@@ -28,9 +28,9 @@ ghz = tot / (r["latency_us"] * 1e3)
 print("shader clock GHz (cycles/latency):", round(float(np.median(ghz)), 3))
 ev, it = r["evals"].astype(float), r["iters"].astype(float)
 for i, nm in enumerate(NAMES):
-    if nm == "-": continue
-    per = pr[:, i] / (ev if i < 6 else it)
-    print("%-18s %6.1f%%   %9.0f cycles per %s" % (nm, 100 * pr[:, i].sum() / tot.sum(), np.median(per), "eval" if i < 6 else "iter"))
+    if pr[:, i].sum() == 0: continue
+    per = pr[:, i] / (ev if i < 6 or i in (9, 11) else it)
+    print("%-18s %6.1f%%   %9.0f cycles per %s" % (nm, 100 * pr[:, i].sum() / tot.sum(), np.median(per), "eval" if i < 6 or i in (9, 11) else "iter"))
 hs = r["hist_sum"].astype(float)
 print("two-loop cycles per history step (2 per entry per iteration):", round(float(np.median(pr[:, 8] / (2 * hs))), 1),
       " mean depth", round(float((hs / it).mean()), 1))
