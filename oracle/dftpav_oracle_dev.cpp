@@ -663,7 +663,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
         ++bound;
         bound = m < bound ? m : bound;
         end = (end + 1) % m;
-        if (n <= 64) {
+        if (n <= 64 && m >= kLoopBlock) { // the kernel's condition for the blocked form (a block must fit the ring)
           // Two-loop recursion (lbfgs.hpp:716-739) in blocks of kLoopBlock stored pairs, as the kernel runs
           // it: the kLoopBlock dot products of a block are taken against the direction as it stands at the
           // start of the block, and the effect of the block's earlier steps on a later dot product is
@@ -722,7 +722,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           for (int i = 0; i < bound; ++i) {
             j = (j + m - 1) % m;
             const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-            double a = (n <= 64 ? lane_dot(sj, d.data(), n) : wave_dot(sj, d.data(), n)) / ys_h[j];
+            double a = wave_dot(sj, d.data(), n) / ys_h[j];
             alpha_h[j] = a;
             double na = -a;
             for (int e = 0; e < n; e++) d[e] += na * yj[e];
@@ -731,7 +731,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           for (int e = 0; e < n; e++) d[e] *= sc0;
           for (int i = 0; i < bound; ++i) {
             const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-            double beta = (n <= 64 ? lane_dot(yj, d.data(), n) : wave_dot(yj, d.data(), n)) / ys_h[j];
+            double beta = wave_dot(yj, d.data(), n) / ys_h[j];
             double cf = alpha_h[j] - beta;
             for (int e = 0; e < n; e++) d[e] += cf * sj[e];
             j = (j + 1) % m;

@@ -742,3 +742,33 @@ def test_every_launch_shape_matches_oracle(hiplib, oracle, monkeypatch, mode, cf
         assert np.array_equal(r[k], ro[k]), k
     bt.close()
     h.close()
+
+
+def test_random_layouts_and_short_histories(hiplib, oracle, monkeypatch):
+    """Randomly shaped problems (1-3 gear segments of 2-12 pieces, sample resolutions 3-24, with and without moving
+    obstacles, every launch shape, L-BFGS memories down to 4 pairs -- shorter than a block of the two-loop
+    recursion, which then runs in its plain form on both sides): every field bit-identical to the device-order
+    oracle.  scripts/fuzz_parity.py is the long version of this test."""
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    for c in range(24):
+        rng = np.random.default_rng(7000 + c)
+        M = int(rng.choice([1, 1, 2, 3]))
+        pieces = [int(rng.integers(2, 13)) for _ in range(M)]
+        sing = [int(rng.choice([1, -1]))]
+        for _ in range(M - 1):
+            sing.append(-sing[-1])
+        K, Kd, B = int(rng.integers(3, 25)), int(rng.integers(3, 25)), int(rng.integers(1, 5))
+        moving = c % 6 == 5 and sum(pieces) <= 12
+        monkeypatch.setenv("DFTPAV_MODE", str(c % 3))
+        p = hiplib.default_params()
+        s = sc.make_scenario(pieces, sing, K, Kd, B, seed=9000 + c, with_moving=moving, n_obs=int(rng.integers(0, 60)))
+        s.apply_resolution(p)
+        if c % 4 == 0:
+            p.lbfgs_mem_size = [4, 7, 8, 9, 17, 64][(c // 4) % 6]
+        h, bt = _batch(hiplib, s, p)
+        r = bt.solve()
+        ro = oracle.solve_batch(p, s, order=1)
+        for k in keys:
+            assert np.array_equal(r[k], ro[k]), (c, pieces, sing, K, Kd, B, moving, p.lbfgs_mem_size, k)
+        bt.close()
+        h.close()
