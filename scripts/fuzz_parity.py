@@ -32,6 +32,15 @@ for c in range(n_cases):
     s.apply_resolution(p)
     if rng.uniform() < 0.3:
         p.lbfgs_mem_size = int(rng.choice([4, 8, 17, 64]))
+    if rng.uniform() < 0.4:  # tighter limits and other weights: every penalty branch gets traffic
+        p.max_forward_vel *= float(rng.uniform(0.3, 1.0)); p.max_backward_vel *= float(rng.uniform(0.3, 1.0))
+        p.max_forward_acc *= float(rng.uniform(0.2, 1.0)); p.max_backward_acc *= float(rng.uniform(0.2, 1.0))
+        p.max_forward_cur *= float(rng.uniform(0.2, 1.0)); p.max_backward_cur *= float(rng.uniform(0.2, 1.0))
+        p.wei_obs *= float(rng.uniform(0.1, 10)); p.wei_feas *= float(rng.uniform(0.1, 10)); p.wei_time *= float(rng.uniform(0.1, 10))
+    if rng.uniform() < 0.3:
+        s.help_eps = float(rng.choice([1e-3, 0.05]))
+    if moving:
+        s.t_now = float(rng.uniform(0.0, 5.0))
     h = capi.Handle(p); h.set_surround(s.surround)
     bt = capi.Batch(h, s.layout, B); bt.upload(s)
     r = bt.solve()
