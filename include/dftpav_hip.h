@@ -326,8 +326,11 @@ int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst);
  * x/y), piece_dt [B][M]. */
 int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piece_dt);
 
-/* Duration in ms of the last solve kernel, measured with HIP events recorded
- * on the handle's stream around the launch. */
+/* Duration in ms of the last solve of this batch, measured with HIP events recorded
+ * on the handle's stream around its launches.  After dftpav_batch_solve_chained(b, prev)
+ * this is the GPU time of the call: b's queue launch, including the trajectories adopted
+ * from prev; a later dftpav_batch_finish(b) or adoption of b's stragglers moves the end
+ * event to where b became complete. */
 int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms);
 
 /* ---- validation of the result, the step after the solve ----
