@@ -806,6 +806,7 @@ static void clamp_col(double *col, double lim) { // traj_optimizer.cpp:65-76
 
 extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) {
   if (!b || !d || !d->ini_states || !d->fin_states || !d->inner_pts || !d->init_Ts) return DFTPAV_E_INVALID;
+  b->pending = false; // new inputs: whatever a chained solve of the old ones left suspended is moot
   dftpav_handle *h = b->h;
   const dftpav_params &p = h->params;
   const DevLayout &L = b->L;
@@ -871,6 +872,7 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
 
 extern "C" int dftpav_batch_corridor_from_hypotheses(dftpav_batch *b, const double *states, int n_restarts) {
   if (!b || !states || n_restarts < 1 || b->B % n_restarts) return DFTPAV_E_INVALID;
+  b->pending = false; // as dftpav_batch_upload
   dftpav_handle *h = b->h;
   if (!h->d_cells) return DFTPAV_E_INVALID;       // no map
   if (b->L.H != 4) return DFTPAV_E_UNSUPPORTED;   // rectangles

@@ -311,7 +311,8 @@ int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *st
  * chained solve that names it as `prev`, or after dftpav_batch_finish(b) -- which dftpav_batch_sync / _results /
  * _pack_results / _coeffs / _validate / _sample_states call by themselves.  b and prev must be different batches
  * of the same handle with the same layout, size, parameters and plan; otherwise (or with prev == NULL, or for
- * batches too small to be scheduled) the call degrades to finishing prev and solving b unchained. */
+ * batches too small to be scheduled) the call degrades to finishing prev and solving b unchained.  New inputs
+ * for a batch (dftpav_batch_upload, dftpav_batch_corridor_from_*) discard what it still had suspended. */
 int dftpav_batch_solve_chained(dftpav_batch *b, dftpav_batch *prev);
 int dftpav_batch_finish(dftpav_batch *b);
 
