@@ -30,7 +30,7 @@ EXPORTS = [
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
-    "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
+    "dftpav_reeds_shepp_shots", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
 ]
 
 
@@ -123,6 +123,23 @@ class Handle:
         s = surround_set.c_struct()
         self._check(lib().dftpav_set_surround(self._h, C.byref(s)), "set_surround")
         self._sur_keep = surround_set
+
+    def reeds_shepp_shots(self, from_, to, max_cur=1.0, checkl=0.2, max_samples=512, vertex_res=0.1, check_collision=False):
+        """KinoAstar::computeShotTraj / is_shot_sucess on the device for n pose pairs (x, y, yaw): dict(length, type, seg,
+        samples [n][max_samples][3], n_samples, collides or None)."""
+        f = np.ascontiguousarray(from_, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(to, dtype=np.float64).reshape(-1, 3)
+        n = f.shape[0]
+        out = dict(length=np.zeros(n), type=np.zeros(n, dtype=np.int32), seg=np.zeros((n, 5)),
+                   samples=np.zeros((n, int(max_samples), 3)), n_samples=np.zeros(n, dtype=np.int32),
+                   collides=np.zeros(n, dtype=np.int32) if check_collision else None)
+        fn = lib().dftpav_reeds_shepp_shots
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double] + [C.c_void_p] * 6
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        self._check(fn(self._h, ptr(f), ptr(t), n, float(max_cur), float(checkl), int(max_samples), float(vertex_res),
+                       ptr(out["length"]), ptr(out["type"]), ptr(out["seg"]), ptr(out["samples"]), ptr(out["n_samples"]),
+                       ptr(out["collides"])), "reeds_shepp_shots")
+        return out
 
     def set_surround_wire(self, blobs):
         """Installs serialised trajectories (wire_pack) as the moving obstacles; each blob becomes one obstacle."""

@@ -39,6 +39,10 @@ hipError_t launch_validate(const unsigned char *cells, int size_x, int size_y, d
                            int n_v, int *collision, int *first_sample, hipStream_t stream);
 hipError_t launch_states(const double *coeffs, const double *piece_dt, const DevLayout &L, int B, double wheel_base, double t0,
                          double sample_dt, int n_samples, int filter, double *states, int *n_valid, hipStream_t stream);
+hipError_t launch_shots(const double *from, const double *to, int n, double rho, double checkl, int max_samples,
+                        const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
+                        double veh_width, double veh_length, double veh_dcr, const double *v_tab, int n_v, double *length, int *type,
+                        double *seg, double *samples, int *n_samples, int *collides, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream);
 }
@@ -396,6 +400,66 @@ extern "C" int dftpav_get_surround(dftpav_handle *h, int *S, int *n_pieces, int 
   if (total_duration) HIPCHK(h, hipMemcpy(total_duration, h->d_sur_total, sizeof(double) * h->S, hipMemcpyDeviceToHost));
   if (start_time) HIPCHK(h, hipMemcpy(start_time, h->d_sur_start, sizeof(double) * h->S, hipMemcpyDeviceToHost));
   return DFTPAV_OK;
+}
+
+// ------------------------------------------------- Reeds-Shepp shots
+extern "C" int dftpav_reeds_shepp_shots(dftpav_handle *h, const double *from, const double *to, int n, double max_cur,
+                                        double checkl, int max_samples, double vertex_res, double *length, int *type, double *seg,
+                                        double *samples, int *n_samples, int *collides) {
+  if (!h || n < 0 || !(max_cur > 0.0) || !(checkl > 0.0) || max_samples < 1 || max_samples > 4096) return DFTPAV_E_INVALID;
+  if (n == 0) return DFTPAV_OK;
+  if (!from || !to) return DFTPAV_E_INVALID;
+  if (collides && (!h->d_cells || !(vertex_res > 0.0))) return DFTPAV_E_INVALID; // a collision check needs the map
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->cev0) HIPCHK(h, hipEventCreate(&h->cev0));
+  if (!h->cev1) HIPCHK(h, hipEventCreate(&h->cev1));
+  std::vector<double> vv; // spacing of the outline points as the reference's running sum (shapes.cc:128)
+  if (collides) {
+    const double longest = std::max(h->params.veh_length, h->params.veh_width) + 1.0;
+    for (double dl = vertex_res; dl < longest; dl += vertex_res) vv.push_back(dl);
+  }
+  if (vv.empty()) vv.push_back(1.0);
+  double *d_from = nullptr, *d_to = nullptr, *d_len = nullptr, *d_seg = nullptr, *d_smp = nullptr, *d_v = nullptr;
+  int *d_type = nullptr, *d_ns = nullptr, *d_col = nullptr;
+  int rc = DFTPAV_OK;
+  auto chk = [&](hipError_t e) {
+    if (e != hipSuccess && rc == DFTPAV_OK) {
+      h->err = hipGetErrorString(e);
+      rc = DFTPAV_E_HIP;
+    }
+  };
+  const size_t nsmp = (size_t)n * max_samples * 3;
+  chk(hipMalloc(&d_from, sizeof(double) * 3 * (size_t)n));
+  chk(hipMalloc(&d_to, sizeof(double) * 3 * (size_t)n));
+  chk(hipMalloc(&d_len, sizeof(double) * (size_t)n));
+  chk(hipMalloc(&d_seg, sizeof(double) * 5 * (size_t)n));
+  chk(hipMalloc(&d_smp, sizeof(double) * nsmp));
+  chk(hipMalloc(&d_v, sizeof(double) * vv.size()));
+  chk(hipMalloc(&d_type, sizeof(int) * (size_t)n));
+  chk(hipMalloc(&d_ns, sizeof(int) * (size_t)n));
+  chk(hipMalloc(&d_col, sizeof(int) * (size_t)n));
+  if (rc == DFTPAV_OK) {
+    chk(hipMemcpyAsync(d_from, from, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    chk(hipMemcpyAsync(d_to, to, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    chk(hipMemcpyAsync(d_v, vv.data(), sizeof(double) * vv.size(), hipMemcpyHostToDevice, h->stream));
+    chk(hipEventRecord(h->cev0, h->stream));
+    chk(launch_shots(d_from, d_to, n, 1.0 / max_cur, checkl, max_samples, collides ? h->d_cells : nullptr, h->map.size_x,
+                     h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, h->params.veh_width, h->params.veh_length,
+                     h->params.veh_d_cr, d_v, (int)vv.size(), d_len, d_type, d_seg, d_smp, d_ns, d_col, h->stream));
+    chk(hipEventRecord(h->cev1, h->stream));
+    if (length) chk(hipMemcpyAsync(length, d_len, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (type) chk(hipMemcpyAsync(type, d_type, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (seg) chk(hipMemcpyAsync(seg, d_seg, sizeof(double) * 5 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (samples) chk(hipMemcpyAsync(samples, d_smp, sizeof(double) * nsmp, hipMemcpyDeviceToHost, h->stream));
+    if (n_samples) chk(hipMemcpyAsync(n_samples, d_ns, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    if (collides) chk(hipMemcpyAsync(collides, d_col, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    chk(hipStreamSynchronize(h->stream));
+    h->ctimed = rc == DFTPAV_OK;
+  }
+  for (void *p : {(void *)d_from, (void *)d_to, (void *)d_len, (void *)d_seg, (void *)d_smp, (void *)d_v, (void *)d_type, (void *)d_ns,
+                  (void *)d_col})
+    if (p) (void)hipFree(p);
+  return rc;
 }
 
 extern "C" int dftpav_set_grid_map(dftpav_handle *h, const dftpav_grid_map *map) {

@@ -81,6 +81,14 @@ int main() {
   ok2 = ok2 && flat.size() == 1 && steps.getRectangleConst(flat[0].states);
   double front = 0.0;
   if (ok2) front = steps.hPolys()[0](2, 1); // x of the front edge of the first rectangle: stops short of the wall
+  // the analytic shot to a goal behind the wall at x = 15 collides, the one to a goal in front of it is free
+  std::vector<std::array<double, 3>> shot;
+  double shot_len = 0.0;
+  ok2 = ok2 && steps.computeShotTraj({0.0, 0.0, 0.0}, {8.0, 3.0, 0.6}, shot, shot_len, 0.5, 0.2);
+  const bool free_shot = steps.is_shot_sucess({0.0, 0.0, 0.0}, {8.0, 3.0, 0.6}, 0.5), blocked_shot = steps.is_shot_sucess({0.0, 0.0, 0.0}, {25.0, 0.0, 0.0}, 0.5);
+  ok2 = ok2 && free_shot && !blocked_shot && shot.size() > 10 && shot_len > 8.0 && shot_len < 12.0;
+  std::printf("computeShotTraj -> %zu poses over %.3f m; is_shot_sucess: free %d, through the wall %d\n", shot.size(), shot_len,
+              (int)free_shot, (int)blocked_shot);
   std::vector<std::vector<PredictedState>> sur(1);
   for (int k = 0; k <= 10; k++) sur[0].push_back({-5.0 + 1.0 * k, 4.0, 0.0, 1.0, 0.0, 0.0, 1.0 * k});
   ok2 = ok2 && steps.ConverSurroundTrajFromPoints(sur);

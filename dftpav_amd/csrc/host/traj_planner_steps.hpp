@@ -7,6 +7,7 @@
 //   map_itf_->GetObstacleMap(&grid_map)             MGR:1216           setObstacleMap(cells, size_x, size_y, resolution, origin)
 //   KinoAstar::getKinoNode(flat_trajs) + the        KA:606-743,        getKinoNode(SampleTraj, start_state, end_state, start_ctrl)
 //     resampling loop of RunMINCOParking            MGR:531-568          -> std::vector<FlatTrajData> (one per gear segment)
+//   KinoAstar::computeShotTraj / is_shot_sucess     KA:304-345         computeShotTraj(state1, state2, path_list, len) / is_shot_sucess(state1, state2)
 //   TrajPlanner::getRectangleConst(statelist)       MGR:1213-1469      getRectangleConst(statelist) -> hPolys_
 //   TrajPlanner::ConverSurroundTrajFromPoints(...)  MGR:743-789        ConverSurroundTrajFromPoints(sur_trajs) (installs them)
 //   collision part of CheckReplan                   SRV:385-397        CheckCollision(batch) -> per trajectory bool
@@ -116,6 +117,29 @@ class TrajPlannerSteps {
       for (const auto &s : t) st.insert(st.end(), {s.x, s.y, s.angle, s.velocity, s.acceleration, s.curvature, s.time_stamp});
     }
     return ok(dftpav_fit_surround(h_, st.data(), (int)sur_trajs.size(), (int)n));
+  }
+
+  // the Reeds-Shepp shot from a pose to the goal (turning radius 1 / max_cur, samples every checkl)
+  bool computeShotTraj(const std::array<double, 3> &state1, const std::array<double, 3> &state2,
+                       std::vector<std::array<double, 3>> &path_list, double &len, double max_cur = 1.0, double checkl = 0.2) {
+    const int cap = 4096;
+    std::vector<double> smp((size_t)cap * 3);
+    int n = 0;
+    path_list.clear();
+    if (!ok(dftpav_reeds_shepp_shots(h_, state1.data(), state2.data(), 1, max_cur, checkl, cap, 0.1, &len, nullptr, nullptr, smp.data(),
+                                     &n, nullptr)))
+      return false;
+    for (int i = 0; i < n && i < cap; i++) path_list.push_back({smp[3 * i], smp[3 * i + 1], smp[3 * i + 2]});
+    return true;
+  }
+  // ... and whether it is free on the map of setObstacleMap
+  bool is_shot_sucess(const std::array<double, 3> &state1, const std::array<double, 3> &state2, double max_cur = 1.0,
+                      double checkl = 0.2) {
+    int hit = 1;
+    if (!ok(dftpav_reeds_shepp_shots(h_, state1.data(), state2.data(), 1, max_cur, checkl, 4096, 0.1, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, &hit)))
+      return false;
+    return hit == 0;
   }
 
   // the collision loop of CheckReplan for every trajectory of a solved batch

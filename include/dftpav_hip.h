@@ -396,6 +396,22 @@ int dftpav_wire_unpack(const void *buf, size_t size, int *singuls, int *piece_nu
                        double *durations, double *coeffs);
 int dftpav_set_surround_wire(dftpav_handle *h, const void *const *bufs, const size_t *sizes, int S);
 
+/* ---- Reeds-Shepp shots: analytic hypotheses ------------------
+ * Replaces KinoAstar::computeShotTraj and is_shot_sucess (kino_astar.cpp:304-345) for n (from, to) pose
+ * pairs (x, y, yaw): the shortest Reeds-Shepp path of turning radius 1 / max_cur
+ * (ompl::base::ReedsSheppStateSpace, kino_astar.cpp:423 -- OMPL is not part of the reference tree; the
+ * published algorithm is restated in dftpav_amd/csrc/rs_math.h), its length (ReedsSheppStateSpace::distance),
+ * word (type 0..17, the rows of OMPL's reedsSheppPathType table) and signed segment lengths in units of the
+ * turning radius, the poses at l = 0, checkl, checkl + checkl, ... <= length (ReedsSheppStateSpace::
+ * interpolate; 0.2 in the reference, minco_config.pb.txt:59) and, if `collides` is given, whether any of
+ * them collides on the map of dftpav_set_grid_map (CheckCollisionUsingPosAndYaw, outline spacing vertex_res).
+ * samples [n][max_samples][3]: at most max_samples poses are stored per pair, n_samples reports how many the
+ * loop visits.  Any output may be NULL.  The sampled path is what dftpav_frontend_resample takes as a searched
+ * path (the reference appends it to the searched prefix, kino_astar.cpp:585-599). */
+int dftpav_reeds_shepp_shots(dftpav_handle *h, const double *from, const double *to, int n, double max_cur, double checkl,
+                             int max_samples, double vertex_res, double *length, int *type, double *seg, double *samples,
+                             int *n_samples, int *collides);
+
 /* One-shot convenience == OptimizeTrajectory for B trajectories. */
 int dftpav_solve_batch(dftpav_handle *h, const dftpav_layout *layout, int B,
                        const dftpav_batch_data *d, double *x, double *final_cost,

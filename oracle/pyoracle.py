@@ -297,6 +297,31 @@ def sample_states(coeffs, piece_dt, piece_nums, singuls, t0=0.0, sample_dt=0.01,
     return st, nv
 
 
+def reeds_shepp_shots(from_, to, max_cur=1.0, checkl=0.2, max_samples=512, grid=None, resolution=0.3, origin=(0.0, 0.0),
+                      veh=(1.90, 4.88, 1.015), vertex_res=0.1, order=0):
+    """KinoAstar::computeShotTraj / is_shot_sucess (kino_astar.cpp:304-345) for n pose pairs: dict(length [n], type [n],
+    seg [n][5], samples [n][max_samples][3], n_samples [n], collides [n] or None)."""
+    L = lib()
+    f = np.ascontiguousarray(from_, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(to, dtype=np.float64).reshape(-1, 3)
+    n = f.shape[0]
+    out = dict(length=np.zeros(n), type=np.zeros(n, dtype=np.int32), seg=np.zeros((n, 5)),
+               samples=np.zeros((n, int(max_samples), 3)), n_samples=np.zeros(n, dtype=np.int32),
+               collides=np.zeros(n, dtype=np.int32) if grid is not None else None)
+    g = np.ascontiguousarray(grid, dtype=np.uint8) if grid is not None else None
+    fn = L.oracle_reeds_shepp_shots
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                   C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(g.ctypes.data if g is not None else None, g.shape[1] if g is not None else 0, g.shape[0] if g is not None else 0,
+       float(resolution), float(origin[0]), float(origin[1]), f.ctypes.data, t.ctypes.data, n, 1.0 / float(max_cur), float(checkl),
+       int(max_samples), float(veh[0]), float(veh[1]), float(veh[2]), float(vertex_res), int(order), out["length"].ctypes.data,
+       out["type"].ctypes.data, out["seg"].ctypes.data, out["samples"].ctypes.data, out["n_samples"].ctypes.data,
+       out["collides"].ctypes.data if out["collides"] is not None else None)
+    return out
+
+
 def fit_surround(states, order=0):
     """ConverSurroundTrajFromPoints (traj_manager.cpp:743-789): states [S][n][7] (x, y, angle, velocity, acceleration,
     curvature, time_stamp) -> dict(durations [S][n-1], coeffs [S][n-1][12], total [S], start [S])."""

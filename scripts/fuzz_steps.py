@@ -40,6 +40,17 @@ for c in range(n_cases):
     st = np.column_stack([rng.uniform(origin[0] - 8, ex + 8, n), rng.uniform(origin[1] - 8, ey + 8, n), rng.uniform(-10, 10, n)])
     h.set_grid_map(grid, res, origin)
     check("corridor", c, np.array_equal(h.corridor_rectangles(st), po.corridor_rectangles(grid, res, origin, st, veh=veh, order=1)))
+    # ---- Reeds-Shepp shots (on the map above)
+    m = int(rng.integers(1, 400))
+    sp = float(rng.choice([1.0, 5.0, 40.0]))
+    fr = np.column_stack([rng.uniform(origin[0], ex, m), rng.uniform(origin[1], ey, m), rng.uniform(-7, 7, m)])
+    to = fr + np.column_stack([rng.uniform(-sp, sp, m), rng.uniform(-sp, sp, m), rng.uniform(-4, 4, m)])
+    mc, cl, ms = float(rng.uniform(0.15, 3.0)), float(rng.uniform(0.03, 1.0)), int(rng.integers(1, 600))
+    vr = float(rng.uniform(0.05, 0.5))
+    got = h.reeds_shepp_shots(fr, to, max_cur=mc, checkl=cl, max_samples=ms, vertex_res=vr, check_collision=True)
+    want = po.reeds_shepp_shots(fr, to, max_cur=mc, checkl=cl, max_samples=ms, grid=grid, resolution=res, origin=origin, veh=veh,
+                                vertex_res=vr, order=1)
+    check("shots", c, all(np.array_equal(got[k], want[k]) for k in want))
     # ---- front end
     ng = int(rng.integers(1, 5))
     g0 = int(rng.choice([1, -1]))

@@ -291,6 +291,8 @@ def test_cpp_host_mirror_runs(hiplib):
     assert "getKinoNode -> 1 segment(s)" in out.stdout and "surround fit -> 1" in out.stdout
     # the read-out (GetStates) and the plan as bytes, installed as an obstacle
     assert "GetStates -> " in out.stdout and "installed as an obstacle -> 1" in out.stdout
+    # the Reeds-Shepp shot of the front end
+    assert "is_shot_sucess: free 1, through the wall 0" in out.stdout
 
 
 def _corridor_scene(seed):
@@ -772,3 +774,58 @@ def test_random_layouts_and_short_histories(hiplib, oracle, monkeypatch):
             assert np.array_equal(r[k], ro[k]), (c, pieces, sing, K, Kd, B, moving, p.lbfgs_mem_size, k)
         bt.close()
         h.close()
+
+
+def test_reeds_shepp_shots_match_oracle(hiplib, oracle):
+    """§8(f)-3, hypothesis generation: KinoAstar::computeShotTraj / is_shot_sucess (kino_astar.cpp:304-345) on the
+    device -- shortest Reeds-Shepp word, its length, the sampled poses and the collision verdict -- bit for bit
+    against the oracle's device-order mode, and to rounding against its libm mode."""
+    rng = np.random.default_rng(3)
+    n = 3000
+    f = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.uniform(-4, 4, n)])
+    t = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-20, 20, n), rng.uniform(-4, 4, n)])
+    t[:50] = f[:50] + rng.normal(0, 0.05, (50, 3))  # nearly coincident poses
+    t[50:60] = f[50:60]                              # coincident: zero length, one sample
+    obs = np.column_stack([rng.uniform(-20, 20, 40), rng.uniform(-20, 20, 40), rng.uniform(0.5, 2.0, 40)])
+    grid, origin = sc.occupancy_grid(obs, arena=60.0)
+    h = hiplib.Handle(hiplib.default_params())
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    for max_cur, checkl, ms in [(1.0, 0.2, 512), (0.4, 0.5, 64), (2.0, 0.05, 300)]:
+        got = h.reeds_shepp_shots(f, t, max_cur=max_cur, checkl=checkl, max_samples=ms, check_collision=True)
+        want = oracle.reeds_shepp_shots(f, t, max_cur=max_cur, checkl=checkl, max_samples=ms, grid=grid, resolution=sc.MAP_RESL,
+                                        origin=origin, order=1)
+        for k in ("length", "type", "seg", "samples", "n_samples", "collides"):
+            assert np.array_equal(got[k], want[k]), (max_cur, k)
+        lit = oracle.reeds_shepp_shots(f, t, max_cur=max_cur, checkl=checkl, max_samples=ms, grid=grid, resolution=sc.MAP_RESL,
+                                       origin=origin, order=0)
+        assert np.allclose(got["length"], lit["length"], rtol=0, atol=1e-9) and (got["type"] == lit["type"]).mean() > 0.99
+        assert 0.05 < got["collides"].mean() < 0.995 and (got["collides"] == lit["collides"]).mean() > 0.98
+    assert h.corridor_last_ms() > 0.0
+    # without a collision output no map is needed; a zero-sized call is fine
+    h2 = hiplib.Handle(hiplib.default_params())
+    r = h2.reeds_shepp_shots(f[:5], t[:5])
+    assert r["collides"] is None and np.array_equal(r["length"], got["length"][:0].tolist() or r["length"])
+    assert h2.reeds_shepp_shots(np.zeros((0, 3)), np.zeros((0, 3)))["length"].shape == (0,)
+    with pytest.raises(hiplib.DftpavError):
+        h2.reeds_shepp_shots(f[:5], t[:5], check_collision=True)  # no map installed
+    h2.close()
+    # a shot is a searched path: resampling -> corridor -> solve -> validation accept it
+    from dftpav_amd.pods import FrontendParams
+    s0 = np.array([[-12.0, -12.0, 0.3]])
+    s1 = np.array([[9.0, 6.0, 1.2]])
+    empty = np.full_like(grid, 127)
+    h.set_grid_map(empty, sc.MAP_RESL, origin)
+    shot = h.reeds_shepp_shots(s0, s1, max_cur=0.5, checkl=0.2, max_samples=1024)
+    npt = int(shot["n_samples"][0])
+    path = np.zeros((1, npt + 1, 3))
+    path[0, :npt] = shot["samples"][0, :npt]
+    path[0, npt] = s1[0]  # the goal closes the list, kino_astar.cpp:599
+    fp = FrontendParams.default(K=8, Kd=8)
+    fe = h.frontend_resample(path, np.array([npt + 1], dtype=np.int32), np.array([[s0[0, 0], s0[0, 1], s0[0, 2], 0.5]]),
+                             np.array([[s1[0, 0], s1[0, 1], s1[0, 2], 0.2]]), np.zeros((1, 2)), fp)
+    fo = oracle.frontend_resample(path, np.array([npt + 1], dtype=np.int32), np.array([[s0[0, 0], s0[0, 1], s0[0, 2], 0.5]]),
+                                  np.array([[s1[0, 0], s1[0, 1], s1[0, 2], 0.2]]), np.zeros((1, 2)), fp, order=1)
+    for k in fo:
+        assert np.array_equal(fe[k], fo[k]), k
+    assert fe["n_seg"][0] >= 1
+    h.close()

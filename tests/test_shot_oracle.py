@@ -1,0 +1,114 @@
+"""CPU checks of the Reeds-Shepp shot (oracle/shot_oracle.cpp over dftpav_amd/csrc/rs_math.h):
+KinoAstar::computeShotTraj (kino_astar.cpp:327-345) needs ompl::base::ReedsSheppStateSpace, which is not in the
+reference tree, so the published algorithm is restated.  OMPL cannot be run here (parity unpinned); the pins are the
+properties a shortest Reeds-Shepp path must have."""
+import numpy as np
+
+L, S, R = 1, 2, 3
+TYPES = [(L, R, L), (R, L, R), (L, R, L, R), (R, L, R, L), (L, R, S, L), (R, L, S, R), (L, S, R, L), (R, S, L, R), (L, R, S, R),
+         (R, L, S, L), (R, S, R, L), (L, S, L, R), (L, S, R), (R, S, L), (L, S, L), (R, S, R), (L, R, S, L, R), (R, L, S, R, L)]
+
+
+def _end_pose(frm, typ, seg, rho):
+    """integrates the segments of a path (unit turning radius, signed lengths) from `frm`"""
+    x, y, yaw = 0.0, 0.0, frm[2]
+    for kind, v in zip(TYPES[typ], seg):
+        if kind == L:
+            x += np.sin(yaw + v) - np.sin(yaw); y += -np.cos(yaw + v) + np.cos(yaw); yaw += v
+        elif kind == R:
+            x += -np.sin(yaw - v) + np.sin(yaw); y += np.cos(yaw - v) - np.cos(yaw); yaw -= v
+        else:
+            x += v * np.cos(yaw); y += v * np.sin(yaw)
+    return frm[0] + rho * x, frm[1] + rho * y, yaw
+
+
+def _pairs(n, seed, spread=12.0):
+    rng = np.random.default_rng(seed)
+    f = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(-np.pi, np.pi, n)])
+    t = np.column_stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(-np.pi, np.pi, n)])
+    return f, t
+
+
+def test_paths_end_on_the_goal(oracle):
+    """every returned word, integrated segment by segment, reaches the goal pose -- near and far goals, three radii"""
+    for rho, spread, seed in [(1.0, 12.0, 1), (1.0, 1.5, 2), (2.5, 6.0, 3), (0.4, 30.0, 4)]:
+        f, t = _pairs(3000, seed, spread)
+        for order in (0, 1):
+            r = oracle.reeds_shepp_shots(f, t, max_cur=1.0 / rho, checkl=0.5, max_samples=4, order=order)
+            seen = set()
+            for i in range(len(f)):
+                ex, ey, eyaw = _end_pose(f[i], r["type"][i], r["seg"][i], rho)
+                assert abs(ex - t[i, 0]) < 1e-7 and abs(ey - t[i, 1]) < 1e-7, (rho, i, r["type"][i])
+                assert abs(np.angle(np.exp(1j * (eyaw - t[i, 2])))) < 1e-7
+                seen.add(int(r["type"][i]))
+            assert np.allclose(r["length"], rho * np.abs(r["seg"]).sum(axis=1), rtol=0, atol=1e-12)
+            assert (r["length"] + 1e-9 >= np.hypot(*(t[:, :2] - f[:, :2]).T)).all()
+        assert len(seen) >= 14  # the words in use: CSC, CCC, CCCC, CCSC, CCSCC families all occur
+
+
+def test_known_paths(oracle):
+    f = np.array([[0, 0, 0.0], [0, 0, 0.0], [0, 0, 0.0], [1, 2, 0.5], [0, 0, 0.0]])
+    t = np.array([[5, 0, 0.0], [-3, 0, 0.0], [0, 2, np.pi], [1, 2, 0.5], [0, 0, np.pi / 2]])
+    r = oracle.reeds_shepp_shots(f, t, max_cur=1.0, checkl=0.2, max_samples=64, order=1)
+    assert abs(r["length"][0] - 5.0) < 1e-12          # straight ahead
+    assert abs(r["length"][1] - 3.0) < 1e-12          # straight back: one reverse segment
+    assert abs(r["length"][2] - np.pi) < 1e-12        # half a left circle of radius 1
+    assert r["length"][3] < 1e-12 and r["n_samples"][3] == 1  # already there: the sample loop runs once (l = 0 <= 0)
+    assert abs(r["length"][4] - np.pi / 2) < 1e-9     # turning on the spot costs a quarter circle of manoeuvres (L+ R- L+ ...)
+    # samples: l = 0, 0.2, ... <= length as a running sum; first sample is the start pose, spacing is arc length
+    n0 = r["n_samples"][0]
+    l, cnt = 0.0, 0
+    while l <= r["length"][0]:
+        l += 0.2; cnt += 1
+    assert n0 == cnt
+    assert np.allclose(r["samples"][0, :n0, 0], 0.2 * np.arange(n0), atol=1e-12) and np.allclose(r["samples"][0, :n0, 1:], 0.0, atol=1e-12)
+    assert (r["samples"][0, n0:] == 0.0).all()
+
+
+def test_samples_follow_a_feasible_path(oracle):
+    rho = 1.25
+    f, t = _pairs(400, 7, 10.0)
+    r = oracle.reeds_shepp_shots(f, t, max_cur=1.0 / rho, checkl=0.05, max_samples=2048, order=1)
+    for i in range(len(f)):
+        n = r["n_samples"][i]
+        assert n <= 2048
+        s = r["samples"][i, :n]
+        assert np.array_equal(s[0], f[i])
+        d = np.hypot(*np.diff(s[:, :2], axis=0).T)
+        assert (d <= 0.05 + 1e-9).all()                       # chord <= arc
+        dyaw = np.abs(np.angle(np.exp(1j * np.diff(s[:, 2]))))
+        assert (dyaw <= 0.05 / rho + 1e-9).all()               # curvature bound 1 / rho
+        # the path ends within one sample spacing of the goal
+        assert np.hypot(*(s[-1, :2] - t[i, :2])) <= 0.05 + 1e-9
+
+
+def test_symmetries_and_orders(oracle):
+    f, t = _pairs(2000, 11, 8.0)
+    a = oracle.reeds_shepp_shots(f, t, checkl=1.0, max_samples=2, order=1)
+    b = oracle.reeds_shepp_shots(t, f, checkl=1.0, max_samples=2, order=1)
+    assert np.allclose(a["length"], b["length"], rtol=0, atol=1e-9)  # a path driven backwards is a path
+    # rigid motion of both poses
+    th, dx, dy = 0.83, 3.0, -7.0
+    c, s = np.cos(th), np.sin(th)
+    mv = lambda p: np.column_stack([c * p[:, 0] - s * p[:, 1] + dx, s * p[:, 0] + c * p[:, 1] + dy, p[:, 2] + th])
+    m = oracle.reeds_shepp_shots(mv(f), mv(t), checkl=1.0, max_samples=2, order=1)
+    assert np.allclose(a["length"], m["length"], rtol=0, atol=1e-9)
+    # mirror image (y -> -y, yaw -> -yaw)
+    mi = lambda p: np.column_stack([p[:, 0], -p[:, 1], -p[:, 2]])
+    k = oracle.reeds_shepp_shots(mi(f), mi(t), checkl=1.0, max_samples=2, order=1)
+    assert np.allclose(a["length"], k["length"], rtol=0, atol=1e-9)
+    # libm against the portable functions: the same path up to rounding (a tie between two words may flip the type)
+    z = oracle.reeds_shepp_shots(f, t, checkl=1.0, max_samples=2, order=0)
+    assert np.allclose(a["length"], z["length"], rtol=0, atol=1e-9) and (a["type"] == z["type"]).mean() > 0.99
+
+
+def test_collision_of_a_shot(oracle):
+    grid = np.full((200, 200), 127, dtype=np.uint8)
+    origin = (-30.0, -30.0)
+    f = np.array([[-10.0, 0.0, 0.0]])
+    t = np.array([[10.0, 0.0, 0.0]])
+    r = oracle.reeds_shepp_shots(f, t, grid=grid, resolution=0.3, origin=origin, order=1)
+    assert r["collides"][0] == 0
+    grid[:, int(round((0.0 - origin[0]) / 0.3))] = 80  # a wall across the straight path
+    r = oracle.reeds_shepp_shots(f, t, grid=grid, resolution=0.3, origin=origin, order=1)
+    assert r["collides"][0] == 1
