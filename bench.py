@@ -264,6 +264,20 @@ def main():
                               "states_per_s": float(nv.sum()) / (rd_ms * 1e-3), "written_GB_per_s": rd.nbytes / (rd_ms * 1e-3) / 1e9,
                               "oracle_bit_exact_on_first_64": bool(np.array_equal(rd[:64], ord_) and np.array_equal(nv[:64], onv))}
             del rd
+            # ---- hypothesis generation: Reeds-Shepp shots between random poses of the map, sampled and checked
+            rng_s = np.random.default_rng(args.seed)
+            n_sh = 16384
+            lo_xy = np.array(origin); hi_xy = lo_xy + sc.MAP_RESL * np.array([grid.shape[1], grid.shape[0]])
+            fr = np.column_stack([rng_s.uniform(lo_xy[0], hi_xy[0], n_sh), rng_s.uniform(lo_xy[1], hi_xy[1], n_sh), rng_s.uniform(-np.pi, np.pi, n_sh)])
+            to = np.column_stack([rng_s.uniform(lo_xy[0], hi_xy[0], n_sh), rng_s.uniform(lo_xy[1], hi_xy[1], n_sh), rng_s.uniform(-np.pi, np.pi, n_sh)])
+            sh = h.reeds_shepp_shots(fr, to, max_cur=1.0, checkl=0.2, max_samples=1024, check_collision=True)
+            sh_ms = h.corridor_last_ms()
+            so_ = po.reeds_shepp_shots(fr[:256], to[:256], max_cur=1.0, checkl=0.2, max_samples=1024, grid=grid, resolution=sc.MAP_RESL,
+                                       origin=origin, order=1)
+            out["shots"] = {"pairs": n_sh, "poses": int(sh["n_samples"].sum()), "kernel_ms": sh_ms, "shots_per_s": n_sh / (sh_ms * 1e-3),
+                            "free": float(1.0 - sh["collides"].mean()),
+                            "oracle_bit_exact_on_first_256": bool(all(np.array_equal(sh[k][:256], so_[k]) for k in so_))}
+            del sh
             nchk = min(2000, len(st))
             out["corridor"] = {"states": int(len(st)), "map_cells": [int(grid.shape[1]), int(grid.shape[0])],
                                "kernel_ms": cor_ms, "rectangles_per_s": len(st) / (cor_ms * 1e-3),
