@@ -266,13 +266,13 @@ def main():
             del rd
             # ---- hypothesis generation: Reeds-Shepp shots between random poses of the map, sampled and checked
             rng_s = np.random.default_rng(args.seed)
-            n_sh = 16384
+            n_sh = 8192
             lo_xy = np.array(origin); hi_xy = lo_xy + sc.MAP_RESL * np.array([grid.shape[1], grid.shape[0]])
             fr = np.column_stack([rng_s.uniform(lo_xy[0], hi_xy[0], n_sh), rng_s.uniform(lo_xy[1], hi_xy[1], n_sh), rng_s.uniform(-np.pi, np.pi, n_sh)])
             to = np.column_stack([rng_s.uniform(lo_xy[0], hi_xy[0], n_sh), rng_s.uniform(lo_xy[1], hi_xy[1], n_sh), rng_s.uniform(-np.pi, np.pi, n_sh)])
-            sh = h.reeds_shepp_shots(fr, to, max_cur=1.0, checkl=0.2, max_samples=1024, check_collision=True)
+            sh = h.reeds_shepp_shots(fr, to, max_cur=1.0, checkl=0.2, max_samples=768, check_collision=True)
             sh_ms = h.corridor_last_ms()
-            so_ = po.reeds_shepp_shots(fr[:256], to[:256], max_cur=1.0, checkl=0.2, max_samples=1024, grid=grid, resolution=sc.MAP_RESL,
+            so_ = po.reeds_shepp_shots(fr[:256], to[:256], max_cur=1.0, checkl=0.2, max_samples=768, grid=grid, resolution=sc.MAP_RESL,
                                        origin=origin, order=1)
             out["shots"] = {"pairs": n_sh, "poses": int(sh["n_samples"].sum()), "kernel_ms": sh_ms, "shots_per_s": n_sh / (sh_ms * 1e-3),
                             "free": float(1.0 - sh["collides"].mean()),
