@@ -829,3 +829,29 @@ def test_reeds_shepp_shots_match_oracle(hiplib, oracle):
         assert np.array_equal(fe[k], fo[k]), k
     assert fe["n_seg"][0] >= 1
     h.close()
+
+
+def test_golden_steps_on_device(hiplib):
+    """The kernels of the steps around the solve against the committed vectors (tests/golden/steps.npz): no oracle in
+    the loop, the frozen device-order outputs are the reference."""
+    import os
+    from dftpav_amd.pods import FrontendParams
+    Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "steps.npz"))
+    h = hiplib.Handle(hiplib.default_params())
+    grid, origin = Z["grid"], tuple(Z["origin"])
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    assert np.array_equal(h.corridor_rectangles(Z["cor_states"]), Z["cor_out"])
+    sh = h.reeds_shepp_shots(Z["shot_from"], Z["shot_to"], max_cur=0.8, checkl=0.25, max_samples=96, check_collision=True)
+    for k, v in sh.items():
+        assert np.array_equal(v, Z["shot_out_" + k]), k
+    fe = h.frontend_resample(Z["fe_paths"], Z["fe_len"], Z["fe_ss"], Z["fe_es"], Z["fe_ct"], FrontendParams.default(K=6, Kd=9))
+    for k in fe:
+        assert np.array_equal(fe[k], Z["fe_out_" + k]), k
+    ri, rd = h.sample_restarts(Z["rs_inner"], Z["rs_durs"], 5, sigma=0.3, lo=0.8, hi=1.25, seed=77)
+    assert np.array_equal(ri, Z["rs_out_inner"]) and np.array_equal(rd, Z["rs_out_durs"])
+    h.fit_surround(Z["fit_states"])
+    g = h.get_surround()
+    S, ns = Z["fit_states"].shape[0], Z["fit_states"].shape[1]
+    assert np.array_equal(g["durations"].reshape(S, -1), Z["fit_dur"]) and np.array_equal(g["coeffs"].reshape(S, ns - 1, 12), Z["fit_coef"])
+    assert np.array_equal(g["total"], Z["fit_total"]) and np.array_equal(g["start"], Z["fit_start"])
+    h.close()
