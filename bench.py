@@ -48,8 +48,11 @@ def main():
                     help="trajectories timed on the host cores (-1 = 4 per core, 0 = skip)")
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-256 / single-trajectory side runs (profiling)")
-    ap.add_argument("--no-chain", action="store_true",
-                    help="every step a plain solve of one resident batch (the tail of each batch runs on a nearly empty device)")
+    ap.add_argument("--schedule", choices=["overlap", "chain", "plain"], default="overlap",
+                    help="overlap: two batches on two HIP streams, every trajectory stays in its queue launch, the next batch's "
+                         "launch fills the slots the previous one frees (default); chain: one stream, the stragglers of a batch are "
+                         "adopted by the next batch's launch; plain: isolated solves (the tail of each batch runs on a nearly empty device)")
+    ap.add_argument("--no-chain", action="store_true", help="same as --schedule plain")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,77 +73,87 @@ def main():
     B_total = args.batch_per_gpu * world
     params = capi.default_params()
     lo, hi = dd.shard_range(B_total, rank, world)
-    # Two resident batches of different problems, solved alternately: a stream of planning cycles.  Chained
-    # (default), the last trajectories of a batch are worked off inside the full-occupancy phase of the next one
-    # (dftpav_batch_solve_chained); the records of batch k are packed and all-gathered once batch k+1's queue launch
-    # has finished them, and the last batch is flushed inside the timed region.  --no-chain: plain solves.
+    # Two resident batches of different problems, solved alternately: a stream of planning cycles.  A step launches
+    # one batch and delivers the records of the batch that this completes (pack + all-gather); after the last step
+    # the outstanding batch is completed and delivered INSIDE the timed region, so K steps deliver K batches.
+    #   overlap (default): each batch on its own handle = HIP stream, hand-over 0: every trajectory finishes in its
+    #     queue launch, and while that launch thins out the other stream's launch takes the freed workgroup slots.
+    #   chain: one stream; the last trajectories of a batch are adopted by the next batch's queue launch
+    #     (dftpav_batch_solve_chained), the last batch is flushed in the latency shape.
+    #   plain: isolated solves, a step waits for its own batch.
+    schedule = "plain" if args.no_chain else args.schedule
     shards = [sc.baseline_config(args.config, B=hi - lo, seed=args.seed + 7919 * rank + 104729 * i) for i in range(2)]
     for sh in shards:
         sh.apply_resolution(params)
     shard = scen = shards[0]
     h = capi.Handle(params, device=local_rank)
     h.set_surround(shard.surround)
+    hs = [h, h]
+    if schedule == "overlap":
+        hs = [h, capi.Handle(params, device=local_rank)]
+        hs[1].set_surround(shard.surround)
     bts = []
-    for sh in shards:
-        b_ = capi.Batch(h, sh.layout, sh.B)
+    for hh, sh in zip(hs, shards):
+        b_ = capi.Batch(hh, sh.layout, sh.B)
         b_.upload(sh)  # resident in HBM from here on
+        if schedule == "overlap":
+            b_.set_hand_over(0)
         bts.append(b_)
     bt = bts[0]
-    chained = not args.no_chain
     rec_dev = [torch.zeros((shard.B, dd.RECORD_BYTES), dtype=torch.uint8, device="cuda") for _ in range(2)]
     state = {"k": 0, "prev": None, "rec": None}
 
-    def gather(i):
-        if distributed:
-            return dd.allgather_records(rec_dev[i], B_total)
-        return rec_dev[i]
-
-    def step():
-        i = state["k"] % 2
-        cur = bts[i]
-        state["k"] += 1
-        if not chained:
-            cur.solve_async()
-            cur.pack_results(rec_dev[i].data_ptr())
-            cur.sync()
-            state["rec"] = (gather(i), i)
-            return cur.last_solve_ms()
-        prev = state["prev"]
-        cur.solve_chained(bts[prev] if prev is not None else None)
-        if prev is not None:  # complete in stream order: its stragglers were adopted by the launch above
-            bts[prev].pack_results(rec_dev[prev].data_ptr())
-            bts[prev].sync()
-            state["rec"] = (gather(prev), prev)
-        state["prev"] = i
-        return cur.last_solve_ms()
-
-    def flush():
-        """the last batch of a chain: its stragglers in the latency shape, then its records"""
-        if not chained or state["prev"] is None:
-            return 0.0
-        i = state["prev"]
-        before = bts[i].last_solve_ms()
-        bts[i].finish()
+    def deliver(i):
         bts[i].pack_results(rec_dev[i].data_ptr())
         bts[i].sync()
-        state["rec"] = (gather(i), i)
-        state["prev"] = None
-        return max(0.0, bts[i].last_solve_ms() - before)
+        state["rec"] = (dd.allgather_records(rec_dev[i], B_total) if distributed else rec_dev[i], i)
 
-    for _ in range(args.warmup):
-        step()
+    def step(last=False):
+        i = state["k"] % 2
+        cur, prev = bts[i], state["prev"]
+        state["k"] += 1
+        if schedule == "plain":
+            cur.solve_async()
+            deliver(i)
+            return
+        if schedule == "chain":
+            cur.solve_chained(bts[prev] if prev is not None else None)  # prev is complete when this call's launches are
+        else:
+            # prev keeps running on the other stream.  Nothing follows the last launch of a run, so it ends with the
+            # default end game (its stragglers in the latency shape) instead of thinning out alone.
+            cur.set_hand_over(-1 if last else 0)
+            cur.solve_async()
+        if prev is not None:
+            deliver(prev)
+        state["prev"] = i
+
+    def flush():
+        """the outstanding batch: its stragglers in the latency shape (chain) / the rest of its launch (overlap)"""
+        if state["prev"] is not None:
+            if schedule == "chain":
+                bts[state["prev"]].finish()
+            deliver(state["prev"])
+            state["prev"] = None
+
+    for j in range(args.warmup):
+        step(last=(j == args.warmup - 1))
+    flush()  # the warm-up leaves nothing in flight: the timed region starts on an idle device
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    kern_ms = []
+    first = state["k"] % 2
+    hs[first].mark(0)  # HIP events on the library's own streams around the timed region
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        kern_ms.append(step())  # HIP events on the library's own stream
-    kern_ms.append(flush())
+    for j in range(args.steps):
+        step(last=(j == args.steps - 1))
+    flush()
+    last_h = hs[state["rec"][1]]
+    last_h.mark(1)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gpu_ms = last_h.elapsed_since(hs[first], 0, 1)
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -158,7 +171,7 @@ def main():
         lay = shard.layout
         eb = [float(algorithmic_bytes(lay, shard.n_points, lay.H, lay.M, q["iters"], q["evals"], q["hist_sum"]).sum()) for q in rs]
         ebytes_steps = sum(eb[(state["k"] - args.steps + j) % 2] for j in range(args.steps))  # the batches the timed steps solved
-        kms = float(np.sum(kern_ms)) / args.steps  # GPU time per step, the final flush shared out
+        kms = gpu_ms / args.steps  # device time of the timed region (marker events on the library's streams) per step
         achieved = ebytes_steps / args.steps / (kms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -180,10 +193,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "solver_kernel", "kernel_ms": kms,
-                         "launches_per_step": 2 if shard.B >= 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count else 1,
+                         "launches_per_step": 1 if (schedule == "overlap" or shard.B < 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count) else 2,
                          "algorithmic_bytes_per_launch": ebytes_steps / args.steps},
-            "schedule": ("chained: the stragglers of a batch finish inside the next batch's queue launch, the last batch is "
-                         "flushed inside the timed region" if chained else "plain: every batch finishes on its own"),
+            "schedule": {"overlap": "overlap: two batches alternate on two HIP streams, every trajectory finishes in its queue launch, "
+                                    "the next launch takes the slots the previous one frees; the last batch completes inside the timed region",
+                         "chain": "chain: one stream, the stragglers of a batch finish inside the next batch's queue launch, the last "
+                                  "batch is flushed inside the timed region",
+                         "plain": "plain: every batch finishes on its own"}[schedule],
             "p50_ms_per_solve": float(np.median(r["latency_us"])) * 1e-3,
             "p95_ms_per_solve": float(np.percentile(r["latency_us"], 95)) * 1e-3,
             "mean_iters": float(r["iters"].mean()), "mean_evals": float(r["evals"].mean()),
@@ -209,6 +225,7 @@ def main():
                         "p50_ms_per_solve": float(np.median(r2["latency_us"])) * 1e-3, "mean_iters": float(r2["iters"].mean())}
             # the same batch as isolated solves (no chaining: its tail runs on a nearly empty device)
             iso = []
+            bt.set_hand_over(-1)  # the plan's default end game (the overlap schedule runs with 0)
             for _ in range(3):
                 bt.solve_async(); bt.sync(); iso.append(bt.last_solve_ms())
             out["isolated"] = {"batch": int(shard.B), "kernel_ms": float(np.mean(iso)), "solves_per_s": shard.B / (float(np.mean(iso)) * 1e-3)}
@@ -313,7 +330,8 @@ def main():
         print(json.dumps(out), flush=True)
     for b_ in bts:
         b_.close()
-    h.close()
+    for hh in set(hs):
+        hh.close()
     if distributed:
         dist.destroy_process_group()
 

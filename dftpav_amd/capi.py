@@ -30,7 +30,7 @@ EXPORTS = [
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
-    "dftpav_reeds_shepp_shots", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
+    "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
 ]
 
 
@@ -140,6 +140,20 @@ class Handle:
                        ptr(out["length"]), ptr(out["type"]), ptr(out["seg"]), ptr(out["samples"]), ptr(out["n_samples"]),
                        ptr(out["collides"])), "reeds_shepp_shots")
         return out
+
+    def mark(self, slot=0):
+        """Records one of the handle's two marker events on its stream (dftpav_mark)."""
+        fn = lib().dftpav_mark
+        fn.argtypes = [C.c_void_p, C.c_int]
+        self._check(fn(self._h, int(slot)), "mark")
+
+    def elapsed_since(self, other, other_slot=0, slot=1):
+        """Device time in ms from marker `other_slot` of handle `other` to marker `slot` of this handle."""
+        fn = lib().dftpav_marks_elapsed_ms
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        ms = C.c_float(0.0)
+        self._check(fn(other._h, int(other_slot), self._h, int(slot), C.byref(ms)), "marks_elapsed_ms")
+        return float(ms.value)
 
     def set_surround_wire(self, blobs):
         """Installs serialised trajectories (wire_pack) as the moving obstacles; each blob becomes one obstacle."""
@@ -361,6 +375,12 @@ class Batch:
         fn = lib().dftpav_batch_solve_chained
         fn.argtypes = [C.c_void_p, C.c_void_p]
         self.handle._check(fn(self._b, prev._b if prev is not None else None), "solve_chained")
+
+    def set_hand_over(self, hand_over):
+        """End game of a scheduled solve (dftpav_batch_set_hand_over): 0 keeps every trajectory in the queue launch."""
+        fn = lib().dftpav_batch_set_hand_over
+        fn.argtypes = [C.c_void_p, C.c_int]
+        self.handle._check(fn(self._b, int(hand_over)), "set_hand_over")
 
     def finish(self):
         fn = lib().dftpav_batch_finish

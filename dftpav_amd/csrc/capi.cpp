@@ -66,6 +66,7 @@ struct dftpav_handle {
   double *d_dl = nullptr;
   int n_dl = 0;
   hipEvent_t cev0 = nullptr, cev1 = nullptr; // around the last corridor kernel
+  hipEvent_t mark[2] = {nullptr, nullptr};   // dftpav_mark
   bool ctimed = false;
 };
 
@@ -227,6 +228,8 @@ extern "C" void dftpav_destroy(dftpav_handle *h) {
   if (h->d_cells) (void)hipFree(h->d_cells);
   if (h->d_bits) (void)hipFree(h->d_bits);
   if (h->d_dl) (void)hipFree(h->d_dl);
+  for (hipEvent_t &e : h->mark)
+    if (e) (void)hipEventDestroy(e);
   if (h->cev0) (void)hipEventDestroy(h->cev0);
   if (h->cev1) (void)hipEventDestroy(h->cev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1134,6 +1137,37 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   }
   HIPCHK(h, hipEventRecord(b->ev1, h->stream));
   b->timed = true;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_mark(dftpav_handle *h, int slot) {
+  if (!h || slot < 0 || slot > 1) return DFTPAV_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->mark[slot]) HIPCHK(h, hipEventCreate(&h->mark[slot]));
+  HIPCHK(h, hipEventRecord(h->mark[slot], h->stream));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_marks_elapsed_ms(dftpav_handle *from, int from_slot, dftpav_handle *to, int to_slot, float *ms) {
+  if (!from || !to || !ms || from_slot < 0 || from_slot > 1 || to_slot < 0 || to_slot > 1 || !from->mark[from_slot] ||
+      !to->mark[to_slot] || from->device != to->device)
+    return DFTPAV_E_INVALID;
+  HIPCHK(to, hipSetDevice(to->device));
+  HIPCHK(to, hipEventSynchronize(to->mark[to_slot]));
+  HIPCHK(to, hipEventElapsedTime(ms, from->mark[from_slot], to->mark[to_slot]));
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_set_hand_over(dftpav_batch *b, int hand_over) {
+  if (!b) return DFTPAV_E_INVALID;
+  if (int rc = finish_pending(b)) return rc;
+  if (hand_over < 0) { // back to the plan's default: one trajectory per CU
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, b->h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    hand_over = n_cu;
+  }
+  b->hand_over = hand_over < b->B ? hand_over : b->B;
   return DFTPAV_OK;
 }
 

@@ -316,6 +316,19 @@ int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *st
 int dftpav_batch_solve_chained(dftpav_batch *b, dftpav_batch *prev);
 int dftpav_batch_finish(dftpav_batch *b);
 
+/* Timing across solves and handles: dftpav_mark records one of a handle's two marker events on its stream,
+ * dftpav_marks_elapsed_ms returns the device time between a marker of one handle and a marker of another (same
+ * device) after waiting for the second -- the HIP-event clock bench.py puts around its timed region. */
+int dftpav_mark(dftpav_handle *h, int slot);
+int dftpav_marks_elapsed_ms(dftpav_handle *from, int from_slot, dftpav_handle *to, int to_slot, float *ms);
+
+/* The end game of a scheduled solve: once no more than `hand_over` trajectories of the batch are unfinished they
+ * leave the queue launch and finish in the latency shape (default: one per CU; negative restores it).  0 keeps every
+ * trajectory in the queue launch to its end -- the setting for a stream of batches solved alternately on TWO handles
+ * (two HIP streams): the queue launch of the next batch then fills the workgroup slots the previous one frees while
+ * it thins out, which keeps the device full without any hand-over (bench.py's default). */
+int dftpav_batch_set_hand_over(dftpav_batch *b, int hand_over);
+
 /* Multi-GPU hand-off: packs one 16-byte record {f64 final_cost, i32 status, i32 iters}
  * per trajectory into caller-owned DEVICE memory (asynchronously, on the handle's
  * stream) — the send buffer of the single all-gather of SURVEY §8(e). */

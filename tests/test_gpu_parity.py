@@ -855,3 +855,48 @@ def test_golden_steps_on_device(hiplib):
     assert np.array_equal(g["durations"].reshape(S, -1), Z["fit_dur"]) and np.array_equal(g["coeffs"].reshape(S, ns - 1, 12), Z["fit_coef"])
     assert np.array_equal(g["total"], Z["fit_total"]) and np.array_equal(g["start"], Z["fit_start"])
     h.close()
+
+
+def test_overlapped_streams_and_hand_over_zero(hiplib, monkeypatch):
+    """bench.py's default schedule: two handles (two HIP streams), hand-over 0 so that every trajectory finishes in its
+    queue launch, batches launched alternately without waiting for the previous one -- results equal the plain
+    solves bit for bit; the marker events give the device time across the two streams."""
+    monkeypatch.setenv("DFTPAV_SCHED", "1")
+    monkeypatch.setenv("DFTPAV_SLOTS", "8")
+    monkeypatch.setenv("DFTPAV_SLICE", "7")
+    p = hiplib.default_params()
+    B = 36
+    scen = [sc.baseline_config(3, B=B, seed=4242 + 17 * k) for k in range(2)]
+    for s in scen:
+        s.apply_resolution(p)
+    hs = [hiplib.Handle(p), hiplib.Handle(p)]
+    bts = []
+    for h, s in zip(hs, scen):
+        bt = hiplib.Batch(h, s.layout, B)
+        bt.upload(s)
+        bts.append(bt)
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    plain = [bt.solve() for bt in bts]
+    for bt in bts:
+        bt.set_hand_over(0)
+    hs[0].mark(0)
+    for k in range(6):
+        bts[k % 2].solve_async()
+        if k:
+            bts[(k - 1) % 2].sync()
+    bts[1].sync()
+    hs[1].mark(1)
+    assert hs[1].elapsed_since(hs[0], 0, 1) > 0.0
+    for bt, ref in zip(bts, plain):
+        got = bt.results()
+        for k in keys:
+            assert np.array_equal(got[k], ref[k]), k
+    # back to the default end game, and a hand-over larger than the batch is clamped
+    bts[0].set_hand_over(-1)
+    assert np.array_equal(bts[0].solve()["x"], plain[0]["x"])
+    bts[0].set_hand_over(10 ** 6)
+    assert np.array_equal(bts[0].solve()["x"], plain[0]["x"])
+    for bt in bts:
+        bt.close()
+    for h in hs:
+        h.close()
