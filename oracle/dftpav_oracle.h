@@ -7,12 +7,18 @@
  *   src/Plan/traj_planner/include/plan_utils/poly_traj_utils.hpp
  *   src/Plan/traj_planner/include/geo_utils2d/lbfgs.hpp
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or known-answer
- * fixtures for this path, and it cannot be compiled here (needs Eigen, ROS,
- * protobuf — none present).  This restatement is pinned only by self-made
- * checks (tests/test_oracle_*.py): finite-difference gradients, MINCO
- * invariants, adjoint-vs-FD, L-BFGS on analytic functions, frozen golden
- * vectors produced by this oracle.
+ * PARITY PIN: the reference ships no tests, golden vectors or known-answer
+ * fixtures for this path.  The literal order of this restatement is pinned
+ * against the reference's OWN code: oracle/_ref (recipe oracle/Makefile.ref)
+ * compiles traj_optimizer.cpp, poly_traj_utils.hpp and lbfgs.hpp unmodified
+ * from /root/reference against interface stand-ins for Eigen / ROS / the
+ * protobuf config (oracle/ref_shim; its arithmetic contract — sequential
+ * reductions, expressions evaluated as written — is stated at the top of
+ * ref_shim/Eigen/Eigen).  tests/test_ref_pin.py: cost, gradient, iterates and
+ * whole solves are BIT-EQUAL to that build on every BASELINE config and on
+ * random layouts; tests/golden/ref_*.npz are vectors that build wrote.
+ * Beyond that: finite-difference gradients, MINCO invariants, adjoint-vs-FD
+ * (tests/test_oracle_*.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * call into this library.  The product (dftpav_amd/, libdftpav_hip.so) never

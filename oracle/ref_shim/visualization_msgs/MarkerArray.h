@@ -1,0 +1,5 @@
+#pragma once
+#include <visualization_msgs/Marker.h>
+namespace visualization_msgs {
+struct MarkerArray { std::vector<Marker> markers; };
+}  // namespace visualization_msgs

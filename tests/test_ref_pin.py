@@ -1,0 +1,190 @@
+"""PARITY PIN: the restatement oracle/dftpav_oracle.c (literal order) against the reference's OWN code.
+
+oracle/_ref/libdftpav_ref.so is /root/reference/src/Plan/traj_planner/{src/traj_optimizer.cpp,
+include/plan_utils/poly_traj_utils.hpp, include/geo_utils2d/lbfgs.hpp} compiled unmodified (oracle/Makefile.ref) against
+interface stand-ins for Eigen / ROS / the protobuf config (oracle/ref_shim).  Two kinds of test:
+  * `ref` tests call the reference build beside the oracle (they skip where the library is absent);
+  * golden tests check the oracle against vectors the reference build wrote (tests/golden/ref_*.npz), anywhere.
+The bar is bit equality: same evaluation points, same costs, same gradients, same iterates, same counts.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import ref_cases
+from dftpav_amd import scenarios as sc
+from golden_util import CASES, GOLDEN_DIR, load
+
+REF_SRC = "/root/reference/src/Plan/traj_planner"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import pyref
+    if os.path.exists(REF_SRC):
+        pyref.build()
+    if not pyref.available():
+        pytest.skip("oracle/_ref is not built here and /root/reference is absent")
+    pyref.lib()
+    return pyref
+
+
+def test_ref_is_built_from_the_reference_tree_not_from_copies(ref):
+    """the recipe compiles the files where they lie; nothing of them is in the repository"""
+    mk = open(os.path.join(ROOT, "oracle", "Makefile.ref")).read()
+    assert "$(REF)/src/traj_optimizer.cpp" in mk and "REF ?= /root/reference/src/Plan/traj_planner" in mk
+    for dirpath, _, files in os.walk(ROOT):
+        if ".git" in dirpath or "gpurun_out" in dirpath:
+            continue
+        assert "traj_optimizer.cpp" not in files and "lbfgs.hpp" not in files and "poly_traj_utils.hpp" not in files
+    if os.path.exists(REF_SRC):
+        for line in open(os.path.join(ROOT, "oracle", "_ref", "SOURCES.sha256")):
+            digest, path = line.split()
+            assert hashlib.sha256(open(path, "rb").read()).hexdigest() == digest
+
+
+@pytest.mark.parametrize("case", [c[0] for c in ref_cases.LBFGS_CASES])
+def test_lbfgs_is_bit_equal_to_the_reference(ref, oracle, case):
+    """lbfgs_optimize + line_search_lewisoverton (lbfgs.hpp:276-390, 440-751) on analytic functions"""
+    name, fn, x0, kw = [c for c in ref_cases.LBFGS_CASES if c[0] == case][0]
+    p = ref_cases.with_fields(oracle.default_params(), kw)
+    a, b = ref.lbfgs(fn, x0, p), oracle.lbfgs(fn, x0, p)
+    assert a["ret"] == b["ret"] and a["iters"] == b["iters"] and a["evals"] == b["evals"]
+    assert a["f"] == b["f"] and np.array_equal(a["x"], b["x"])
+    assert a["iters"] >= 2
+
+
+def test_banded_system_is_bit_equal_to_the_reference(ref, oracle):
+    """BandedSystem::factorizeLU / solve (poly_traj_utils.hpp:776-826): the oracle's dense operator is built column by
+    column with its restatement of that LU, so each column must equal the reference's solve of the same unit vector."""
+    for N in (2, 5, 16):
+        A = sc.minco_matrix(N)
+        op = oracle.minco_operator(N)  # [6N][N+5]: columns = non-zero RHS rows 0,1,2, 6i+5, 6N-3..6N-1
+        rows = [0, 1, 2] + [6 * i + 5 for i in range(N - 1)] + [6 * N - 3, 6 * N - 2, 6 * N - 1]
+        E = np.zeros((6 * N, len(rows)))
+        for c, r in enumerate(rows):
+            E[r, c] = 1.0
+        X = ref.banded_solve(A, 6, 6, E)
+        assert np.array_equal(X, op)
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 16, 32])
+def test_minco_is_bit_equal_to_the_reference(ref, oracle, N):
+    """MinJerkOpt::reset / generate / getTrajJerkCost (poly_traj_utils.hpp:880-1009)"""
+    inner, dT, head, tail = ref_cases.minco_inputs(N, 100 + N)
+    r = ref.minco(inner, dT, head, tail)
+    c, J = oracle.minco_generate(inner, dT, head, tail)
+    assert np.array_equal(c, r["coeffs"]) and J == r["energy"]
+
+
+def _compare_problem(ref, oracle, p, s, b):
+    o = oracle.OracleProblem(p, s, b, order=0)
+    r = ref.RefProblem(p, s, b)
+    rr = r.optimize(trace=True)
+    x0 = o.x0()
+    assert np.array_equal(rr["eval_x"][0], x0)            # packing + RealT2VirtualT (traj_optimizer.cpp:96-115, 360-369)
+    fo, go = o.eval(x0)
+    assert fo == rr["eval_f"][0] and np.array_equal(go, rr["eval_g"][0])
+    co, dto = o.coeffs()
+    fr, gr = r.eval(x0)
+    cr, dtr = r.coeffs()
+    assert fo == fr and np.array_equal(go, gr)
+    assert np.array_equal(co, cr) and np.array_equal(dto, dtr)  # generate + VirtualT2RealT
+    xo, ro = o.solve()
+    assert np.array_equal(xo, rr["x"]) and ro.final_cost == rr["final_cost"]
+    assert (ro.status, ro.iters, ro.evals, bool(ro.success)) == (rr["status"], rr["iters"], rr["evals"], rr["ok"])
+    # a point in the middle of the solve, where penalties are active differently than at x0
+    xm = rr["iter_x"][len(rr["iter_x"]) // 2]
+    fo, go = o.eval(xm)
+    fr, gr = r.eval(xm)
+    assert fo == fr and np.array_equal(go, gr)
+    return rr
+
+
+@pytest.mark.parametrize("cfg,B", [(1, 3), (2, 3), (3, 4), (5, 2)])
+def test_cost_gradient_and_whole_solve_are_bit_equal_to_the_reference(ref, oracle, cfg, B):
+    """costFunctionCallback and OptimizeTrajectory of the reference on the BASELINE configs against the literal oracle"""
+    p = oracle.default_params()
+    s = sc.baseline_config(cfg, B=B)
+    s.apply_resolution(p)
+    for b in range(B):
+        rr = _compare_problem(ref, oracle, p, s, b)
+        assert rr["ok"] and rr["iters"] > 20
+
+
+def test_random_layouts_are_bit_equal_to_the_reference(ref, oracle):
+    """a seeded slice of scripts/fuzz_ref.py: gear patterns, resolutions, limits, weights, help_eps, obstacle clock, memory"""
+    for c in range(16):
+        rng = np.random.default_rng(7000 + c)
+        M = int(rng.choice([1, 2, 3]))
+        pieces = [int(rng.integers(2, 9)) for _ in range(M)]
+        sing = [int(rng.choice([1, -1]))]
+        for _ in range(M - 1):
+            sing.append(-sing[-1])
+        moving = c % 4 == 0 and sum(pieces) <= 12
+        p = oracle.default_params()
+        s = sc.make_scenario(pieces, sing, int(rng.integers(3, 17)), int(rng.integers(3, 17)), 1, seed=8000 + c, with_moving=moving,
+                             n_obs=int(rng.integers(0, 60)))
+        s.apply_resolution(p)
+        if c % 3 == 0:
+            p.lbfgs_mem_size = int(rng.choice([4, 8, 17]))
+        if c % 2 == 0:
+            p.max_forward_vel *= 0.5; p.max_backward_vel *= 0.6; p.max_forward_acc *= 0.4; p.max_forward_cur *= 0.3
+            p.wei_obs *= 3.0; p.wei_time *= 0.3
+        if c % 5 == 0:
+            s.help_eps = 1e-3
+        if moving:
+            s.t_now = float(rng.uniform(0.0, 5.0))
+        _compare_problem(ref, oracle, p, s, 0)
+
+
+def test_scalar_pieces_match_the_reference(ref, oracle):
+    """positiveSmoothedL1 (traj_optimizer.cpp:783-806)"""
+    p = oracle.default_params()
+    import ctypes as C
+    for x in np.concatenate([np.linspace(-1e-4, 3e-4, 41), [1e-4, 0.99999e-4, 1.0, 37.5]]):
+        f, df = C.c_double(0), C.c_double(0)
+        oracle.lib().oracle_smoothed_l1(float(x), C.byref(f), C.byref(df))
+        assert (f.value, df.value) == ref.smoothed_l1(p, x)
+
+
+# ---------------------------------------------------------------- golden vectors written by the reference build
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_the_reference_builds_vectors(oracle, name):
+    s, _ = load(name)
+    z = np.load(os.path.join(GOLDEN_DIR, "ref_" + name + ".npz"))
+    p = oracle.default_params()
+    s.apply_resolution(p)
+    for b in range(s.B):
+        o = oracle.OracleProblem(p, s, b, order=0)
+        x0 = o.x0()
+        assert np.array_equal(x0, z["x0"][b])
+        f, g = o.eval(x0)
+        assert f == z["f0"][b] and np.array_equal(g, z["g0"][b])
+        x, r = o.solve()
+        assert np.array_equal(x, z["x"][b]) and r.final_cost == z["cost"][b]
+        assert (r.status, r.iters, r.evals, r.success) == (z["status"][b], z["iters"][b], z["evals"][b], z["ok"][b])
+        # every accepted iterate of the reference's solve is reproduced when the oracle is evaluated there
+        xi, fi = z["iter_x_%d" % b], z["iter_fx_%d" % b]
+        for k in (0, len(fi) // 3, len(fi) - 1):
+            assert o.eval(xi[k])[0] == fi[k]
+
+
+def test_oracle_lbfgs_and_minco_reproduce_the_reference_builds_vectors(oracle):
+    z = np.load(os.path.join(GOLDEN_DIR, "ref_units.npz"))
+    p = oracle.default_params()
+    got = ref_cases.run_lbfgs(oracle, p)
+    for k, v in got.items():
+        assert np.array_equal(v, z[k]), k
+    for N in (2, 3, 8, 16, 32):
+        inner, dT, head, tail = ref_cases.minco_inputs(N, 100 + N)
+        c, J = oracle.minco_generate(inner, dT, head, tail)
+        assert np.array_equal(c, z["minco_%d_coeffs" % N]) and J == z["minco_%d_energy" % N][0]
+    import ctypes as C
+    for x, (f0, d0) in zip(z["l1_x"], z["l1_f"]):
+        f, df = C.c_double(0), C.c_double(0)
+        oracle.lib().oracle_smoothed_l1(float(x), C.byref(f), C.byref(df))
+        assert (f.value, df.value) == (f0, d0)
