@@ -31,6 +31,7 @@ EXPORTS = [
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
     "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
+    "dftpav_batch_trace", "dftpav_batch_get_trace",
 ]
 
 
@@ -41,12 +42,12 @@ class DftpavError(RuntimeError):
 
 
 def build(force=False):
-    """Compile libdftpav_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile libdftpav_hip.so for gfx950 (hipcc cross-compiles without a GPU).  Always goes through make: the
+    Makefile tracks every source and header, so a stale library cannot pass for a fresh one."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("solver.hip", "capi.cpp", "device_types.h", "traj_math.h")]
-    srcs.append(os.path.join(_HERE, "..", "include", "dftpav_hip.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
-    if force or stale:
+    if force:
+        subprocess.check_call(["make", "-C", src_dir, "-s", "clean"])
+    if os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(LIB_PATH):
         subprocess.check_call(["make", "-C", src_dir, "-s"])
     return LIB_PATH
 
@@ -386,6 +387,25 @@ class Batch:
         fn = lib().dftpav_batch_finish
         fn.argtypes = [C.c_void_p]
         self.handle._check(fn(self._b), "finish")
+
+    def trace(self, traj, max_evals=4096):
+        """Record every evaluation of trajectory `traj` during the following solves (dftpav_batch_trace); 0 = off."""
+        fn = lib().dftpav_batch_trace
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.handle._check(fn(self._b, int(traj), int(max_evals)), "batch_trace")
+        self._trace_cap = int(max_evals)
+
+    def get_trace(self):
+        """-> dict(x [E][n], g [E][n], d [E][n], f [E], stp [E], k [E], count [E]) of the traced trajectory"""
+        fn = lib().dftpav_batch_get_trace
+        fn.argtypes = [C.c_void_p, c_double_p, c_int_p]
+        n = self.layout.n_vars
+        rows = np.zeros((self._trace_cap, 3 * n + 4))
+        cnt = C.c_int(0)
+        self.handle._check(fn(self._b, dptr(rows), C.byref(cnt)), "batch_get_trace")
+        r = rows[:cnt.value]
+        return dict(x=r[:, :n].copy(), g=r[:, n:2 * n].copy(), d=r[:, 2 * n:3 * n].copy(), f=r[:, 3 * n].copy(),
+                    stp=r[:, 3 * n + 1].copy(), k=r[:, 3 * n + 2].astype(np.int64), count=r[:, 3 * n + 3].astype(np.int64))
 
     def profile(self, enable=True):
         """Debug: switch the in-kernel phase profiler (thread 0 shader-clock deltas) on or off."""

@@ -68,6 +68,7 @@ struct dftpav_handle {
   hipEvent_t cev0 = nullptr, cev1 = nullptr; // around the last corridor kernel
   hipEvent_t mark[2] = {nullptr, nullptr};   // dftpav_mark
   bool ctimed = false;
+  std::vector<struct dftpav_batch *> batches; // every live batch of this handle (obstacle changes finish their chained stragglers)
 };
 
 struct dftpav_batch {
@@ -107,8 +108,12 @@ struct dftpav_batch {
   int dev_version = -1;
   bool prof_on = false;
   double *d_coef = nullptr, *d_dt = nullptr;
+  double *d_f_eval = nullptr; // costs of dftpav_batch_eval (kept apart from the solve's final costs)
+  double *d_trace = nullptr;  // dftpav_batch_trace
+  int trace_b = -1, trace_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
+  bool timed = false;  // a solve was enqueued: ev0 / ev1 are recorded
+  bool solved = false; // results of a solve of the CURRENT inputs exist (cleared by dftpav_batch_upload)
 };
 
 #define HIPCHK(h, call)                                                                  \
@@ -206,6 +211,15 @@ extern "C" int dftpav_create(const dftpav_params *params, int device, dftpav_han
     return DFTPAV_E_NO_DEVICE;
   }
   *out = h;
+  return DFTPAV_OK;
+}
+
+static int finish_pending(dftpav_batch *b);
+// The obstacle set is captured by every batch's launch descriptor: suspended stragglers of a chained solve must finish
+// against the obstacles they started with, so they are finished before the set changes.
+static int finish_batches_of(dftpav_handle *h) {
+  for (dftpav_batch *b : h->batches)
+    if (int rc = finish_pending(b)) return rc;
   return DFTPAV_OK;
 }
 
@@ -344,6 +358,7 @@ extern "C" int dftpav_frontend_resample(dftpav_handle *h, const dftpav_frontend_
 extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S, int n_states) {
   if (!h || (S > 0 && !states) || S < 0 || (S > 0 && n_states < 3)) return DFTPAV_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_batches_of(h)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_surround(h);
   h->sur_version++;
@@ -552,6 +567,7 @@ extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states
 extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   if (!h) return DFTPAV_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_batches_of(h)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   free_surround(h);
   h->sur_version++;
@@ -652,7 +668,12 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histU, b->d_histV,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
-                  b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2};
+                  b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
+                  b->d_f_eval, b->d_trace};
+  {
+    auto &v = b->h->batches;
+    v.erase(std::remove(v.begin(), v.end(), b), v.end());
+  }
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int i = 0; i < kMaxSeg; i++) {
@@ -793,6 +814,7 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   BCHK(hipMalloc(&b->d_x_in, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_x_out, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_f, sizeof(double) * (size_t)B));
+  BCHK(hipMalloc(&b->d_f_eval, sizeof(double) * (size_t)B));
   BCHK(hipMalloc(&b->d_g, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_status, sizeof(int) * (size_t)B));
   BCHK(hipMalloc(&b->d_success, sizeof(int) * (size_t)B));
@@ -852,6 +874,7 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   }
 #undef BCHK
   (void)rc;
+  h->batches.push_back(b);
   *out = b;
   return DFTPAV_OK;
 }
@@ -927,6 +950,9 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   HIPCHK(h, hipMemcpy(b->d_x0, b->x0_host.data(), sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(b->d_iniS, ini.data(), sizeof(double) * ini.size(), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(b->d_finS, fin.data(), sizeof(double) * fin.size(), hipMemcpyHostToDevice));
+  // a new upload without half-planes does not inherit the previous cycle's: they must follow from
+  // dftpav_batch_corridor_from_states / _from_hypotheses before the next solve
+  b->have_corridor = false;
   if (d->corridor) {
     HIPCHK(h, hipMemcpy(b->d_corridor, cor.data(), sizeof(double) * cor.size(), hipMemcpyHostToDevice));
     b->have_corridor = true;
@@ -934,6 +960,8 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   b->t_now = d->t_now;
   b->epis = d->help_eps;
   b->uploaded = true;
+  b->solved = false;
+  b->dev_version = -1; // t_now / help_eps live in the device copy of the launch descriptor: refresh it
   return DFTPAV_OK;
 }
 
@@ -1006,6 +1034,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.x_out = b->d_x_out;
   D.f_out = b->d_f;
   D.g_out = b->d_g;
+  D.f_eval = b->d_f_eval;
   D.status = b->d_status;
   D.success = b->d_success;
   D.iters = b->d_iters;
@@ -1015,6 +1044,9 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.prof = b->prof_on ? b->d_prof : nullptr;
   D.coef_out = b->d_coef;
   D.dt_out = b->d_dt;
+  D.trace = b->d_trace;
+  D.trace_b = b->trace_b;
+  D.trace_cap = b->trace_cap;
   return D;
 }
 
@@ -1049,6 +1081,56 @@ extern "C" int dftpav_debug_profile(dftpav_batch *b, int enable, long long *out)
   return DFTPAV_OK;
 }
 
+// Records every evaluation of one trajectory during the following solves (what lbfgs_optimize shows its progress callback,
+// lbfgs.hpp:242-249,617-624, but per evaluation): used by the lockstep parity test against the reference's line search.
+extern "C" int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals) {
+  if (!b || max_evals < 0 || (max_evals > 0 && (traj < 0 || traj >= b->B))) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_pending(b)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (b->d_trace) {
+    HIPCHK(h, hipFree(b->d_trace));
+    b->d_trace = nullptr;
+  }
+  b->trace_b = -1;
+  b->trace_cap = 0;
+  if (max_evals > 0) {
+    const size_t nd = 8 + (size_t)max_evals * (3 * (size_t)b->L.npad + 8);
+    HIPCHK(h, hipMalloc(&b->d_trace, sizeof(double) * nd));
+    HIPCHK(h, hipMemset(b->d_trace, 0, sizeof(double) * nd));
+    b->trace_b = traj;
+    b->trace_cap = max_evals;
+  }
+  b->dev_version = -1;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals) {
+  if (!b || !n_evals || !b->d_trace) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_pending(b)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int n = b->L.n, npad = b->L.npad;
+  const size_t stride = 3 * (size_t)npad + 8;
+  std::vector<double> raw(8 + (size_t)b->trace_cap * stride);
+  HIPCHK(h, hipMemcpy(raw.data(), b->d_trace, sizeof(double) * raw.size(), hipMemcpyDeviceToHost));
+  int cnt = (int)raw[0];
+  if (cnt > b->trace_cap) cnt = b->trace_cap;
+  *n_evals = cnt;
+  if (out)
+    for (int i = 0; i < cnt; i++) {
+      const double *r = raw.data() + 8 + (size_t)i * stride;
+      double *o = out + (size_t)i * (3 * n + 4);
+      std::memcpy(o, r, sizeof(double) * n);
+      std::memcpy(o + n, r + npad, sizeof(double) * n);
+      std::memcpy(o + 2 * n, r + 2 * npad, sizeof(double) * n);
+      std::memcpy(o + 3 * n, r + 3 * npad, sizeof(double) * 4);
+    }
+  return DFTPAV_OK;
+}
+
 extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g) {
   if (!b || !x || !b->uploaded || !b->have_corridor) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
@@ -1058,7 +1140,7 @@ extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, do
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, launch_solver(D, b->d_dev, kModeEval, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
-  if (f) HIPCHK(h, hipMemcpyAsync(f, b->d_f, sizeof(double) * b->B, hipMemcpyDeviceToHost, h->stream));
+  if (f) HIPCHK(h, hipMemcpyAsync(f, b->d_f_eval, sizeof(double) * b->B, hipMemcpyDeviceToHost, h->stream));
   if (g) HIPCHK(h, hipMemcpyAsync(g, b->d_g, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFTPAV_OK;
@@ -1137,6 +1219,7 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   }
   HIPCHK(h, hipEventRecord(b->ev1, h->stream));
   b->timed = true;
+  b->solved = true;
   return DFTPAV_OK;
 }
 
@@ -1200,7 +1283,7 @@ extern "C" int dftpav_batch_last_solve_ms(dftpav_batch *b, float *ms) {
 
 extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_cost, int *status, int *success,
                                     int *iters, int *evals, long long *hist_sum, double *latency_us) {
-  if (!b) return DFTPAV_E_INVALID;
+  if (!b || !b->solved) return DFTPAV_E_INVALID; // nothing solved since the last upload
   dftpav_handle *h = b->h;
   const int B = b->B;
   if (int rc = finish_pending(b)) return rc;
@@ -1222,7 +1305,7 @@ extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_co
 }
 
 extern "C" int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst) {
-  if (!b || !device_dst) return DFTPAV_E_INVALID;
+  if (!b || !device_dst || !b->solved) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
@@ -1232,7 +1315,7 @@ extern "C" int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst) {
 }
 
 extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piece_dt) {
-  if (!b || !b->uploaded) return DFTPAV_E_INVALID;
+  if (!b || !b->uploaded || !b->solved) return DFTPAV_E_INVALID; // the coefficients are those of the solution x
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
@@ -1247,7 +1330,7 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
 }
 
 extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double vertex_res, int *collision, int *first_sample) {
-  if (!b || !b->uploaded || !b->timed || !(sample_dt > 0.0) || !(vertex_res > 0.0)) return DFTPAV_E_INVALID; // nothing solved yet
+  if (!b || !b->uploaded || !b->solved || !(sample_dt > 0.0) || !(vertex_res > 0.0)) return DFTPAV_E_INVALID; // nothing solved yet
   dftpav_handle *h = b->h;
   if (!h->d_cells) return DFTPAV_E_INVALID; // no map
   HIPCHK(h, hipSetDevice(h->device));
@@ -1299,7 +1382,7 @@ extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double v
 
 extern "C" int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sample_dt, int n_samples, int filter_singularity,
                                           double *states, int *n_valid) {
-  if (!b || !b->uploaded || !b->timed || !(sample_dt > 0.0) || n_samples <= 0 || !states) return DFTPAV_E_INVALID;
+  if (!b || !b->uploaded || !b->solved || !(sample_dt > 0.0) || n_samples <= 0 || !states) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;

@@ -85,12 +85,17 @@ struct DevBatch {
   double *x_out;      // [B][n]
   double *f_out;      // [B]
   double *g_out;      // eval mode: [B][n]
+  double *f_eval;     // eval mode: [B] (apart from f_out, which holds the final costs of the last solve)
   int *status, *success, *iters, *evals;
   long long *hist_sum;
   long long *ticks; // per-trajectory solve time in wall_clock64 ticks (100 MHz)
   long long *prof;  // optional [B][12] shader-clock phase profile (nullptr = off)
   double *coef_out; // [B][Ntot][6][2]
   double *dt_out;   // [B][M]
+  // optional record of every evaluation of one trajectory (dftpav_batch_trace; nullptr = off):
+  // 8 doubles of header ([0] = records written), then records of 3 npad + 8 doubles: x, g, d, {f, stp, k, count}
+  double *trace;
+  int trace_b, trace_cap;
 };
 
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };

@@ -1586,8 +1586,34 @@ __device__ inline void queue_push(unsigned *ctl, int *ring, int cap, int id) {
   __threadfence();
   unsigned t = atomicAdd(&ctl[2], 1u);
   __hip_atomic_store(&ring[t % (unsigned)cap], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  while (atomicCAS(&ctl[1], t, t + 1) != t) { // publish in reservation order
+  // publish in reservation order, with release semantics: the ring entry (and everything fenced above) is visible
+  // to whoever acquire-loads the new tail in queue_pop, also behind another XCD's L2
+  while (true) {
+    unsigned expect = t;
+    if (__hip_atomic_compare_exchange_strong(&ctl[1], &expect, t + 1, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
   }
+}
+
+// dftpav_batch_trace: the evaluation that just finished (x, g in LDS, f in st[sF]) of the traced trajectory
+__device__ inline void trace_eval(const DevBatch &Db, const Smem &sm, int b, int tid, int T) {
+  if (Db.trace == nullptr || b != Db.trace_b) return; // uniform
+  const int idx = sm.ist[iPHASE] == 0 ? 0 : sm.ist[iEVALS];
+  if (idx >= Db.trace_cap) return;
+  const int n = Db.L.n, npad = Db.L.npad;
+  double *rec = Db.trace + 8 + (size_t)idx * (3 * npad + 8);
+  for (int e = tid; e < n; e += T) {
+    rec[e] = sm.x[e];
+    rec[npad + e] = sm.g[e];
+    rec[2 * npad + e] = idx == 0 ? 0.0 : sm.d[e];
+  }
+  if (tid == 0) {
+    rec[3 * npad + 0] = sm.st[sF];
+    rec[3 * npad + 1] = idx == 0 ? 0.0 : sm.st[sSTP];
+    rec[3 * npad + 2] = (double)sm.ist[iK];
+    rec[3 * npad + 3] = idx == 0 ? 0.0 : (double)(sm.ist[iCOUNT] + 1);
+    Db.trace[0] = (double)(idx + 1);
+  }
+  __syncthreads(); // wave 0 rewrites x / g / d next (every condition above is uniform)
 }
 
 // solver state of one trajectory <-> its record in DevBatch::state (everything lbfgs_advance keeps in LDS)
@@ -1749,10 +1775,11 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     const int k_start = sm.ist[iK];
 
     block_eval<SUR>(D, cor_b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
+    if (mode == kModeSolve) trace_eval(Db, sm, b, tid, T);
 
     if (mode == kModeEval) {
       for (int e = tid; e < n; e += T) Db.g_out[(size_t)b * n + e] = sm.g[e];
-      if (tid == 0) Db.f_out[b] = sm.st[sF];
+      if (tid == 0) Db.f_eval[b] = sm.st[sF];
       return;
     }
     if (mode == kModeCoeffs) {
@@ -1772,6 +1799,7 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
         break;
       }
       block_eval<SUR>(D, cor_b, sm, sm.x, sm.g, pr);
+      trace_eval(Db, sm, b, tid, T);
     }
 
     const long long spent = wall_clock64() - tick0;

@@ -280,6 +280,19 @@ int dftpav_batch_get_x0(dftpav_batch *b, double *x0);
  * vectors at once: x [B][n] -> f [B], g [B][n].  Host buffers. */
 int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g);
 
+/* Observation of one trajectory's solve, the role of lbfgs_progress_t
+ * (lbfgs.hpp:242-249; the reference passes NULL, traj_optimizer.cpp:164) at
+ * the granularity of the evaluation callback (lbfgs.hpp:200-202): during the
+ * following solves every cost/gradient evaluation of trajectory `traj` is
+ * recorded, up to max_evals of them (0 switches it off).  dftpav_batch_get_trace
+ * returns n_evals rows of 3 n + 4 doubles: the evaluated x [n], its gradient
+ * g [n], the search direction d [n] in force, then f, the trial step stp, the
+ * iteration k and the evaluation's number within its line search (row 0 is the
+ * evaluation of x0: d, stp and the count are 0).  Used by the lockstep parity
+ * test against the reference's line search and two-loop recursion. */
+int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals);
+int dftpav_batch_get_trace(dftpav_batch *b, double *rows, int *n_evals);
+
 /* L2 cut (production) == lbfgs::lbfgs_optimize driven from
  * OptimizeTrajectory (traj_optimizer.cpp:159-166, lbfgs.hpp:440-751): one
  * persistent kernel launch runs every trajectory's whole L-BFGS solve on the

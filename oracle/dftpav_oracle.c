@@ -1561,10 +1561,10 @@ static double now_s(void) {
   return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
-int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, const dftpav_batch_data *d,
-                       const dftpav_surround *s, int nthreads, int order, double *x, double *final_cost,
-                       int *status, int *success, int *iters, int *evals, long long *hist_sum,
-                       double *seconds_each) {
+int oracle_batch_op(const dftpav_params *p, const dftpav_layout *l, int B, const dftpav_batch_data *d,
+                    const dftpav_surround *s, int nthreads, int order, int op, double *x, double *g_out, double *final_cost,
+                    int *status, int *success, int *iters, int *evals, long long *hist_sum,
+                    double *seconds_each) {
   oracle_problem proto;
   memset(&proto, 0, sizeof(proto));
   proto.M = l->M;
@@ -1601,9 +1601,16 @@ int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, co
     }
     double *xb = x + (size_t)b * n;
     oracle_set_order(c, order);
-    oracle_pack_x0(c, xb);
     oracle_result r;
-    oracle_solve(c, xb, &r);
+    memset(&r, 0, sizeof(r));
+    if (op == ORACLE_OP_EVAL) { /* costFunctionCallback at the given x */
+      r.final_cost = oracle_eval(c, xb, g_out + (size_t)b * n);
+      r.evals = 1;
+      r.success = 1;
+    } else {
+      if (op == ORACLE_OP_SOLVE) oracle_pack_x0(c, xb); /* ORACLE_OP_RESTART: lbfgs_optimize from the given x */
+      oracle_solve(c, xb, &r);
+    }
     double t1 = now_s();
     if (final_cost) final_cost[b] = r.final_cost;
     if (status) status[b] = r.status;
@@ -1616,4 +1623,12 @@ int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, co
   }
   (void)nthreads;
   return err_any;
+}
+
+int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B, const dftpav_batch_data *d,
+                       const dftpav_surround *s, int nthreads, int order, double *x, double *final_cost,
+                       int *status, int *success, int *iters, int *evals, long long *hist_sum,
+                       double *seconds_each) {
+  return oracle_batch_op(p, l, B, d, s, nthreads, order, ORACLE_OP_SOLVE, x, NULL, final_cost, status, success, iters, evals,
+                         hist_sum, seconds_each);
 }

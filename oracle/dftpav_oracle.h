@@ -100,6 +100,15 @@ int oracle_solve_batch(const dftpav_params *p, const dftpav_layout *l, int B,
                        double *x, double *final_cost, int *status, int *success, int *iters,
                        int *evals, long long *hist_sum, double *seconds_each);
 
+/* the same loop with a choice of what runs per trajectory (bench.py's parity legs):
+ *   ORACLE_OP_SOLVE    pack x0, lbfgs_optimize                      (== oracle_solve_batch)
+ *   ORACLE_OP_RESTART  lbfgs_optimize from the x handed in          (x in/out)
+ *   ORACLE_OP_EVAL     costFunctionCallback at the x handed in: f -> final_cost, g -> g_out [B][n] */
+enum { ORACLE_OP_SOLVE = 0, ORACLE_OP_RESTART = 1, ORACLE_OP_EVAL = 2 };
+int oracle_batch_op(const dftpav_params *p, const dftpav_layout *l, int B, const dftpav_batch_data *d,
+                    const dftpav_surround *s, int nthreads, int order, int op, double *x, double *g_out, double *final_cost,
+                    int *status, int *success, int *iters, int *evals, long long *hist_sum, double *seconds_each);
+
 /* ---- generic pieces exposed for unit tests ------------------------------- */
 typedef double (*oracle_eval_fn)(void *instance, const double *x, double *g, int n);
 /* lbfgs::lbfgs_optimize, lbfgs.hpp:440-751 (stepbound/progress callbacks NULL as at traj_optimizer.cpp:163-164) */

@@ -196,6 +196,32 @@ def solve_batch(params, scen, nthreads=1, order=0):
                 hist_sum=hist, seconds=secs)
 
 
+def batch_op(params, scen, op, x, nthreads=1, order=0):
+    """oracle_batch_op: op 'restart' = lbfgs_optimize from the rows of x, 'eval' = f, g at the rows of x."""
+    B, n = scen.B, scen.layout.n_vars
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    assert x.shape == (B, n)
+    g = np.zeros((B, n))
+    fc = np.zeros(B)
+    status = np.zeros(B, dtype=np.int32)
+    success = np.zeros(B, dtype=np.int32)
+    iters = np.zeros(B, dtype=np.int32)
+    evals = np.zeros(B, dtype=np.int32)
+    hist = np.zeros(B, dtype=np.int64)
+    secs = np.zeros(B)
+    lay = scen.layout.c_struct()
+    d = scen.batch_data()
+    sur = scen.surround.c_struct() if scen.surround is not None else None
+    fn = lib().oracle_batch_op
+    fn.argtypes = [C.POINTER(Params), C.POINTER(Layout), C.c_int, C.POINTER(BatchData), C.POINTER(Surround), C.c_int, C.c_int, C.c_int,
+                   c_double_p, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_ll_p, c_double_p]
+    rc = fn(C.byref(params), C.byref(lay), B, C.byref(d), C.byref(sur) if sur is not None else None, nthreads, order,
+            {"solve": 0, "restart": 1, "eval": 2}[op], dptr(x), dptr(g), dptr(fc), iptr(status), iptr(success), iptr(iters),
+            iptr(evals), llptr(hist), dptr(secs))
+    return dict(rc=rc, x=x, g=g, final_cost=fc, f=fc, status=status, success=success, iters=iters, evals=evals, hist_sum=hist,
+                seconds=secs)
+
+
 def lbfgs(fn, x0, params=None):
     """oracle_lbfgs with a Python callback fn(x)->(f,g)."""
     params = params or default_params()
