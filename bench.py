@@ -467,7 +467,7 @@ def main():
             rel_f = np.abs(ev["f"] - r["final_cost"]) / np.maximum(1.0, np.abs(ev["f"]))
             rst = po.batch_op(params, shard, "restart", r["x"], nthreads=cores, order=0)
             drop = (ev["f"] - rst["final_cost"]) / np.maximum(1.0, np.abs(ev["f"]))
-            nl = args.literal_sample if args.literal_sample >= 0 else int(min(shard.B, max(64, 20.0 * cores / max(t1, 1e-3))))
+            nl = args.literal_sample if args.literal_sample >= 0 else int(min(shard.B, max(64, 8.0 * cores / max(t1, 1e-3))))
             lit = {"trajectories": int(shard.B),
                    "literal_cost_at_kernel_x_max_rel_diff": float(rel_f.max()),
                    "literal_restart_from_kernel_x": {"iters_p50": float(np.median(rst["iters"])), "iters_p95": float(np.percentile(rst["iters"], 95)),
@@ -477,14 +477,31 @@ def main():
                                                      "rel_cost_decrease_max": float(drop.max())}}
             if nl > 0:
                 pl = (np.arange(nl) * max(1, shard.B // nl)) % shard.B
-                ls = po.solve_batch(params, shard.subset(pl), nthreads=cores, order=0)
+                subl = shard.subset(pl)
+                ls = po.solve_batch(params, subl, nthreads=cores, order=0)
+                # the reference's own sensitivity, for scale: the same literal solves with one waypoint coordinate moved by one ulp,
+                # and the literal solver restarted from its own final points
+                sub1 = shard.subset(pl)
+                sub1.inner_pts = np.ascontiguousarray(sub1.inner_pts).copy()
+                sub1.inner_pts[:, 0] = np.nextafter(sub1.inner_pts[:, 0], np.inf)
+                l1 = po.solve_batch(params, sub1, nthreads=cores, order=0)
+                rel_1 = np.abs(l1["final_cost"] - ls["final_cost"]) / np.maximum(1.0, np.abs(ls["final_cost"]))
+                rs2 = po.batch_op(params, subl, "restart", ls["x"], nthreads=cores, order=0)
                 rel_c = (r["final_cost"][pl] - ls["final_cost"]) / np.maximum(1.0, np.abs(ls["final_cost"]))
                 lit["literal_solve_from_same_x0"] = {
                     "trajectories": int(nl), "success_rate_kernel": float(r["success"][pl].mean()), "success_rate_literal": float(ls["success"].mean()),
                     "rel_final_cost_diff_abs_p50": float(np.median(np.abs(rel_c))), "rel_final_cost_diff_abs_p95": float(np.percentile(np.abs(rel_c), 95)),
                     "rel_final_cost_diff_signed_mean": float(rel_c.mean()),
                     "frac_within_1e-5": float((np.abs(rel_c) <= 1e-5).mean()), "frac_kernel_cost_not_worse_by_1e-3": float((rel_c <= 1e-3).mean()),
-                    "mean_iters_kernel": float(r["iters"][pl].mean()), "mean_iters_literal": float(ls["iters"].mean())}
+                    "mean_iters_kernel": float(r["iters"][pl].mean()), "mean_iters_literal": float(ls["iters"].mean()),
+                    "median_cost_kernel": float(np.median(r["final_cost"][pl])), "median_cost_literal": float(np.median(ls["final_cost"])),
+                    "mean_cost_kernel": float(r["final_cost"][pl].mean()), "mean_cost_literal": float(ls["final_cost"].mean())}
+                lit["literal_vs_literal_with_x0_moved_by_one_ulp"] = {
+                    "trajectories": int(nl), "rel_final_cost_diff_abs_p50": float(np.median(rel_1)),
+                    "rel_final_cost_diff_abs_p95": float(np.percentile(rel_1, 95)), "frac_within_1e-5": float((rel_1 <= 1e-5).mean())}
+                lit["literal_restart_from_literal_x"] = {"iters_p50": float(np.median(rs2["iters"])), "iters_p95": float(np.percentile(rs2["iters"], 95)),
+                                                         "iters_max": int(rs2["iters"].max()), "frac_stopping_within_3": float((rs2["iters"] <= 3).mean()),
+                                                         "frac_stopping_within_5": float((rs2["iters"] <= 5).mean())}
             out["parity"]["literal"] = lit
             # (3) one trajectory in lockstep with the reference's line search and two-loop recursion (tests/lockstep.py)
             try:

@@ -14,7 +14,7 @@ import numpy as np
 from .pods import (BatchData, Layout, Params, Surround, c_double_p, c_int_p, c_ll_p, dptr, iptr, llptr)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdftpav_hip.so")
+LIB_PATH = os.environ.get("DFTPAV_LIB") or os.path.join(_HERE, "libdftpav_hip.so")  # DFTPAV_LIB: an experimental build (scripts/build_variant.sh)
 _LIB = None
 
 OK = 0
@@ -47,6 +47,8 @@ def build(force=False):
     src_dir = os.path.join(_HERE, "csrc")
     if force:
         subprocess.check_call(["make", "-C", src_dir, "-s", "clean"])
+    if os.environ.get("DFTPAV_LIB"):
+        return LIB_PATH
     if os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(LIB_PATH):
         subprocess.check_call(["make", "-C", src_dir, "-s"])
     return LIB_PATH

@@ -18,6 +18,7 @@
 
 #include "../../include/dftpav_hip.h"
 #include "device_types.h"
+#include "e4_plan.h"
 #include "traj_math.h"
 
 namespace dftpav {
@@ -83,7 +84,7 @@ struct dftpav_batch {
   // shape above, the stragglers it hands over finish in the latency shape below
   bool sched = false;
   int slots = 0, slice = 0, hand_over = 0;
-  int threads2 = 0, ppt2 = 0;
+  int threads2 = 0;
   bool op_in_lds2 = false, cor_in_lds2 = false;
   int *d_queue = nullptr, *d_stragglers = nullptr, *d_stragglers2 = nullptr, *d_sflag = nullptr, *d_iota = nullptr;
   int qcap = 0;
@@ -91,7 +92,9 @@ struct dftpav_batch {
   unsigned *d_qctl = nullptr;
   double *d_state = nullptr;
   DevBatch *d_dev2 = nullptr;
-  int ppt = 1;
+  // E4 lane plans (e4_plan.h) of the two launch shapes: host copies of the sizes, device tables
+  E4Sizes e4{}, e4b{};
+  int *d_e4[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}; // slot, wave, round, piece
   int NptsPad = 0;
   std::vector<double> x0_host;
   bool uploaded = false;
@@ -676,6 +679,9 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   }
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  for (int w = 0; w < 2; w++)
+    for (int t = 0; t < 4; t++)
+      if (b->d_e4[w][t]) (void)hipFree(b->d_e4[w][t]);
   for (int i = 0; i < kMaxSeg; i++) {
     if (b->d_opM[i]) (void)hipFree(b->d_opM[i]);
     if (b->d_opMT[i]) (void)hipFree(b->d_opMT[i]);
@@ -744,12 +750,10 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     if (const char *e = std::getenv("DFTPAV_MODE")) shape = std::atoi(e); // 0 latency, 1 two per CU, 2 four per CU
     b->threads = solver_threads(L, shape);
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
-    b->ppt = solver_ppt(L, b->threads, shape);
-    if (const char *e = std::getenv("DFTPAV_PPT")) b->ppt = std::atoi(e) > 0 ? std::atoi(e) : b->ppt;
     // LDS budget per workgroup: the whole CU, half of it, a quarter of it
     const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : 38 * 1024);
-    b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, true, false) + 64 <= budget;
-    b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds, true) + 64 <= budget;
+    b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, true, false) + 64 <= budget;
+    b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, true) + 64 <= budget;
     if (const char *e = std::getenv("DFTPAV_LDS")) { // bit 0 operators, bit 1 corridor
       int v = std::atoi(e);
       b->op_in_lds = (v & 1) != 0;
@@ -771,11 +775,10 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     if (const char *e = std::getenv("DFTPAV_SCHED")) b->sched = std::atoi(e) != 0 && b->slots > 0 && b->slice > 0;
     if (b->hand_over > B) b->hand_over = B;
     b->threads2 = solver_threads(L, 0);
-    b->ppt2 = solver_ppt(L, b->threads2, 0);
-    b->op_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->ppt2, true, false) + 64 <= 158 * 1024;
-    b->cor_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->ppt2, b->op_in_lds2, true) + 64 <= 158 * 1024;
+    b->op_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, true, false) + 64 <= 158 * 1024;
+    b->cor_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->op_in_lds2, true) + 64 <= 158 * 1024;
   }
-  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->ppt, b->op_in_lds, b->cor_in_lds) + 64;
+  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, b->cor_in_lds) + 64;
   if (lds > 160 * 1024 || b->threads < 64 || b->threads > 512 || b->threads % 64) {
     delete b;
     return DFTPAV_E_UNSUPPORTED;
@@ -862,6 +865,16 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
       }
     BCHK(hipMemcpy(b->d_pt_piece, pp.data(), sizeof(int16_t) * L.Npts, hipMemcpyHostToDevice));
     BCHK(hipMemcpy(b->d_pt_j, pj.data(), sizeof(int16_t) * L.Npts, hipMemcpyHostToDevice));
+  }
+  // E4 lane plans of the two launch shapes
+  for (int which = 0; which < 2; which++) {
+    const E4Plan pl = build_e4_plan(L, which == 0 ? b->threads : b->threads2);
+    (which == 0 ? b->e4 : b->e4b) = E4Sizes{pl.rounds, pl.groups, pl.left, pl.lcap};
+    const std::vector<int> *tabs[4] = {&pl.slot, &pl.wave, &pl.round, &pl.piece};
+    for (int t = 0; t < 4; t++) {
+      BCHK(hipMalloc(&b->d_e4[which][t], sizeof(int) * tabs[t]->size()));
+      BCHK(hipMemcpy(b->d_e4[which][t], tabs[t]->data(), sizeof(int) * tabs[t]->size(), hipMemcpyHostToDevice));
+    }
   }
   for (int sg = 0; sg < M; sg++) {
     int N = L.piece_nums[sg];
@@ -1001,7 +1014,14 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.pt_j = b->d_pt_j;
   D.op_in_lds = b->op_in_lds ? 1 : 0;
   D.cor_in_lds = b->cor_in_lds ? 1 : 0;
-  D.ppt = b->ppt;
+  D.e4_rounds = b->e4.rounds;
+  D.e4_groups = b->e4.groups;
+  D.e4_left = b->e4.left;
+  D.e4_lcap = b->e4.lcap;
+  D.e4_slot = b->d_e4[0][0];
+  D.e4_wave = b->d_e4[0][1];
+  D.e4_round = b->d_e4[0][2];
+  D.e4_piece = b->d_e4[0][3];
   int off = 0;
   for (int i = 0; i < kMaxSeg; i++) {
     D.opM[i] = b->d_opM[i];
@@ -1060,7 +1080,14 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
     DevBatch D2 = D; // the same batch in the latency shape (follow-up launch of a scheduled solve)
     D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
     D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
-    D2.ppt = b->ppt2;
+    D2.e4_rounds = b->e4b.rounds;
+    D2.e4_groups = b->e4b.groups;
+    D2.e4_left = b->e4b.left;
+    D2.e4_lcap = b->e4b.lcap;
+    D2.e4_slot = b->d_e4[1][0];
+    D2.e4_wave = b->d_e4[1][1];
+    D2.e4_round = b->d_e4[1][2];
+    D2.e4_piece = b->d_e4[1][3];
     HIPCHK(h, hipMemcpyAsync(b->d_dev2, &D2, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream)); // D, D2 live on this stack frame
     b->dev_version = version;
@@ -1152,7 +1179,14 @@ static int launch_stragglers(dftpav_batch *b, const DevBatch &D, int source) {
   DevBatch D2 = D;
   D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
   D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
-  D2.ppt = b->ppt2;
+  D2.e4_rounds = b->e4b.rounds;
+  D2.e4_groups = b->e4b.groups;
+  D2.e4_left = b->e4b.left;
+  D2.e4_lcap = b->e4b.lcap;
+  D2.e4_slot = b->d_e4[1][0];
+  D2.e4_wave = b->d_e4[1][1];
+  D2.e4_round = b->d_e4[1][2];
+  D2.e4_piece = b->d_e4[1][3];
   HIPCHK(h, launch_solver(D2, b->d_dev2, kModeSolve, b->threads2, b->hand_over, SchedArgs{source, 0, 0, nullptr}, h->stream));
   return DFTPAV_OK;
 }
@@ -1172,8 +1206,8 @@ static int finish_pending(dftpav_batch *b) {
 }
 
 static bool chain_compatible(const dftpav_batch *a, const dftpav_batch *b) {
-  return a->h == b->h && a->sched && b->sched && a->B == b->B && a->threads == b->threads && a->ppt == b->ppt &&
-         a->op_in_lds == b->op_in_lds && a->cor_in_lds == b->cor_in_lds && a->threads2 == b->threads2 && a->ppt2 == b->ppt2 &&
+  return a->h == b->h && a->sched && b->sched && a->B == b->B && a->threads == b->threads &&
+         a->op_in_lds == b->op_in_lds && a->cor_in_lds == b->cor_in_lds && a->threads2 == b->threads2 &&
          a->hand_over == b->hand_over && a->hand_over > 0 && a->NptsPad == b->NptsPad && a->prof_on == b->prof_on &&
          std::memcmp(&a->L, &b->L, sizeof(DevLayout)) == 0 && std::memcmp(&a->P, &b->P, sizeof(DevParams)) == 0 &&
          a->t_now == b->t_now && a->epis == b->epis;

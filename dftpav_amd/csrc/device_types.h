@@ -44,6 +44,14 @@ struct DevSurround {
   const double *start;     // [S]
 };
 
+// ---- how the constraint points of a trajectory are mapped onto the lanes of a workgroup (solver.hip, E4)
+// The K+1 points of a piece are taken in groups of G consecutive points, G = 32 or 16 lanes of one wave: a group's 14
+// per-piece sums (12 entries of gdC, gdT, cost) are formed by a cross-lane tree inside the wave, no LDS round trip.
+// What does not fill a group (point 33 of a 33-point piece; every point of a piece shorter than 16) is a "leftover":
+// evaluated in densely packed lanes, its contributions staged in LDS and chained onto the piece in point order.
+// Per piece and output the sum is   start value + group 0 + group 1 + ... + leftovers in point order.
+inline int e4_group_size(int points) { return points >= 32 ? 32 : (points >= 16 ? 16 : 0); }
+
 // Everything one launch needs. Device pointers.
 struct DevBatch {
   DevLayout L;
@@ -62,7 +70,12 @@ struct DevBatch {
   const double *opMT[kMaxSeg]; // its transpose [N+5][6N]
   int op_in_lds;               // operators are staged in LDS at kernel start
   int cor_in_lds;              // the trajectory's half-planes are staged in LDS at kernel start
-  int ppt;                     // constraint points per thread and chunk (chunk = ppt * blockDim)
+  // E4 lane plan for this launch shape (see e4_group_size): rounds of blockDim slots
+  int e4_rounds, e4_groups, e4_left, e4_lcap; // rounds; groups and leftover points per trajectory; leftover capacity of the LDS staging
+  const int *e4_slot;          // [e4_rounds][blockDim] piece | j << 16, or -1 for an idle lane
+  const int *e4_wave;          // [e4_rounds][blockDim / 64][2] per wave: kind (32, 16: group size; 0: leftovers; -1: idle), base (first group id / first leftover index)
+  const int *e4_round;         // [e4_rounds][2] leftovers evaluated in the round (0 = none: no chain pass after it), index of the first
+  const int *e4_piece;         // [Ntot][4] first group, groups, first leftover, leftovers of a piece
   int op_off[kMaxSeg];         // offset (doubles) of each segment's operator inside the LDS copy
   DevSurround sur;
   double t_now, epis;
@@ -113,10 +126,13 @@ struct SchedArgs {
 // doubles of solver state per suspended trajectory
 inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { return 5 * L.npad + 24 + 8 + 2 * P.mem_size; }
 
+// host-side E4 lane plan of a layout for a workgroup size (tables of DevBatch::e4_*)
+struct E4Sizes {
+  int rounds, groups, left, lcap;
+};
+E4Sizes e4_sizes(const DevLayout &L, int threads);
 // size in bytes of the dynamic LDS a launch needs
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds, bool cor_lds);
-// constraint points each thread handles per chunk
-int solver_ppt(const DevLayout &L, int threads, int shape);
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds);
 // picks the workgroup size for a layout; shape 0/1/2 = at most one / two / more trajectories per CU
 int solver_threads(const DevLayout &L, int shape);
 

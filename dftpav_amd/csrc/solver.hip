@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
+#include "e4_plan.h"
 #include "traj_math.h"
 
 namespace dftpav {
@@ -46,7 +47,8 @@ struct Smem {
   double *rhs;  // [rhs_tot][2]
   double *b, *c, *gdC; // [6*Ntot][2]
   double *adj;  // [rhs_tot][2]
-  double *part; // [8][chunk]
+  double *gsum;  // [e4_groups][16] the 14 per-piece sums of every group of constraint points (E4)
+  double *lpart; // [14][e4_lcap + 2] contributions of the leftover points of one round
   double *pE, *pGsm, *pGdT, *pCost; // [Ntot]
   double *ys, *rinv, *alpha; // [mem]
   double *st;     // [sNUM] scalar solver state
@@ -54,7 +56,10 @@ struct Smem {
   double *opM, *opMT; // operators of all segments back to back (only when D.op_in_lds)
   double *cor;        // [4H][NptsPad] half-planes of this trajectory (only when D.cor_in_lds)
   int *ist;     // [iNUM]
-  int *ptinfo;  // [Npts] piece | j<<16
+  int *slot;    // [e4_rounds][T] piece | j<<16 of the constraint point a lane evaluates in a round (-1: idle)
+  int *wtab;    // [e4_rounds][T/64][2] what a wave does in a round: kind, base (e4_plan.h)
+  int *rtab;    // [e4_rounds][2] leftovers of a round, first index
+  int *pgrp;    // [Ntot][4] first group, groups, first leftover, leftovers of a piece
   int *pcinfo;  // [Ntot][8] pt0, K, tab, segment, lp, N, singul, operator offset
   int *rowinfo; // [rhs_tot][4] segment, column, N, first piece of the segment
 };
@@ -72,16 +77,7 @@ __host__ __device__ inline size_t opT_lds_doubles(const DevLayout &L) {
   for (int i = 0; i < L.M; i++) n += (size_t)(6 * L.piece_nums[i] + kOpTPad) * (L.piece_nums[i] + 5);
   return n;
 }
-__host__ __device__ inline int chunk_points(const DevLayout &L, int T, int ppt) {
-  int c = T * ppt;
-  return c < L.Npts ? c : ((L.Npts + 63) / 64) * 64;
-}
-
-// row stride of the per-point partial buffer: the x and y rows of a quantity are read together by the
-// transposed reduction, so consecutive rows start 8 banks apart instead of on the same bank
-__host__ __device__ inline int part_stride(const DevLayout &L, int T, int ppt) { return chunk_points(L, T, ppt) + 4; }
-
-__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int T, int ppt, bool op_lds, bool cor_lds) {
+__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int groups, int lcap, bool op_lds, bool cor_lds) {
   size_t n = 0;
   n += 5 * (size_t)L.npad;
   n += (size_t)L.M * 12;
@@ -90,7 +86,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   n += (size_t)L.rhs_tot * 2;
   n += 3 * (size_t)L.Ntot * 12;
   n += (size_t)L.rhs_tot * 2;
-  n += 8 * (size_t)part_stride(L, T, ppt);
+  n += 16 * (size_t)groups + 14 * (size_t)(lcap + 2);
   n += 4 * (size_t)L.Ntot;
   n += 3 * (size_t)mem;
   n += sNUM;
@@ -99,19 +95,26 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   if (cor_lds) n += (size_t)4 * L.H * (((size_t)L.Npts + 63) / 64 * 64);
   return n;
 }
-__host__ __device__ inline size_t smem_ints(const DevLayout &L) {
-  return iNUM + (size_t)L.Npts + 8 * (size_t)L.Ntot + 4 * (size_t)L.rhs_tot;
+__host__ __device__ inline size_t smem_ints(const DevLayout &L, int rounds, int T) {
+  return iNUM + (size_t)rounds * T + (size_t)rounds * (T / kWave) * 2 + (size_t)rounds * 2 + 4 * (size_t)L.Ntot + 8 * (size_t)L.Ntot +
+         4 * (size_t)L.rhs_tot;
 }
 
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, int ppt, bool op_lds, bool cor_lds) {
-  return smem_doubles(L, P.mem_size, threads, ppt, op_lds, cor_lds) * sizeof(double) + smem_ints(L) * sizeof(int);
+E4Sizes e4_sizes(const DevLayout &L, int threads) {
+  const E4Plan pl = build_e4_plan(L, threads);
+  return E4Sizes{pl.rounds, pl.groups, pl.left, pl.lcap};
+}
+
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds) {
+  const E4Sizes z = e4_sizes(L, threads);
+  return smem_doubles(L, P.mem_size, z.groups, z.lcap, op_lds, cor_lds) * sizeof(double) + smem_ints(L, z.rounds, threads) * sizeof(int);
 }
 
 int solver_threads(const DevLayout &L, int shape) {
   // Every stage is a strided loop, so any multiple of 64 works; the choice trades the latency of one
   // solve against how many trajectories a CU holds (256 VGPRs per lane => 8 waves per CU).  Measured on
   // 528-point problems (scripts/profile_phases.py):
-  //   shape 0, <= 1 trajectory per CU : two constraint points per thread, up to 8 waves
+  //   shape 0, <= 1 trajectory per CU : about two constraint points per thread, up to 8 waves
   //   shape 1, <= 2 per CU            : 4 waves, two workgroups resident per CU
   //   shape 2, more                   : 2 waves, four workgroups resident per CU
   int T;
@@ -131,15 +134,8 @@ int solver_threads(const DevLayout &L, int shape) {
   return T;
 }
 
-int solver_ppt(const DevLayout &L, int threads, int shape) {
-  int ppt = (L.Npts + threads - 1) / threads;
-  if (shape == 2 && ppt > 2) ppt = 2; // small chunks keep the per-workgroup LDS under a quarter of the CU
-  // keep the per-chunk partials (64 B per point) within ~48 KB of LDS
-  while (ppt > 1 && (size_t)ppt * threads * 64 > 48 * 1024) --ppt;
-  return ppt;
-}
-
-__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int ppt, bool op_lds, bool cor_lds) {
+__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int rounds, int groups, int lcap, bool op_lds,
+                             bool cor_lds) {
   double *p = base;
   s.x = p; p += L.npad;
   s.xp = p; p += L.npad;
@@ -154,7 +150,8 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.c = p; p += L.Ntot * 12;
   s.gdC = p; p += L.Ntot * 12;
   s.adj = p; p += L.rhs_tot * 2;
-  s.part = p; p += 8 * part_stride(L, T, ppt);
+  s.gsum = p; p += 16 * groups;
+  s.lpart = p; p += 14 * (lcap + 2);
   s.pE = p; p += L.Ntot;
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
@@ -174,8 +171,11 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.cor = p;
   if (cor_lds) p += (size_t)4 * L.H * ((L.Npts + 63) / 64 * 64);
   s.ist = reinterpret_cast<int *>(p);
-  s.ptinfo = s.ist + iNUM;
-  s.pcinfo = s.ptinfo + L.Npts;
+  s.slot = s.ist + iNUM;
+  s.wtab = s.slot + rounds * T;
+  s.rtab = s.wtab + rounds * (T / kWave) * 2;
+  s.pgrp = s.rtab + rounds * 2;
+  s.pcinfo = s.pgrp + 4 * L.Ntot;
   s.rowinfo = s.pcinfo + 8 * L.Ntot;
 }
 
@@ -262,6 +262,52 @@ __device__ inline double wave_max(double v) {
   return first_lane_f64(wave_max_raw<LV>(v));
 }
 
+// Sixteen sums over the lanes of a 16-lane row (LV = 4) or of two adjacent rows (LV = 5) with shared butterflies: at
+// distance 1 a lane keeps the eight values whose index bit 0 equals its k0 and hands the other eight to its partner,
+// at distance 2 it keeps four (bit 1 = k1), at distance 4 (row_half_mirror) two (bit 2 = k2), at distance 8
+// (row_mirror) one (bit 3 = k3); LV = 5 adds the two rows (v_permlane16_swap).  The k's are chosen so that mirror
+// partners agree on the lower ones: k0 = b0^b2, k1 = b1^b2, k2 = b2^b3, k3 = b3 (b = lane bits).  The lane pairs added
+// at every distance are those of the plain butterfly (wave_sum_raw), so each total has its bits; 15 exchanged values
+// instead of 64.  Lane l ends with the total of value reduce16_index(l).
+__device__ inline int reduce16_index(int lane) {
+  const int b0 = lane & 1, b1 = (lane >> 1) & 1, b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1;
+  return (b0 ^ b2) | ((b1 ^ b2) << 1) | ((b2 ^ b3) << 2) | (b3 << 3);
+}
+template <int LV>
+__device__ __forceinline__ double reduce16(const double (&v)[16], int lane) {
+  const bool k0 = ((lane ^ (lane >> 2)) & 1) != 0;
+  const bool k1 = (((lane >> 1) ^ (lane >> 2)) & 1) != 0;
+  const bool k2 = (((lane >> 2) ^ (lane >> 3)) & 1) != 0;
+  const bool k3 = ((lane >> 3) & 1) != 0;
+  double w[8], z[4], y[2];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const double keep = k0 ? v[2 * k + 1] : v[2 * k], send = k0 ? v[2 * k] : v[2 * k + 1];
+    w[k] = keep + mov_dpp<0xB1>(send); // quad_perm [1,0,3,2]
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double keep = k1 ? w[2 * k + 1] : w[2 * k], send = k1 ? w[2 * k] : w[2 * k + 1];
+    z[k] = keep + mov_dpp<0x4E>(send); // quad_perm [2,3,0,1]
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const double keep = k2 ? z[2 * k + 1] : z[2 * k], send = k2 ? z[2 * k] : z[2 * k + 1];
+    y[k] = keep + mov_dpp<0x141>(send); // row_half_mirror
+  }
+  double r;
+  {
+    const double keep = k3 ? y[1] : y[0], send = k3 ? y[0] : y[1];
+    r = keep + mov_dpp<0x140>(send); // row_mirror
+  }
+  if (LV >= 5) {
+    double a, b;
+    swap16(r, a, b);
+    r = a + b;
+  }
+  return r;
+}
+
 // a / b from the correctly rounded reciprocal y = 1/b (Markstein): q0 = a*y,
 // r = a - b*q0 (exact in an FMA), q = q0 + r*y.  With y correctly rounded and
 // no over/underflow this is the correctly rounded quotient — the same bits as
@@ -331,7 +377,6 @@ typedef PitchedPlanes<cor_l_t> LdsPlanes;
 // Out-of-range slots re-read the last valid element and are masked at use; the sums keep their order.
 typedef const double __attribute__((address_space(1))) *opg_t; // operator in global memory: global_load, vmcnt only
 constexpr int kOpChunk = 24;
-constexpr int kRedChunk = 11; // points per batch of the transposed reduction (a full piece of 33 = 3 batches)
 template <class P> __device__ __forceinline__ double op_row_dot(P Mrow, const double *rh, int ncol) {
   double acc = 0.0;
   for (int c0 = 0; c0 < ncol; c0 += kOpChunk) {
@@ -447,7 +492,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
   // cor_b: half-planes of this trajectory, &corridor[b][0][0] of the batch it belongs to
   const DevLayout &L = D.L; // uniform accesses only (scalar loads)
   const DevParams &P = D.P;
-  const int tid = threadIdx.x, T = blockDim.x;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
   const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, rhs_tot = L.rhs_tot, Kmax1 = L.Kmax + 1;
   const double *iniS = sm.bnd, *finS = sm.bnd + 6 * M; // boundary states of this trajectory, staged with x
 
@@ -585,196 +630,103 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
     sm.pCost[p] = 0.0;
   }
 
-  // ---- E4: penalty integral over the constraint points (traj_optimizer.cpp:486-779), in chunks
-  const int chunk = chunk_points(L, T, D.ppt);
-  const int pstride = part_stride(L, T, D.ppt);
-  for (int base = 0; base < Npts; base += chunk) {
-    for (int r = 0; r < D.ppt; r++) {
-      int loc = tid + r * T;
-      int pt = base + loc;
-      if (loc >= chunk) break;
-      double o[8];
-      if (pt < Npts) {
-        int info = sm.ptinfo[pt];
-        int p = info & 0xffff;
-        const int *pc = sm.pcinfo + 8 * p;
-        SampleIn in;
-        in.j = info >> 16;
-        in.K = pc[1];
-        int sg = pc[3];
-        in.lp = pc[4];
-        in.N = pc[5];
-        in.singul = pc[6];
-        in.dt = sm.seg[sg * 16 + 1];
-        in.s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
-        in.cc = sm.c + 12 * p;
-        in.epis = D.epis;
-        in.H = L.H;
-        in.trajid = sg;
-        in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
-        in.t_now = D.t_now;
-        const double *cb = cor_b + pt;
-        if (D.cor_in_lds) {
-          LdsPlanes pl{(cor_l_t)(sm.cor + pt), (size_t)((Npts + 63) / 64 * 64)};
-          if (L.H <= 4) sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
-          else sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
-        } else if (L.H <= 4) {
-          double cor[16]; // all half-plane loads issued up front (unconditionally: rows past 4 H re-read row 0 and
-                          // are never used), consumed after the state evaluation
-          const cor_g_t cg = (cor_g_t)cb;
+  // ---- E4: penalty integral over the constraint points (traj_optimizer.cpp:486-779)
+  // Lanes take points by the plan of e4_plan.h.  A group of 32 (16) consecutive points of one piece sits in 32 (16)
+  // adjacent lanes: each lane turns its point's subtotals into the 14 contributions to the piece (12 entries of gdC,
+  // gdT, cost) and the group sums them with one cross-lane tree (reduce16) -- no LDS round trip, no barrier.  Points
+  // that fill no group ("leftovers") are packed densely, their contributions staged in LDS.  After the last group round
+  // (and after every round with leftovers) one chain pass adds, per piece and output in this order: the value E3 left,
+  // the group sums, the leftovers in point order.
+  {
+    const int nwv = T >> 6, wv = tid >> 6;
+    const int lstride = D.e4_lcap + 2;
+    bool groups_added = false;
+    for (int r = 0; r < D.e4_rounds; r++) {
+      const int info = sm.slot[r * T + tid];
+      const int kind = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 2]);
+      const int wbase = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 2 + 1]);
+      const int nleft = sm.rtab[2 * r], lbase = sm.rtab[2 * r + 1];
+      if (kind >= 0) { // wave-uniform: this wave has points in this round
+        double o[8];
+        double s1 = 0.0;
+        if (info >= 0) {
+          const int p = info & 0xffff;
+          const int *pc = sm.pcinfo + 8 * p;
+          SampleIn in;
+          in.j = info >> 16;
+          in.K = pc[1];
+          const int sg = pc[3];
+          in.lp = pc[4];
+          in.N = pc[5];
+          in.singul = pc[6];
+          in.dt = sm.seg[sg * 16 + 1];
+          in.s1 = s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+          in.cc = sm.c + 12 * p;
+          in.epis = D.epis;
+          in.H = L.H;
+          in.trajid = sg;
+          in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
+          in.t_now = D.t_now;
+          const int pt = pc[0] + in.j;
+          const double *cb = cor_b + pt;
+          if (D.cor_in_lds) {
+            LdsPlanes pl{(cor_l_t)(sm.cor + pt), (size_t)((Npts + 63) / 64 * 64)};
+            if (L.H <= 4) sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
+            else sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
+          } else if (L.H <= 4) {
+            double cor[16]; // all half-plane loads issued up front (unconditionally: rows past 4 H re-read row 0 and
+                            // are never used), consumed after the state evaluation
+            const cor_g_t cg = (cor_g_t)cb;
 #pragma unroll
-          for (int k = 0; k < 16; k++) cor[k] = cg[(size_t)(k < 4 * L.H ? k : 0) * D.NptsPad];
-          RegPlanes pl{cor};
-          sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
+            for (int k = 0; k < 16; k++) cor[k] = cg[(size_t)(k < 4 * L.H ? k : 0) * D.NptsPad];
+            RegPlanes pl{cor};
+            sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
+          } else {
+            GlobalPlanes pl{(cor_g_t)cb, (size_t)D.NptsPad};
+            sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
+          }
         } else {
-          GlobalPlanes pl{(cor_g_t)cb, (size_t)D.NptsPad};
-          sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
+#pragma unroll
+          for (int k = 0; k < 8; k++) o[k] = 0.0;
         }
-      } else {
+        double v[16];
+        point_contributions(s1, o, v);
+        v[14] = 0.0;
+        v[15] = 0.0;
+        if (kind > 0) { // a wave of groups
+          double tot;
+          if (kind == 32) tot = reduce16<5>(v, lane);
+          else tot = reduce16<4>(v, lane);
+          const int idx = reduce16_index(lane);
+          if (info >= 0 && (lane & (kind - 1)) < 16 && idx < 14) sm.gsum[(wbase + lane / kind) * 16 + idx] = tot;
+        } else if (info >= 0) { // a wave of leftovers
+          const int li = wbase - lbase + lane;
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[k] = 0.0;
+          for (int k = 0; k < 14; k++) sm.lpart[k * lstride + li] = v[k];
+        }
       }
-#pragma unroll
-      for (int k = 0; k < 8; k++) sm.part[k * pstride + loc] = o[k];
-    }
-    __syncthreads();
-    pr.tick(kPE3S);
-    // transposed reduction, 16 threads per piece: 12 chain (A,B,C) onto gdC, 2 more chain gdT and cost
-    int lim = base + chunk < Npts ? base + chunk : Npts;
-    // Narrow workgroups (the throughput shape, 128 threads): 8 lanes per piece instead, lane k < 6 chaining both
-    // dimensions of row k -- the three powers of a point are read once for x and y (9 LDS reads per point and two
-    // outputs instead of 12), and 16 pieces fit one pass.  Every chain is the same sequence of additions as below.
-    if (T <= 128) {
-      for (int w = tid; w < 8 * Ntot; w += T) {
-        const int p = w >> 3, q = w & 7;
-        const int *pc = sm.pcinfo + 8 * p;
-        const int pt0 = pc[0], K = pc[1];
-        const int j0 = base > pt0 ? base - pt0 : 0;
-        const int j1 = (pt0 + K + 1 < lim ? pt0 + K + 1 : lim) - pt0; // exclusive
-        if (j1 <= j0) continue;
-        typedef const double __attribute__((address_space(3))) *lds_t;
-        if (q < 6) {
-          const int k = q;
-          const double *tab = sm.spow + (size_t)pc[2] * Kmax1 * 6;
-          const int k1 = k >= 1 ? k - 1 : 0, k2 = k >= 2 ? k - 2 : 0;
-          const double kd = (double)k, kkd = (double)(k * (k - 1));
-          const lds_t ek = (lds_t)(tab + k), ek1 = (lds_t)(tab + k1), ek2 = (lds_t)(tab + k2);
-          const lds_t a0 = (lds_t)(sm.part + 0 * pstride + (pt0 - base)), a1 = (lds_t)(sm.part + 1 * pstride + (pt0 - base));
-          const lds_t b0p = (lds_t)(sm.part + 2 * pstride + (pt0 - base)), b1p = (lds_t)(sm.part + 3 * pstride + (pt0 - base));
-          const lds_t c0 = (lds_t)(sm.part + 4 * pstride + (pt0 - base)), c1 = (lds_t)(sm.part + 5 * pstride + (pt0 - base));
-          double accx = sm.gdC[12 * p + 2 * k], accy = sm.gdC[12 * p + 2 * k + 1];
-          constexpr int RC = 8;
-          int jb = j0;
-          for (; jb + RC <= j1; jb += RC) {
-            double e0[RC], e1[RC], e2[RC], ax[RC], ay[RC], bx[RC], by[RC], cx[RC], cy[RC];
-#pragma unroll
-            for (int t = 0; t < RC; t++) {
-              e0[t] = ek[6 * (jb + t)];
-              e1[t] = ek1[6 * (jb + t)];
-              e2[t] = ek2[6 * (jb + t)];
-              ax[t] = a0[jb + t]; ay[t] = a1[jb + t];
-              bx[t] = b0p[jb + t]; by[t] = b1p[jb + t];
-              cx[t] = c0[jb + t]; cy[t] = c1[jb + t];
-            }
-#pragma unroll
-            for (int t = 0; t < RC; t++) {
-              const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
-              accx += fma_(b2, cx[t], fma_(b1, bx[t], b0 * ax[t]));
-              accy += fma_(b2, cy[t], fma_(b1, by[t], b0 * ay[t]));
-            }
-          }
-          for (; jb < j1; jb++) { // at most RC - 1 points
-            const double b0 = ek[6 * jb], b1 = kd * ek1[6 * jb], b2 = kkd * ek2[6 * jb];
-            accx += fma_(b2, c0[jb], fma_(b1, b0p[jb], b0 * a0[jb]));
-            accy += fma_(b2, c1[jb], fma_(b1, b1p[jb], b0 * a1[jb]));
-          }
-          sm.gdC[12 * p + 2 * k] = accx;
-          sm.gdC[12 * p + 2 * k + 1] = accy;
-        } else {
-          const double *pv = sm.part + q * pstride + (pt0 - base); // row 6: gdT, row 7: cost
-          double acc = q == 6 ? sm.pGdT[p] : sm.pCost[p];
-#pragma unroll 8
-          for (int j = j0; j < j1; j++) acc += pv[j];
-          if (q == 6) sm.pGdT[p] = acc;
+      pr.tick(kPE3S);
+      if (nleft > 0 || r == D.e4_rounds - 1) { // uniform
+        __syncthreads();
+        for (int w = tid; w < 16 * Ntot; w += T) {
+          const int p = w >> 4, q = w & 15;
+          if (q >= 14) continue;
+          const int *pg = sm.pgrp + 4 * p;
+          double acc = q < 12 ? sm.gdC[12 * p + q] : (q == 12 ? sm.pGdT[p] : sm.pCost[p]);
+          if (!groups_added)
+            for (int gi = 0; gi < pg[1]; gi++) acc += sm.gsum[(pg[0] + gi) * 16 + q];
+          const int l0 = pg[2] > lbase ? pg[2] : lbase;
+          const int l1 = pg[2] + pg[3] < lbase + nleft ? pg[2] + pg[3] : lbase + nleft;
+          for (int l = l0; l < l1; l++) acc += sm.lpart[q * lstride + (l - lbase)];
+          if (q < 12) sm.gdC[12 * p + q] = acc;
+          else if (q == 12) sm.pGdT[p] = acc;
           else sm.pCost[p] = acc;
         }
-      }
-    } else
-    for (int w = tid; w < 16 * Ntot; w += T) {
-      int p = w >> 4, q = w & 15;
-      if (q >= 14) continue;
-      const int *pc = sm.pcinfo + 8 * p;
-      int pt0 = pc[0], K = pc[1];
-      int j0 = base > pt0 ? base - pt0 : 0;
-      int j1 = (pt0 + K + 1 < lim ? pt0 + K + 1 : lim) - pt0; // exclusive
-      if (j1 <= j0) continue;
-      if (q < 12) {
-        int k = q >> 1, d = q & 1;
-        const double *pa = sm.part + (0 + d) * pstride + (pt0 - base);
-        const double *pb = sm.part + (2 + d) * pstride + (pt0 - base);
-        const double *pc2 = sm.part + (4 + d) * pstride + (pt0 - base);
-        // beta0[k] = s^k, beta1[k] = k s^(k-1), beta2[k] = k(k-1) s^(k-2): the same products as
-        // traj_optimizer.cpp:505-507 (x1.0 and x0.0 are exact), read from the power table without branching
-        const double *tab = sm.spow + (size_t)pc[2] * Kmax1 * 6;
-        const int k1 = k >= 1 ? k - 1 : 0, k2 = k >= 2 ? k - 2 : 0;
-        const double kd = (double)k, kkd = (double)(k * (k - 1));
-        double acc = sm.gdC[12 * p + q]; // continue the chain that starts at the smoothness gradient
-        // batches of kRedChunk points: every LDS read of a batch is issued before the first add, the chain itself
-        // stays in point order.  A full batch uses constant offsets from one address per array, which lets the
-        // compiler pair the reads (ds_read2_b64: the cost here is per LDS instruction, ~14 cycles each); the last,
-        // partial batch re-reads its last point in the unused slots and masks them.
-        typedef const double __attribute__((address_space(3))) *lds_t;
-        const lds_t ek = (lds_t)(tab + k), ek1 = (lds_t)(tab + k1), ek2 = (lds_t)(tab + k2);
-        const lds_t la = (lds_t)pa, lb = (lds_t)pb, lc = (lds_t)pc2;
-        int jb = j0;
-        for (; jb + kRedChunk <= j1; jb += kRedChunk) {
-          double e0[kRedChunk], e1[kRedChunk], e2[kRedChunk], va[kRedChunk], vb[kRedChunk], vc[kRedChunk];
-#pragma unroll
-          for (int t = 0; t < kRedChunk; t++) {
-            e0[t] = ek[6 * (jb + t)];
-            e1[t] = ek1[6 * (jb + t)];
-            e2[t] = ek2[6 * (jb + t)];
-            va[t] = la[jb + t];
-            vb[t] = lb[jb + t];
-            vc[t] = lc[jb + t];
-          }
-#pragma unroll
-          for (int t = 0; t < kRedChunk; t++) {
-            const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
-            acc += fma_(b2, vc[t], fma_(b1, vb[t], b0 * va[t]));
-          }
-        }
-        if (jb < j1) {
-          double e0[kRedChunk], e1[kRedChunk], e2[kRedChunk], va[kRedChunk], vb[kRedChunk], vc[kRedChunk];
-#pragma unroll
-          for (int t = 0; t < kRedChunk - 1; t++) {
-            const int j = jb + t < j1 ? jb + t : j1 - 1;
-            e0[t] = ek[6 * j];
-            e1[t] = ek1[6 * j];
-            e2[t] = ek2[6 * j];
-            va[t] = la[j];
-            vb[t] = lb[j];
-            vc[t] = lc[j];
-          }
-#pragma unroll
-          for (int t = 0; t < kRedChunk - 1; t++) {
-            const double b0 = e0[t], b1 = kd * e1[t], b2 = kkd * e2[t];
-            const double nx = acc + fma_(b2, vc[t], fma_(b1, vb[t], b0 * va[t]));
-            acc = jb + t < j1 ? nx : acc;
-          }
-        }
-        sm.gdC[12 * p + q] = acc;
-      } else {
-        const double *pv = sm.part + (q == 12 ? 6 : 7) * pstride + (pt0 - base);
-        double acc = q == 12 ? sm.pGdT[p] : sm.pCost[p];
-#pragma unroll 8
-        for (int j = j0; j < j1; j++) acc += pv[j];
-        if (q == 12) sm.pGdT[p] = acc;
-        else sm.pCost[p] = acc;
+        groups_added = true;
+        __syncthreads();
+        pr.tick(kPE4R);
       }
     }
-    __syncthreads();
-    pr.tick(kPE4R);
   }
 
   // ---- E5: adjoint through A^{-T} (MinJerkOpt::calGrads_PT, poly_traj_utils.hpp:1037-1064)
@@ -1665,11 +1617,14 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   const int lane = tid & 63;
   const int n = L.n;
   Smem sm;
-  carve(sm, lds_raw, L, D.P.mem_size, T, D.ppt, D.op_in_lds != 0, D.cor_in_lds != 0);
+  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0);
   Prof pr;
 
   // ---- one-time staging: role tables and operators (the same for every trajectory of the batch)
-  for (int pt = tid; pt < L.Npts; pt += T) sm.ptinfo[pt] = (int)D.pt_piece[pt] | ((int)D.pt_j[pt] << 16);
+  for (int i = tid; i < D.e4_rounds * T; i += T) sm.slot[i] = D.e4_slot[i];
+  for (int i = tid; i < D.e4_rounds * (T >> 6) * 2; i += T) sm.wtab[i] = D.e4_wave[i];
+  for (int i = tid; i < D.e4_rounds * 2; i += T) sm.rtab[i] = D.e4_round[i];
+  for (int i = tid; i < 4 * L.Ntot; i += T) sm.pgrp[i] = D.e4_piece[i];
   for (int p = tid; p < L.Ntot; p += T) {
     int sg = 0, p0 = 0, N = 0, pt0s = 0, sgl = 0, ooff = 0;
     for (int s = 0, a = 0; s < L.M; s++) {
@@ -1912,7 +1867,7 @@ static hipError_t launch_lv(int n, const DevBatch *d_dev, int grid, int mode, in
 // d_dev: device copy of the DevBatch `D` describes; grid: workgroups to launch (D.B unless the launch is scheduled)
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
                          hipStream_t stream) {
-  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.ppt, D.op_in_lds != 0, D.cor_in_lds != 0);
+  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.op_in_lds != 0, D.cor_in_lds != 0);
   if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
   return launch_lv<false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
 }

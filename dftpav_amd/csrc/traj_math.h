@@ -287,6 +287,22 @@ DFTPAV_HD inline void beta_row(int k, double s1, double &b0, double &b1, double 
   }
 }
 
+// What one constraint point adds to its piece: the 12 entries of gdC (row k, dimension d at v[2 k + d]), gdT (v[12])
+// and the cost (v[13]), from the point's subtotals o = {d/dsigma (2), d/dsigma' (2), d/dsigma'' (2), gdT, cost}:
+// beta0[k] a_d + beta1[k] b_d + beta2[k] c_d with the beta vectors of traj_optimizer.cpp:505-507 at offset s1.
+DFTPAV_HD inline void point_contributions(double s1, const double o[8], double v[14]) {
+  const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  const double b0[6] = {1.0, s1, s2, s3, s4, s5};
+  const double b1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  const double b2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+  for (int k = 0; k < 6; k++) {
+    v[2 * k] = fma_(b2[k], o[4], fma_(b1[k], o[2], b0[k] * o[0]));
+    v[2 * k + 1] = fma_(b2[k], o[5], fma_(b1[k], o[3], b0[k] * o[1]));
+  }
+  v[12] = o[6];
+  v[13] = o[7];
+}
+
 // 2x2 helpers, m = {m00, m01, m10, m11}
 DFTPAV_HD inline void mat_vec(const double m[4], const double v[2], double o[2]) {
   o[0] = m[0] * v[0] + m[1] * v[1];

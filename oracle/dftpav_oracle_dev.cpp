@@ -216,8 +216,9 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
     D.pGdT[p] = 0.0;
     D.pCost[p] = 0.0;
   }
-  // ---- E4: per-point subtotals, then per-piece chains in point order
-  const int NP = L.Npts;
+  // ---- E4: per point the 14 contributions to its piece; per piece and output: the value E3 left, then the groups of 32
+  // (16) consecutive points, each summed by the kernel's cross-lane tree (pairs at distance 1, 2, 4, 8, 16), then the
+  // points that fill no group, in point order (device_types.h: e4_group_size; solver.hip: reduce16)
   {
     int pt = 0;
     for (int sg = 0; sg < L.M; sg++)
@@ -226,6 +227,8 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
         bool edge = (lp == 0 || lp == N - 1);
         int K = edge ? L.Kd : L.K;
         int p = L.seg_piece0[sg] + lp;
+        const int G = e4_group_size(K + 1), nf = G ? (K + 1) / G : 0;
+        std::vector<double> contrib((size_t)(K + 1) * 14);
         for (int j = 0; j <= K; j++, pt++) {
           SampleIn in;
           in.j = j;
@@ -245,36 +248,26 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
           double o[8];
           if (D.S.S > 0) sample_point_math<true, 0>(P, D.S, in, pl, o);
           else sample_point_math<false, 0>(P, D.S, in, pl, o);
-          for (int k = 0; k < 8; k++) D.part[(size_t)k * NP + pt] = o[k];
+          point_contributions(in.s1, o, &contrib[(size_t)j * 14]);
+        }
+        for (int q = 0; q < 14; q++) {
+          double acc = q < 12 ? D.gdC[12 * p + q] : (q == 12 ? D.pGdT[p] : D.pCost[p]);
+          for (int g = 0; g < nf; g++) {
+            double v[32];
+            for (int l = 0; l < G; l++) v[l] = contrib[(size_t)(g * G + l) * 14 + q];
+            for (int o = 1; o < G; o <<= 1) {
+              double w[32];
+              for (int l = 0; l < G; l++) w[l] = v[l] + v[l ^ o];
+              for (int l = 0; l < G; l++) v[l] = w[l];
+            }
+            acc += v[0];
+          }
+          for (int j = nf * G; j <= K; j++) acc += contrib[(size_t)j * 14 + q];
+          if (q < 12) D.gdC[12 * p + q] = acc;
+          else if (q == 12) D.pGdT[p] = acc;
+          else D.pCost[p] = acc;
         }
       }
-  }
-  for (int p = 0; p < L.Ntot; p++) {
-    int sg = seg_of_piece(L, p);
-    int lp = p - L.seg_piece0[sg];
-    int N = L.piece_nums[sg];
-    bool edge = (lp == 0 || lp == N - 1);
-    int K = edge ? L.Kd : L.K;
-    int pt0 = L.seg_pt0[sg] + (lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1));
-    const double *tab = &D.stab[(sg * 2 + (edge ? 1 : 0)) * (L.Kmax + 1)];
-    for (int q = 0; q < 12; q++) {
-      int k = q >> 1, d = q & 1;
-      const double *pa = &D.part[(size_t)(0 + d) * NP + pt0];
-      const double *pb = &D.part[(size_t)(2 + d) * NP + pt0];
-      const double *pc = &D.part[(size_t)(4 + d) * NP + pt0];
-      double acc = D.gdC[12 * p + q];
-      for (int j = 0; j <= K; j++) {
-        double b0, b1, b2;
-        beta_row(k, tab[j], b0, b1, b2);
-        acc += fma_(b2, pc[j], fma_(b1, pb[j], b0 * pa[j]));
-      }
-      D.gdC[12 * p + q] = acc;
-    }
-    double ag = D.pGdT[p], ac = D.pCost[p];
-    for (int j = 0; j <= K; j++) ag += D.part[(size_t)6 * NP + pt0 + j];
-    for (int j = 0; j <= K; j++) ac += D.part[(size_t)7 * NP + pt0 + j];
-    D.pGdT[p] = ag;
-    D.pCost[p] = ac;
   }
   // ---- E5: four strided partial chains per output (rows q, q+4, ...), combined (p0+p1)+(p2+p3)
   for (int w = 0; w < 2 * L.rhs_tot; w++) {
