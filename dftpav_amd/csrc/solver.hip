@@ -1004,8 +1004,9 @@ __device__ __forceinline__ double wave_sum8_transposed(const double (&v)[kLoopBl
 struct HistBlock {
   double s[kLoopBlock], y[kLoopBlock];
   double coef[kLoopBlock - 1];
-  double ys, ri;
-  double al[kLoopBlock]; // second loop: alpha of every step of the block (uniform)
+  double al; // second loop: alpha of the step this lane owns (broadcast per step with a v_readlane pair, as the first loop
+             // does with the alpha it has just formed; eight uniform copies per block would cost 14 more registers per
+             // block, which pushes the function into callee-saved registers: 8 KB of scratch traffic per call)
 };
 // the three LDS arrays the recursion touches, as pointers that carry their address space (the recursion is an
 // out-of-line function: a generic pointer would turn every access into a flat one)
@@ -1023,8 +1024,7 @@ __device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr
   js = js < 0 ? js + m : (js >= m ? js - m : js);
 #pragma unroll
   for (int u = 0; u < kLoopBlock - 1; u++) R.coef[u] = hB[(size_t)js * 8 + (st > u ? st - u - 1 : 0)];
-  R.ys = sm.ys[js];
-  R.ri = sm.rinv[js];
+  if (LOOP2) R.al = sm.alpha[js];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) {
     {
@@ -1034,7 +1034,6 @@ __device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr
       R.s[q] = sy.x;
       R.y[q] = sy.y;
     }
-    if (LOOP2) R.al[q] = sm.alpha[jl];
     if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
     else jl = jl == m - 1 ? 0 : jl + 1;
   }
@@ -1054,6 +1053,9 @@ __device__ __forceinline__ void pin_block(HistBlock &R) {
 template <int LV, bool FULL>
 __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopLds &sm, int i0, int nb, int m, bool act, int lane,
                                                  int &j, double &dreg) {
+  int jown = j - step_of_lane(lane); // slot of the step this lane owns (the block starts at slot j and walks downwards)
+  jown = jown < 0 ? jown + m : jown;
+  const double ys_ = sm.ys[jown], ri_ = sm.rinv[jown]; // first used after the reduction below
   double v[kLoopBlock];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.s[q] : 0.0) * dreg; // lm_s.col(j).dot(d), steps past nb unused
@@ -1065,7 +1067,7 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
 #pragma unroll
   for (int u = 0; u < kLoopBlock; u++) {
     if (FULL || i0 + u < nb) { // uniform
-      const double t = div_by_rcp(acc, R.ys, R.ri);             // ... / lm_ys(j): only the owner's quotient is used
+      const double t = div_by_rcp(acc, ys_, ri_);               // ... / lm_ys(j): only the owner's quotient is used
       const double au = readlane_f64(t, lane_of_step(u));       // alpha of step u for everybody
       if (u < kLoopBlock - 1) {
         const double nacc = __builtin_fma(-au, R.coef[u], acc);
@@ -1075,7 +1077,7 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
     }
   }
   // lanes 0..7 own one step each; their sum stopped changing at their own step, so its quotient is their alpha
-  const double mine = div_by_rcp(acc, R.ys, R.ri);
+  const double mine = div_by_rcp(acc, ys_, ri_);
   int js = j - st;
   js = js < 0 ? js + m : js;
   if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[js] = mine;
@@ -1084,7 +1086,13 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
   j = j < 0 ? j + m : j;
 }
 template <int LV, bool FULL>
-__device__ __forceinline__ void second_loop_block(const HistBlock &R, int i0, int nb, bool act, int lane, double &dreg) {
+__device__ __forceinline__ void second_loop_block(const HistBlock &R, const LoopLds &sm, int i0, int nb, int m, bool act, int lane, int &j2,
+                                                  double &dreg) {
+  int jown = j2 + step_of_lane(lane); // the block starts at slot j2 and walks upwards
+  jown = jown >= m ? jown - m : jown;
+  const double ys_ = sm.ys[jown], ri_ = sm.rinv[jown];
+  j2 += kLoopBlock;
+  j2 = j2 >= m ? j2 - m : j2;
   double v[kLoopBlock];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.y[q] : 0.0) * dreg; // lm_y.col(j).dot(d), steps past nb unused
@@ -1094,14 +1102,15 @@ __device__ __forceinline__ void second_loop_block(const HistBlock &R, int i0, in
 #pragma unroll
   for (int u = 0; u < kLoopBlock; u++) {
     if (FULL || i0 + u < nb) { // uniform
-      const double t = div_by_rcp(acc, R.ys, R.ri);
-      const double bu = readlane_f64(t, lane_of_step(u)); // beta of step u
+      const double t = div_by_rcp(acc, ys_, ri_);
+      const double bu = readlane_f64(t, lane_of_step(u));    // beta of step u
+      const double au = readlane_f64(R.al, lane_of_step(u)); // alpha of step u (first loop), from the lane that owns the step
       if (u < kLoopBlock - 1) {
-        double nacc = __builtin_fma(R.al[u], R.coef[u], acc);
+        double nacc = __builtin_fma(au, R.coef[u], acc);
         nacc = __builtin_fma(-bu, R.coef[u], nacc);
         acc = st > u ? nacc : acc;
       }
-      dreg = __builtin_fma(R.al[u] - bu, act ? R.s[u] : 0.0, dreg);
+      dreg = __builtin_fma(au - bu, act ? R.s[u] : 0.0, dreg);
     }
   }
 }
@@ -1112,9 +1121,10 @@ __device__ __forceinline__ void first_loop_step(const HistBlock &R, const LoopLd
   else if (i0 < nb) first_loop_block<LV, false>(R, sm, i0, nb, m, act, lane, j, dreg);
 }
 template <int LV>
-__device__ __forceinline__ void second_loop_step(const HistBlock &R, int i0, int nb, bool act, int lane, double &dreg) {
-  if (i0 + kLoopBlock <= nb) second_loop_block<LV, true>(R, i0, nb, act, lane, dreg);
-  else if (i0 < nb) second_loop_block<LV, false>(R, i0, nb, act, lane, dreg);
+__device__ __forceinline__ void second_loop_step(const HistBlock &R, const LoopLds &sm, int i0, int nb, int m, bool act, int lane, int &j2,
+                                                 double &dreg) {
+  if (i0 + kLoopBlock <= nb) second_loop_block<LV, true>(R, sm, i0, nb, m, act, lane, j2, dreg);
+  else if (i0 < nb) second_loop_block<LV, false>(R, sm, i0, nb, m, act, lane, j2, dreg);
 }
 
 // History columns (global memory: they live in L2 / Infinity Cache) are double-buffered in registers:
@@ -1167,14 +1177,15 @@ __device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_
   dreg *= ys_new / yy_new;
   // ---- second loop: oldest -> newest, starting one past the slot the first loop ended on
   jl = j == m - 1 ? 0 : j + 1;
+  int j2 = jl; // slot of the first step of the block being reduced
   load_block<+1, true>(A, sm, hS, hY, hV, npad, m, ln, lane, jl);
   for (int i0 = 0; i0 < nb; i0 += 2 * PB) {
     pin_block(A);
     load_block<+1, true>(B, sm, hS, hY, hV, npad, m, ln, lane, jl);
-    second_loop_step<LV>(A, i0, nb, act, lane, dreg);
+    second_loop_step<LV>(A, sm, i0, nb, m, act, lane, j2, dreg);
     pin_block(B);
     load_block<+1, true>(A, sm, hS, hY, hV, npad, m, ln, lane, jl);
-    second_loop_step<LV>(B, i0 + PB, nb, act, lane, dreg);
+    second_loop_step<LV>(B, sm, i0 + PB, nb, m, act, lane, j2, dreg);
   }
   return dreg;
 }
