@@ -59,7 +59,7 @@ struct dftpav_handle {
   int sur_pieces = 0; // pieces of all obstacles together
   int sur_version = 0; // bumped by dftpav_set_surround so batches refresh their device descriptor
   int *d_sur_off = nullptr;
-  double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr;
+  double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr, *d_sur_theta = nullptr;
   // obstacle map of the corridor generator (device copy) and the table of sample offsets along a line
   dftpav_grid_map map{};
   unsigned char *d_cells = nullptr;
@@ -226,14 +226,58 @@ static int finish_batches_of(dftpav_handle *h) {
   return DFTPAV_OK;
 }
 
+// DevSurround::theta: for piece k of an obstacle the largest double t with f_k(t) <= duration_k, where f_k is the
+// reference's walk t -= d_0, ..., t -= d_{k-1} (poly_traj_utils.hpp:515-521) in fp64.  f_k is non-decreasing in t, so the
+// boundary is found by bisection over the bit patterns of the non-negative doubles with that same arithmetic.  Returns
+// false (no table: the kernels walk) if a duration is not positive and finite or the thresholds do not increase.
+static bool build_theta(const std::vector<int> &off, const std::vector<double> &dur, std::vector<double> &theta) {
+  theta.assign(dur.size(), 0.0);
+  for (size_t u = 0; u + 1 < off.size(); u++) {
+    const double *d = dur.data() + off[u];
+    const int np = off[u + 1] - off[u];
+    double prev = -1.0;
+    for (int k = 0; k < np; k++) {
+      if (!(d[k] > 0.0) || !std::isfinite(d[k])) return false;
+      auto stops = [&](double t) {
+        for (int i = 0; i < k; i++) t -= d[i];
+        return !(t > d[k]);
+      };
+      unsigned long long lo = 0, hi; // bit patterns: stops(lo) holds, stops(hi) does not
+      const double big = 1.0e300;
+      std::memcpy(&hi, &big, 8);
+      while (hi - lo > 1) {
+        const unsigned long long mid = lo + (hi - lo) / 2;
+        double t;
+        std::memcpy(&t, &mid, 8);
+        if (stops(t)) lo = mid;
+        else hi = mid;
+      }
+      double th;
+      std::memcpy(&th, &lo, 8);
+      if (!(th >= prev)) return false;
+      prev = th;
+      theta[off[u] + k] = th;
+    }
+  }
+  return true;
+}
+static int upload_theta(dftpav_handle *h, const std::vector<int> &off, const std::vector<double> &dur) {
+  std::vector<double> theta;
+  if (!build_theta(off, dur, theta) || theta.empty()) return DFTPAV_OK; // d_sur_theta stays null: the kernels walk
+  HIPCHK(h, hipMalloc(&h->d_sur_theta, sizeof(double) * theta.size()));
+  HIPCHK(h, hipMemcpy(h->d_sur_theta, theta.data(), sizeof(double) * theta.size(), hipMemcpyHostToDevice));
+  return DFTPAV_OK;
+}
+
 static void free_surround(dftpav_handle *h) {
   if (h->d_sur_off) (void)hipFree(h->d_sur_off);
   if (h->d_sur_dur) (void)hipFree(h->d_sur_dur);
+  if (h->d_sur_theta) (void)hipFree(h->d_sur_theta);
   if (h->d_sur_coef) (void)hipFree(h->d_sur_coef);
   if (h->d_sur_total) (void)hipFree(h->d_sur_total);
   if (h->d_sur_start) (void)hipFree(h->d_sur_start);
   h->d_sur_off = nullptr;
-  h->d_sur_dur = h->d_sur_coef = h->d_sur_total = h->d_sur_start = nullptr;
+  h->d_sur_dur = h->d_sur_coef = h->d_sur_total = h->d_sur_start = h->d_sur_theta = nullptr;
   h->S = 0;
   h->sur_pieces = 0;
 }
@@ -398,6 +442,11 @@ extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S
   chk(hipStreamSynchronize(h->stream)); // off / Mop live on this stack frame
   (void)hipFree(d_states);
   (void)hipFree(d_op);
+  if (rc == DFTPAV_OK) {
+    std::vector<double> dur(np);
+    if (hipMemcpy(dur.data(), h->d_sur_dur, sizeof(double) * np, hipMemcpyDeviceToHost) != hipSuccess) rc = DFTPAV_E_HIP;
+    if (rc == DFTPAV_OK) rc = upload_theta(h, off, dur);
+  }
   if (rc == DFTPAV_OK) {
     h->S = S;
     h->sur_pieces = np;
@@ -587,6 +636,8 @@ extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   HIPCHK(h, hipMemcpy(h->d_sur_coef, s->coeffs, sizeof(double) * 12 * np, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_sur_total, s->total_duration, sizeof(double) * S, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_sur_start, s->start_time, sizeof(double) * S, hipMemcpyHostToDevice));
+  if (int rc = upload_theta(h, std::vector<int>(s->piece_offsets, s->piece_offsets + S + 1), std::vector<double>(s->durations, s->durations + np)))
+    return rc;
   h->sur_pieces = np;
   h->S = S;
   return DFTPAV_OK;
@@ -752,8 +803,8 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
     // LDS budget per workgroup: the whole CU, half of it, a quarter of it
     const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : 38 * 1024);
-    b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, true, false) + 64 <= budget;
-    b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, true) + 64 <= budget;
+    b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, true, false, 512) + 64 <= budget;
+    b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, true, 512) + 64 <= budget;
     if (const char *e = std::getenv("DFTPAV_LDS")) { // bit 0 operators, bit 1 corridor
       int v = std::atoi(e);
       b->op_in_lds = (v & 1) != 0;
@@ -775,10 +826,10 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     if (const char *e = std::getenv("DFTPAV_SCHED")) b->sched = std::atoi(e) != 0 && b->slots > 0 && b->slice > 0;
     if (b->hand_over > B) b->hand_over = B;
     b->threads2 = solver_threads(L, 0);
-    b->op_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, true, false) + 64 <= 158 * 1024;
-    b->cor_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->op_in_lds2, true) + 64 <= 158 * 1024;
+    b->op_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, true, false, 512) + 64 <= 158 * 1024;
+    b->cor_in_lds2 = solver_lds_bytes(L, b->P, b->threads2, b->op_in_lds2, true, 512) + 64 <= 158 * 1024;
   }
-  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, b->cor_in_lds) + 64;
+  size_t lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, b->cor_in_lds, 512) + 64;
   if (lds > 160 * 1024 || b->threads < 64 || b->threads > 512 || b->threads % 64) {
     delete b;
     return DFTPAV_E_UNSUPPORTED;
@@ -1031,8 +1082,10 @@ static DevBatch make_dev(dftpav_batch *b) {
   }
   dftpav_handle *h = b->h;
   D.sur.S = h->S;
+  D.sur_np = h->sur_pieces;
   D.sur.piece_off = h->d_sur_off;
   D.sur.durations = h->d_sur_dur;
+  D.sur.theta = h->d_sur_theta;
   D.sur.coeffs = h->d_sur_coef;
   D.sur.total = h->d_sur_total;
   D.sur.start = h->d_sur_start;
@@ -1073,6 +1126,11 @@ static DevBatch make_dev(dftpav_batch *b) {
 // refreshes the device copy of the launch descriptor when something it captures changed
 static int sync_dev(dftpav_batch *b, DevBatch &D) {
   dftpav_handle *h = b->h;
+  // the kernel numbers (constraint point, obstacle) pairs with 16 bits and keeps a 16-bit mask of obstacles per point
+  if (h->S > 16 || (long long)b->L.Npts * h->S > 65535 || h->sur_pieces > 512) {
+    h->err = "too many moving obstacles for this layout (S <= 16, Npts * S <= 65535, <= 512 pieces in all)";
+    return DFTPAV_E_UNSUPPORTED;
+  }
   D = make_dev(b);
   int version = h->sur_version * 4 + (b->prof_on ? 1 : 0) + (b->uploaded ? 2 : 0);
   if (version != b->dev_version) {

@@ -42,6 +42,11 @@ struct DevSurround {
   const double *coeffs;    // [np][12], col 0 multiplies t^5 (poly_traj_utils.hpp:993)
   const double *total;     // [S]
   const double *start;     // [S]
+  // [np] or nullptr.  theta[k] of an obstacle = the largest t for which Trajectory::locatePieceIdx (poly_traj_utils.hpp:510-528,
+  // a walk of dependent subtractions t -= duration) stops at piece k or earlier, found on the host by bisection over the
+  // doubles with that same walk (capi.cpp, build_theta): the piece index is then a search in theta, and only the local
+  // time is formed by the reference's subtractions.  Same result for every t by construction; nullptr = walk.
+  const double *theta;
 };
 
 // ---- how the constraint points of a trajectory are mapped onto the lanes of a workgroup (solver.hip, E4)
@@ -78,6 +83,7 @@ struct DevBatch {
   const int *e4_piece;         // [Ntot][4] first group, groups, first leftover, leftovers of a piece
   int op_off[kMaxSeg];         // offset (doubles) of each segment's operator inside the LDS copy
   DevSurround sur;
+  int sur_np;                  // pieces of all moving obstacles together (their durations are staged in LDS)
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
   double *histS, *histY; // one buffer [B][mem][npad][2]: (s, y) interleaved per element, histY == histS + 1
@@ -132,7 +138,7 @@ struct E4Sizes {
 };
 E4Sizes e4_sizes(const DevLayout &L, int threads);
 // size in bytes of the dynamic LDS a launch needs
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds);
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np);
 // picks the workgroup size for a layout; shape 0/1/2 = at most one / two / more trajectories per CU
 int solver_threads(const DevLayout &L, int shape);
 

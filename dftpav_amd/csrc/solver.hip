@@ -49,6 +49,9 @@ struct Smem {
   double *adj;  // [rhs_tot][2]
   double *gsum;  // [e4_groups][16] the 14 per-piece sums of every group of constraint points (E4)
   double *lpart; // [14][e4_lcap + 2] contributions of the leftover points of one round
+  double *dpart; // [14][T + 2] contributions of T (point, moving obstacle) pairs (kernels with moving obstacles only)
+  double *sdur;  // [sur_np] piece durations of the moving obstacles: Trajectory::locatePieceIdx (poly_traj_utils.hpp:510-528)
+                 // walks them one dependent load after the other -- from LDS that is ~100 cycles a step instead of an L2 round trip
   double *pE, *pGsm, *pGdT, *pCost; // [Ntot]
   double *ys, *rinv, *alpha; // [mem]
   double *st;     // [sNUM] scalar solver state
@@ -60,6 +63,7 @@ struct Smem {
   int *wtab;    // [e4_rounds][T/64][2] what a wave does in a round: kind, base (e4_plan.h)
   int *rtab;    // [e4_rounds][2] leftovers of a round, first index
   int *pgrp;    // [Ntot][4] first group, groups, first leftover, leftovers of a piece
+  int *dinfo;   // [Npts + 1] moving obstacles near a point (bits 16..31) | index of its first pair (kernels with moving obstacles only)
   int *pcinfo;  // [Ntot][8] pt0, K, tab, segment, lp, N, singul, operator offset
   int *rowinfo; // [rhs_tot][4] segment, column, N, first piece of the segment
 };
@@ -77,7 +81,9 @@ __host__ __device__ inline size_t opT_lds_doubles(const DevLayout &L) {
   for (int i = 0; i < L.M; i++) n += (size_t)(6 * L.piece_nums[i] + kOpTPad) * (L.piece_nums[i] + 5);
   return n;
 }
-__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int groups, int lcap, bool op_lds, bool cor_lds) {
+constexpr int kSurCoefLds = 170; // obstacle pieces whose 2x6 coefficient blocks are staged in LDS as well (16 KB)
+__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int groups, int lcap, int T, bool op_lds, bool cor_lds, int sur_np) {
+  const bool sur = sur_np > 0;
   size_t n = 0;
   n += 5 * (size_t)L.npad;
   n += (size_t)L.M * 12;
@@ -86,7 +92,13 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   n += (size_t)L.rhs_tot * 2;
   n += 3 * (size_t)L.Ntot * 12;
   n += (size_t)L.rhs_tot * 2;
-  n += 16 * (size_t)groups + 14 * (size_t)(lcap + 2);
+  {
+    // the static stage's group sums + leftover staging and the pair staging of the moving-obstacle stage share their space
+    // (the static chain pass has consumed the former before the first pair is written)
+    const size_t a = 16 * (size_t)groups + 14 * (size_t)(lcap + 2), b = sur ? 14 * (size_t)(T + 2) : 0;
+    n += a > b ? a : b;
+  }
+  if (sur) n += 2 * (size_t)sur_np + (sur_np <= kSurCoefLds ? 12 * (size_t)sur_np : 0);
   n += 4 * (size_t)L.Ntot;
   n += 3 * (size_t)mem;
   n += sNUM;
@@ -95,8 +107,8 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   if (cor_lds) n += (size_t)4 * L.H * (((size_t)L.Npts + 63) / 64 * 64);
   return n;
 }
-__host__ __device__ inline size_t smem_ints(const DevLayout &L, int rounds, int T) {
-  return iNUM + (size_t)rounds * T + (size_t)rounds * (T / kWave) * 2 + (size_t)rounds * 2 + 4 * (size_t)L.Ntot + 8 * (size_t)L.Ntot +
+__host__ __device__ inline size_t smem_ints(const DevLayout &L, int rounds, int T, bool sur) {
+  return (sur ? (size_t)L.Npts + 2 : 0) + iNUM + (size_t)rounds * T + (size_t)rounds * (T / kWave) * 2 + (size_t)rounds * 2 + 4 * (size_t)L.Ntot + 8 * (size_t)L.Ntot +
          4 * (size_t)L.rhs_tot;
 }
 
@@ -105,9 +117,10 @@ E4Sizes e4_sizes(const DevLayout &L, int threads) {
   return E4Sizes{pl.rounds, pl.groups, pl.left, pl.lcap};
 }
 
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds) {
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np) {
+  const bool sur = sur_np > 0;
   const E4Sizes z = e4_sizes(L, threads);
-  return smem_doubles(L, P.mem_size, z.groups, z.lcap, op_lds, cor_lds) * sizeof(double) + smem_ints(L, z.rounds, threads) * sizeof(int);
+  return smem_doubles(L, P.mem_size, z.groups, z.lcap, threads, op_lds, cor_lds, sur_np) * sizeof(double) + smem_ints(L, z.rounds, threads, sur) * sizeof(int);
 }
 
 int solver_threads(const DevLayout &L, int shape) {
@@ -135,7 +148,8 @@ int solver_threads(const DevLayout &L, int shape) {
 }
 
 __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int rounds, int groups, int lcap, bool op_lds,
-                             bool cor_lds) {
+                             bool cor_lds, int sur_np) {
+  const bool sur = sur_np > 0;
   double *p = base;
   s.x = p; p += L.npad;
   s.xp = p; p += L.npad;
@@ -150,8 +164,15 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.c = p; p += L.Ntot * 12;
   s.gdC = p; p += L.Ntot * 12;
   s.adj = p; p += L.rhs_tot * 2;
-  s.gsum = p; p += 16 * groups;
-  s.lpart = p; p += 14 * (lcap + 2);
+  s.gsum = p;
+  s.lpart = p + 16 * groups;
+  s.dpart = p; // shares the space of gsum / lpart (see smem_doubles)
+  {
+    const int a = 16 * groups + 14 * (lcap + 2), b = sur ? 14 * (T + 2) : 0;
+    p += a > b ? a : b;
+  }
+  s.sdur = p; // durations, then their thresholds (DevSurround::theta), then the coefficient blocks if they fit
+  if (sur) p += 2 * sur_np + (sur_np <= kSurCoefLds ? 12 * sur_np : 0);
   s.pE = p; p += L.Ntot;
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
@@ -177,6 +198,7 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.pgrp = s.rtab + rounds * 2;
   s.pcinfo = s.pgrp + 4 * L.Ntot;
   s.rowinfo = s.pcinfo + 8 * L.Ntot;
+  s.dinfo = s.rowinfo + 4 * L.rhs_tot;
 }
 
 // ------------------------------------------------------------ device helpers
@@ -667,23 +689,25 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
           in.trajid = sg;
           in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16]; // trajtimes[trajid] = T_{i-1}, traj_optimizer.cpp:230-234
           in.t_now = D.t_now;
-          const int pt = pc[0] + in.j;
-          const double *cb = cor_b + pt;
-          if (D.cor_in_lds) {
-            LdsPlanes pl{(cor_l_t)(sm.cor + pt), (size_t)((Npts + 63) / 64 * 64)};
-            if (L.H <= 4) sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
-            else sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
-          } else if (L.H <= 4) {
-            double cor[16]; // all half-plane loads issued up front (unconditionally: rows past 4 H re-read row 0 and
-                            // are never used), consumed after the state evaluation
-            const cor_g_t cg = (cor_g_t)cb;
+          {
+            const int pt = pc[0] + in.j;
+            const double *cb = cor_b + pt;
+            if (D.cor_in_lds) {
+              LdsPlanes pl{(cor_l_t)(sm.cor + pt), (size_t)((Npts + 63) / 64 * 64)};
+              if (L.H <= 4) sample_point_math<false, 4>(P, D.sur, in, pl, o);
+              else sample_point_math<false, 0>(P, D.sur, in, pl, o);
+            } else if (L.H <= 4) {
+              double cor[16]; // all half-plane loads issued up front (unconditionally: rows past 4 H re-read row 0 and
+                              // are never used), consumed after the state evaluation
+              const cor_g_t cg = (cor_g_t)cb;
 #pragma unroll
-            for (int k = 0; k < 16; k++) cor[k] = cg[(size_t)(k < 4 * L.H ? k : 0) * D.NptsPad];
-            RegPlanes pl{cor};
-            sample_point_math<SUR, 4>(P, D.sur, in, pl, o);
-          } else {
-            GlobalPlanes pl{(cor_g_t)cb, (size_t)D.NptsPad};
-            sample_point_math<SUR, 0>(P, D.sur, in, pl, o);
+              for (int k = 0; k < 16; k++) cor[k] = cg[(size_t)(k < 4 * L.H ? k : 0) * D.NptsPad];
+              RegPlanes pl{cor};
+              sample_point_math<false, 4>(P, D.sur, in, pl, o);
+            } else {
+              GlobalPlanes pl{(cor_g_t)cb, (size_t)D.NptsPad};
+              sample_point_math<false, 0>(P, D.sur, in, pl, o);
+            }
           }
         } else {
 #pragma unroll
@@ -698,7 +722,9 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
           if (kind == 32) tot = reduce16<5>(v, lane);
           else tot = reduce16<4>(v, lane);
           const int idx = reduce16_index(lane);
-          if (info >= 0 && (lane & (kind - 1)) < 16 && idx < 14) sm.gsum[(wbase + lane / kind) * 16 + idx] = tot;
+          if (info >= 0 && (lane & (kind - 1)) < 16 && idx < 14) {
+            sm.gsum[(wbase + lane / kind) * 16 + idx] = tot;
+          }
         } else if (info >= 0) { // a wave of leftovers
           const int li = wbase - lbase + lane;
 #pragma unroll
@@ -706,7 +732,8 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         }
       }
       pr.tick(kPE3S);
-      if (nleft > 0 || r == D.e4_rounds - 1) { // uniform
+      const bool chain = nleft > 0 || r == D.e4_rounds - 1; // uniform
+      if (chain) {
         __syncthreads();
         for (int w = tid; w < 16 * Ntot; w += T) {
           const int p = w >> 4, q = w & 15;
@@ -726,6 +753,129 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         __syncthreads();
         pr.tick(kPE4R);
       }
+    }
+  }
+
+
+  // ---- E4, moving obstacles (traj_optimizer.cpp:636-638): one (constraint point, obstacle) PAIR per lane, and only the
+  // pairs that pass the distance gate of traj_optimizer.cpp:1393.  First every point marks the obstacles near it (a bit
+  // mask); an exclusive prefix sum over the points numbers the marked pairs in (point, obstacle) order; then the pairs
+  // are evaluated T at a time, densely packed -- a lane finds its pair by bisection in the prefix sums -- and after
+  // every T pairs a chain pass adds their contributions to the pieces in that order.
+  if (SUR) {
+    const int dstride = T + 2;
+    DevSurround surL = D.sur;
+    surL.durations = sm.sdur;
+    if (D.sur.theta != nullptr) surL.theta = sm.sdur + D.sur_np;
+    if (D.sur_np <= kSurCoefLds) surL.coeffs = sm.sdur + 2 * D.sur_np;
+    for (int r = 0; r < D.e4_rounds; r++) {
+      const int info = sm.slot[r * T + tid];
+      if (info >= 0) {
+        const int p = info & 0xffff;
+        const int *pc = sm.pcinfo + 8 * p;
+        SampleIn in;
+        in.j = info >> 16;
+        in.K = pc[1];
+        const int sg = pc[3];
+        in.lp = pc[4];
+        in.N = pc[5];
+        in.singul = pc[6];
+        in.dt = sm.seg[sg * 16 + 1];
+        in.s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+        in.cc = sm.c + 12 * p;
+        in.epis = D.epis;
+        in.H = L.H;
+        in.trajid = sg;
+        in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16];
+        in.t_now = D.t_now;
+        sm.dinfo[pc[0] + in.j] = (int)(dynamic_gate_mask(P, surL, in) << 16);
+      }
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive prefix sum of the pair counts: a contiguous run of points per lane, then across the lanes
+      const int seg = (Npts + 63) >> 6, start = lane * seg;
+      int sum = 0;
+      for (int i = start; i < start + seg && i < Npts; i++) sum += __builtin_popcount((unsigned)sm.dinfo[i] >> 16);
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      int run = incl - sum;
+      for (int i = start; i < start + seg && i < Npts; i++) {
+        const unsigned m = (unsigned)sm.dinfo[i];
+        sm.dinfo[i] = (int)((m & 0xffff0000u) | (unsigned)run);
+        run += __builtin_popcount(m >> 16);
+      }
+      if (lane == 63) sm.dinfo[Npts] = incl;
+    }
+    __syncthreads();
+    pr.tick(kPX);
+    const int n_pairs = sm.dinfo[Npts];
+    for (int c0 = 0; c0 < n_pairs; c0 += T) {
+      const int i = c0 + tid;
+      if (i < n_pairs) {
+        int lo = 0, hi = Npts; // the last point whose first pair index is <= i: it holds pair i
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if ((sm.dinfo[mid] & 0xffff) <= i) lo = mid;
+          else hi = mid;
+        }
+        const int pt = lo;
+        const unsigned w = (unsigned)sm.dinfo[pt];
+        int kth = i - (int)(w & 0xffffu);
+        unsigned mask = w >> 16;
+        for (; kth > 0; kth--) mask &= mask - 1; // drop the kth lowest set bits
+        const int u = __builtin_ctz(mask);
+        int plo = 0, phi = Ntot; // the piece of the point
+        while (phi - plo > 1) {
+          const int mid = (plo + phi) >> 1;
+          if (sm.pcinfo[8 * mid] <= pt) plo = mid;
+          else phi = mid;
+        }
+        const int p = plo;
+        const int *pc = sm.pcinfo + 8 * p;
+        SampleIn in;
+        in.j = pt - pc[0];
+        in.K = pc[1];
+        const int sg = pc[3];
+        in.lp = pc[4];
+        in.N = pc[5];
+        in.singul = pc[6];
+        in.dt = sm.seg[sg * 16 + 1];
+        in.s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+        in.cc = sm.c + 12 * p;
+        in.epis = D.epis;
+        in.H = L.H;
+        in.trajid = sg;
+        in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16];
+        in.t_now = D.t_now;
+        double o[8], v[14];
+        dynamic_pair_math(P, surL, in, u, o);
+        point_contributions(in.s1, o, v);
+#pragma unroll
+        for (int k = 0; k < 14; k++) sm.dpart[k * dstride + tid] = v[k];
+      }
+      pr.tick(kPMISC);
+      __syncthreads();
+      for (int w = tid; w < 16 * Ntot; w += T) {
+        const int p = w >> 4, q = w & 15;
+        if (q >= 14) continue;
+        const int *pc = sm.pcinfo + 8 * p;
+        const int pt0 = pc[0], pt1 = pt0 + pc[1] + 1;
+        int i0 = sm.dinfo[pt0] & 0xffff, i1 = pt1 < Npts ? (sm.dinfo[pt1] & 0xffff) : n_pairs;
+        i0 = i0 > c0 ? i0 : c0;
+        i1 = i1 < c0 + T ? i1 : c0 + T;
+        if (i1 <= i0) continue;
+        double acc = q < 12 ? sm.gdC[12 * p + q] : (q == 12 ? sm.pGdT[p] : sm.pCost[p]);
+        for (int i2 = i0; i2 < i1; i2++) acc += sm.dpart[q * dstride + (i2 - c0)];
+        if (q < 12) sm.gdC[12 * p + q] = acc;
+        else if (q == 12) sm.pGdT[p] = acc;
+        else sm.pCost[p] = acc;
+      }
+      __syncthreads();
+      pr.tick(kPE4R);
     }
   }
 
@@ -1628,7 +1778,7 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   const int lane = tid & 63;
   const int n = L.n;
   Smem sm;
-  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0);
+  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0, SUR ? D.sur_np : 0);
   Prof pr;
 
   // ---- one-time staging: role tables and operators (the same for every trajectory of the batch)
@@ -1636,6 +1786,13 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   for (int i = tid; i < D.e4_rounds * (T >> 6) * 2; i += T) sm.wtab[i] = D.e4_wave[i];
   for (int i = tid; i < D.e4_rounds * 2; i += T) sm.rtab[i] = D.e4_round[i];
   for (int i = tid; i < 4 * L.Ntot; i += T) sm.pgrp[i] = D.e4_piece[i];
+  if (SUR)
+    for (int i = tid; i < D.sur_np; i += T) {
+      sm.sdur[i] = D.sur.durations[i];
+      if (D.sur.theta != nullptr) sm.sdur[D.sur_np + i] = D.sur.theta[i];
+    }
+  if (SUR && D.sur_np <= kSurCoefLds)
+    for (int i = tid; i < 12 * D.sur_np; i += T) sm.sdur[2 * D.sur_np + i] = D.sur.coeffs[i];
   for (int p = tid; p < L.Ntot; p += T) {
     int sg = 0, p0 = 0, N = 0, pt0s = 0, sgl = 0, ooff = 0;
     for (int s = 0, a = 0; s < L.M; s++) {
@@ -1878,7 +2035,7 @@ static hipError_t launch_lv(int n, const DevBatch *d_dev, int grid, int mode, in
 // d_dev: device copy of the DevBatch `D` describes; grid: workgroups to launch (D.B unless the launch is scheduled)
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
                          hipStream_t stream) {
-  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.op_in_lds != 0, D.cor_in_lds != 0);
+  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.op_in_lds != 0, D.cor_in_lds != 0, D.sur.S > 0 ? D.sur_np : 0);
   if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
   return launch_lv<false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
 }

@@ -26,6 +26,14 @@
 #define DFTPAV_HD
 #endif
 
+// Keeps the instruction scheduler from interleaving the iterations of an unrolled loop (each iteration's temporaries then
+// die before the next one starts).  Only where the kernel is out of registers; no effect on results, nothing on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DFTPAV_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DFTPAV_SCHED_FENCE() ((void)0)
+#endif
+
 namespace dftpav {
 
 // Fused multiply-add with a single rounding, written out where it is wanted: v_fma_f64 on gfx950 and the
@@ -325,8 +333,31 @@ DFTPAV_HD inline SurEval sur_locate(const DevSurround &S, int u, double t) {
   int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
   const double *durs = S.durations + p0;
   int idx;
-  double dur = 0.0;
-  for (idx = 0; idx < np && t > (dur = durs[idx]); idx++) t -= dur;
+  if (S.theta != nullptr) {
+    // the index from the thresholds (see DevSurround::theta), the local time by the reference's subtractions: their
+    // operands no longer depend on a comparison, so the loads go out together instead of one round trip per piece
+    const double *th = S.theta + p0;
+    int lo = 0, hi = np; // number of pieces k with t > theta[k]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (t > th[mid]) lo = mid + 1;
+      else hi = mid;
+    }
+    idx = lo;
+    const int nsub = idx < np ? idx : np;
+    int k = 0;
+    for (; k + 4 <= nsub; k += 4) {
+      const double d0 = durs[k], d1 = durs[k + 1], d2 = durs[k + 2], d3 = durs[k + 3];
+      t -= d0;
+      t -= d1;
+      t -= d2;
+      t -= d3;
+    }
+    for (; k < nsub; k++) t -= durs[k];
+  } else {
+    double dur = 0.0;
+    for (idx = 0; idx < np && t > (dur = durs[idx]); idx++) t -= dur;
+  }
   if (idx == np) {
     idx--;
     t += durs[idx];
@@ -382,17 +413,52 @@ DFTPAV_HD inline double log_sum_exp(double alpha, double *v, double &exp_sum) {
   for (int j = 0; j < NV; j++) {
     v[j] = p_exp(alpha * (v[j] - d0));
     exp_sum += v[j];
+    DFTPAV_SCHED_FENCE();
   }
   return p_log(exp_sum) / alpha + d0;
 }
 
-// dynamicObsGradCostP, traj_optimizer.cpp:1311-1684.
-// Adds d/dsigma into A, d/dsigma' into Bv, the duration gradient into gdT; returns the cost.
-DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, double t_now, double omg, double step,
-                                    double t, double gama, int pieceid, int trajres, const double sigma[2],
-                                    const double dsigma[2], const double ddsigma[2], const double ego_R[4],
-                                    int singul_, int trajid, int Ntraj, double trajtime, double A[2], double Bv[2],
-                                    double &gdT) {
+// dynamicObsGradCostP, traj_optimizer.cpp:1311-1684, for ONE moving obstacle u (the body of its loop over the obstacles).
+// dyn_obstacle_near: position / velocity / acceleration of obstacle u at the time of the constraint point
+// (traj_optimizer.cpp:1367-1389) and the distance gate of :1393; false = the obstacle is skipped at this point.
+struct DynObs {
+  double sp[2], sv[2], sa[2];
+  double pt_time;
+};
+DFTPAV_HD inline bool dyn_obstacle_near(const DevParams &P, const DevSurround &S, int u, double t_now, double t, double trajtime,
+                                        const double sigma[2], DynObs &ob) {
+  double dur = S.total[u];
+  double offsettime = t_now - S.start[u] + trajtime; // traj_optimizer.cpp:1367-1369
+  double pt_time = offsettime + t;
+  double *sp = ob.sp, *sv = ob.sv, *sa = ob.sa;
+  if (pt_time < dur) {
+    SurEval e = sur_locate(S, u, pt_time);
+    piece_pos(e, sp);
+    piece_vel(e, sv);
+    piece_acc(e, sa);
+  } else { // traj_optimizer.cpp:1379-1389
+    SurEval e = sur_locate(S, u, dur);
+    double vd[2], pd[2];
+    piece_acc(e, sa);
+    piece_vel(e, vd);
+    piece_pos(e, pd);
+    double ex = pt_time - dur;
+    sv[0] = vd[0] + ex * sa[0];
+    sv[1] = vd[1] + ex * sa[1];
+    sp[0] = pd[0] + ex * vd[0] + 0.5 * sa[0] * ex * ex;
+    sp[1] = pd[1] + ex * vd[1] + 0.5 * sa[1] * ex * ex;
+  }
+  ob.pt_time = pt_time;
+  double dx = sp[0] - sigma[0], dy = sp[1] - sigma[1];
+  return !(sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5); // traj_optimizer.cpp:1393
+}
+// The penalty of obstacle u at the point and its gradients: adds d/dsigma into A, d/dsigma' into Bv, the duration
+// gradient into gdT; returns the cost (0 when the smoothed distance stays above the clearance).
+DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, int u, const DynObs &ob, double omg, double step,
+                                     double gama, int pieceid, int trajres, const double sigma[2],
+                                     const double dsigma[2], const double ddsigma[2], const double ego_R[4],
+                                     int singul_, int trajid, int Ntraj, double A[2], double Bv[2],
+                                     double &gdT) {
   const double B_h[4] = {0.0, -1.0, 1.0, 0.0};
   const double B_hT[4] = {0.0, 1.0, -1.0, 0.0};
   const double alpha = 100.0;
@@ -403,33 +469,9 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
   double temp3 = temp0_reci * temp0_reci;
   double totalPenalty = 0.0;
   const double(*vle)[2] = P.vec_le; // vec_lo_ == vec_le_, traj_optimizer.cpp:1769
-
-  for (int u = 0; u < S.S; u++) {
-    double dur = S.total[u];
-    double offsettime = t_now - S.start[u] + trajtime; // traj_optimizer.cpp:1367-1369
-    double pt_time = offsettime + t;
-    double sp[2], sv[2], sa[2];
-    if (pt_time < dur) {
-      SurEval e = sur_locate(S, u, pt_time);
-      piece_pos(e, sp);
-      piece_vel(e, sv);
-      piece_acc(e, sa);
-    } else { // traj_optimizer.cpp:1379-1389
-      SurEval e = sur_locate(S, u, dur);
-      double vd[2], pd[2];
-      piece_acc(e, sa);
-      piece_vel(e, vd);
-      piece_pos(e, pd);
-      double ex = pt_time - dur;
-      sv[0] = vd[0] + ex * sa[0];
-      sv[1] = vd[1] + ex * sa[1];
-      sp[0] = pd[0] + ex * vd[0] + 0.5 * sa[0] * ex * ex;
-      sp[1] = pd[1] + ex * vd[1] + 0.5 * sa[1] * ex * ex;
-    }
-    {
-      double dx = sp[0] - sigma[0], dy = sp[1] - sigma[1];
-      if (sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5) continue; // traj_optimizer.cpp:1393
-    }
+  const double *sp = ob.sp, *sv = ob.sv;
+  const double pt_time = ob.pt_time;
+  {
     // getR / getRdot extrapolate the last polynomial piece past the duration (traj_optimizer.cpp:1410,1599)
     double sR[4], Rud[4];
     {
@@ -446,31 +488,27 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
       Rud[2] = (a[1] / nv - v[1] / nv3 * va);
       Rud[3] = (a[0] / nv - v[0] / nv3 * va);
     }
+    DFTPAV_SCHED_FENCE();
 
+    // d(R l)/d(sigma') for a body-frame vector l (the F matrices of traj_optimizer.cpp:1423-1440).  They are formed where
+    // they are used (the gradient loops below) from the same expressions, instead of being kept for all four edges: 32
+    // doubles fewer are live through the log-sum-exp stage, where the GPU kernel is out of registers.
+    auto f_matrix = [&](const double l[2], const double Rl[2], double F[4]) {
+      double LT[4] = {l[0], l[1], -l[1], l[0]};
+      F[0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rl[0] * temp3;
+      F[1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rl[1] * temp3;
+      F[2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rl[0] * temp3;
+      F[3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rl[1] * temp3;
+    };
     double s2e_sum[4], d_test[8];
-    double egoN[4][2], dUo[4][4], Fdl[4][4], Fl[4][4];
+    double egoN[4][2], dUo[4][4];
     for (int e = 0; e < 4; e++) { // traj_optimizer.cpp:1417-1461
       const double *le = vle[e];
       double dl[2] = {vle[e + 1][0] - le[0], vle[e + 1][1] - le[1]};
       double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
       double dlni = 1 / dln;
-      double Rdl[2], Rle[2];
-      mat_vec(ego_R, dl, Rdl);
+      double Rle[2];
       mat_vec(ego_R, le, Rle);
-      {
-        double LT[4] = {dl[0], dl[1], -dl[1], dl[0]};
-        Fdl[e][0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rdl[0] * temp3;
-        Fdl[e][1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rdl[1] * temp3;
-        Fdl[e][2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rdl[0] * temp3;
-        Fdl[e][3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rdl[1] * temp3;
-      }
-      {
-        double LT[4] = {le[0], le[1], -le[1], le[0]};
-        Fl[e][0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rle[0] * temp3;
-        Fl[e][1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rle[1] * temp3;
-        Fl[e][2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rle[0] * temp3;
-        Fl[e][3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rle[1] * temp3;
-      }
       double BR[4], Ht[2];
       mat_mat(B_h, ego_R, BR);
       mat_vec(BR, dl, Ht);
@@ -485,6 +523,7 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
       double es;
       d_test[e] = log_sum_exp<4>(-alpha, dUo[e], es) + dUt;
       s2e_sum[e] = es;
+      DFTPAV_SCHED_FENCE();
     }
     double e2s_sum[4];
     double surN[4][2], dEe[4][4];
@@ -508,10 +547,12 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
       double es;
       d_test[4 + o] = log_sum_exp<4>(-alpha, dEe[o], es) + dEt;
       e2s_sum[o] = es;
+      DFTPAV_SCHED_FENCE();
     }
+    DFTPAV_SCHED_FENCE();
     double exp_sum_d = 0;
     double costp = d_min - log_sum_exp<8>(alpha, d_test, exp_sum_d); // traj_optimizer.cpp:1498-1502
-    if (costp <= 0) continue;
+    if (costp <= 0) return 0.0;
     double pena, penaD;
     smoothed_l1(costp, pena, penaD);
     totalPenalty += omg * step * P.wei_surround * pena;
@@ -532,18 +573,21 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
       const double *le = vle[e];
       double dl[2] = {vle[e + 1][0] - le[0], vle[e + 1][1] - le[1]};
       double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
-      double Rle[2];
+      double Rle[2], Rdl[2], Fdl_e[4], Fl_e[4];
       mat_vec(ego_R, le, Rle);
+      mat_vec(ego_R, dl, Rdl);
+      f_matrix(dl, Rdl, Fdl_e);
+      f_matrix(le, Rle, Fl_e);
       double uu[2] = {-sp[0] + sigma[0] + Rle[0], -sp[1] + sigma[1] + Rle[1]};
       double FB[4], t1[2], FlB[4], FlBR[4], t2[2];
-      mat_mat(Fdl[e], B_h, FB);
+      mat_mat(Fdl_e, B_h, FB);
       mat_vec(FB, uu, t1);
-      mat_mat(Fl[e], B_h, FlB);
+      mat_mat(Fl_e, B_h, FlB);
       mat_mat(FlB, ego_R, FlBR);
       mat_vec(FlBR, dl, t2);
       double pdU[2] = {(t1[0] - t2[0]) / dln, (t1[1] - t2[1]) / dln};
       double FBT[4];
-      mat_mat(Fdl[e], B_hT, FBT);
+      mat_mat(Fdl_e, B_hT, FBT);
       for (int o = 0; o < 4; o++) {
         double Rlo[2], q[2];
         mat_vec(sR, vle[o], Rlo);
@@ -553,10 +597,12 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
         double w = dUo[e][o] / s2e_sum[e];
         pdU[0] += w * q[0];
         pdU[1] += w * q[1];
+        DFTPAV_SCHED_FENCE();
       }
       double w = d_test[e] / exp_sum_d;
       pGds[0] -= w * pdU[0];
       pGds[1] -= w * pdU[1];
+      DFTPAV_SCHED_FENCE();
     }
     for (int o = 0; o < 4; o++) {
       const double *lo = vle[o];
@@ -564,8 +610,10 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
       double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
       double pdE[2] = {0.0, 0.0};
       for (int e = 0; e < 4; e++) {
-        double FB[4], FBR[4], q[2];
-        mat_mat(Fl[e], B_h, FB);
+        double FB[4], FBR[4], q[2], Rle[2], Fl_e[4];
+        mat_vec(ego_R, vle[e], Rle);
+        f_matrix(vle[e], Rle, Fl_e);
+        mat_mat(Fl_e, B_h, FB);
         mat_mat(FB, sR, FBR);
         mat_vec(FBR, dl, q);
         q[0] /= dln;
@@ -573,11 +621,14 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
         double w = dEe[o][e] / e2s_sum[o];
         pdE[0] += w * q[0];
         pdE[1] += w * q[1];
+        DFTPAV_SCHED_FENCE();
       }
       double w = d_test[o + 4] / exp_sum_d;
       pGds[0] -= w * pdE[0];
       pGds[1] -= w * pdE[1];
+      DFTPAV_SCHED_FENCE();
     }
+    DFTPAV_SCHED_FENCE();
     double pGtbar = (pGs[0] * dsigma[0] + pGs[1] * dsigma[1]) + (pGds[0] * ddsigma[0] + pGds[1] * ddsigma[1]);
 
     double pGthat = 0.0; // traj_optimizer.cpp:1586-1646
@@ -590,6 +641,7 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
         acc += dUo[e][o] / s2e_sum[e] * ptv;
       }
       pGthat -= d_test[e] / exp_sum_d * acc;
+      DFTPAV_SCHED_FENCE();
     }
     for (int o = 0; o < 4; o++) {
       const double *lo = vle[o];
@@ -612,8 +664,10 @@ DFTPAV_HD inline double dynamic_obs(const DevParams &P, const DevSurround &S, do
         double r2[2] = {r1[0] * Rud[0] + r1[1] * Rud[2], r1[0] * Rud[1] + r1[1] * Rud[3]};
         double ptv = (r2[0] * dl[0] + r2[1] * dl[1]) / dln;
         acc += dEe[o][e] / e2s_sum[o] * ptv;
+        DFTPAV_SCHED_FENCE();
       }
       pGthat -= d_test[o + 4] / exp_sum_d * acc;
+      DFTPAV_SCHED_FENCE();
     }
 
     double gradViolaPt = gama * pGtbar; // traj_optimizer.cpp:1649-1676
@@ -825,16 +879,6 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     }
   }
 
-  // ---- moving obstacles, traj_optimizer.cpp:636-638
-  if (SUR) {
-    if (S.S > 0) {
-      double t = 0.0;
-      for (int q = 0; q < lp; q++) t += dt; // t += getDt() per piece, traj_optimizer.cpp:775
-      cost += dynamic_obs(P, S, in.t_now, omg, step, t + step * j, alpha, lp, K, sigma, dsigma, ddsigma, ego_R, singul_,
-                          in.trajid, N, in.trajtime, A, Bv, gdT);
-    }
-  }
-
   // ---- velocity, traj_optimizer.cpp:642-653
   if (violaVel > 0.0) {
     double pena, penaD;
@@ -907,6 +951,85 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   out[0] = A[0]; out[1] = A[1];
   out[2] = Bv[0]; out[3] = Bv[1];
   out[4] = Cv[0]; out[5] = Cv[1];
+  out[6] = gdT;
+  out[7] = cost;
+}
+
+// ---- the moving-obstacle term (traj_optimizer.cpp:636-638 -> dynamicObsGradCostP) as a pass of its own
+// The kernels evaluate it per (constraint point, obstacle) PAIR, only for the pairs that pass the distance gate of
+// traj_optimizer.cpp:1393, one pair per lane (fused into sample_point_math it spilled ~2500 VGPRs and every lane of a wave
+// waited for the few that had an obstacle near).  The point's state is formed again from the same expressions as in
+// sample_point_math; a pair's result has the layout of a point's, {d/dsigma (2), d/dsigma' (2), 0, 0, gdT, cost}, and is
+// added to the per-piece sums after the static part, pairs in (point, obstacle) order (solver.hip, E4).
+struct DynPoint {
+  double sigma[2], dsigma[2], ddsigma[2], ego_R[4];
+  double omg, step, alpha, t;
+  bool skip;
+};
+DFTPAV_HD inline void dynamic_point_state(const SampleIn &in, DynPoint &q) {
+  const int j = in.j, K = in.K, lp = in.lp, N = in.N;
+  const double dt = in.dt;
+  const double Kd = (double)K, rK = 1.0 / Kd;
+  q.step = div_rcp(dt, Kd, rK);
+  const double s1 = in.s1;
+  double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+  double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+  q.alpha = rK * j;
+  const double *cc = in.cc;
+  double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0};
+  for (int k = 0; k < 6; k++) {
+    double c0 = cc[2 * k], c1 = cc[2 * k + 1];
+    sigma[0] = fma_(c0, beta0[k], sigma[0]);
+    sigma[1] = fma_(c1, beta0[k], sigma[1]);
+    dsigma[0] = fma_(c0, beta1[k], dsigma[0]);
+    dsigma[1] = fma_(c1, beta1[k], dsigma[1]);
+    ddsigma[0] = fma_(c0, beta2[k], ddsigma[0]);
+    ddsigma[1] = fma_(c1, beta2[k], ddsigma[1]);
+  }
+  q.omg = (j == 0 || j == K) ? 0.5 : 1.0;
+  double z_h0 = sqrt(fma_(dsigma[0], dsigma[0], dsigma[1] * dsigma[1]));
+  q.skip = z_h0 < 1e-4 || (j == 0 && lp == 0) || (lp == N - 1 && j == K); // traj_optimizer.cpp:550-553
+  z_h0 = 1.0 / z_h0;
+  const int singul_ = in.singul;
+  q.ego_R[0] = singul_ * dsigma[0] * z_h0;
+  q.ego_R[1] = singul_ * -dsigma[1] * z_h0;
+  q.ego_R[2] = singul_ * dsigma[1] * z_h0;
+  q.ego_R[3] = singul_ * dsigma[0] * z_h0;
+  for (int d = 0; d < 2; d++) {
+    q.sigma[d] = sigma[d];
+    q.dsigma[d] = dsigma[d];
+    q.ddsigma[d] = ddsigma[d];
+  }
+  double t = 0.0;
+  for (int p = 0; p < lp; p++) t += dt; // t += getDt() per piece, traj_optimizer.cpp:775
+  q.t = t + q.step * j;
+}
+// bit u set: obstacle u passes the distance gate at this point (no bits for a point the sample loop skips)
+DFTPAV_HD inline unsigned dynamic_gate_mask(const DevParams &P, const DevSurround &S, const SampleIn &in) {
+  DynPoint q;
+  dynamic_point_state(in, q);
+  if (q.skip) return 0u;
+  unsigned mask = 0u;
+  for (int u = 0; u < S.S; u++) {
+    DynObs ob;
+    if (dyn_obstacle_near(P, S, u, in.t_now, q.t, in.trajtime, q.sigma, ob)) mask |= 1u << u;
+  }
+  return mask;
+}
+// one (point, obstacle) pair that passed the gate
+DFTPAV_HD inline void dynamic_pair_math(const DevParams &P, const DevSurround &S, const SampleIn &in, int u, double out[8]) {
+  for (int k = 0; k < 8; k++) out[k] = 0.0;
+  DynPoint q;
+  dynamic_point_state(in, q);
+  DynObs ob;
+  if (q.skip || !dyn_obstacle_near(P, S, u, in.t_now, q.t, in.trajtime, q.sigma, ob)) return;
+  double A[2] = {0, 0}, Bv[2] = {0, 0}, gdT = 0.0;
+  const double cost = dynamic_pair(P, S, u, ob, q.omg, q.step, q.alpha, in.lp, in.K, q.sigma, q.dsigma, q.ddsigma, q.ego_R,
+                                   in.singul, in.trajid, in.N, A, Bv, gdT);
+  out[0] = A[0]; out[1] = A[1];
+  out[2] = Bv[0]; out[3] = Bv[1];
   out[6] = gdT;
   out[7] = cost;
 }

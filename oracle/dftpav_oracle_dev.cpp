@@ -43,7 +43,7 @@ namespace {
 struct DevState {
   DevLayout L;
   DevParams P;
-  DevSurround S;
+  DevSurround S{};
   std::vector<int> sur_off;
   std::vector<double> sur_total, sur_start;
   std::vector<std::vector<double>> opM, opMT; // per segment
@@ -228,7 +228,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
         int K = edge ? L.Kd : L.K;
         int p = L.seg_piece0[sg] + lp;
         const int G = e4_group_size(K + 1), nf = G ? (K + 1) / G : 0;
-        std::vector<double> contrib((size_t)(K + 1) * 14);
+        std::vector<double> contrib((size_t)(K + 1) * 14), contrib_d; // contrib_d: 14 values per (point, obstacle) pair of the piece
         for (int j = 0; j <= K; j++, pt++) {
           SampleIn in;
           in.j = j;
@@ -246,23 +246,34 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
           in.t_now = c->t_now;
           HostPlanes pl{c->cfgHs + (size_t)pt * L.H * 4};
           double o[8];
-          if (D.S.S > 0) sample_point_math<true, 0>(P, D.S, in, pl, o);
-          else sample_point_math<false, 0>(P, D.S, in, pl, o);
+          sample_point_math<false, 0>(P, D.S, in, pl, o);
           point_contributions(in.s1, o, &contrib[(size_t)j * 14]);
+          if (D.S.S > 0) { // the kernel's pair stage: every obstacle that passes the distance gate at this point, in order
+            const unsigned mask = dynamic_gate_mask(P, D.S, in);
+            for (int u = 0; u < D.S.S; u++)
+              if (mask >> u & 1u) {
+                double v[14];
+                dynamic_pair_math(P, D.S, in, u, o);
+                point_contributions(in.s1, o, v);
+                contrib_d.insert(contrib_d.end(), v, v + 14);
+              }
+          }
         }
         for (int q = 0; q < 14; q++) {
           double acc = q < 12 ? D.gdC[12 * p + q] : (q == 12 ? D.pGdT[p] : D.pCost[p]);
-          for (int g = 0; g < nf; g++) {
+          auto tree = [&](const std::vector<double> &cv, int g) {
             double v[32];
-            for (int l = 0; l < G; l++) v[l] = contrib[(size_t)(g * G + l) * 14 + q];
+            for (int l = 0; l < G; l++) v[l] = cv[(size_t)(g * G + l) * 14 + q];
             for (int o = 1; o < G; o <<= 1) {
               double w[32];
               for (int l = 0; l < G; l++) w[l] = v[l] + v[l ^ o];
               for (int l = 0; l < G; l++) v[l] = w[l];
             }
-            acc += v[0];
-          }
+            return v[0];
+          };
+          for (int g = 0; g < nf; g++) acc += tree(contrib, g);
           for (int j = nf * G; j <= K; j++) acc += contrib[(size_t)j * 14 + q];
+          for (size_t i = 0; i < contrib_d.size() / 14; i++) acc += contrib_d[i * 14 + q]; // pairs in (point, obstacle) order
           if (q < 12) D.gdC[12 * p + q] = acc;
           else if (q == 12) D.pGdT[p] = acc;
           else D.pCost[p] = acc;
@@ -462,6 +473,7 @@ extern "C" void oracle_dev_init(oracle_ctx *c) {
     D->S.coeffs = c->sur_coeffs;
     D->S.total = D->sur_total.data();
     D->S.start = D->sur_start.data();
+    D->S.theta = nullptr; // the oracle walks the pieces as the reference does (the kernels search a threshold table)
   }
   D->opM.resize(L.M);
   D->opMT.resize(L.M);
