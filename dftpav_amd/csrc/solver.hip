@@ -508,6 +508,25 @@ __device__ __forceinline__ void op_col_dot2(P MT, const double *gc, const double
   ay = acc1;
 }
 
+// Segment durations of the decision vector x (VirtualT2RealT, traj_optimizer.cpp:371-379), the piece duration and its
+// powers (poly_traj_utils.hpp:961-966) into sm.seg, one lane per segment.  Wave 0 runs it as soon as an x to be evaluated
+// is in place (before the first evaluation of a pass; at the end of lbfgs_advance), so that the evaluation starts with
+// them instead of every right-hand-side lane dividing for itself.
+__device__ inline void prep_durations(const DevBatch &D, const Smem &sm, const double *x, int lane) {
+  const DevLayout &L = D.L;
+  if (lane < L.M) {
+    const int sg = lane;
+    int N = 0;
+    for (int s_ = 0; s_ < L.M; s_++) N = (s_ == sg) ? L.piece_nums[s_] : N;
+    const double Tr = virtual_to_real(x[L.x_tau0 + sg], D.P.mini_T);
+    const double dt = Tr / N;
+    double *s = sm.seg + sg * 16;
+    s[0] = Tr;
+    s[1] = dt;
+    duration_powers(dt, s + 2);
+  }
+}
+
 template <bool SUR>
 __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_b, const Smem &sm, const double *x, double *g,
                                            Prof &pr) {
@@ -518,18 +537,18 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
   const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, rhs_tot = L.rhs_tot, Kmax1 = L.Kmax + 1;
   const double *iniS = sm.bnd, *finS = sm.bnd + 6 * M; // boundary states of this trajectory, staged with x
 
-  // ---- E1: segment durations, sample-offset power tables, MINCO right-hand sides
+  // ---- E1: MINCO right-hand sides and the sample-offset power tables.  The segment durations T, dt and the powers of
+  // dt are already in sm.seg: prep_durations formed them on wave 0 as soon as this x was written.
   {
     const int n_rhs = 2 * rhs_tot;
     const int n_rhs_pad = (n_rhs + 63) & ~63; // the per-segment workers start on a wave of their own
-    for (int w = tid; w < n_rhs_pad + 3 * M; w += T) {
+    for (int w = tid; w < n_rhs_pad + 2 * M; w += T) {
       if (w >= n_rhs && w < n_rhs_pad) continue;
       if (w < n_rhs) {
         int row = w >> 1, d = w & 1;
         const int *ri = sm.rowinfo + 4 * row;
         int sg = ri[0], col = ri[1], N = ri[2];
-        double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
-        double dt = Tr / N;
+        const double dt = sm.seg[sg * 16 + 1];
         // Every entry is one stored value (a waypoint or junction position from x, or a boundary state) times
         // 1, dt or dt^2 (poly_traj_utils.hpp:968-977), so it is formed without branching: the lanes of a wave hold
         // all kinds of rows and a branch per kind serialises them (each with its own LDS round trip).  x * 1.0 is x.
@@ -552,27 +571,28 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         }
         sm.rhs[w] = v;
       } else {
-        int q = w - n_rhs_pad; // 3 workers per segment: 0 duration powers, 1/2 offset tables (K / Kd)
-        int sg = q / 3, role = q - 3 * sg;
-        int N = 0;
-        for (int s = 0; s < M; s++) N = (s == sg) ? L.piece_nums[s] : N;
-        double Tr = virtual_to_real(x[L.x_tau0 + sg], P.mini_T);
-        double dt = Tr / N;
-        if (role == 0) {
-          double *s = sm.seg + sg * 16;
-          s[0] = Tr;
-          s[1] = dt;
-          duration_powers(dt, s + 2); // poly_traj_utils.hpp:961-966
-        } else {
-          int which = role - 1;
-          int K = which ? L.Kd : L.K;
-          double step = dt / K;
-          double *tab = sm.spow + (size_t)(sg * 2 + which) * Kmax1 * 6;
-          double s1 = 0.0;
-          for (int j = 0; j <= K; j++) {
-            tab[6 * j + 1] = s1;
-            s1 += step; // traj_optimizer.cpp:513
-          }
+        int q = w - n_rhs_pad; // 2 workers per segment: the offset tables for K and Kd
+        int sg = q >> 1, which = q & 1;
+        const double dt = sm.seg[sg * 16 + 1];
+        int K = which ? L.Kd : L.K;
+        double step = dt / K;
+        // offsets s1 = 0, += step, ... (traj_optimizer.cpp:513): one dependent chain of additions by definition; four
+        // links at a time are formed in registers and their stores trail behind them
+        typedef double __attribute__((address_space(3))) *ldsw_t;
+        ldsw_t tab = (ldsw_t)(sm.spow + (size_t)(sg * 2 + which) * Kmax1 * 6);
+        double s1 = 0.0;
+        int j = 0;
+        for (; j + 4 <= K + 1; j += 4) {
+          const double a0 = s1, a1 = a0 + step, a2 = a1 + step, a3 = a2 + step;
+          s1 = a3 + step;
+          tab[6 * j + 1] = a0;
+          tab[6 * j + 7] = a1;
+          tab[6 * j + 13] = a2;
+          tab[6 * j + 19] = a3;
+        }
+        for (; j <= K; j++) {
+          tab[6 * j + 1] = s1;
+          s1 += step;
         }
       }
     }
@@ -1896,6 +1916,8 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     }
     __syncthreads();
     const int k_start = sm.ist[iK];
+    if (tid < 64) prep_durations(D, sm, sm.x, lane);
+    __syncthreads();
 
     block_eval<SUR>(D, cor_b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
     if (mode == kModeSolve) trace_eval(Db, sm, b, tid, T);
@@ -1914,7 +1936,14 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     // ---- lbfgs_optimize (lbfgs.hpp:440-751): wave 0 advances the solver state between evaluations
     bool finished = true;
     while (true) {
-      if (tid < 64) lbfgs_advance<LV>(D, sm, hS_b, hU_b, hV_b, lane, pr);
+      if (tid < 64) {
+        // the serial part of the trajectory: the other waves of the workgroup wait for it, the waves this one shares its
+        // SIMD with belong to other trajectories -- let the arbiter prefer it
+        __builtin_amdgcn_s_setprio(3);
+        lbfgs_advance<LV>(D, sm, hS_b, hU_b, hV_b, lane, pr);
+        if (sm.ist[iACTION] == kActEval) prep_durations(D, sm, sm.x, lane); // the trial point is in place
+        __builtin_amdgcn_s_setprio(0);
+      }
       __syncthreads();
       if (sm.ist[iACTION] == kActDone) break;
       if (sched.source == 1 && sched.slice > 0 && sm.ist[iK] - k_start >= sched.slice) { // uniform

@@ -7,7 +7,7 @@ name=$1; expr=$2; shift 2 || true
 cd "$(dirname "$0")/../dftpav_amd/csrc"
 mkdir -p ../variants /tmp/variant_$name
 sed "$expr" solver.hip > /tmp/variant_$name/solver.hip
-cp device_types.h traj_math.h rs_math.h /tmp/variant_$name/
+cp device_types.h traj_math.h rs_math.h e4_plan.h /tmp/variant_$name/
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed "$@" \
   -c /tmp/variant_$name/solver.hip -o /tmp/variant_$name/solver.o
 make -s
