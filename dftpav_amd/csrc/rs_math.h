@@ -4,12 +4,17 @@
 // `ompl::base::ReedsSheppStateSpace(1 / max_cur_)` (kino_astar.cpp:423) and uses its `distance` and
 // `interpolate` for the analytic "shot" from a search node to the goal (kino_astar.cpp:327-345, 585-599).  OMPL
 // is found with find_package, version unpinned (traj_planner/CMakeLists.txt); nothing of it is vendored.
-// What follows restates the published algorithm that class implements: J. A. Reeds, L. A. Shepp, "Optimal
+// What follows is a RESTATEMENT OF OMPL'S IMPLEMENTATION (src/ompl/base/spaces/src/ReedsSheppStateSpace.cpp, BSD
+// licence; written from knowledge of that file's structure, function by function: LpSpLp, LpSpRp, CSC, LpRmL, CCC,
+// tauOmega, LpRupLumRm, LpRumLumRp, CCCC, LpRmSmLm, LpRmSmRm, CCSC, LpRmSLmRp, CCSCC, the `if (f(...) && Lmin > ...)`
+// ladder and the 18-row path-type table) -- not only of the paper it implements: J. A. Reeds, L. A. Shepp, "Optimal
 // paths for a car that goes both forwards and backwards", Pacific J. Math. 145 (1990) — the 48 words as 18
 // path types x {time flip, reflection, backwards}, formulas 8.1-8.11 with the two corrections OMPL's source
 // documents (8.3/8.4 and 8.11) — in OMPL's conventions: unit turning radius in normalised coordinates,
 // segment lengths signed (negative = reverse), candidates tried in the order CSC, CCC, CCCC, CCSC, CCSCC,
-// a candidate replacing the best one only if strictly shorter.
+// a candidate replacing the best one only if strictly shorter.  The independent check of this file is
+// oracle/shot_oracle_literal.cpp, written from the paper with another organisation (base words x symmetries, every
+// candidate validated by integration) and libm; tests/test_shot_oracle.py and tests/test_gpu_parity.py compare the two.
 //
 // `M` supplies sin / cos / atan2 / sqrt: the portable routines of traj_math.h on the device and in the
 // oracle's device-order mode (bit-identical results), libm in the oracle's literal mode.  asin and acos are

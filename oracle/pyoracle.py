@@ -348,6 +348,32 @@ def reeds_shepp_shots(from_, to, max_cur=1.0, checkl=0.2, max_samples=512, grid=
     return out
 
 
+def reeds_shepp_literal(from_, to, max_cur=1.0, checkl=0.2, max_samples=512):
+    """The independent Reeds-Shepp restatement (oracle/shot_oracle_literal.cpp: the paper's base words x symmetries, libm,
+    every candidate validated by integration): dict(length, kinds [n][5], seg [n][5], samples, n_samples, n_valid)."""
+    L = lib()
+    f = np.ascontiguousarray(from_, dtype=np.float64).reshape(-1, 3)
+    t = np.ascontiguousarray(to, dtype=np.float64).reshape(-1, 3)
+    n = f.shape[0]
+    out = dict(length=np.zeros(n), kinds=np.zeros((n, 5), dtype=np.int32), seg=np.zeros((n, 5)),
+               samples=np.zeros((n, int(max_samples), 3)), n_samples=np.zeros(n, dtype=np.int32), n_valid=np.zeros(n, dtype=np.int32))
+    fn = L.oracle_reeds_shepp_literal
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p]
+    fn(f.ctypes.data, t.ctypes.data, n, 1.0 / float(max_cur), float(checkl), int(max_samples), out["length"].ctypes.data,
+       out["kinds"].ctypes.data, out["seg"].ctypes.data, out["samples"].ctypes.data, out["n_samples"].ctypes.data,
+       out["n_valid"].ctypes.data)
+    return out
+
+
+# segment kinds of the 18 path types of dftpav_amd/csrc/rs_math.h (0 none, 1 left, 2 straight, 3 right)
+RS_TYPE_KINDS = np.array([[1, 3, 1, 0, 0], [3, 1, 3, 0, 0], [1, 3, 1, 3, 0], [3, 1, 3, 1, 0], [1, 3, 2, 1, 0], [3, 1, 2, 3, 0],
+                          [1, 2, 3, 1, 0], [3, 2, 1, 3, 0], [1, 3, 2, 3, 0], [3, 1, 2, 1, 0], [3, 2, 3, 1, 0], [1, 2, 1, 3, 0],
+                          [1, 2, 3, 0, 0], [3, 2, 1, 0, 0], [1, 2, 1, 0, 0], [3, 2, 3, 0, 0], [1, 3, 2, 1, 3], [3, 1, 2, 3, 1]],
+                         dtype=np.int32)
+
+
 def fit_surround(states, order=0):
     """ConverSurroundTrajFromPoints (traj_manager.cpp:743-789): states [S][n][7] (x, y, angle, velocity, acceleration,
     curvature, time_stamp) -> dict(durations [S][n-1], coeffs [S][n-1][12], total [S], start [S])."""

@@ -1,0 +1,112 @@
+"""The N > 1 path of SURVEY §8(e) with the PRODUCT in it, on the one GPU a test box has:
+  * RCCL (backend "nccl") at world size 1: init, the all-gather of device-packed records, barrier — the calls the bench makes;
+  * two processes, gloo between them, each solving ITS shard with the HIP solver on cuda:0 and packing its records on the
+    device (dftpav_batch_pack_results): the gathered records equal those of one process solving the whole batch;
+  * bench.py end to end with DFTPAV_BENCH_FORCE_DIST=1.
+(Two RCCL ranks cannot share one device; the 8-GPU run is the driver's.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dftpav_amd import distributed as dd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    return port
+
+
+def _solve_shard(B, lo, hi):
+    from dftpav_amd import capi, scenarios as sc
+    p = capi.default_params()
+    s = sc.baseline_config(3, B=B)
+    s.apply_resolution(p)
+    sub = s.subset(np.arange(lo, hi))
+    h = capi.Handle(p, device=0)
+    bt = capi.Batch(h, sub.layout, sub.B)
+    bt.upload(sub)
+    bt.solve_async()
+    rec = torch.zeros((sub.B, dd.RECORD_BYTES), dtype=torch.uint8, device="cuda:0")
+    bt.pack_results(rec.data_ptr())
+    bt.sync()
+    r = bt.results()
+    bt.close()
+    h.close()
+    return rec, r
+
+
+def test_rccl_allgather_of_device_packed_records(hiplib):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 6
+        rec, r = _solve_shard(B, 0, B)
+        allrec = dd.allgather_records(rec, B)
+        dist.barrier()
+        torch.cuda.synchronize()
+        c, st, it = dd.unpack_records(allrec.cpu().numpy())
+        assert np.array_equal(c, r["final_cost"]) and np.array_equal(st, r["status"]) and np.array_equal(it, r["iters"])
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = dd.shard_range(B, rank, world)
+    rec, _ = _solve_shard(B, lo, hi)                   # the product: HIP solve + device-side record packing
+    allrec = dd.allgather_records(rec.cpu(), B)        # gloo carries the bytes
+    q.put((rank, allrec.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_hip_solver_equal_one_process(hiplib):
+    B, world = 7, 2  # uneven shards: 3 + 4
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(got[0], got[1])
+    _, ref = _solve_shard(B, 0, B)
+    c, st, it = dd.unpack_records(got[0])
+    assert np.array_equal(c, ref["final_cost"]) and np.array_equal(st, ref["status"]) and np.array_equal(it, ref["iters"])
+
+
+def test_bench_takes_the_rccl_path_when_forced(hiplib):
+    env = dict(os.environ, DFTPAV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--batch-per-gpu", "1024", "--no-extras", "--cpu-sample", "0"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 1024

@@ -800,6 +800,20 @@ def test_reeds_shepp_shots_match_oracle(hiplib, oracle):
                                        origin=origin, order=0)
         assert np.allclose(got["length"], lit["length"], rtol=0, atol=1e-9) and (got["type"] == lit["type"]).mean() > 0.99
         assert 0.05 < got["collides"].mean() < 0.995 and (got["collides"] == lit["collides"]).mean() > 0.98
+        # and against the INDEPENDENT restatement (oracle/shot_oracle_literal.cpp: no shared header, libm, candidates
+        # validated by integration): lengths to rounding, the same word except at ties, the same sampled poses
+        ind = oracle.reeds_shepp_literal(f, t, max_cur=max_cur, checkl=checkl, max_samples=ms)
+        rel = np.abs(got["length"] - ind["length"]) / np.maximum(1.0, ind["length"])
+        assert rel.max() <= 1e-12
+        same = (oracle.RS_TYPE_KINDS[got["type"]] == ind["kinds"]).all(axis=1) | (got["length"] == 0.0)
+        assert same.mean() > 0.97
+        assert np.abs(got["seg"][same & (got["length"] > 0)] - ind["seg"][same & (got["length"] > 0)]).max() <= 1e-9
+        assert np.array_equal(got["n_samples"][same], ind["n_samples"][same])
+        for i in np.where(same & (got["length"] > 0))[0][::17]:
+            k = min(int(got["n_samples"][i]), ms)
+            d = np.abs(got["samples"][i, :k] - ind["samples"][i, :k])
+            d[:, 2] = np.abs((d[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+            assert d.max() <= 1e-9
     assert h.corridor_last_ms() > 0.0
     # without a collision output no map is needed; a zero-sized call is fine
     h2 = hiplib.Handle(hiplib.default_params())

@@ -112,3 +112,30 @@ def test_collision_of_a_shot(oracle):
     grid[:, int(round((0.0 - origin[0]) / 0.3))] = 80  # a wall across the straight path
     r = oracle.reeds_shepp_shots(f, t, grid=grid, resolution=0.3, origin=origin, order=1)
     assert r["collides"][0] == 1
+
+
+def test_shared_header_agrees_with_the_independent_restatement(oracle):
+    """rs_math.h (kernel + oracle/shot_oracle.cpp) against oracle/shot_oracle_literal.cpp, which does not include it: the
+    paper's eight base words under the eight symmetries, libm, every candidate validated by integrating it to the goal.
+    Lengths to rounding; the same word except where two words tie (then the lengths agree to rounding); the same poses."""
+    rng = np.random.default_rng(11)
+    n = 12000
+    fr = np.column_stack([rng.uniform(-15, 15, n), rng.uniform(-15, 15, n), rng.uniform(-np.pi, np.pi, n)])
+    to = np.column_stack([rng.uniform(-15, 15, n), rng.uniform(-15, 15, n), rng.uniform(-np.pi, np.pi, n)])
+    to[:1500, :2] = fr[:1500, :2] + rng.uniform(-2, 2, (1500, 2))     # close pairs: the CCC / CCCC families
+    to[1500:1700] = fr[1500:1700] + np.array([3.0, 0.0, 0.0])          # same heading, offset along a fixed direction
+    lit = oracle.reeds_shepp_literal(fr, to, max_cur=1.0, checkl=0.2, max_samples=512)
+    assert lit["n_valid"].min() >= 1
+    for order in (0, 1):
+        o = oracle.reeds_shepp_shots(fr, to, max_cur=1.0, checkl=0.2, max_samples=512, order=order)
+        rel = np.abs(o["length"] - lit["length"]) / np.maximum(1.0, lit["length"])
+        assert rel.max() <= 1e-12
+        same = (oracle.RS_TYPE_KINDS[o["type"]] == lit["kinds"]).all(axis=1)
+        assert same.mean() > 0.98                       # the rest are ties between two words of equal length
+        assert np.array_equal(o["n_samples"], lit["n_samples"])
+        for i in np.where(same)[0][::23]:
+            k = min(int(o["n_samples"][i]), 512)
+            d = np.abs(o["samples"][i, :k] - lit["samples"][i, :k])
+            d[:, 2] = np.abs((d[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+            assert d.max() <= 1e-9
+        assert np.abs(o["seg"][same] - lit["seg"][same]).max() <= 1e-9
