@@ -31,7 +31,7 @@ EXPORTS = [
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
     "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
-    "dftpav_batch_trace", "dftpav_batch_get_trace",
+    "dftpav_batch_trace", "dftpav_batch_get_trace", "dftpav_plan_cycle", "dftpav_plan_cycle_fetch",
 ]
 
 
@@ -389,6 +389,31 @@ class Batch:
         fn = lib().dftpav_batch_finish
         fn.argtypes = [C.c_void_p]
         self.handle._check(fn(self._b), "finish")
+
+    def plan_cycle(self, scen, states, n_restarts=1, check_dt=0.05, vertex_res=0.1, t0=0.0, state_dt=0.01, n_samples=100,
+                   filter_singularity=True):
+        """dftpav_plan_cycle: upload, corridor from the map, solve, collision re-check and read-out enqueued in one call."""
+        d = scen.batch_data() if hasattr(scen, "batch_data") else scen
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        fn = lib().dftpav_plan_cycle
+        fn.argtypes = [C.c_void_p, C.POINTER(BatchData), C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                       C.c_int]
+        self._pc_keep = (d, st)
+        self._pc_n = int(n_samples)
+        self.handle._check(fn(self._b, C.byref(d), st.ctypes.data_as(C.c_void_p), int(n_restarts), float(check_dt), float(vertex_res),
+                              float(t0), float(state_dt), int(n_samples), int(bool(filter_singularity))), "plan_cycle")
+
+    def plan_cycle_fetch(self):
+        """-> dict(x, final_cost, status, success, iters, collision, first_sample, states [B][n_samples][8], n_valid)"""
+        B, n = self.B, self.layout.n_vars
+        r = dict(x=np.zeros((B, n)), final_cost=np.zeros(B), status=np.zeros(B, dtype=np.int32), success=np.zeros(B, dtype=np.int32),
+                 iters=np.zeros(B, dtype=np.int32), collision=np.zeros(B, dtype=np.int32), first_sample=np.zeros(B, dtype=np.int32),
+                 states=np.zeros((B, self._pc_n, 8)), n_valid=np.zeros(B, dtype=np.int32))
+        fn = lib().dftpav_plan_cycle_fetch
+        fn.argtypes = [C.c_void_p, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_double_p, c_int_p]
+        self.handle._check(fn(self._b, dptr(r["x"]), dptr(r["final_cost"]), iptr(r["status"]), iptr(r["success"]), iptr(r["iters"]),
+                              iptr(r["collision"]), iptr(r["first_sample"]), dptr(r["states"]), iptr(r["n_valid"])), "plan_cycle_fetch")
+        return r
 
     def trace(self, traj, max_evals=4096):
         """Record every evaluation of trajectory `traj` during the following solves (dftpav_batch_trace); 0 = off."""

@@ -45,6 +45,7 @@ hipError_t launch_shots(const double *from, const double *to, int n, double rho,
                         double veh_width, double veh_length, double veh_dcr, const double *v_tab, int n_v, double *length, int *type,
                         double *seg, double *samples, int *n_samples, int *collides, hipStream_t stream);
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
+hipError_t launch_corridor_layout(const double *raw, double *out, int B, int Npts, int H, int NptsPad, hipStream_t stream);
 hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream);
 }
 using namespace dftpav;
@@ -113,6 +114,16 @@ struct dftpav_batch {
   double *d_coef = nullptr, *d_dt = nullptr;
   double *d_f_eval = nullptr; // costs of dftpav_batch_eval (kept apart from the solve's final costs)
   double *d_trace = nullptr;  // dftpav_batch_trace
+  double *d_cor_raw = nullptr; // the caller's hPoly columns as uploaded (normalised and laid out on the device)
+  // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
+  struct PlanCycle {
+    double *d_poses = nullptr, *d_t = nullptr, *d_v = nullptr, *d_rd = nullptr;
+    int *d_col = nullptr, *d_first = nullptr, *d_valid = nullptr;
+    size_t n_poses = 0, n_t = 0, n_v = 0, n_rd = 0;
+    std::vector<double> poses, tt, vv; // host sources of the asynchronous copies
+    int n_samples = 0;
+    bool in_flight = false;
+  } pc;
   int trace_b = -1, trace_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;  // a solve was enqueued: ev0 / ev1 are recorded
@@ -723,7 +734,8 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
                   b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
-                  b->d_f_eval, b->d_trace};
+                  b->d_f_eval, b->d_trace, b->d_cor_raw, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
+                  b->pc.d_valid};
   {
     auto &v = b->h->batches;
     v.erase(std::remove(v.begin(), v.end(), b), v.end());
@@ -996,21 +1008,8 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
       x[L.x_ang0 + i] = std::atan2(F[3], F[2]);
     }
   }
-  // corridor: private normalised copy (traj_optimizer.cpp:15,49-52), transposed to
-  // [trajectory][plane*4+component][point] so that lanes (points) read contiguous doubles
-  const size_t per = (size_t)L.H * 4 * b->NptsPad;
-  std::vector<double> cor(d->corridor ? (size_t)B * per : 0, 0.0);
-  for (int t = 0; t < B && d->corridor; t++)
-    for (int pt = 0; pt < L.Npts; pt++)
-      for (int k = 0; k < L.H; k++) {
-        const double *col = d->corridor + (((size_t)t * L.Npts + pt) * L.H + k) * 4;
-        double nrm = std::sqrt(col[0] * col[0] + col[1] * col[1]);
-        double *dst = cor.data() + (size_t)t * per + (size_t)(4 * k) * b->NptsPad + pt;
-        dst[0] = col[0] / nrm;
-        dst[(size_t)b->NptsPad] = col[1] / nrm;
-        dst[(size_t)2 * b->NptsPad] = col[2];
-        dst[(size_t)3 * b->NptsPad] = col[3];
-      }
+  // corridor: the private normalised copy of traj_optimizer.cpp:15,49-52 is made on the device (corridor_layout_kernel):
+  // the caller's columns go up as they are, one copy, and are normalised and transposed there
   HIPCHK(h, hipMemcpy(b->d_x0, b->x0_host.data(), sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(b->d_iniS, ini.data(), sizeof(double) * ini.size(), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(b->d_finS, fin.data(), sizeof(double) * fin.size(), hipMemcpyHostToDevice));
@@ -1018,7 +1017,11 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   // dftpav_batch_corridor_from_states / _from_hypotheses before the next solve
   b->have_corridor = false;
   if (d->corridor) {
-    HIPCHK(h, hipMemcpy(b->d_corridor, cor.data(), sizeof(double) * cor.size(), hipMemcpyHostToDevice));
+    const size_t nraw = (size_t)B * L.Npts * L.H * 4;
+    if (!b->d_cor_raw) HIPCHK(h, hipMalloc(&b->d_cor_raw, sizeof(double) * nraw));
+    HIPCHK(h, hipMemcpyAsync(b->d_cor_raw, d->corridor, sizeof(double) * nraw, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_corridor_layout(b->d_cor_raw, b->d_corridor, B, L.Npts, L.H, b->NptsPad, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream)); // the caller's buffer is free again when this returns
     b->have_corridor = true;
   }
   b->t_now = d->t_now;
@@ -1508,6 +1511,113 @@ extern "C" int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sam
   if (d_states) (void)hipFree(d_states);
   if (d_valid) (void)hipFree(d_valid);
   return rc;
+}
+
+// ------------------------------------------------- one planning cycle, stream-ordered
+// TrajPlanner::RunMINCOParking from getRectangleConst on (traj_manager.cpp:551-626) and the consumers of its result
+// (CheckReplan's collision re-check, traj_server_ros.cpp:385-397; the state playback, :244-259,335-356) as ONE enqueue:
+// upload of the boundary states / waypoints / durations, then on the handle's stream and without the host in between
+//   constraint-point poses -> rectangles of every hypothesis (corridor.hip) -> solve (solver.hip) -> coefficients of the
+//   solutions -> collision re-check (validate.hip) -> state read-out (states.hip).
+// dftpav_plan_cycle returns when everything is enqueued; dftpav_plan_cycle_fetch waits and copies the results out.
+static int grow(dftpav_handle *h, void **p, size_t *have, size_t want, size_t elem) {
+  if (*have >= want && *p) return DFTPAV_OK;
+  if (*p) HIPCHK(h, hipFree(*p));
+  *p = nullptr;
+  HIPCHK(h, hipMalloc(p, elem * want));
+  *have = want;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_plan_cycle(dftpav_batch *b, const dftpav_batch_data *d, const double *states, int n_restarts, double check_dt,
+                                 double vertex_res, double t0, double state_dt, int n_samples, int filter_singularity) {
+  if (!b || !d || !states || n_restarts < 1 || b->B % n_restarts || !(check_dt > 0.0) || !(vertex_res > 0.0) || !(state_dt > 0.0) ||
+      n_samples < 1)
+    return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (!h->d_cells) return DFTPAV_E_INVALID;     // no map
+  if (b->L.H != 4) return DFTPAV_E_UNSUPPORTED; // rectangles
+  dftpav_batch_data dd = *d;
+  dd.corridor = nullptr; // the half-planes come from the map
+  if (int rc = dftpav_batch_upload(b, &dd)) return rc; // waits for the previous cycle of this handle, then copies the small inputs
+  HIPCHK(h, hipSetDevice(h->device));
+  auto &pc = b->pc;
+  const int B = b->B, n_hyp = B / n_restarts;
+  const size_t n_poses = (size_t)n_hyp * b->L.Npts;
+  pc.poses.assign(states, states + 3 * n_poses);
+  {
+    void *p = pc.d_poses;
+    if (int rc = grow(h, &p, &pc.n_poses, 3 * n_poses, sizeof(double))) return rc;
+    pc.d_poses = (double *)p;
+  }
+  if (!h->cev0) HIPCHK(h, hipEventCreate(&h->cev0));
+  if (!h->cev1) HIPCHK(h, hipEventCreate(&h->cev1));
+  HIPCHK(h, hipMemcpyAsync(pc.d_poses, pc.poses.data(), sizeof(double) * 3 * n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, launch_corridor(h->d_cells, h->d_bits, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y,
+                            pc.d_poses, (int)n_poses, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, h->d_dl, h->n_dl,
+                            nullptr, b->d_corridor, b->L.Npts, b->NptsPad, n_restarts, h->stream));
+  b->have_corridor = true;
+  if (int rc = solve_impl(b, nullptr, false)) return rc;
+  DevBatch D;
+  if (int rc = sync_dev(b, D)) return rc;
+  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  // the two running sums of the reference, tabulated (as dftpav_batch_validate)
+  pc.tt.clear();
+  pc.vv.clear();
+  {
+    double t = 0.0;
+    for (int k = 0; k < 4096; k++, t += check_dt) pc.tt.push_back(t);
+    const double longest = std::max(h->params.veh_length, h->params.veh_width) + 1.0;
+    for (double dl = vertex_res; dl < longest; dl += vertex_res) pc.vv.push_back(dl);
+    if (pc.vv.empty()) pc.vv.push_back(vertex_res);
+  }
+  {
+    void *p = pc.d_t;
+    if (int rc = grow(h, &p, &pc.n_t, pc.tt.size(), sizeof(double))) return rc;
+    pc.d_t = (double *)p;
+    p = pc.d_v;
+    if (int rc = grow(h, &p, &pc.n_v, pc.vv.size(), sizeof(double))) return rc;
+    pc.d_v = (double *)p;
+    size_t nb = pc.d_col ? (size_t)B : 0;
+    p = pc.d_col;
+    if (int rc = grow(h, &p, &nb, (size_t)B, sizeof(int))) return rc;
+    pc.d_col = (int *)p;
+    nb = pc.d_first ? (size_t)B : 0;
+    p = pc.d_first;
+    if (int rc = grow(h, &p, &nb, (size_t)B, sizeof(int))) return rc;
+    pc.d_first = (int *)p;
+    nb = pc.d_valid ? (size_t)B : 0;
+    p = pc.d_valid;
+    if (int rc = grow(h, &p, &nb, (size_t)B, sizeof(int))) return rc;
+    pc.d_valid = (int *)p;
+    p = pc.d_rd;
+    if (int rc = grow(h, &p, &pc.n_rd, (size_t)B * n_samples * 8, sizeof(double))) return rc;
+    pc.d_rd = (double *)p;
+  }
+  HIPCHK(h, hipMemcpyAsync(pc.d_t, pc.tt.data(), sizeof(double) * pc.tt.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(pc.d_v, pc.vv.data(), sizeof(double) * pc.vv.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, launch_validate(h->d_cells, h->map.size_x, h->map.size_y, h->map.resolution, h->map.origin_x, h->map.origin_y, b->d_coef, b->d_dt,
+                            b->L, b->B, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, pc.d_t, (int)pc.tt.size(), check_dt,
+                            pc.d_v, (int)pc.vv.size(), pc.d_col, pc.d_first, h->stream));
+  HIPCHK(h, launch_states(b->d_coef, b->d_dt, b->L, b->B, h->params.veh_wheel_base, t0, state_dt, n_samples, filter_singularity != 0,
+                          pc.d_rd, pc.d_valid, h->stream));
+  pc.n_samples = n_samples;
+  pc.in_flight = true;
+  return DFTPAV_OK;
+}
+
+extern "C" int dftpav_plan_cycle_fetch(dftpav_batch *b, double *x, double *final_cost, int *status, int *success, int *iters, int *collision,
+                                       int *first_sample, double *states, int *n_valid) {
+  if (!b || !b->pc.in_flight) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (int rc = dftpav_batch_results(b, x, final_cost, status, success, iters, nullptr, nullptr, nullptr)) return rc; // waits for the stream
+  const size_t B = (size_t)b->B;
+  if (collision) HIPCHK(h, hipMemcpy(collision, b->pc.d_col, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (first_sample) HIPCHK(h, hipMemcpy(first_sample, b->pc.d_first, sizeof(int) * B, hipMemcpyDeviceToHost));
+  if (states) HIPCHK(h, hipMemcpy(states, b->pc.d_rd, sizeof(double) * B * b->pc.n_samples * 8, hipMemcpyDeviceToHost));
+  if (n_valid) HIPCHK(h, hipMemcpy(n_valid, b->pc.d_valid, sizeof(int) * B, hipMemcpyDeviceToHost));
+  b->pc.in_flight = false;
+  return DFTPAV_OK;
 }
 
 // ------------------------------------------------- serialised trajectories (include/dftpav_hip.h, "DPTJ" v1)

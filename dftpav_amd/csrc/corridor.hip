@@ -214,4 +214,33 @@ hipError_t launch_corridor(const unsigned char *cells, const unsigned *bits, int
   return hipGetLastError();
 }
 
+// The set-up of OptimizeTrajectory on the corridor (traj_optimizer.cpp:15,49-52): a private copy whose normals are
+// normalised, here written straight into the solver's layout [trajectory][plane * 4 + component][point] (lanes = points read
+// contiguous doubles).  raw: the caller's hPoly columns [B][Npts][H][4] (n_x, n_y, p_x, p_y) as uploaded.  One thread per
+// (trajectory, point, plane); the division and the square root are the IEEE operations the host code used before
+// (contraction off), so the bits are those of the former host loop.
+__global__ void corridor_layout_kernel(const double *__restrict__ raw, double *__restrict__ out, int B, int Npts, int H, int NptsPad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * Npts * H;
+  if (i >= total) return;
+  const int k = (int)(i % H);
+  const size_t tp = i / H;
+  const int pt = (int)(tp % Npts);
+  const size_t t = tp / Npts;
+  const double *col = raw + i * 4;
+  const double c0 = col[0], c1 = col[1], c2 = col[2], c3 = col[3];
+  const double nrm = sqrt(c0 * c0 + c1 * c1);
+  double *dst = out + t * (size_t)H * 4 * NptsPad + (size_t)(4 * k) * NptsPad + pt;
+  dst[0] = c0 / nrm;
+  dst[(size_t)NptsPad] = c1 / nrm;
+  dst[(size_t)2 * NptsPad] = c2;
+  dst[(size_t)3 * NptsPad] = c3;
+}
+hipError_t launch_corridor_layout(const double *raw, double *out, int B, int Npts, int H, int NptsPad, hipStream_t stream) {
+  const size_t total = (size_t)B * Npts * H;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(corridor_layout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, raw, out, B, Npts, H, NptsPad);
+  return hipGetLastError();
+}
+
 } // namespace dftpav

@@ -390,6 +390,27 @@ int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double vertex_res, 
 int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sample_dt, int n_samples, int filter_singularity,
                                double *states, int *n_valid);
 
+/* ---- one planning cycle, stream-ordered ------------
+ * Replaces the body of TrajPlanner::RunMINCOParking from getRectangleConst on
+ * (traj_manager.cpp:551-626) together with the consumers of its result: the
+ * collision re-check of CheckReplan (traj_server_ros.cpp:385-397) and the state
+ * playback (traj_server_ros.cpp:244-259,335-356).  After the boundary states,
+ * waypoints and durations of `d` are uploaded (d->corridor is ignored), every
+ * stage is enqueued on the handle's stream without the host in between:
+ *   rectangles of every hypothesis from the installed map
+ *     (states [B / n_restarts][Npts][3], as dftpav_batch_corridor_from_hypotheses)
+ *   -> solve -> coefficients of the solutions
+ *   -> collision re-check every check_dt seconds (outline points every vertex_res m)
+ *   -> states at t0 + k * state_dt, k < n_samples (as dftpav_batch_sample_states).
+ * dftpav_plan_cycle returns once everything is enqueued; dftpav_plan_cycle_fetch
+ * waits for the stream and copies out whatever is asked for (any pointer may be
+ * NULL): the arrays of dftpav_batch_results, dftpav_batch_validate and
+ * dftpav_batch_sample_states, bit for bit what the separate calls return. */
+int dftpav_plan_cycle(dftpav_batch *b, const dftpav_batch_data *d, const double *states, int n_restarts, double check_dt,
+                      double vertex_res, double t0, double state_dt, int n_samples, int filter_singularity);
+int dftpav_plan_cycle_fetch(dftpav_batch *b, double *x, double *final_cost, int *status, int *success, int *iters, int *collision,
+                            int *first_sample, double *states, int *n_valid);
+
 /* ---- serialised form of a trajectory -----------------------
  * The reference declares traj_planner/msg/PolyTraj.msg:1-9 (drone_id, traj_id,
  * start_time, order, float32 coefficients, durations) and never uses it; plans

@@ -914,3 +914,56 @@ def test_overlapped_streams_and_hand_over_zero(hiplib, monkeypatch):
         bt.close()
     for h in hs:
         h.close()
+
+
+def test_plan_cycle_equals_the_separate_stages(hiplib, oracle):
+    """dftpav_plan_cycle (upload -> rectangles from the map -> solve -> collision re-check -> read-out, one enqueue on the
+    handle's stream) against the same stages called one by one, and the solve against the oracle chain; a second cycle on
+    the same batch with other inputs reuses the work buffers."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(3, B=8)
+    s.apply_resolution(p)
+    st = s.meta["states"]
+    c = (0.5 * (st[..., 0].min() + st[..., 0].max()), 0.5 * (st[..., 1].min() + st[..., 1].max()))
+    obs = np.vstack([s.meta["obstacles"], np.column_stack([st[0, 200:203, 0], st[0, 200:203, 1], [0.6, 0.6, 0.6]])])  # some on the path
+    grid, origin = sc.occupancy_grid(obs, arena=120.0, centre=c)
+    order = np.argsort(s.meta["hyp_of"], kind="stable")  # trajectory = hypothesis * n_restarts + restart
+    nr = s.B // st.shape[0]
+    s3 = s.subset(order)
+    h = hiplib.Handle(p)
+    h.set_grid_map(grid, sc.MAP_RESL, origin)
+    n_rd = 400
+    # the stages one by one
+    b1 = hiplib.Batch(h, s.layout, s.B)
+    b1.upload(s3, with_corridor=False)
+    b1.corridor_from_states(st, n_restarts=nr)
+    r1 = b1.solve()
+    col1, first1 = b1.validate(sample_dt=0.05, vertex_res=0.1)
+    rd1, nv1 = b1.sample_states(t0=0.0, sample_dt=0.05, n_samples=n_rd)
+    # one enqueue
+    b2 = hiplib.Batch(h, s.layout, s.B)
+    b2.plan_cycle(s3, st, n_restarts=nr, check_dt=0.05, vertex_res=0.1, t0=0.0, state_dt=0.05, n_samples=n_rd)
+    r2 = b2.plan_cycle_fetch()
+    for k in ("x", "final_cost", "status", "success", "iters"):
+        assert np.array_equal(r2[k], r1[k]), k
+    assert np.array_equal(r2["collision"], col1) and np.array_equal(r2["first_sample"], first1)
+    assert np.array_equal(r2["states"], rd1) and np.array_equal(r2["n_valid"], nv1)
+    assert r2["success"].all()
+    # against the oracle chain: rectangles -> solve
+    Ho = oracle.corridor_rectangles(grid, sc.MAP_RESL, origin, st.reshape(-1, 3), order=1).reshape(st.shape[0], st.shape[1], 4, 4)
+    so = s.subset(order)
+    so.corridor = np.ascontiguousarray(np.repeat(Ho, nr, axis=0))
+    ro = oracle.solve_batch(p, so, nthreads=4, order=1)
+    assert np.array_equal(r2["final_cost"], ro["final_cost"]) and np.array_equal(r2["x"], ro["x"])
+    # a second cycle: other restarts of the same hypotheses (reversed order inside each hypothesis)
+    perm = np.concatenate([np.arange(i * nr, (i + 1) * nr)[::-1] for i in range(st.shape[0])])
+    s4 = s3.subset(perm)
+    b2.plan_cycle(s4, st, n_restarts=nr, check_dt=0.05, vertex_res=0.1, t0=0.0, state_dt=0.05, n_samples=n_rd)
+    r4 = b2.plan_cycle_fetch()
+    assert np.array_equal(r4["x"], r2["x"][perm]) and np.array_equal(r4["collision"], col1[perm])
+    assert np.array_equal(r4["states"], rd1[perm])
+    with pytest.raises(hiplib.DftpavError):
+        b2.plan_cycle_fetch()  # nothing in flight
+    b1.close()
+    b2.close()
+    h.close()
