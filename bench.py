@@ -311,12 +311,13 @@ def main():
                 for _ in range(reps):
                     b2.solve_async(); b2.sync(); ms.append(b2.last_solve_ms())
                 r2 = b2.results()
-                # a stream of such batches (planning cycles back to back): 4 resident batches on 4 HIP streams, 3 rounds
-                hx = [capi.Handle(p2, device=local_rank) for _ in range(3)]
-                bx = [b2]
+                # a stream of such batches (planning cycles back to back on several planner threads): 8 resident batches on 8 HIP
+                # streams in the throughput residency (four workgroups per CU, dftpav_batch_create_shaped), 3 rounds
+                hx = [capi.Handle(p2, device=local_rank) for _ in range(8)]
+                bx = []
                 for hh in hx:
                     hh.set_surround(s2.surround)
-                    bb = capi.Batch(hh, s2.layout, B)
+                    bb = capi.Batch(hh, s2.layout, B, residency=2)
                     bb.upload(s2)
                     bx.append(bb)
                 for bb in bx:
@@ -332,10 +333,10 @@ def main():
                 for bb in bx:
                     bb.sync()
                 stream_s = time.perf_counter() - t1
-                same = bool(all(np.array_equal(bb.results()["x"], r2["x"]) for bb in bx[1:]))
+                same = bool(all(np.array_equal(bb.results()["x"], r2["x"]) for bb in bx))
                 pick = (np.arange(n_check) * max(1, B // n_check)) % B
                 ok = bit_check(p2, s2, r2, pick)
-                for bb in bx[1:]:
+                for bb in bx:
                     bb.close()
                 b2.close(); h2.close()
                 for hh in hx:

@@ -31,7 +31,7 @@ EXPORTS = [
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
     "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
-    "dftpav_batch_trace", "dftpav_batch_get_trace", "dftpav_plan_cycle", "dftpav_plan_cycle_fetch",
+    "dftpav_batch_trace", "dftpav_batch_get_trace", "dftpav_plan_cycle", "dftpav_plan_cycle_fetch", "dftpav_batch_create_shaped",
 ]
 
 
@@ -277,14 +277,20 @@ class GridMap(C.Structure):
 class Batch:
     """dftpav_batch: B trajectories of one layout, resident in HBM."""
 
-    def __init__(self, handle, layout_spec, B):
+    def __init__(self, handle, layout_spec, B, residency=-1):
+        """residency: -1 by B (dftpav_batch_create); 0 / 1 / 2 = one / two / four workgroups per CU (dftpav_batch_create_shaped)"""
         self.handle = handle
         self.layout = layout_spec
         self.B = B
         self.n = layout_spec.n_vars
         self._b = C.c_void_p()
         lay = layout_spec.c_struct()
-        rc = lib().dftpav_batch_create(handle._h, C.byref(lay), B, C.byref(self._b))
+        if residency < 0:
+            rc = lib().dftpav_batch_create(handle._h, C.byref(lay), B, C.byref(self._b))
+        else:
+            fn = lib().dftpav_batch_create_shaped
+            fn.argtypes = [C.c_void_p, C.POINTER(Layout), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+            rc = fn(handle._h, C.byref(lay), B, int(residency), C.byref(self._b))
         if rc != OK:
             self._b = None
             handle._check(rc, "batch_create")

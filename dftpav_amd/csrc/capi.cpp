@@ -95,7 +95,7 @@ struct dftpav_batch {
   DevBatch *d_dev2 = nullptr;
   // E4 lane plans (e4_plan.h) of the two launch shapes: host copies of the sizes, device tables
   E4Sizes e4{}, e4b{};
-  int *d_e4[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}; // slot, wave, round, piece
+  int *d_e4[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}}; // gtab, ltab, wave, round, piece
   int NptsPad = 0;
   std::vector<double> x0_host;
   bool uploaded = false;
@@ -743,7 +743,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int w = 0; w < 2; w++)
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 5; t++)
       if (b->d_e4[w][t]) (void)hipFree(b->d_e4[w][t]);
   for (int i = 0; i < kMaxSeg; i++) {
     if (b->d_opM[i]) (void)hipFree(b->d_opM[i]);
@@ -754,7 +754,17 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   delete b;
 }
 
+static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int B, int residency, dftpav_batch **out);
 extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out) {
+  return batch_create_impl(h, layout, B, -1, out);
+}
+// residency: -1 = by the batch size (dftpav_batch_create); 0 = one workgroup per CU (lowest latency of a solve), 1 = two,
+// 2 = four per CU (highest throughput): for callers that keep several small batches in flight on several handles
+extern "C" int dftpav_batch_create_shaped(dftpav_handle *h, const dftpav_layout *layout, int B, int residency, dftpav_batch **out) {
+  if (residency < -1 || residency > 2) return DFTPAV_E_INVALID;
+  return batch_create_impl(h, layout, B, residency, out);
+}
+static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int B, int residency, dftpav_batch **out) {
   if (!h || !layout || !out || B < 1) return DFTPAV_E_INVALID;
   *out = nullptr;
   if (layout->M < 1 || layout->M > kMaxSeg || layout->H < 1) return DFTPAV_E_UNSUPPORTED;
@@ -810,11 +820,12 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     int shape = B <= n_cu ? 0 : (B <= 2 * n_cu ? 1 : 2);
+    if (residency >= 0) shape = residency;
     if (const char *e = std::getenv("DFTPAV_MODE")) shape = std::atoi(e); // 0 latency, 1 two per CU, 2 four per CU
     b->threads = solver_threads(L, shape);
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
     // LDS budget per workgroup: the whole CU, half of it, a quarter of it
-    const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : 38 * 1024);
+    const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : 19 * 1024 + 512);
     b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, true, false, 512) + 64 <= budget;
     b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, true, 512) + 64 <= budget;
     if (const char *e = std::getenv("DFTPAV_LDS")) { // bit 0 operators, bit 1 corridor
@@ -827,9 +838,9 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
     // workgroups take trajectories from a queue, run them `slice` iterations at a time and put the
     // unfinished ones back, so all trajectories advance together; when no more than `hand_over` are left
     // they are finished by a second launch in the latency shape (one wide workgroup per CU).
-    const int per_cu = shape == 0 ? 1 : (shape == 1 ? 2 : 4);
+    const int per_cu = shape == 0 ? 1 : (shape == 1 ? 2 : 8);
     b->slots = n_cu * per_cu;
-    b->slice = 48;
+    b->slice = 128;
     b->hand_over = n_cu;
     if (const char *e = std::getenv("DFTPAV_SLOTS")) b->slots = std::atoi(e);
     if (const char *e = std::getenv("DFTPAV_SLICE")) b->slice = std::atoi(e);
@@ -933,8 +944,8 @@ extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout
   for (int which = 0; which < 2; which++) {
     const E4Plan pl = build_e4_plan(L, which == 0 ? b->threads : b->threads2);
     (which == 0 ? b->e4 : b->e4b) = E4Sizes{pl.rounds, pl.groups, pl.left, pl.lcap};
-    const std::vector<int> *tabs[4] = {&pl.slot, &pl.wave, &pl.round, &pl.piece};
-    for (int t = 0; t < 4; t++) {
+    const std::vector<int> *tabs[5] = {&pl.gtab, &pl.ltab, &pl.wave, &pl.round, &pl.piece};
+    for (int t = 0; t < 5; t++) {
       BCHK(hipMalloc(&b->d_e4[which][t], sizeof(int) * tabs[t]->size()));
       BCHK(hipMemcpy(b->d_e4[which][t], tabs[t]->data(), sizeof(int) * tabs[t]->size(), hipMemcpyHostToDevice));
     }
@@ -1072,10 +1083,11 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.e4_groups = b->e4.groups;
   D.e4_left = b->e4.left;
   D.e4_lcap = b->e4.lcap;
-  D.e4_slot = b->d_e4[0][0];
-  D.e4_wave = b->d_e4[0][1];
-  D.e4_round = b->d_e4[0][2];
-  D.e4_piece = b->d_e4[0][3];
+  D.e4_gtab = b->d_e4[0][0];
+  D.e4_ltab = b->d_e4[0][1];
+  D.e4_wave = b->d_e4[0][2];
+  D.e4_round = b->d_e4[0][3];
+  D.e4_piece = b->d_e4[0][4];
   int off = 0;
   for (int i = 0; i < kMaxSeg; i++) {
     D.opM[i] = b->d_opM[i];
@@ -1145,10 +1157,11 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
     D2.e4_groups = b->e4b.groups;
     D2.e4_left = b->e4b.left;
     D2.e4_lcap = b->e4b.lcap;
-    D2.e4_slot = b->d_e4[1][0];
-    D2.e4_wave = b->d_e4[1][1];
-    D2.e4_round = b->d_e4[1][2];
-    D2.e4_piece = b->d_e4[1][3];
+    D2.e4_gtab = b->d_e4[1][0];
+    D2.e4_ltab = b->d_e4[1][1];
+    D2.e4_wave = b->d_e4[1][2];
+    D2.e4_round = b->d_e4[1][3];
+    D2.e4_piece = b->d_e4[1][4];
     HIPCHK(h, hipMemcpyAsync(b->d_dev2, &D2, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream)); // D, D2 live on this stack frame
     b->dev_version = version;
@@ -1244,10 +1257,11 @@ static int launch_stragglers(dftpav_batch *b, const DevBatch &D, int source) {
   D2.e4_groups = b->e4b.groups;
   D2.e4_left = b->e4b.left;
   D2.e4_lcap = b->e4b.lcap;
-  D2.e4_slot = b->d_e4[1][0];
-  D2.e4_wave = b->d_e4[1][1];
-  D2.e4_round = b->d_e4[1][2];
-  D2.e4_piece = b->d_e4[1][3];
+  D2.e4_gtab = b->d_e4[1][0];
+  D2.e4_ltab = b->d_e4[1][1];
+  D2.e4_wave = b->d_e4[1][2];
+  D2.e4_round = b->d_e4[1][3];
+  D2.e4_piece = b->d_e4[1][4];
   HIPCHK(h, launch_solver(D2, b->d_dev2, kModeSolve, b->threads2, b->hand_over, SchedArgs{source, 0, 0, nullptr}, h->stream));
   return DFTPAV_OK;
 }

@@ -77,8 +77,10 @@ struct DevBatch {
   int cor_in_lds;              // the trajectory's half-planes are staged in LDS at kernel start
   // E4 lane plan for this launch shape (see e4_group_size): rounds of blockDim slots
   int e4_rounds, e4_groups, e4_left, e4_lcap; // rounds; groups and leftover points per trajectory; leftover capacity of the LDS staging
-  const int *e4_slot;          // [e4_rounds][blockDim] piece | j << 16, or -1 for an idle lane
-  const int *e4_wave;          // [e4_rounds][blockDim / 64][2] per wave: kind (32, 16: group size; 0: leftovers; -1: idle), base (first group id / first leftover index)
+  const int *e4_gtab;          // [e4_groups] piece | (first j) << 16 of a group
+  const int *e4_ltab;          // [e4_left] piece | j << 16 of a leftover point
+  const int *e4_wave;          // [e4_rounds][blockDim / 64][3] per wave: kind (32, 16: group size; 0: leftovers; -1: idle), base (first
+                               // group id / first leftover index), count (groups / leftover points it holds)
   const int *e4_round;         // [e4_rounds][2] leftovers evaluated in the round (0 = none: no chain pass after it), index of the first
   const int *e4_piece;         // [Ntot][4] first group, groups, first leftover, leftovers of a piece
   int op_off[kMaxSeg];         // offset (doubles) of each segment's operator inside the LDS copy

@@ -10,8 +10,10 @@ namespace dftpav {
 
 struct E4Plan {
   int T = 0, nw = 0, rounds = 0, groups = 0, left = 0, lcap = 16;
-  std::vector<int> slot;  // [rounds][T]     piece | j << 16, -1 = idle lane
-  std::vector<int> wave;  // [rounds][nw][2] kind (32 / 16 group size, 0 leftovers, -1 idle), base (first group id / first leftover index)
+  std::vector<int> gtab;  // [groups]        piece | (first j of the group) << 16
+  std::vector<int> ltab;  // [left]          piece | j << 16 of a leftover point
+  std::vector<int> wave;  // [rounds][nw][3] kind (32 / 16 group size, 0 leftovers, -1 idle), base (first group id / first leftover
+                          //                 index), count (groups / leftover points the wave holds)
   std::vector<int> round; // [rounds][2]     leftovers evaluated in the round, index of the first of them
   std::vector<int> piece; // [Ntot][4]       first group, groups, first leftover, leftovers
 };
@@ -66,8 +68,11 @@ inline E4Plan build_e4_plan(const DevLayout &L, int T) {
   }
   pl.rounds = (int)((tasks.size() + pl.nw - 1) / pl.nw);
   if (pl.rounds < 1) pl.rounds = 1;
-  pl.slot.assign((size_t)pl.rounds * T, -1);
-  pl.wave.assign((size_t)pl.rounds * pl.nw * 2, -1);
+  pl.gtab.resize(grp.size() ? grp.size() : 1, 0);
+  for (size_t i = 0; i < grp.size(); i++) pl.gtab[i] = grp[i].piece | (grp[i].j0 << 16);
+  pl.ltab.resize(left.size() ? left.size() : 1, 0);
+  for (size_t i = 0; i < left.size(); i++) pl.ltab[i] = left[i].first | (left[i].second << 16);
+  pl.wave.assign((size_t)pl.rounds * pl.nw * 3, -1);
   pl.round.assign((size_t)pl.rounds * 2, 0);
   int lmax = 0;
   for (int r = 0; r < pl.rounds; r++) {
@@ -76,12 +81,14 @@ inline E4Plan build_e4_plan(const DevLayout &L, int T) {
       const size_t ti = (size_t)r * pl.nw + w;
       if (ti >= tasks.size()) continue;
       const Task &t = tasks[ti];
-      pl.wave[(ti) * 2 + 0] = t.kind;
-      pl.wave[(ti) * 2 + 1] = t.base;
-      for (int l = 0; l < kWave; l++) pl.slot[(size_t)r * T + w * kWave + l] = t.lane[l];
+      int held = 0;
+      for (int l = 0; l < kWave; l += (t.kind ? t.kind : 1)) held += t.lane[l] >= 0;
+      pl.wave[ti * 3 + 0] = t.kind;
+      pl.wave[ti * 3 + 1] = t.base;
+      pl.wave[ti * 3 + 2] = held;
       if (t.kind == 0) {
         if (first < 0) first = t.base;
-        for (int l = 0; l < kWave; l++) cnt += t.lane[l] >= 0;
+        cnt += held;
       }
     }
     pl.round[2 * r + 0] = cnt;

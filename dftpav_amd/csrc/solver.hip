@@ -43,7 +43,7 @@ struct Smem {
   double *x, *xp, *g, *gp, *d;
   double *bnd;  // [2][M][6] iniStates, finStates of the trajectory being solved
   double *seg;  // [M][16]  0:T 1:dt 2..7:t^k 8..13:t^-k
-  double *spow; // [M][2][Kmax+1][6] powers of the accumulated sample offset (s1 += step, traj_optimizer.cpp:513)
+  double *spow; // [M][2][Kmax+1] the accumulated sample offsets (s1 += step, traj_optimizer.cpp:513), for K and for Kd
   double *rhs;  // [rhs_tot][2]
   double *b, *c, *gdC; // [6*Ntot][2]
   double *adj;  // [rhs_tot][2]
@@ -53,14 +53,15 @@ struct Smem {
   double *sdur;  // [sur_np] piece durations of the moving obstacles: Trajectory::locatePieceIdx (poly_traj_utils.hpp:510-528)
                  // walks them one dependent load after the other -- from LDS that is ~100 cycles a step instead of an L2 round trip
   double *pE, *pGsm, *pGdT, *pCost; // [Ntot]
-  double *ys, *rinv, *alpha; // [mem]
+  double *ys, *rinv; // [mem]  (alpha of the two-loop recursion lives in the unused 8th entry of the histU rows)
   double *st;     // [sNUM] scalar solver state
   double *segsum; // [M][8] per-segment sums: 0 jerk energy, 1 penalty cost, 2 d(jerk)/dT, 3 penalty gdT, 4 chain-rule gdT
   double *opM, *opMT; // operators of all segments back to back (only when D.op_in_lds)
   double *cor;        // [4H][NptsPad] half-planes of this trajectory (only when D.cor_in_lds)
   int *ist;     // [iNUM]
-  int *slot;    // [e4_rounds][T] piece | j<<16 of the constraint point a lane evaluates in a round (-1: idle)
-  int *wtab;    // [e4_rounds][T/64][2] what a wave does in a round: kind, base (e4_plan.h)
+  int *gtab;    // [e4_groups] piece | (first j) << 16 of a group of constraint points
+  int *ltab;    // [e4_left] piece | j << 16 of a leftover point
+  int *wtab;    // [e4_rounds][T/64][3] what a wave does in a round: kind, base, count (e4_plan.h)
   int *rtab;    // [e4_rounds][2] leftovers of a round, first index
   int *pgrp;    // [Ntot][4] first group, groups, first leftover, leftovers of a piece
   int *dinfo;   // [Npts + 1] moving obstacles near a point (bits 16..31) | index of its first pair (kernels with moving obstacles only)
@@ -88,7 +89,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   n += 5 * (size_t)L.npad;
   n += (size_t)L.M * 12;
   n += (size_t)L.M * 16;
-  n += (size_t)L.M * 2 * (L.Kmax + 1) * 6;
+  n += (size_t)L.M * 2 * (L.Kmax + 1);
   n += (size_t)L.rhs_tot * 2;
   n += 3 * (size_t)L.Ntot * 12;
   n += (size_t)L.rhs_tot * 2;
@@ -100,16 +101,16 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   }
   if (sur) n += 2 * (size_t)sur_np + (sur_np <= kSurCoefLds ? 12 * (size_t)sur_np : 0);
   n += 4 * (size_t)L.Ntot;
-  n += 3 * (size_t)mem;
+  n += 2 * (size_t)mem;
   n += sNUM;
   n += (size_t)L.M * 8;
   if (op_lds) n += op_doubles(L) + opT_lds_doubles(L);
   if (cor_lds) n += (size_t)4 * L.H * (((size_t)L.Npts + 63) / 64 * 64);
   return n;
 }
-__host__ __device__ inline size_t smem_ints(const DevLayout &L, int rounds, int T, bool sur) {
-  return (sur ? (size_t)L.Npts + 2 : 0) + iNUM + (size_t)rounds * T + (size_t)rounds * (T / kWave) * 2 + (size_t)rounds * 2 + 4 * (size_t)L.Ntot + 8 * (size_t)L.Ntot +
-         4 * (size_t)L.rhs_tot;
+__host__ __device__ inline size_t smem_ints(const DevLayout &L, int rounds, int groups, int left, int T, bool sur) {
+  return (sur ? (size_t)L.Npts + 2 : 0) + iNUM + (size_t)(groups > 0 ? groups : 1) + (size_t)(left > 0 ? left : 1) + (size_t)rounds * (T / kWave) * 3 +
+         (size_t)rounds * 2 + 4 * (size_t)L.Ntot + 8 * (size_t)L.Ntot + 4 * (size_t)L.rhs_tot;
 }
 
 E4Sizes e4_sizes(const DevLayout &L, int threads) {
@@ -120,7 +121,7 @@ E4Sizes e4_sizes(const DevLayout &L, int threads) {
 size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np) {
   const bool sur = sur_np > 0;
   const E4Sizes z = e4_sizes(L, threads);
-  return smem_doubles(L, P.mem_size, z.groups, z.lcap, threads, op_lds, cor_lds, sur_np) * sizeof(double) + smem_ints(L, z.rounds, threads, sur) * sizeof(int);
+  return smem_doubles(L, P.mem_size, z.groups, z.lcap, threads, op_lds, cor_lds, sur_np) * sizeof(double) + smem_ints(L, z.rounds, z.groups, z.left, threads, sur) * sizeof(int);
 }
 
 int solver_threads(const DevLayout &L, int shape) {
@@ -129,10 +130,10 @@ int solver_threads(const DevLayout &L, int shape) {
   // 528-point problems (scripts/profile_phases.py):
   //   shape 0, <= 1 trajectory per CU : about two constraint points per thread, up to 8 waves
   //   shape 1, <= 2 per CU            : 4 waves, two workgroups resident per CU
-  //   shape 2, more                   : 2 waves, four workgroups resident per CU
+  //   shape 2, more                   : 1 wave, eight workgroups resident per CU (the 256-VGPR budget allows 8 waves)
   int T;
   if (shape == 2) {
-    T = 128;
+    T = kWave; // one wave per trajectory: no wave of a workgroup ever waits for the serial part of another
   } else if (shape == 1) {
     T = 256;
     if (L.Npts <= 128) T = 128;
@@ -142,12 +143,12 @@ int solver_threads(const DevLayout &L, int shape) {
     if (need > 512) need = 512;
     if (T < need) T = (need + kWave - 1) / kWave * kWave;
   }
-  if (T < 128) T = 128;
+  if (T < 128 && shape != 2) T = 128;
   if (T > 512) T = 512;
   return T;
 }
 
-__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int rounds, int groups, int lcap, bool op_lds,
+__device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int rounds, int groups, int left, int lcap, bool op_lds,
                              bool cor_lds, int sur_np) {
   const bool sur = sur_np > 0;
   double *p = base;
@@ -158,7 +159,7 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.d = p; p += L.npad;
   s.bnd = p; p += L.M * 12;
   s.seg = p; p += L.M * 16;
-  s.spow = p; p += L.M * 2 * (L.Kmax + 1) * 6;
+  s.spow = p; p += L.M * 2 * (L.Kmax + 1);
   s.rhs = p; p += L.rhs_tot * 2;
   s.b = p; p += L.Ntot * 12;
   s.c = p; p += L.Ntot * 12;
@@ -179,7 +180,6 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.pCost = p; p += L.Ntot;
   s.ys = p; p += mem;
   s.rinv = p; p += mem;
-  s.alpha = p; p += mem;
   s.st = p; p += sNUM;
   s.segsum = p; p += L.M * 8;
   s.opM = p;
@@ -192,9 +192,10 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.cor = p;
   if (cor_lds) p += (size_t)4 * L.H * ((L.Npts + 63) / 64 * 64);
   s.ist = reinterpret_cast<int *>(p);
-  s.slot = s.ist + iNUM;
-  s.wtab = s.slot + rounds * T;
-  s.rtab = s.wtab + rounds * (T / kWave) * 2;
+  s.gtab = s.ist + iNUM;
+  s.ltab = s.gtab + (groups > 0 ? groups : 1);
+  s.wtab = s.ltab + (left > 0 ? left : 1);
+  s.rtab = s.wtab + rounds * (T / kWave) * 3;
   s.pgrp = s.rtab + rounds * 2;
   s.pcinfo = s.pgrp + 4 * L.Ntot;
   s.rowinfo = s.pcinfo + 8 * L.Ntot;
@@ -508,6 +509,17 @@ __device__ __forceinline__ void op_col_dot2(P MT, const double *gc, const double
   ay = acc1;
 }
 
+// the constraint point a lane evaluates in a round of the E4 plan (e4_plan.h): piece | j << 16, or -1
+__device__ inline int e4_lane_point(const Smem &sm, int kind, int base, int count, int lane) {
+  if (kind > 0) { // a wave of groups: `count` groups of `kind` consecutive points each
+    const int g = lane / kind;
+    if (g >= count) return -1;
+    return sm.gtab[base + g] + ((lane & (kind - 1)) << 16);
+  }
+  if (kind == 0) return lane < count ? sm.ltab[base + lane] : -1; // a wave of leftover points
+  return -1;
+}
+
 // Segment durations of the decision vector x (VirtualT2RealT, traj_optimizer.cpp:371-379), the piece duration and its
 // powers (poly_traj_utils.hpp:961-966) into sm.seg, one lane per segment.  Wave 0 runs it as soon as an x to be evaluated
 // is in place (before the first evaluation of a pass; at the end of lbfgs_advance), so that the evaluation starts with
@@ -537,7 +549,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
   const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, rhs_tot = L.rhs_tot, Kmax1 = L.Kmax + 1;
   const double *iniS = sm.bnd, *finS = sm.bnd + 6 * M; // boundary states of this trajectory, staged with x
 
-  // ---- E1: MINCO right-hand sides and the sample-offset power tables.  The segment durations T, dt and the powers of
+  // ---- E1: MINCO right-hand sides and the sample offsets.  The segment durations T, dt and the powers of
   // dt are already in sm.seg: prep_durations formed them on wave 0 as soon as this x was written.
   {
     const int n_rhs = 2 * rhs_tot;
@@ -579,31 +591,24 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         // offsets s1 = 0, += step, ... (traj_optimizer.cpp:513): one dependent chain of additions by definition; four
         // links at a time are formed in registers and their stores trail behind them
         typedef double __attribute__((address_space(3))) *ldsw_t;
-        ldsw_t tab = (ldsw_t)(sm.spow + (size_t)(sg * 2 + which) * Kmax1 * 6);
+        ldsw_t tab = (ldsw_t)(sm.spow + (size_t)(sg * 2 + which) * Kmax1);
         double s1 = 0.0;
         int j = 0;
         for (; j + 4 <= K + 1; j += 4) {
           const double a0 = s1, a1 = a0 + step, a2 = a1 + step, a3 = a2 + step;
           s1 = a3 + step;
-          tab[6 * j + 1] = a0;
-          tab[6 * j + 7] = a1;
-          tab[6 * j + 13] = a2;
-          tab[6 * j + 19] = a3;
+          tab[j] = a0;
+          tab[j + 1] = a1;
+          tab[j + 2] = a2;
+          tab[j + 3] = a3;
         }
         for (; j <= K; j++) {
-          tab[6 * j + 1] = s1;
+          tab[j] = s1;
           s1 += step;
         }
       }
     }
-    __syncthreads();
-    // powers of the offsets (the beta vectors of traj_optimizer.cpp:500-509 are built from these)
-    for (int w = tid; w < 2 * M * Kmax1; w += T) {
-      double *e = sm.spow + (size_t)w * 6;
-      double s1 = e[1];
-      double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
-      e[0] = 1.0; e[2] = s2; e[3] = s3; e[4] = s4; e[5] = s5;
-    }
+    __syncthreads(); // the right-hand sides for E2; the offsets (their powers are formed per point, E4) for E4
   }
   pr.tick(kPE1);
 
@@ -684,9 +689,10 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
     const int lstride = D.e4_lcap + 2;
     bool groups_added = false;
     for (int r = 0; r < D.e4_rounds; r++) {
-      const int info = sm.slot[r * T + tid];
-      const int kind = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 2]);
-      const int wbase = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 2 + 1]);
+      const int kind = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 3]);
+      const int wbase = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 3 + 1]);
+      const int wcount = __builtin_amdgcn_readfirstlane(sm.wtab[(r * nwv + wv) * 3 + 2]);
+      const int info = e4_lane_point(sm, kind, wbase, wcount, lane); // piece | j << 16 of this lane's point, -1: none
       const int nleft = sm.rtab[2 * r], lbase = sm.rtab[2 * r + 1];
       if (kind >= 0) { // wave-uniform: this wave has points in this round
         double o[8];
@@ -702,7 +708,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
           in.N = pc[5];
           in.singul = pc[6];
           in.dt = sm.seg[sg * 16 + 1];
-          in.s1 = s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+          in.s1 = s1 = sm.spow[(size_t)pc[2] * Kmax1 + in.j];
           in.cc = sm.c + 12 * p;
           in.epis = D.epis;
           in.H = L.H;
@@ -789,7 +795,8 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
     if (D.sur.theta != nullptr) surL.theta = sm.sdur + D.sur_np;
     if (D.sur_np <= kSurCoefLds) surL.coeffs = sm.sdur + 2 * D.sur_np;
     for (int r = 0; r < D.e4_rounds; r++) {
-      const int info = sm.slot[r * T + tid];
+      const int wv_ = tid >> 6, nwv_ = T >> 6;
+      const int info = e4_lane_point(sm, sm.wtab[(r * nwv_ + wv_) * 3], sm.wtab[(r * nwv_ + wv_) * 3 + 1], sm.wtab[(r * nwv_ + wv_) * 3 + 2], lane);
       if (info >= 0) {
         const int p = info & 0xffff;
         const int *pc = sm.pcinfo + 8 * p;
@@ -801,7 +808,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         in.N = pc[5];
         in.singul = pc[6];
         in.dt = sm.seg[sg * 16 + 1];
-        in.s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+        in.s1 = sm.spow[(size_t)pc[2] * Kmax1 + in.j];
         in.cc = sm.c + 12 * p;
         in.epis = D.epis;
         in.H = L.H;
@@ -864,7 +871,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         in.N = pc[5];
         in.singul = pc[6];
         in.dt = sm.seg[sg * 16 + 1];
-        in.s1 = sm.spow[((size_t)pc[2] * Kmax1 + in.j) * 6 + 1];
+        in.s1 = sm.spow[(size_t)pc[2] * Kmax1 + in.j];
         in.cc = sm.c + 12 * p;
         in.epis = D.epis;
         in.H = L.H;
@@ -1182,7 +1189,8 @@ struct HistBlock {
 // out-of-line function: a generic pointer would turn every access into a flat one)
 typedef double __attribute__((address_space(3))) *lds_rw_t;
 struct LoopLds {
-  lds_rw_t ys, rinv, alpha;
+  lds_rw_t ys, rinv;
+  gwptr_t alpha; // histU: alpha of slot j at [8 j + 7] (the row's products use entries 0..6)
 };
 // loads the block whose first step sits in slot `jl`, walking downwards (DIR = -1) or upwards (+1)
 // with wrap-around; unconditional loads from always-valid addresses, nothing consumes them here
@@ -1194,7 +1202,7 @@ __device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr
   js = js < 0 ? js + m : (js >= m ? js - m : js);
 #pragma unroll
   for (int u = 0; u < kLoopBlock - 1; u++) R.coef[u] = hB[(size_t)js * 8 + (st > u ? st - u - 1 : 0)];
-  if (LOOP2) R.al = sm.alpha[js];
+  if (LOOP2) R.al = sm.alpha[(size_t)js * 8 + 7];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) {
     {
@@ -1250,7 +1258,7 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
   const double mine = div_by_rcp(acc, ys_, ri_);
   int js = j - st;
   js = js < 0 ? js + m : js;
-  if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[js] = mine;
+  if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[(size_t)js * 8 + 7] = mine;
   const int done = FULL ? kLoopBlock : nb - i0;
   j -= done;
   j = j < 0 ? j + m : j;
@@ -1321,11 +1329,11 @@ __device__ __forceinline__ lds_rw_t uni_lds(lds_rw_t p) {
 #endif
 }
 template <int LV>
-__device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_t l_rinv, lds_rw_t l_alpha, gptr_t hS, gptr_t hY,
+__device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_t l_rinv, gptr_t hS, gptr_t hY,
                                                           gptr_t hU, gptr_t hV, int npad, int n, int m, int nb, int ne,
                                                           double ys_new, double yy_new, int lane, double dreg) {
-  const LoopLds sm{uni_lds(l_ys), uni_lds(l_rinv), uni_lds(l_alpha)};
   hS = uni_ptr(hS); hY = uni_ptr(hY); hU = uni_ptr(hU); hV = uni_ptr(hV);
+  const LoopLds sm{uni_lds(l_ys), uni_lds(l_rinv), (gwptr_t)hU};
   npad = uni(npad); n = uni(n); m = uni(m); ne = uni(ne);
   const bool act = lane < n;
   const int ln = act ? lane : 0;
@@ -1345,6 +1353,7 @@ __device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_
     first_loop_step<LV>(B, sm, i0 + PB, nb, m, act, lane, j, dreg);
   }
   dreg *= ys_new / yy_new;
+  __builtin_amdgcn_s_waitcnt(0); // the alphas this wave has just stored are read back (by other lanes) in the second loop
   // ---- second loop: oldest -> newest, starting one past the slot the first loop ended on
   jl = j == m - 1 ? 0 : j + 1;
   int j2 = jl; // slot of the first step of the block being reduced
@@ -1651,7 +1660,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         }
         // the newest column was written by these same lanes: program order makes it visible to them
         double dreg = lane < n ? sm.d[lane] : 0.0;
-        dreg = two_loop_lane<LV>((lds_rw_t)sm.ys, (lds_rw_t)sm.rinv, (lds_rw_t)sm.alpha, (gptr_t)hS, (gptr_t)hY, (gptr_t)hU,
+        dreg = two_loop_lane<LV>((lds_rw_t)sm.ys, (lds_rw_t)sm.rinv, (gptr_t)hS, (gptr_t)hY, (gptr_t)hU,
                                  (gptr_t)hV, npad, n, m, bound, ne, ys, yy, lane, dreg);
         if (lane < n) sm.d[lane] = dreg;
       } else {
@@ -1663,19 +1672,20 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
           for (int e = lane; e < n; e += 64) acc += sj[2 * e] * sm.d[e];
           acc = wave_sum<LV>(acc);
           double a = acc / sm.ys[j];
-          if (lane == 0) sm.alpha[j] = a;
+          if (lane == 0) hU_b[(size_t)j * 8 + 7] = a;
           double na = -a;
           for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[2 * e];
         }
         double sc0 = ys / yy;
         for (int e = lane; e < n; e += 64) sm.d[e] *= sc0;
+        __threadfence_block(); // lane 0 stored the alphas, every lane reads them below
         for (int i = 0; i < bound; ++i) {
           const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += yj[2 * e] * sm.d[e];
           acc = wave_sum<LV>(acc);
           double beta = acc / sm.ys[j];
-          double cf = sm.alpha[j] - beta;
+          double cf = ((gptr_t)hU_b)[(size_t)j * 8 + 7] - beta;
           for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[2 * e];
           j = j == m - 1 ? 0 : j + 1;
         }
@@ -1798,12 +1808,13 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   const int lane = tid & 63;
   const int n = L.n;
   Smem sm;
-  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0, SUR ? D.sur_np : 0);
+  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_left, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0, SUR ? D.sur_np : 0);
   Prof pr;
 
   // ---- one-time staging: role tables and operators (the same for every trajectory of the batch)
-  for (int i = tid; i < D.e4_rounds * T; i += T) sm.slot[i] = D.e4_slot[i];
-  for (int i = tid; i < D.e4_rounds * (T >> 6) * 2; i += T) sm.wtab[i] = D.e4_wave[i];
+  for (int i = tid; i < D.e4_groups; i += T) sm.gtab[i] = D.e4_gtab[i];
+  for (int i = tid; i < D.e4_left; i += T) sm.ltab[i] = D.e4_ltab[i];
+  for (int i = tid; i < D.e4_rounds * (T >> 6) * 3; i += T) sm.wtab[i] = D.e4_wave[i];
   for (int i = tid; i < D.e4_rounds * 2; i += T) sm.rtab[i] = D.e4_round[i];
   for (int i = tid; i < 4 * L.Ntot; i += T) sm.pgrp[i] = D.e4_piece[i];
   if (SUR)

@@ -253,6 +253,11 @@ int dftpav_corridor_last_ms(dftpav_handle *h, float *ms);
 
 /* Device-resident batch of B trajectories with a common layout. */
 int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out);
+/* The same with the residency plan chosen by the caller instead of by B: 0 = one workgroup per CU, the trajectory's
+ * half-planes and the MINCO operators staged in LDS (lowest latency of one solve; the default for B <= #CUs), 1 = two per
+ * CU, 2 = four per CU (highest throughput; the default for large B), -1 = by B.  For callers that keep several small
+ * batches in flight on several handles (a PolyTrajOptimizer per planner thread, traj_optimizer.h:80-92). */
+int dftpav_batch_create_shaped(dftpav_handle *h, const dftpav_layout *layout, int B, int residency, dftpav_batch **out);
 void dftpav_batch_destroy(dftpav_batch *b);
 
 /* The setup half of OptimizeTrajectory (traj_optimizer.cpp:26-115): validates,

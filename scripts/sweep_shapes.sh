@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-run() { echo "== $*"; env "$@" timeout 300 python bench.py --steps 10 --warmup 3 --no-extras --cpu-sample 0 2>&1 | python -c "
+run() { echo "== $*"; env "$@" timeout 300 python bench.py --steps 8 --warmup 2 --no-extras --cpu-sample 0 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
@@ -7,8 +7,7 @@ for l in sys.stdin:
     elif 'rror' in l: print(l.strip())
 "; }
 run A=0
-run DFTPAV_SLICE=32
-run DFTPAV_SLICE=64
+run DFTPAV_SLOTS=1792
+run DFTPAV_SLOTS=1536
+run DFTPAV_THREADS=128 DFTPAV_SLOTS=1024
 run DFTPAV_SLICE=96
-run DFTPAV_SLICE=160
-run DFTPAV_SLOTS=1280
