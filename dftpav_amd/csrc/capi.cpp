@@ -104,7 +104,7 @@ struct dftpav_batch {
   double *d_x0 = nullptr, *d_iniS = nullptr, *d_finS = nullptr, *d_corridor = nullptr;
   int16_t *d_pt_piece = nullptr, *d_pt_j = nullptr;
   double *d_opM[kMaxSeg] = {nullptr}, *d_opMT[kMaxSeg] = {nullptr};
-  double *d_histS = nullptr, *d_histY = nullptr, *d_histU = nullptr, *d_histV = nullptr;
+  double *d_histS = nullptr, *d_histY = nullptr, *d_histU = nullptr, *d_histV = nullptr, *d_histR = nullptr;
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
@@ -730,7 +730,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->h->device);
   (void)hipStreamSynchronize(b->h->stream);
-  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histU, b->d_histV,
+  void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histU, b->d_histV, b->d_histR,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
                   b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
@@ -823,9 +823,20 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
     if (residency >= 0) shape = residency;
     if (const char *e = std::getenv("DFTPAV_MODE")) shape = std::atoi(e); // 0 latency, 1 two per CU, 2 four per CU
     b->threads = solver_threads(L, shape);
+    int per_cu = shape == 0 ? 1 : (shape == 1 ? 2 : 8);
+    if (shape == 2) {
+      // one wave per trajectory and eight per CU when a workgroup's LDS fits an eighth of the CU; layouts with more state
+      // (many pieces or points: BASELINE configs[4]) take two waves per trajectory and as many workgroups as their LDS allows
+      const size_t l64 = solver_lds_bytes(L, b->P, kWave, false, false, 0) + 64;
+      if (l64 > 20 * 1024 || L.Npts > 1024) {
+        b->threads = 2 * kWave;
+        const size_t l128 = solver_lds_bytes(L, b->P, b->threads, false, false, 0) + 64;
+        per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / l128));
+      }
+    }
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
-    // LDS budget per workgroup: the whole CU, half of it, a quarter of it
-    const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : 19 * 1024 + 512);
+    // LDS budget per workgroup: the whole CU, half of it, its share in the throughput shape
+    const size_t budget = shape == 0 ? 158 * 1024 : (shape == 1 ? 78 * 1024 : (size_t)(160 * 1024) / per_cu - 512);
     b->op_in_lds = solver_lds_bytes(L, b->P, b->threads, true, false, 512) + 64 <= budget;
     b->cor_in_lds = solver_lds_bytes(L, b->P, b->threads, b->op_in_lds, true, 512) + 64 <= budget;
     if (const char *e = std::getenv("DFTPAV_LDS")) { // bit 0 operators, bit 1 corridor
@@ -838,9 +849,10 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
     // workgroups take trajectories from a queue, run them `slice` iterations at a time and put the
     // unfinished ones back, so all trajectories advance together; when no more than `hand_over` are left
     // they are finished by a second launch in the latency shape (one wide workgroup per CU).
-    const int per_cu = shape == 0 ? 1 : (shape == 1 ? 2 : 8);
     b->slots = n_cu * per_cu;
-    b->slice = 128;
+    // iterations per slice: long slices cost fewer suspensions, short ones balance the end of a solve better; layouts with
+    // many constraint points (costly iterations, few trajectories per slot) take the short ones (measured)
+    b->slice = L.Npts > 1024 ? 48 : 128;
     b->hand_over = n_cu;
     if (const char *e = std::getenv("DFTPAV_SLOTS")) b->slots = std::atoi(e);
     if (const char *e = std::getenv("DFTPAV_SLICE")) b->slice = std::atoi(e);
@@ -888,6 +900,8 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
   BCHK(hipMalloc(&b->d_histV, sizeof(double) * (size_t)B * b->P.mem_size * 8));
   BCHK(hipMemset(b->d_histU, 0, sizeof(double) * (size_t)B * b->P.mem_size * 8));
   BCHK(hipMemset(b->d_histV, 0, sizeof(double) * (size_t)B * b->P.mem_size * 8));
+  BCHK(hipMalloc(&b->d_histR, sizeof(double) * (size_t)B * b->P.mem_size * 2));
+  BCHK(hipMemset(b->d_histR, 0, sizeof(double) * (size_t)B * b->P.mem_size * 2));
   BCHK(hipMalloc(&b->d_x_in, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_x_out, sizeof(double) * (size_t)B * n));
   BCHK(hipMalloc(&b->d_f, sizeof(double) * (size_t)B));
@@ -1110,6 +1124,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.histY = b->d_histY;
   D.histU = b->d_histU;
   D.histV = b->d_histV;
+  D.histR = b->d_histR;
   D.queue = b->d_queue;
   D.qctl = b->d_qctl;
   D.stragglers = b->d_stragglers;

@@ -92,6 +92,7 @@ struct DevBatch {
   // products of neighbouring stored pairs, [B][mem][8] (solver.hip, two_loop_lane):
   //   histU[j][d] = s_j . y_(the d+1-th pair after j),  histV[j][d] = y_j . s_(the d+1-th pair before j)
   double *histU, *histV;
+  double *histR; // [B][mem][2] (ys, 1 / ys) of the stored pairs (lbfgs.hpp:685 lm_ys and its reciprocal)
   // time-sliced scheduling of batches larger than the device holds at once (solver.hip, solver_kernel)
   int *queue;          // [B] ring of trajectories waiting for a workgroup
   unsigned *qctl;      // [0] head  [1] published tail  [2] reserved tail  [3] unfinished  [4] number of stragglers
@@ -132,7 +133,7 @@ struct SchedArgs {
                        // this batch's queue tagged with kAltTag (same layout, parameters and launch shape)
 };
 // doubles of solver state per suspended trajectory
-inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { return 5 * L.npad + 24 + 8 + 2 * P.mem_size; }
+inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { (void)P; return 5 * L.npad + 24 + 8; }
 
 // host-side E4 lane plan of a layout for a workgroup size (tables of DevBatch::e4_*)
 struct E4Sizes {

@@ -53,7 +53,7 @@ struct Smem {
   double *sdur;  // [sur_np] piece durations of the moving obstacles: Trajectory::locatePieceIdx (poly_traj_utils.hpp:510-528)
                  // walks them one dependent load after the other -- from LDS that is ~100 cycles a step instead of an L2 round trip
   double *pE, *pGsm, *pGdT, *pCost; // [Ntot]
-  double *ys, *rinv; // [mem]  (alpha of the two-loop recursion lives in the unused 8th entry of the histU rows)
+  double *alpha; // [mem] alpha of the two-loop recursion (lbfgs.hpp:725); ys and 1 / ys of the stored pairs live in DevBatch::histR
   double *st;     // [sNUM] scalar solver state
   double *segsum; // [M][8] per-segment sums: 0 jerk energy, 1 penalty cost, 2 d(jerk)/dT, 3 penalty gdT, 4 chain-rule gdT
   double *opM, *opMT; // operators of all segments back to back (only when D.op_in_lds)
@@ -101,7 +101,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
   }
   if (sur) n += 2 * (size_t)sur_np + (sur_np <= kSurCoefLds ? 12 * (size_t)sur_np : 0);
   n += 4 * (size_t)L.Ntot;
-  n += 2 * (size_t)mem;
+  n += (size_t)mem;
   n += sNUM;
   n += (size_t)L.M * 8;
   if (op_lds) n += op_doubles(L) + opT_lds_doubles(L);
@@ -178,8 +178,7 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
   s.pCost = p; p += L.Ntot;
-  s.ys = p; p += mem;
-  s.rinv = p; p += mem;
+  s.alpha = p; p += mem;
   s.st = p; p += sNUM;
   s.segsum = p; p += L.M * 8;
   s.opM = p;
@@ -1189,8 +1188,8 @@ struct HistBlock {
 // out-of-line function: a generic pointer would turn every access into a flat one)
 typedef double __attribute__((address_space(3))) *lds_rw_t;
 struct LoopLds {
-  lds_rw_t ys, rinv;
-  gwptr_t alpha; // histU: alpha of slot j at [8 j + 7] (the row's products use entries 0..6)
+  gptr_t ysr;     // [mem][2] (ys, 1 / ys) of the stored pairs, global memory (written once per pair, lbfgs_advance)
+  lds_rw_t alpha; // [mem]
 };
 // loads the block whose first step sits in slot `jl`, walking downwards (DIR = -1) or upwards (+1)
 // with wrap-around; unconditional loads from always-valid addresses, nothing consumes them here
@@ -1202,7 +1201,7 @@ __device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr
   js = js < 0 ? js + m : (js >= m ? js - m : js);
 #pragma unroll
   for (int u = 0; u < kLoopBlock - 1; u++) R.coef[u] = hB[(size_t)js * 8 + (st > u ? st - u - 1 : 0)];
-  if (LOOP2) R.al = sm.alpha[(size_t)js * 8 + 7];
+  if (LOOP2) R.al = sm.alpha[js];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) {
     {
@@ -1233,7 +1232,9 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
                                                  int &j, double &dreg) {
   int jown = j - step_of_lane(lane); // slot of the step this lane owns (the block starts at slot j and walks downwards)
   jown = jown < 0 ? jown + m : jown;
-  const double ys_ = sm.ys[jown], ri_ = sm.rinv[jown]; // first used after the reduction below
+  typedef double __attribute__((ext_vector_type(2))) d2r_t;
+  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)(sm.ysr + 2 * (size_t)jown); // first used after the reduction below
+  const double ys_ = yr_.x, ri_ = yr_.y;
   double v[kLoopBlock];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.s[q] : 0.0) * dreg; // lm_s.col(j).dot(d), steps past nb unused
@@ -1258,7 +1259,7 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
   const double mine = div_by_rcp(acc, ys_, ri_);
   int js = j - st;
   js = js < 0 ? js + m : js;
-  if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[(size_t)js * 8 + 7] = mine;
+  if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[js] = mine;
   const int done = FULL ? kLoopBlock : nb - i0;
   j -= done;
   j = j < 0 ? j + m : j;
@@ -1268,7 +1269,9 @@ __device__ __forceinline__ void second_loop_block(const HistBlock &R, const Loop
                                                   double &dreg) {
   int jown = j2 + step_of_lane(lane); // the block starts at slot j2 and walks upwards
   jown = jown >= m ? jown - m : jown;
-  const double ys_ = sm.ys[jown], ri_ = sm.rinv[jown];
+  typedef double __attribute__((ext_vector_type(2))) d2r_t;
+  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)(sm.ysr + 2 * (size_t)jown);
+  const double ys_ = yr_.x, ri_ = yr_.y;
   j2 += kLoopBlock;
   j2 = j2 >= m ? j2 - m : j2;
   double v[kLoopBlock];
@@ -1329,11 +1332,11 @@ __device__ __forceinline__ lds_rw_t uni_lds(lds_rw_t p) {
 #endif
 }
 template <int LV>
-__device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_t l_rinv, gptr_t hS, gptr_t hY,
+__device__ __attribute__((noinline)) double two_loop_lane(gptr_t h_ysr, lds_rw_t l_alpha, gptr_t hS, gptr_t hY,
                                                           gptr_t hU, gptr_t hV, int npad, int n, int m, int nb, int ne,
                                                           double ys_new, double yy_new, int lane, double dreg) {
   hS = uni_ptr(hS); hY = uni_ptr(hY); hU = uni_ptr(hU); hV = uni_ptr(hV);
-  const LoopLds sm{uni_lds(l_ys), uni_lds(l_rinv), (gwptr_t)hU};
+  const LoopLds sm{uni_ptr(h_ysr), uni_lds(l_alpha)};
   npad = uni(npad); n = uni(n); m = uni(m); ne = uni(ne);
   const bool act = lane < n;
   const int ln = act ? lane : 0;
@@ -1353,7 +1356,6 @@ __device__ __attribute__((noinline)) double two_loop_lane(lds_rw_t l_ys, lds_rw_
     first_loop_step<LV>(B, sm, i0 + PB, nb, m, act, lane, j, dreg);
   }
   dreg *= ys_new / yy_new;
-  __builtin_amdgcn_s_waitcnt(0); // the alphas this wave has just stored are read back (by other lanes) in the second loop
   // ---- second loop: oldest -> newest, starting one past the slot the first loop ended on
   jl = j == m - 1 ? 0 : j + 1;
   int j2 = jl; // slot of the first step of the block being reduced
@@ -1420,7 +1422,7 @@ __device__ __forceinline__ bool begin_iteration(const DevParams &P, const Smem &
 // search of lbfgs.hpp:312-389 unrolled into it).  Runs on wave 0, every lane computing the same
 // scalars from LDS; sets iACTION to kActEval (a new trial x is in sm.x) or kActDone.
 template <int LV>
-__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, double *hS_b, double *hU_b, double *hV_b, int lane,
+__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, double *hS_b, double *hU_b, double *hV_b, double *hR_b, int lane,
                                               Prof &pr) {
   // hS_b / hU_b / hV_b: this trajectory's history blocks inside the batch it belongs to
   const DevParams &P = D.P;
@@ -1621,8 +1623,11 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
     ss = wave_sum<LV>(ss);
     gpgp = wave_sum<LV>(gpgp);
     if (lane == 0) {
-      sm.ys[end] = ys;
-      sm.rinv[end] = 1.0 / ys;
+      typedef double __attribute__((ext_vector_type(2))) d2r_t;
+      d2r_t yr;
+      yr.x = ys;
+      yr.y = 1.0 / ys;
+      *reinterpret_cast<d2r_t *>(hR_b + 2 * (size_t)end) = yr; // read back by this wave in the recursion below (fenced there)
     }
     double cau = ss * sqrt(gpgp) * P.cautious_factor;
     pr.tick(kPHIST);
@@ -1660,7 +1665,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         }
         // the newest column was written by these same lanes: program order makes it visible to them
         double dreg = lane < n ? sm.d[lane] : 0.0;
-        dreg = two_loop_lane<LV>((lds_rw_t)sm.ys, (lds_rw_t)sm.rinv, (gptr_t)hS, (gptr_t)hY, (gptr_t)hU,
+        dreg = two_loop_lane<LV>((gptr_t)hR_b, (lds_rw_t)sm.alpha, (gptr_t)hS, (gptr_t)hY, (gptr_t)hU,
                                  (gptr_t)hV, npad, n, m, bound, ne, ys, yy, lane, dreg);
         if (lane < n) sm.d[lane] = dreg;
       } else {
@@ -1671,21 +1676,20 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += sj[2 * e] * sm.d[e];
           acc = wave_sum<LV>(acc);
-          double a = acc / sm.ys[j];
-          if (lane == 0) hU_b[(size_t)j * 8 + 7] = a;
+          double a = acc / ((gptr_t)hR_b)[2 * (size_t)j];
+          if (lane == 0) sm.alpha[j] = a;
           double na = -a;
           for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[2 * e];
         }
         double sc0 = ys / yy;
         for (int e = lane; e < n; e += 64) sm.d[e] *= sc0;
-        __threadfence_block(); // lane 0 stored the alphas, every lane reads them below
         for (int i = 0; i < bound; ++i) {
           const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
           double acc = 0.0;
           for (int e = lane; e < n; e += 64) acc += yj[2 * e] * sm.d[e];
           acc = wave_sum<LV>(acc);
-          double beta = acc / sm.ys[j];
-          double cf = ((gptr_t)hU_b)[(size_t)j * 8 + 7] - beta;
+          double beta = acc / ((gptr_t)hR_b)[2 * (size_t)j];
+          double cf = sm.alpha[j] - beta;
           for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[2 * e];
           j = j == m - 1 ? 0 : j + 1;
         }
@@ -1761,7 +1765,7 @@ __device__ inline void trace_eval(const DevBatch &Db, const Smem &sm, int b, int
 
 // solver state of one trajectory <-> its record in DevBatch::state (everything lbfgs_advance keeps in LDS)
 __device__ inline void state_io(const DevBatch &D, const Smem &sm, int b, int tid, int T, bool save) {
-  const int npad = D.L.npad, m = D.P.mem_size;
+  const int npad = D.L.npad;
   double *rec = D.state + (size_t)b * D.state_stride;
   double *vecs[5] = {sm.x, sm.xp, sm.g, sm.gp, sm.d};
   for (int w = tid; w < 5 * npad; w += T) {
@@ -1779,16 +1783,7 @@ __device__ inline void state_io(const DevBatch &D, const Smem &sm, int b, int ti
     if (save) ri[w] = sm.ist[w];
     else sm.ist[w] = ri[w];
   }
-  double *r3 = r2 + 24 + 8;
-  for (int w = tid; w < m; w += T) {
-    if (save) {
-      r3[w] = sm.ys[w];
-      r3[m + w] = sm.rinv[w];
-    } else {
-      sm.ys[w] = r3[w];
-      sm.rinv[w] = r3[m + w];
-    }
-  }
+  // (ys and 1 / ys of the stored pairs live in DevBatch::histR, the history in histS: nothing more to move)
 }
 
 template <bool SUR, int LV, int MAXT>
@@ -1904,6 +1899,7 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     const double *cor_b = Db.corridor + (size_t)b * L.H * 4 * D.NptsPad;
     double *hS_b = Db.histS + (size_t)b * D.P.mem_size * L.npad * 2;
     double *hU_b = Db.histU + (size_t)b * D.P.mem_size * 8, *hV_b = Db.histV + (size_t)b * D.P.mem_size * 8;
+    double *hR_b = Db.histR + (size_t)b * D.P.mem_size * 2;
     const long long tick0 = wall_clock64();
     pr.start(Db.prof != nullptr && mode == kModeSolve);
     const bool resume = mode == kModeSolve && sched.source != 0 && Db.sflag[b] == 1;
@@ -1951,7 +1947,7 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
         // the serial part of the trajectory: the other waves of the workgroup wait for it, the waves this one shares its
         // SIMD with belong to other trajectories -- let the arbiter prefer it
         __builtin_amdgcn_s_setprio(3);
-        lbfgs_advance<LV>(D, sm, hS_b, hU_b, hV_b, lane, pr);
+        lbfgs_advance<LV>(D, sm, hS_b, hU_b, hV_b, hR_b, lane, pr);
         if (sm.ist[iACTION] == kActEval) prep_durations(D, sm, sm.x, lane); // the trial point is in place
         __builtin_amdgcn_s_setprio(0);
       }

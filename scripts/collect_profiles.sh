@@ -1,0 +1,19 @@
+#!/bin/bash
+# GPU box: everything profiles/ is summarised from, for one tag (default r02).  rocprofv3 runs from /tmp with TMPDIR=/tmp;
+# the counter passes are separate runs with --pmc only (never combined with trace domains).
+#   scripts/collect_profiles.sh r02      then, here:  python scripts/summarize_profiles.py r02
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 4 --warmup 1 --no-extras --cpu-sample 0"
+O=$R/gpurun_out
+echo "$CMD" > $O/profile_command_$tag.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- $CMD > $O/prof_$tag.log 2>&1; echo "kernel trace rc=$?"
+pass() { name=$1; shift; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $O/pmc_${name}_$tag -- $CMD > $O/pmc_${name}_$tag.log 2>&1; echo "pmc $name rc=$?"; }
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU
+pass sq2 SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+cd $R
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_line_$tag.json 2> $O/bench_line_$tag.err; echo "bench rc=$?"

@@ -71,6 +71,31 @@ rec = {"tag": tag, "kernel": "solver_kernel", "solves_profiled": steps, "workgro
        "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
        "launches_averaged": len(f)}
 rec.update(kstat)
+cmdf = os.path.join(root, "gpurun_out", "profile_command_%s.txt" % tag)
+rec["command"] = open(cmdf).read().strip().replace(root + "/", "") if os.path.exists(cmdf) else "python bench.py --steps 3 --no-extras"
+rec["collected"] = "round %s, separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE, git %s" % (
+    tag, os.popen("git -C %s rev-parse --short HEAD" % root).read().strip())
+# SQ / instruction-cache / LDS counters of the same command (two more --pmc passes), summed over the solver_kernel dispatches
+sq = {}
+for kind in ("sq1", "sq2", "grbm"):
+    for f in glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_%s" % (kind, tag), "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "solver_kernel" in r["Kernel_Name"]:
+                sq[r["Counter_Name"]] = sq.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+if sq:
+    wc = sq.get("SQ_WAVE_CYCLES", 0.0)
+    d = {"tag": tag, "command": rec["command"], "collected": rec["collected"], "batches_profiled": steps, "counters_summed_over_solver_kernel_dispatches": sq}
+    if wc:
+        d["fractions_of_wave_cycles"] = {k: sq[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in sq}
+    if "SQC_ICACHE_REQ" in sq:
+        d["icache_miss_rate"] = sq.get("SQC_ICACHE_MISSES", 0.0) / sq["SQC_ICACHE_REQ"]
+    if "SQ_INSTS_VALU" in sq:
+        d["valu_instructions_per_solve"] = sq["SQ_INSTS_VALU"] / (steps * (gmax // wg if False else 1)) / 4096.0
+    json.dump(d, open(os.path.join(out, "%s_sq.json" % tag), "w"), indent=1)
+    print(json.dumps(d.get("fractions_of_wave_cycles")), d.get("icache_miss_rate"))
+bl = os.path.join(root, "gpurun_out", "bench_line_%s.json" % tag)
+if os.path.exists(bl):
+    shutil.copy(bl, os.path.join(out, "%s_bench_line.json" % tag))
 json.dump(rec, open(os.path.join(out, "%s_pmc.json" % tag), "w"), indent=1)
 json.dump(rec, open(os.path.join(out, "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(rec))
