@@ -71,6 +71,18 @@ rec = {"tag": tag, "kernel": "solver_kernel", "solves_profiled": steps, "workgro
        "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
        "launches_averaged": len(f)}
 rec.update(kstat)
+# the bench line the profiled command printed: its marker-event time per batch is the figure the timeline has to agree with
+plog = os.path.join(root, "gpurun_out", "prof_%s.log" % tag)
+if os.path.exists(plog):
+    for line in open(plog, errors="replace"):
+        k = line.find('{"metric')
+        if k >= 0:
+            try:
+                b = json.loads(line[k:])
+                rec["bench_kernel_ms_in_profiled_run"] = b["roofline"]["kernel_ms"]
+                rec["bench_ms_per_step_in_profiled_run"] = b["ms_per_step"]
+            except Exception:
+                pass
 cmdf = os.path.join(root, "gpurun_out", "profile_command_%s.txt" % tag)
 rec["command"] = open(cmdf).read().strip().replace(root + "/", "") if os.path.exists(cmdf) else "python bench.py --steps 3 --no-extras"
 rec["collected"] = "round %s, separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE, git %s" % (
