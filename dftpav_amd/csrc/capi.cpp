@@ -60,7 +60,7 @@ struct dftpav_handle {
   int sur_pieces = 0; // pieces of all obstacles together
   int sur_version = 0; // bumped by dftpav_set_surround so batches refresh their device descriptor
   int *d_sur_off = nullptr;
-  double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr, *d_sur_theta = nullptr;
+  double *d_sur_dur = nullptr, *d_sur_coef = nullptr, *d_sur_total = nullptr, *d_sur_start = nullptr, *d_sur_theta = nullptr, *d_sur_bbox = nullptr;
   // obstacle map of the corridor generator (device copy) and the table of sample offsets along a line
   dftpav_grid_map map{};
   unsigned char *d_cells = nullptr;
@@ -272,6 +272,50 @@ static bool build_theta(const std::vector<int> &off, const std::vector<double> &
   }
   return true;
 }
+// DevSurround::bbox: per piece a box that contains the obstacle's position for every local time in [0, duration].  With
+// t = duration * s the piece is a quintic in s on [0, 1]; its Bernstein coefficients B_i = sum_{k<=i} C(i,k)/C(5,k) a_k
+// duration^k span a hull the curve cannot leave, so their minimum and maximum per axis bound it.  The box is widened by
+// 1e-6 m (+ 1e-9 relative): orders of magnitude above the rounding of this computation, of the kernels' evaluation of the
+// position and of a local time that leaves [0, duration] by an ulp.
+static void build_piece_boxes(const std::vector<double> &dur, const std::vector<double> &coef, std::vector<double> &box) {
+  static const double binom5[6] = {1, 5, 10, 10, 5, 1};
+  const size_t np = dur.size();
+  box.assign(4 * np, 0.0);
+  for (size_t k = 0; k < np; k++) {
+    const double *cm = coef.data() + 12 * k; // 2x6 col-major, col 0 multiplies t^5
+    for (int d = 0; d < 2; d++) {
+      double b[6], pw = 1.0;
+      for (int q = 0; q < 6; q++) {
+        b[q] = cm[2 * (5 - q) + d] * pw; // a_q duration^q
+        pw *= dur[k];
+      }
+      double lo = 0, hi = 0, mag = 0;
+      for (int i = 0; i < 6; i++) {
+        double B = 0.0, cik = 1.0; // C(i, q), built up with q
+        for (int q = 0; q <= i; q++) {
+          B += cik / binom5[q] * b[q];
+          cik = cik * (i - q) / (q + 1);
+        }
+        if (i == 0 || B < lo) lo = B;
+        if (i == 0 || B > hi) hi = B;
+        mag = std::fmax(mag, std::fabs(B));
+      }
+      const double m = 1e-6 + 1e-9 * mag;
+      box[4 * k + 2 * d] = lo - m;
+      box[4 * k + 2 * d + 1] = hi + m;
+    }
+  }
+}
+static int upload_boxes(dftpav_handle *h, const std::vector<double> &dur, const std::vector<double> &coef) {
+  for (double v : coef)
+    if (!std::isfinite(v)) return DFTPAV_OK; // no table: nothing is skipped
+  std::vector<double> box;
+  build_piece_boxes(dur, coef, box);
+  if (box.empty()) return DFTPAV_OK;
+  HIPCHK(h, hipMalloc(&h->d_sur_bbox, sizeof(double) * box.size()));
+  HIPCHK(h, hipMemcpy(h->d_sur_bbox, box.data(), sizeof(double) * box.size(), hipMemcpyHostToDevice));
+  return DFTPAV_OK;
+}
 static int upload_theta(dftpav_handle *h, const std::vector<int> &off, const std::vector<double> &dur) {
   std::vector<double> theta;
   if (!build_theta(off, dur, theta) || theta.empty()) return DFTPAV_OK; // d_sur_theta stays null: the kernels walk
@@ -284,11 +328,12 @@ static void free_surround(dftpav_handle *h) {
   if (h->d_sur_off) (void)hipFree(h->d_sur_off);
   if (h->d_sur_dur) (void)hipFree(h->d_sur_dur);
   if (h->d_sur_theta) (void)hipFree(h->d_sur_theta);
+  if (h->d_sur_bbox) (void)hipFree(h->d_sur_bbox);
   if (h->d_sur_coef) (void)hipFree(h->d_sur_coef);
   if (h->d_sur_total) (void)hipFree(h->d_sur_total);
   if (h->d_sur_start) (void)hipFree(h->d_sur_start);
   h->d_sur_off = nullptr;
-  h->d_sur_dur = h->d_sur_coef = h->d_sur_total = h->d_sur_start = h->d_sur_theta = nullptr;
+  h->d_sur_dur = h->d_sur_coef = h->d_sur_total = h->d_sur_start = h->d_sur_theta = h->d_sur_bbox = nullptr;
   h->S = 0;
   h->sur_pieces = 0;
 }
@@ -457,6 +502,11 @@ extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S
     std::vector<double> dur(np);
     if (hipMemcpy(dur.data(), h->d_sur_dur, sizeof(double) * np, hipMemcpyDeviceToHost) != hipSuccess) rc = DFTPAV_E_HIP;
     if (rc == DFTPAV_OK) rc = upload_theta(h, off, dur);
+    if (rc == DFTPAV_OK && h->d_sur_theta) {
+      std::vector<double> coef(12 * (size_t)np);
+      if (hipMemcpy(coef.data(), h->d_sur_coef, sizeof(double) * coef.size(), hipMemcpyDeviceToHost) != hipSuccess) rc = DFTPAV_E_HIP;
+      if (rc == DFTPAV_OK) rc = upload_boxes(h, dur, coef);
+    }
   }
   if (rc == DFTPAV_OK) {
     h->S = S;
@@ -649,6 +699,9 @@ extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   HIPCHK(h, hipMemcpy(h->d_sur_start, s->start_time, sizeof(double) * S, hipMemcpyHostToDevice));
   if (int rc = upload_theta(h, std::vector<int>(s->piece_offsets, s->piece_offsets + S + 1), std::vector<double>(s->durations, s->durations + np)))
     return rc;
+  if (h->d_sur_theta)
+    if (int rc = upload_boxes(h, std::vector<double>(s->durations, s->durations + np), std::vector<double>(s->coeffs, s->coeffs + 12 * (size_t)np)))
+      return rc;
   h->sur_pieces = np;
   h->S = S;
   return DFTPAV_OK;
@@ -711,6 +764,7 @@ static void fill_dev_params(const dftpav_params &p, DevParams &P) {
                      {dcr - Lh / 2.0, W / 2.0}};
   for (int k = 0; k < 4; k++) { P.vec_le[k][0] = le[k][0]; P.vec_le[k][1] = le[k][1]; }
   P.vec_le[4][0] = le[0][0]; P.vec_le[4][1] = le[0][1];
+  fill_footprint_edges(P);
   P.gear_opt = p.gear_opt;
   P.mem_size = p.lbfgs_mem_size;
   P.past = p.lbfgs_past;
@@ -1079,6 +1133,20 @@ extern "C" int dftpav_batch_get_x0(dftpav_batch *b, double *x0) {
   return DFTPAV_OK;
 }
 
+// Whether the obstacles' coefficient blocks (96 B per piece) are staged in LDS for a launch shape: only if that does not
+// cost a resident workgroup -- BASELINE configs[4] at 128 threads holds 3 workgroups per CU without them and 2 with them,
+// and one more workgroup hides far more latency than the LDS copy saves.
+static int sur_coef_in_lds(const dftpav_batch *b, int threads, bool op, bool cor) {
+  const dftpav_handle *h = b->h;
+  if (h->S <= 0 || h->sur_pieces > kSurCoefLds) return 0;
+  const size_t by_waves = std::max<size_t>(1, 512 / (size_t)threads);
+  auto resident = [&](bool coef) {
+    const size_t lds = solver_lds_bytes(b->L, b->P, threads, op, cor, h->sur_pieces, coef) + 64;
+    return std::min<size_t>(by_waves, (160 * 1024) / lds);
+  };
+  return resident(true) == resident(false) ? 1 : 0;
+}
+
 static DevBatch make_dev(dftpav_batch *b) {
   DevBatch D{};
   D.L = b->L;
@@ -1112,9 +1180,11 @@ static DevBatch make_dev(dftpav_batch *b) {
   dftpav_handle *h = b->h;
   D.sur.S = h->S;
   D.sur_np = h->sur_pieces;
+  D.sur_coef_lds = sur_coef_in_lds(b, b->threads, b->op_in_lds, b->cor_in_lds);
   D.sur.piece_off = h->d_sur_off;
   D.sur.durations = h->d_sur_dur;
   D.sur.theta = h->d_sur_theta;
+  D.sur.bbox = h->d_sur_bbox;
   D.sur.coeffs = h->d_sur_coef;
   D.sur.total = h->d_sur_total;
   D.sur.start = h->d_sur_start;
@@ -1168,6 +1238,7 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
     DevBatch D2 = D; // the same batch in the latency shape (follow-up launch of a scheduled solve)
     D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
     D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
+    D2.sur_coef_lds = sur_coef_in_lds(b, b->threads2, b->op_in_lds2, b->cor_in_lds2);
     D2.e4_rounds = b->e4b.rounds;
     D2.e4_groups = b->e4b.groups;
     D2.e4_left = b->e4b.left;
@@ -1268,6 +1339,7 @@ static int launch_stragglers(dftpav_batch *b, const DevBatch &D, int source) {
   DevBatch D2 = D;
   D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
   D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
+  D2.sur_coef_lds = sur_coef_in_lds(b, b->threads2, b->op_in_lds2, b->cor_in_lds2);
   D2.e4_rounds = b->e4b.rounds;
   D2.e4_groups = b->e4b.groups;
   D2.e4_left = b->e4b.left;

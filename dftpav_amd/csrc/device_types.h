@@ -2,6 +2,14 @@
 #pragma once
 #include <cstdint>
 
+#ifndef DFTPAV_HD
+#if defined(__HIPCC__)
+#define DFTPAV_HD __host__ __device__
+#else
+#define DFTPAV_HD
+#endif
+#endif
+
 namespace dftpav {
 
 constexpr int kMaxSeg = 8;        // gear segments per trajectory (trajnum)
@@ -16,6 +24,9 @@ struct DevParams {
   double non_sinv, mini_T, fail_cost;
   double veh_length_infl;    // inflated length, gate of traj_optimizer.cpp:1393
   double vec_le[5][2];       // inflated footprint, first vertex repeated (traj_optimizer.cpp:1765-1775)
+  // the four edges of that footprint as dynamicObsGradCostP forms them for every point (traj_optimizer.cpp:1419-1421,
+  // 1466-1468): direction vec_le[e+1] - vec_le[e], its norm, 1 / norm.  Batch constants, filled by fill_footprint_edges.
+  double edge_d[4][2], edge_len[4], edge_rlen[4];
   int gear_opt;
   // lbfgs_parameter_t (lbfgs.hpp:15-129) as set at traj_optimizer.cpp:127-134
   int mem_size, past, max_iterations, max_linesearch;
@@ -47,6 +58,26 @@ struct DevSurround {
   // doubles with that same walk (capi.cpp, build_theta): the piece index is then a search in theta, and only the local
   // time is formed by the reference's subtractions.  Same result for every t by construction; nullptr = walk.
   const double *theta;
+  // [np][4] or nullptr: {x_min, x_max, y_min, y_max} of a box that contains piece k of an obstacle over its whole duration
+  // (the hull of its Bernstein coefficients, widened by 1e-6 m; capi.cpp, build_piece_boxes).  Only ever used to skip a
+  // (constraint point, obstacle) pair whose distance is certainly above the gate of traj_optimizer.cpp:1393, before the
+  // obstacle's position is evaluated: with or without the table the gate passes the same pairs.
+  const double *bbox;
+  // the accessors traj_math.h uses (the kernels have a second view of the same tables with pointers that carry the
+  // LDS address space, solver.hip: SurLds)
+  DFTPAV_HD bool has_theta() const { return theta != nullptr; }
+  DFTPAV_HD bool far_from_piece(int k, const double sigma[2], double r) const {
+    if (bbox == nullptr) return false;
+    const double *bb = bbox + 4 * (size_t)k;
+    return sigma[0] < bb[0] - r || sigma[0] > bb[1] + r || sigma[1] < bb[2] - r || sigma[1] > bb[3] + r;
+  }
+  // pieces per second of obstacle u: only the starting guess of the search in theta (any value gives the same index)
+  DFTPAV_HD double rate(int u) const { return (double)(piece_off[u + 1] - piece_off[u]) / total[u]; }
+  DFTPAV_HD inline void end_state(int u, double pd[2], double vd[2], double ad[2]) const; // traj_math.h
+  DFTPAV_HD void load_piece(int k, double c[12]) const {
+    const double *cm = coeffs + 12 * (size_t)k;
+    for (int i = 0; i < 12; i++) c[i] = cm[i];
+  }
 };
 
 // ---- how the constraint points of a trajectory are mapped onto the lanes of a workgroup (solver.hip, E4)
@@ -86,6 +117,8 @@ struct DevBatch {
   int op_off[kMaxSeg];         // offset (doubles) of each segment's operator inside the LDS copy
   DevSurround sur;
   int sur_np;                  // pieces of all moving obstacles together (their durations are staged in LDS)
+  int sur_coef_lds;            // their 2x6 coefficient blocks are staged in LDS as well (chosen per launch shape so that
+                               // it does not cost a resident workgroup, capi.cpp: sur_coef_in_lds)
   double t_now, epis;
   // L-BFGS history workspace (lm_s, lm_y of lbfgs.hpp:512-513), one slab per trajectory
   double *histS, *histY; // one buffer [B][mem][npad][2]: (s, y) interleaved per element, histY == histS + 1
@@ -141,7 +174,8 @@ struct E4Sizes {
 };
 E4Sizes e4_sizes(const DevLayout &L, int threads);
 // size in bytes of the dynamic LDS a launch needs
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np);
+constexpr int kSurCoefLds = 170; // most obstacle pieces whose coefficient blocks are ever staged in LDS (16 KB)
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np, bool sur_coef = false);
 // picks the workgroup size for a layout; shape 0/1/2 = at most one / two / more trajectories per CU
 int solver_threads(const DevLayout &L, int shape);
 

@@ -26,6 +26,8 @@
 // All arithmetic is fp64 with contraction off; every sum has a defined order
 // that oracle/dftpav_oracle_dev.cpp replays, and the two agree bit for bit.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 
 #include "device_types.h"
 #include "e4_plan.h"
@@ -50,6 +52,7 @@ struct Smem {
   double *gsum;  // [e4_groups][16] the 14 per-piece sums of every group of constraint points (E4)
   double *lpart; // [14][e4_lcap + 2] contributions of the leftover points of one round
   double *dpart; // [14][T + 2] contributions of T (point, moving obstacle) pairs (kernels with moving obstacles only)
+  double *shead; // [kSurHead] per-obstacle scalars of the moving obstacles (see SurLds)
   double *sdur;  // [sur_np] piece durations of the moving obstacles: Trajectory::locatePieceIdx (poly_traj_utils.hpp:510-528)
                  // walks them one dependent load after the other -- from LDS that is ~100 cycles a step instead of an L2 round trip
   double *pE, *pGsm, *pGdT, *pCost; // [Ntot]
@@ -82,8 +85,50 @@ __host__ __device__ inline size_t opT_lds_doubles(const DevLayout &L) {
   for (int i = 0; i < L.M; i++) n += (size_t)(6 * L.piece_nums[i] + kOpTPad) * (L.piece_nums[i] + 5);
   return n;
 }
-constexpr int kSurCoefLds = 170; // obstacle pieces whose 2x6 coefficient blocks are staged in LDS as well (16 KB)
-__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int groups, int lcap, int T, bool op_lds, bool cor_lds, int sur_np) {
+constexpr int kSurHead = 160;    // per-obstacle scalars in front of them: total [16], start [16], pieces per second [16], piece_off [17 ints
+                                 // in 16 doubles], end state [16][6]
+// The moving obstacles' tables as the evaluation reads them (traj_math.h: the view SV of sur_locate and its callers): every
+// table staged in LDS is reached through a pointer that carries the LDS address space, so the accesses are ds_read
+// instructions that go out together.  Through generic pointers (DevSurround, with its pointers redirected to LDS) every one
+// of them was a flat load followed by a wait for both memory counters: the six loads of a coefficient block and the
+// steps of the search cost a full round trip each, 7 800 cycles per (point, obstacle) in the gate.
+typedef const double __attribute__((address_space(3))) *lds_cd_t;
+typedef const int __attribute__((address_space(3))) *lds_ci_t;
+struct SurLds {
+  int S;
+  lds_ci_t piece_off;                        // [S + 1]
+  lds_cd_t durations, theta, total, start;   // [np], [np], [S], [S]
+  lds_cd_t rate_;                            // [S] pieces per second (the search's starting guess)
+  lds_cd_t bbox_;                            // [np][4] piece boxes (DevSurround::bbox)
+  lds_cd_t end_;                             // [S][6] position, velocity, acceleration at the end of the trajectory
+  lds_cd_t coef_lds;                         // [np][12] when they fit (kSurCoefLds)
+  const double __attribute__((address_space(1))) *coef_glb; // the same blocks in global memory otherwise
+  bool theta_on, coef_in_lds, bbox_on;
+  __device__ __forceinline__ bool has_theta() const { return theta_on; }
+  __device__ __forceinline__ double rate(int u) const { return rate_[u]; }
+  __device__ __forceinline__ bool far_from_piece(int k, const double sigma[2], double r) const {
+    if (!bbox_on) return false; // uniform
+    const lds_cd_t bb = bbox_ + 4 * k;
+    return sigma[0] < bb[0] - r || sigma[0] > bb[1] + r || sigma[1] < bb[2] - r || sigma[1] > bb[3] + r;
+  }
+  __device__ __forceinline__ void end_state(int u, double pd[2], double vd[2], double ad[2]) const {
+    const lds_cd_t q = end_ + 6 * u;
+    pd[0] = q[0]; pd[1] = q[1]; vd[0] = q[2]; vd[1] = q[3]; ad[0] = q[4]; ad[1] = q[5];
+  }
+  __device__ __forceinline__ void load_piece(int k, double c[12]) const {
+    if (coef_in_lds) { // uniform
+      const lds_cd_t cm = coef_lds + 12 * k;
+#pragma unroll
+      for (int i = 0; i < 12; i++) c[i] = cm[i];
+    } else {
+      const double __attribute__((address_space(1))) *cm = coef_glb + 12 * (size_t)k;
+#pragma unroll
+      for (int i = 0; i < 12; i++) c[i] = cm[i];
+    }
+  }
+};
+__host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int groups, int lcap, int T, bool op_lds, bool cor_lds, int sur_np,
+                                               bool sur_coef) {
   const bool sur = sur_np > 0;
   size_t n = 0;
   n += 5 * (size_t)L.npad;
@@ -99,7 +144,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
     const size_t a = 16 * (size_t)groups + 14 * (size_t)(lcap + 2), b = sur ? 14 * (size_t)(T + 2) : 0;
     n += a > b ? a : b;
   }
-  if (sur) n += 2 * (size_t)sur_np + (sur_np <= kSurCoefLds ? 12 * (size_t)sur_np : 0);
+  if (sur) n += kSurHead + 6 * (size_t)sur_np + (sur_coef ? 12 * (size_t)sur_np : 0);
   n += 4 * (size_t)L.Ntot;
   n += (size_t)mem;
   n += sNUM;
@@ -118,10 +163,10 @@ E4Sizes e4_sizes(const DevLayout &L, int threads) {
   return E4Sizes{pl.rounds, pl.groups, pl.left, pl.lcap};
 }
 
-size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np) {
+size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, bool op_lds, bool cor_lds, int sur_np, bool sur_coef) {
   const bool sur = sur_np > 0;
   const E4Sizes z = e4_sizes(L, threads);
-  return smem_doubles(L, P.mem_size, z.groups, z.lcap, threads, op_lds, cor_lds, sur_np) * sizeof(double) + smem_ints(L, z.rounds, z.groups, z.left, threads, sur) * sizeof(int);
+  return smem_doubles(L, P.mem_size, z.groups, z.lcap, threads, op_lds, cor_lds, sur_np, sur_coef) * sizeof(double) + smem_ints(L, z.rounds, z.groups, z.left, threads, sur) * sizeof(int);
 }
 
 int solver_threads(const DevLayout &L, int shape) {
@@ -149,7 +194,7 @@ int solver_threads(const DevLayout &L, int shape) {
 }
 
 __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem, int T, int rounds, int groups, int left, int lcap, bool op_lds,
-                             bool cor_lds, int sur_np) {
+                             bool cor_lds, int sur_np, bool sur_coef) {
   const bool sur = sur_np > 0;
   double *p = base;
   s.x = p; p += L.npad;
@@ -172,8 +217,10 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
     const int a = 16 * groups + 14 * (lcap + 2), b = sur ? 14 * (T + 2) : 0;
     p += a > b ? a : b;
   }
-  s.sdur = p; // durations, then their thresholds (DevSurround::theta), then the coefficient blocks if they fit
-  if (sur) p += 2 * sur_np + (sur_np <= kSurCoefLds ? 12 * sur_np : 0);
+  s.shead = p; // total / start / piece_off of the moving obstacles
+  if (sur) p += kSurHead;
+  s.sdur = p; // durations, their thresholds (DevSurround::theta), the piece boxes, then the coefficient blocks if they fit
+  if (sur) p += 6 * sur_np + (sur_coef ? 12 * sur_np : 0);
   s.pE = p; p += L.Ntot;
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
@@ -789,10 +836,21 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
   // every T pairs a chain pass adds their contributions to the pieces in that order.
   if (SUR) {
     const int dstride = T + 2;
-    DevSurround surL = D.sur;
-    surL.durations = sm.sdur;
-    if (D.sur.theta != nullptr) surL.theta = sm.sdur + D.sur_np;
-    if (D.sur_np <= kSurCoefLds) surL.coeffs = sm.sdur + 2 * D.sur_np;
+    SurLds surL;
+    surL.S = D.sur.S;
+    surL.total = (lds_cd_t)sm.shead;
+    surL.start = (lds_cd_t)(sm.shead + 16);
+    surL.rate_ = (lds_cd_t)(sm.shead + 32);
+    surL.end_ = (lds_cd_t)(sm.shead + 64);
+    surL.piece_off = (lds_ci_t)reinterpret_cast<int *>(sm.shead + 48);
+    surL.durations = (lds_cd_t)sm.sdur;
+    surL.theta = (lds_cd_t)(sm.sdur + D.sur_np);
+    surL.theta_on = D.sur.theta != nullptr;
+    surL.bbox_ = (lds_cd_t)(sm.sdur + 2 * D.sur_np);
+    surL.bbox_on = D.sur.bbox != nullptr;
+    surL.coef_lds = (lds_cd_t)(sm.sdur + 6 * D.sur_np);
+    surL.coef_glb = (const double __attribute__((address_space(1))) *)D.sur.coeffs;
+    surL.coef_in_lds = D.sur_coef_lds != 0;
     for (int r = 0; r < D.e4_rounds; r++) {
       const int wv_ = tid >> 6, nwv_ = T >> 6;
       const int info = e4_lane_point(sm, sm.wtab[(r * nwv_ + wv_) * 3], sm.wtab[(r * nwv_ + wv_) * 3 + 1], sm.wtab[(r * nwv_ + wv_) * 3 + 2], lane);
@@ -1196,18 +1254,31 @@ struct LoopLds {
 template <int DIR, bool LOOP2>
 __device__ __forceinline__ void load_block(HistBlock &R, const LoopLds &sm, gptr_t hS, gptr_t hY, gptr_t hB, int npad, int m, int ln,
                                            int lane, int &jl) {
+  typedef const char __attribute__((address_space(1))) *gbytes_t;
   const int st = step_of_lane(lane);
   int js = jl + DIR * st; // |offset| < kLoopBlock <= m
   js = js < 0 ? js + m : (js >= m ? js - m : js);
+  // Entry 7 of a histU / histV row is never written and stays 0.0 (the buffers are cleared when the batch is created):
+  // the steps a lane does not wait for (u >= its own) get a zero product, so the correction below is an unconditional
+  // multiply-add that leaves the lane's sum as it is -- no compare / select pair in the dependent chain of a step.
+  // Addresses are a uniform 64-bit base plus a 32-bit lane offset (the saddr form of global_load: no 64-bit vector
+  // arithmetic per load).
+  const unsigned row = (unsigned)js * 64u;
 #pragma unroll
-  for (int u = 0; u < kLoopBlock - 1; u++) R.coef[u] = hB[(size_t)js * 8 + (st > u ? st - u - 1 : 0)];
+  for (int u = 0; u < kLoopBlock - 1; u++) {
+    const unsigned idx = st > u ? (unsigned)(st - u - 1) : 7u;
+    R.coef[u] = *(gptr_t)((gbytes_t)hB + (row + idx * 8u));
+  }
   if (LOOP2) R.al = sm.alpha[js];
+  const unsigned lnoff = (unsigned)ln * 16u;
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) {
     {
       // element e of pair j is the double2 (s, y) at [(j * npad + e)]: one 16-byte load instead of two 8-byte ones
       typedef double __attribute__((ext_vector_type(2))) d2_t;
-      const d2_t sy = *(const d2_t __attribute__((address_space(1))) *)(hS + ((size_t)jl * npad + ln) * 2);
+      // (a trajectory's history is mem * npad * 16 bytes, far below 4 GB: the whole offset fits 32 bits)
+      const unsigned off = (unsigned)jl * ((unsigned)npad * 16u) + lnoff;
+      const d2_t sy = *(const d2_t __attribute__((address_space(1))) *)((gbytes_t)hS + off);
       R.s[q] = sy.x;
       R.y[q] = sy.y;
     }
@@ -1233,14 +1304,15 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
   int jown = j - step_of_lane(lane); // slot of the step this lane owns (the block starts at slot j and walks downwards)
   jown = jown < 0 ? jown + m : jown;
   typedef double __attribute__((ext_vector_type(2))) d2r_t;
-  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)(sm.ysr + 2 * (size_t)jown); // first used after the reduction below
+  typedef const char __attribute__((address_space(1))) *gbytes_t;
+  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)((gbytes_t)sm.ysr + (unsigned)jown * 16u); // first used after the reduction below
   const double ys_ = yr_.x, ri_ = yr_.y;
+  // Lanes at and past n hold zeros: their direction element enters as 0.0 and the rows of the history are zero
+  // there (pad elements are never written), so no lane is masked in the products or in the updates below.
   double v[kLoopBlock];
 #pragma unroll
-  for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.s[q] : 0.0) * dreg; // lm_s.col(j).dot(d), steps past nb unused
+  for (int q = 0; q < kLoopBlock; q++) v[q] = R.s[q] * dreg; // lm_s.col(j).dot(d), steps past nb unused
   double acc = wave_sum8_transposed<LV>(v, lane);
-  // (the lane masks below are recomputed from `st` where they are used: kept live across the loop they
-  // would be spilled and every reload is a cross-lane read)
   int st = step_of_lane(lane);
   asm volatile("" : "+v"(st));
 #pragma unroll
@@ -1248,11 +1320,8 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
     if (FULL || i0 + u < nb) { // uniform
       const double t = div_by_rcp(acc, ys_, ri_);               // ... / lm_ys(j): only the owner's quotient is used
       const double au = readlane_f64(t, lane_of_step(u));       // alpha of step u for everybody
-      if (u < kLoopBlock - 1) {
-        const double nacc = __builtin_fma(-au, R.coef[u], acc);
-        acc = st > u ? nacc : acc;
-      }
-      dreg = __builtin_fma(-au, act ? R.y[u] : 0.0, dreg);
+      if (u < kLoopBlock - 1) acc = __builtin_fma(-au, R.coef[u], acc); // coef[u] == 0.0 for the lanes whose step is <= u
+      dreg = __builtin_fma(-au, R.y[u], dreg);
     }
   }
   // lanes 0..7 own one step each; their sum stopped changing at their own step, so its quotient is their alpha
@@ -1270,13 +1339,14 @@ __device__ __forceinline__ void second_loop_block(const HistBlock &R, const Loop
   int jown = j2 + step_of_lane(lane); // the block starts at slot j2 and walks upwards
   jown = jown >= m ? jown - m : jown;
   typedef double __attribute__((ext_vector_type(2))) d2r_t;
-  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)(sm.ysr + 2 * (size_t)jown);
+  typedef const char __attribute__((address_space(1))) *gbytes_t;
+  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)((gbytes_t)sm.ysr + (unsigned)jown * 16u);
   const double ys_ = yr_.x, ri_ = yr_.y;
   j2 += kLoopBlock;
   j2 = j2 >= m ? j2 - m : j2;
   double v[kLoopBlock];
 #pragma unroll
-  for (int q = 0; q < kLoopBlock; q++) v[q] = (act ? R.y[q] : 0.0) * dreg; // lm_y.col(j).dot(d), steps past nb unused
+  for (int q = 0; q < kLoopBlock; q++) v[q] = R.y[q] * dreg; // lm_y.col(j).dot(d), steps past nb unused
   double acc = wave_sum8_transposed<LV>(v, lane);
   int st = step_of_lane(lane);
   asm volatile("" : "+v"(st));
@@ -1287,11 +1357,10 @@ __device__ __forceinline__ void second_loop_block(const HistBlock &R, const Loop
       const double bu = readlane_f64(t, lane_of_step(u));    // beta of step u
       const double au = readlane_f64(R.al, lane_of_step(u)); // alpha of step u (first loop), from the lane that owns the step
       if (u < kLoopBlock - 1) {
-        double nacc = __builtin_fma(au, R.coef[u], acc);
-        nacc = __builtin_fma(-bu, R.coef[u], nacc);
-        acc = st > u ? nacc : acc;
+        acc = __builtin_fma(au, R.coef[u], acc); // coef[u] == 0.0 for the lanes whose step is <= u
+        acc = __builtin_fma(-bu, R.coef[u], acc);
       }
-      dreg = __builtin_fma(au - bu, act ? R.s[u] : 0.0, dreg);
+      dreg = __builtin_fma(au - bu, R.s[u], dreg);
     }
   }
 }
@@ -1339,7 +1408,7 @@ __device__ __attribute__((noinline)) double two_loop_lane(gptr_t h_ysr, lds_rw_t
   const LoopLds sm{uni_ptr(h_ysr), uni_lds(l_alpha)};
   npad = uni(npad); n = uni(n); m = uni(m); ne = uni(ne);
   const bool act = lane < n;
-  const int ln = act ? lane : 0;
+  const int ln = lane < (1 << LV) ? lane : 0; // rows are zero from element n on: the lanes of the butterfly load their own
   nb = __builtin_amdgcn_readfirstlane(nb);
   constexpr int PB = kLoopBlock;
   HistBlock A, B;
@@ -1803,7 +1872,8 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   const int lane = tid & 63;
   const int n = L.n;
   Smem sm;
-  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_left, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0, SUR ? D.sur_np : 0);
+  carve(sm, lds_raw, L, D.P.mem_size, T, D.e4_rounds, D.e4_groups, D.e4_left, D.e4_lcap, D.op_in_lds != 0, D.cor_in_lds != 0, SUR ? D.sur_np : 0,
+        SUR && D.sur_coef_lds != 0);
   Prof pr;
 
   // ---- one-time staging: role tables and operators (the same for every trajectory of the batch)
@@ -1812,13 +1882,29 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
   for (int i = tid; i < D.e4_rounds * (T >> 6) * 3; i += T) sm.wtab[i] = D.e4_wave[i];
   for (int i = tid; i < D.e4_rounds * 2; i += T) sm.rtab[i] = D.e4_round[i];
   for (int i = tid; i < 4 * L.Ntot; i += T) sm.pgrp[i] = D.e4_piece[i];
+  if (SUR) {
+    for (int i = tid; i < D.sur.S; i += T) {
+      sm.shead[i] = D.sur.total[i];
+      sm.shead[16 + i] = D.sur.start[i];
+      sm.shead[32 + i] = D.sur.rate(i);
+    }
+    for (int i = tid; i <= D.sur.S; i += T) reinterpret_cast<int *>(sm.shead + 48)[i] = D.sur.piece_off[i];
+    for (int i = tid; i < D.sur.S; i += T) { // the obstacles' end states (dyn_obstacle_near), from the global tables
+      double pd[2], vd[2], ad[2];
+      sur_end_state(D.sur, i, pd, vd, ad);
+      double *q = sm.shead + 64 + 6 * i;
+      q[0] = pd[0]; q[1] = pd[1]; q[2] = vd[0]; q[3] = vd[1]; q[4] = ad[0]; q[5] = ad[1];
+    }
+  }
   if (SUR)
     for (int i = tid; i < D.sur_np; i += T) {
       sm.sdur[i] = D.sur.durations[i];
       if (D.sur.theta != nullptr) sm.sdur[D.sur_np + i] = D.sur.theta[i];
     }
-  if (SUR && D.sur_np <= kSurCoefLds)
-    for (int i = tid; i < 12 * D.sur_np; i += T) sm.sdur[2 * D.sur_np + i] = D.sur.coeffs[i];
+  if (SUR && D.sur.bbox != nullptr)
+    for (int i = tid; i < 4 * D.sur_np; i += T) sm.sdur[2 * D.sur_np + i] = D.sur.bbox[i];
+  if (SUR && D.sur_coef_lds != 0)
+    for (int i = tid; i < 12 * D.sur_np; i += T) sm.sdur[6 * D.sur_np + i] = D.sur.coeffs[i];
   for (int p = tid; p < L.Ntot; p += T) {
     int sg = 0, p0 = 0, N = 0, pt0s = 0, sgl = 0, ooff = 0;
     for (int s = 0, a = 0; s < L.M; s++) {
@@ -2071,7 +2157,11 @@ static hipError_t launch_lv(int n, const DevBatch *d_dev, int grid, int mode, in
 // d_dev: device copy of the DevBatch `D` describes; grid: workgroups to launch (D.B unless the launch is scheduled)
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
                          hipStream_t stream) {
-  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.op_in_lds != 0, D.cor_in_lds != 0, D.sur.S > 0 ? D.sur_np : 0);
+  size_t lds = solver_lds_bytes(D.L, D.P, threads, D.op_in_lds != 0, D.cor_in_lds != 0, D.sur.S > 0 ? D.sur_np : 0,
+                                D.sur.S > 0 && D.sur_coef_lds != 0);
+  if (std::getenv("DFTPAV_VERBOSE"))
+    std::fprintf(stderr, "[dftpav] launch mode %d: grid %d x %d threads, %zu B of LDS (%d workgroups per CU by LDS), obstacle coefficients in %s\n", mode, grid,
+                 threads, lds, (int)((160 * 1024) / (lds + 64)), D.sur.S > 0 ? (D.sur_coef_lds ? "LDS" : "global memory") : "-");
   if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
   return launch_lv<false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
 }

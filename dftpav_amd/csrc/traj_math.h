@@ -20,12 +20,6 @@
 #pragma once
 #include "device_types.h"
 
-#if defined(__HIPCC__)
-#define DFTPAV_HD __host__ __device__
-#else
-#define DFTPAV_HD
-#endif
-
 // Keeps the instruction scheduler from interleaving the iterations of an unrolled loop (each iteration's temporaries then
 // die before the next one starts).  Only where the kernel is out of registers; no effect on results, nothing on the host.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -325,54 +319,93 @@ DFTPAV_HD inline void mat_mat(const double a[4], const double b[4], double o[4])
 
 // ------------------------------------- moving-obstacle trajectories (R12)
 // Piece evaluators, poly_traj_utils.hpp:77-112,179-211; locatePieceIdx :510-528.
+// The tables are reached through a view SV (DevSurround, or the kernels' SurLds whose pointers carry the LDS address
+// space): S, piece_off, durations, theta / has_theta(), total, start, rate(u), load_piece(k, c), end_state(u, ...),
+// far_from_piece(k, sigma, r).  The 2x6 block of the located
+// piece is fetched into registers in one go (twelve independent loads, one wait) before any arithmetic touches it.
 struct SurEval {
-  const double *cm; // 2x6 col-major, col 0 = t^5
-  double t;         // local time inside the piece
+  double c[12]; // 2x6 col-major, col 0 = t^5
+  double t;     // local time inside the piece
 };
-DFTPAV_HD inline SurEval sur_locate(const DevSurround &S, int u, double t) {
-  int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
-  const double *durs = S.durations + p0;
-  int idx;
-  if (S.theta != nullptr) {
-    // the index from the thresholds (see DevSurround::theta), the local time by the reference's subtractions: their
-    // operands no longer depend on a comparison, so the loads go out together instead of one round trip per piece
-    const double *th = S.theta + p0;
-    int lo = 0, hi = np; // number of pieces k with t > theta[k]
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (t > th[mid]) lo = mid + 1;
-      else hi = mid;
-    }
-    idx = lo;
-    const int nsub = idx < np ? idx : np;
-    int k = 0;
-    for (; k + 4 <= nsub; k += 4) {
-      const double d0 = durs[k], d1 = durs[k + 1], d2 = durs[k + 2], d3 = durs[k + 3];
-      t -= d0;
-      t -= d1;
-      t -= d2;
-      t -= d3;
-    }
-    for (; k < nsub; k++) t -= durs[k];
-  } else {
-    double dur = 0.0;
-    for (idx = 0; idx < np && t > (dur = durs[idx]); idx++) t -= dur;
+// idx = number of pieces k of obstacle u with t > theta[k] (theta is non-decreasing): the piece locatePieceIdx stops at.
+// Started from a guess -- the index a trajectory of equal pieces would have -- and walked to the answer: for any guess
+// the same idx as a bisection, but one round trip to the table instead of log2(np) dependent ones when the guess is
+// right or off by one.  Needs S.has_theta().
+template <class SV>
+DFTPAV_HD inline int sur_index(const SV &S, int u, double t) {
+  const int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
+  const auto th = S.theta + p0;
+  int g = (int)(t * S.rate(u));
+  g = g < 0 ? 0 : (g > np - 1 ? np - 1 : g);
+  const double ta = th[g], tb = th[g > 0 ? g - 1 : 0];
+  if (t > ta) {
+    g++;
+    while (g < np && t > th[g]) g++;
+  } else if (g > 0 && !(t > tb)) {
+    g--;
+    while (g > 0 && !(t > th[g - 1])) g--;
   }
+  return g;
+}
+// the local time inside piece idx by the reference's subtractions (their operands do not depend on a comparison any
+// more, so the loads go out together instead of one round trip per piece), and the piece's coefficient block
+template <class SV>
+DFTPAV_HD inline void sur_local(const SV &S, int u, int idx, double t, SurEval &e) {
+  const int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
+  const auto durs = S.durations + p0;
+  const int nsub = idx < np ? idx : np;
+  int k = 0;
+  for (; k + 8 <= nsub; k += 8) { // the loads of a block first, then the reference's subtractions in their order
+    const double d0 = durs[k], d1 = durs[k + 1], d2 = durs[k + 2], d3 = durs[k + 3];
+    const double d4 = durs[k + 4], d5 = durs[k + 5], d6 = durs[k + 6], d7 = durs[k + 7];
+    t -= d0;
+    t -= d1;
+    t -= d2;
+    t -= d3;
+    t -= d4;
+    t -= d5;
+    t -= d6;
+    t -= d7;
+  }
+  for (; k + 4 <= nsub; k += 4) {
+    const double d0 = durs[k], d1 = durs[k + 1], d2 = durs[k + 2], d3 = durs[k + 3];
+    t -= d0;
+    t -= d1;
+    t -= d2;
+    t -= d3;
+  }
+  for (; k < nsub; k++) t -= durs[k];
   if (idx == np) {
     idx--;
     t += durs[idx];
   }
-  SurEval e;
-  e.cm = S.coeffs + 12 * (size_t)(p0 + idx);
+  S.load_piece(p0 + idx, e.c);
   e.t = t;
-  return e;
+}
+template <class SV>
+DFTPAV_HD inline void sur_locate(const SV &S, int u, double t, SurEval &e) {
+  if (S.has_theta()) {
+    sur_local(S, u, sur_index(S, u, t), t, e);
+    return;
+  }
+  const int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
+  const auto durs = S.durations + p0;
+  int idx;
+  double dur = 0.0;
+  for (idx = 0; idx < np && t > (dur = durs[idx]); idx++) t -= dur;
+  if (idx == np) {
+    idx--;
+    t += durs[idx];
+  }
+  S.load_piece(p0 + idx, e.c);
+  e.t = t;
 }
 DFTPAV_HD inline void piece_pos(const SurEval &e, double o[2]) {
   o[0] = 0.0; o[1] = 0.0;
   double tn = 1.0;
   for (int i = 5; i >= 0; i--) {
-    o[0] += tn * e.cm[2 * i];
-    o[1] += tn * e.cm[2 * i + 1];
+    o[0] += tn * e.c[2 * i];
+    o[1] += tn * e.c[2 * i + 1];
     tn *= e.t;
   }
 }
@@ -381,8 +414,8 @@ DFTPAV_HD inline void piece_vel(const SurEval &e, double o[2]) {
   double tn = 1.0;
   int n = 1;
   for (int i = 4; i >= 0; i--) {
-    o[0] += n * tn * e.cm[2 * i];
-    o[1] += n * tn * e.cm[2 * i + 1];
+    o[0] += n * tn * e.c[2 * i];
+    o[1] += n * tn * e.c[2 * i + 1];
     tn *= e.t;
     n++;
   }
@@ -392,8 +425,8 @@ DFTPAV_HD inline void piece_acc(const SurEval &e, double o[2]) {
   double tn = 1.0;
   int m = 1, n = 2;
   for (int i = 3; i >= 0; i--) {
-    o[0] += m * n * tn * e.cm[2 * i];
-    o[1] += m * n * tn * e.cm[2 * i + 1];
+    o[0] += m * n * tn * e.c[2 * i];
+    o[1] += m * n * tn * e.c[2 * i + 1];
     tn *= e.t;
     m++;
     n++;
@@ -425,23 +458,43 @@ struct DynObs {
   double sp[2], sv[2], sa[2];
   double pt_time;
 };
-DFTPAV_HD inline bool dyn_obstacle_near(const DevParams &P, const DevSurround &S, int u, double t_now, double t, double trajtime,
+// getPos / getVel / getAcc at the obstacle's total duration (traj_optimizer.cpp:1381-1383)
+template <class SV>
+DFTPAV_HD inline void sur_end_state(const SV &S, int u, double pd[2], double vd[2], double ad[2]) {
+  SurEval e;
+  sur_locate(S, u, S.total[u], e);
+  piece_acc(e, ad);
+  piece_vel(e, vd);
+  piece_pos(e, pd);
+}
+DFTPAV_HD inline void DevSurround::end_state(int u, double pd[2], double vd[2], double ad[2]) const { sur_end_state(*this, u, pd, vd, ad); }
+template <class SV>
+DFTPAV_HD inline bool dyn_obstacle_near(const DevParams &P, const SV &S, int u, double t_now, double t, double trajtime,
                                         const double sigma[2], DynObs &ob) {
   double dur = S.total[u];
   double offsettime = t_now - S.start[u] + trajtime; // traj_optimizer.cpp:1367-1369
   double pt_time = offsettime + t;
   double *sp = ob.sp, *sv = ob.sv, *sa = ob.sa;
   if (pt_time < dur) {
-    SurEval e = sur_locate(S, u, pt_time);
+    SurEval e;
+    if (S.has_theta()) {
+      // Before anything is evaluated: if the point is farther than the gate's radius from the box that holds the whole
+      // piece the obstacle is on (DevSurround::bbox, with a margin far above rounding), the distance test below fails.
+      const int idx = sur_index(S, u, pt_time);
+      if (idx < S.piece_off[u + 1] - S.piece_off[u] && S.far_from_piece(S.piece_off[u] + idx, sigma, P.veh_length_infl * 1.5 + 1e-6))
+        return false;
+      sur_local(S, u, idx, pt_time, e);
+    } else {
+      sur_locate(S, u, pt_time, e);
+    }
     piece_pos(e, sp);
     piece_vel(e, sv);
     piece_acc(e, sa);
   } else { // traj_optimizer.cpp:1379-1389
-    SurEval e = sur_locate(S, u, dur);
+    // position, velocity, acceleration of the obstacle at the end of its trajectory: the same for every point
+    // (sur_end_state below; the kernels form them once per launch and keep them beside the other tables)
     double vd[2], pd[2];
-    piece_acc(e, sa);
-    piece_vel(e, vd);
-    piece_pos(e, pd);
+    S.end_state(u, pd, vd, sa);
     double ex = pt_time - dur;
     sv[0] = vd[0] + ex * sa[0];
     sv[1] = vd[1] + ex * sa[1];
@@ -452,15 +505,42 @@ DFTPAV_HD inline bool dyn_obstacle_near(const DevParams &P, const DevSurround &S
   double dx = sp[0] - sigma[0], dy = sp[1] - sigma[1];
   return !(sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5); // traj_optimizer.cpp:1393
 }
+// DevParams::edge_*: the expressions of traj_optimizer.cpp:1419-1421 (dl = vec_le[e+1] - vec_le[e], dl.norm()) evaluated once
+// on the host; IEEE subtraction, multiplication, sqrt and division are correctly rounded there as on the device.
+inline void fill_footprint_edges(DevParams &P) {
+  for (int e = 0; e < 4; e++) {
+    const double dx = P.vec_le[e + 1][0] - P.vec_le[e][0], dy = P.vec_le[e + 1][1] - P.vec_le[e][1];
+    P.edge_d[e][0] = dx;
+    P.edge_d[e][1] = dy;
+    P.edge_len[e] = sqrt(dx * dx + dy * dy);
+    P.edge_rlen[e] = 1 / P.edge_len[e];
+  }
+}
+
+// Products with the constant quarter turn B_h = [0 -1; 1 0] (traj_optimizer.cpp:1330-1333) written out: every entry of such a
+// product is one entry of the other factor, with or without its sign -- 0 * x + (-1) * y is -y exactly -- so no arithmetic
+// is spent on them.  m = {m00, m01, m10, m11}.
+DFTPAV_HD inline void bh_times(const double x[4], double o[4]) { // B_h x
+  o[0] = -x[2]; o[1] = -x[3]; o[2] = x[0]; o[3] = x[1];
+}
+DFTPAV_HD inline void times_bh(const double x[4], double o[4]) { // x B_h
+  o[0] = x[1]; o[1] = -x[0]; o[2] = x[3]; o[3] = -x[2];
+}
+DFTPAV_HD inline void times_bhT(const double x[4], double o[4]) { // x B_h^T
+  o[0] = -x[1]; o[1] = x[0]; o[2] = -x[3]; o[3] = x[2];
+}
+
 // The penalty of obstacle u at the point and its gradients: adds d/dsigma into A, d/dsigma' into Bv, the duration
 // gradient into gdT; returns the cost (0 when the smoothed distance stays above the clearance).
-DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, int u, const DynObs &ob, double omg, double step,
+// Every quotient x / d whose divisor recurs (the edge lengths, the exponential sums, the obstacle's speed) is formed by
+// div_rcp from one reciprocal of d: the correctly rounded quotient, i.e. the bits of x / d, in 3 instructions instead of
+// the ~10 of a division.  Additions keep the reference's order.
+template <class SV>
+DFTPAV_HD inline double dynamic_pair(const DevParams &P, const SV &S, int u, const DynObs &ob, double omg, double step,
                                      double gama, int pieceid, int trajres, const double sigma[2],
                                      const double dsigma[2], const double ddsigma[2], const double ego_R[4],
                                      int singul_, int trajid, int Ntraj, double A[2], double Bv[2],
                                      double &gdT) {
-  const double B_h[4] = {0.0, -1.0, 1.0, 0.0};
-  const double B_hT[4] = {0.0, 1.0, -1.0, 0.0};
   const double alpha = 100.0;
   const double ln8 = 2.07944154167983574766e+00; // std::log(8.0)
   const double d_min = P.surround_clearance + ln8 / alpha; // traj_optimizer.cpp:1336
@@ -472,21 +552,31 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, i
   const double *sp = ob.sp, *sv = ob.sv;
   const double pt_time = ob.pt_time;
   {
+    // the four edges of the footprint: direction, length, 1 / length (the same for the ego vehicle and the obstacle;
+    // batch constants, so they arrive as scalars instead of being formed from vec_le for every pair)
+    const double(*edl)[2] = P.edge_d;
+    const double *dln = P.edge_len, *dlni = P.edge_rlen;
     // getR / getRdot extrapolate the last polynomial piece past the duration (traj_optimizer.cpp:1410,1599)
     double sR[4], Rud[4];
     {
-      SurEval e = sur_locate(S, u, pt_time);
+      SurEval e;
+      sur_locate(S, u, pt_time, e);
       double v[2], a[2];
       piece_vel(e, v);
       piece_acc(e, a);
       double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
-      sR[0] = v[0] / nv; sR[1] = -v[1] / nv; sR[2] = v[1] / nv; sR[3] = v[0] / nv;
+      const double rnv = 1.0 / nv;
+      const double v0n = div_rcp(v[0], nv, rnv), v1n = div_rcp(v[1], nv, rnv);
+      sR[0] = v0n; sR[1] = -v1n; sR[2] = v1n; sR[3] = v0n;
       double nv3 = nv * nv * nv; // pow(norm, 3), poly_traj_utils.hpp:109
+      const double rnv3 = 1.0 / nv3;
       double va = v[0] * a[0] + v[1] * a[1];
-      Rud[0] = (a[0] / nv - v[0] / nv3 * va);
-      Rud[1] = (-a[1] / nv - (-v[1]) / nv3 * va);
-      Rud[2] = (a[1] / nv - v[1] / nv3 * va);
-      Rud[3] = (a[0] / nv - v[0] / nv3 * va);
+      const double a0n = div_rcp(a[0], nv, rnv), a1n = div_rcp(a[1], nv, rnv);
+      const double v0c = div_rcp(v[0], nv3, rnv3), v1c = div_rcp(v[1], nv3, rnv3);
+      Rud[0] = (a0n - v0c * va);
+      Rud[1] = (-a1n - (-v1c) * va);
+      Rud[2] = (a1n - v1c * va);
+      Rud[3] = (a0n - v0c * va);
     }
     DFTPAV_SCHED_FENCE();
 
@@ -500,20 +590,21 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, i
       F[2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rl[0] * temp3;
       F[3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rl[1] * temp3;
     };
+    double BRego[4], BRsur[4], BRud[4];
+    bh_times(ego_R, BRego);
+    bh_times(sR, BRsur);
+    bh_times(Rud, BRud);
     double s2e_sum[4], d_test[8];
     double egoN[4][2], dUo[4][4];
     for (int e = 0; e < 4; e++) { // traj_optimizer.cpp:1417-1461
       const double *le = vle[e];
-      double dl[2] = {vle[e + 1][0] - le[0], vle[e + 1][1] - le[1]};
-      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
-      double dlni = 1 / dln;
+      const double dl[2] = {edl[e][0], edl[e][1]};
       double Rle[2];
       mat_vec(ego_R, le, Rle);
-      double BR[4], Ht[2];
-      mat_mat(B_h, ego_R, BR);
-      mat_vec(BR, dl, Ht);
-      Ht[0] *= dlni;
-      Ht[1] *= dlni;
+      double Ht[2];
+      mat_vec(BRego, dl, Ht);
+      Ht[0] *= dlni[e];
+      Ht[1] *= dlni[e];
       egoN[e][0] = Ht[0];
       egoN[e][1] = Ht[1];
       double w[2] = {sp[0] - sigma[0] - Rle[0], sp[1] - sigma[1] - Rle[1]};
@@ -529,14 +620,11 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, i
     double surN[4][2], dEe[4][4];
     for (int o = 0; o < 4; o++) { // traj_optimizer.cpp:1464-1496
       const double *lo = vle[o];
-      double dl[2] = {vle[o + 1][0] - lo[0], vle[o + 1][1] - lo[1]};
-      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
-      double dlni = 1 / dln;
-      double BR[4], Ht[2], Rlo[2];
-      mat_mat(B_h, sR, BR);
-      mat_vec(BR, dl, Ht);
-      Ht[0] *= dlni;
-      Ht[1] *= dlni;
+      const double dl[2] = {edl[o][0], edl[o][1]};
+      double Ht[2], Rlo[2];
+      mat_vec(BRsur, dl, Ht);
+      Ht[0] *= dlni[o];
+      Ht[1] *= dlni[o];
       surN[o][0] = Ht[0];
       surN[o][1] = Ht[1];
       mat_vec(sR, lo, Rlo);
@@ -557,22 +645,36 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, i
     smoothed_l1(costp, pena, penaD);
     totalPenalty += omg * step * P.wei_surround * pena;
 
+    // the weights of the three log-sum-exp levels, each quotient formed once
+    const double r_esd = 1.0 / exp_sum_d;
+    double wd[8];
+    for (int k = 0; k < 8; k++) wd[k] = div_rcp(d_test[k], exp_sum_d, r_esd);
+    for (int e = 0; e < 4; e++) {
+      const double r = 1.0 / s2e_sum[e];
+      for (int o = 0; o < 4; o++) dUo[e][o] = div_rcp(dUo[e][o], s2e_sum[e], r);
+    }
+    for (int o = 0; o < 4; o++) {
+      const double r = 1.0 / e2s_sum[o];
+      for (int e = 0; e < 4; e++) dEe[o][e] = div_rcp(dEe[o][e], e2s_sum[o], r);
+    }
+    DFTPAV_SCHED_FENCE();
+
     double pGs[2] = {0.0, 0.0}; // traj_optimizer.cpp:1511-1523
     for (int e = 0; e < 4; e++) {
-      double w = d_test[e] / exp_sum_d;
+      double w = wd[e];
       pGs[0] -= w * (-egoN[e][0]);
       pGs[1] -= w * (-egoN[e][1]);
     }
     for (int o = 0; o < 4; o++) {
-      double w = d_test[o + 4] / exp_sum_d;
+      double w = wd[o + 4];
       pGs[0] -= w * surN[o][0];
       pGs[1] -= w * surN[o][1];
     }
     double pGds[2] = {0.0, 0.0}; // traj_optimizer.cpp:1528-1573
     for (int e = 0; e < 4; e++) {
       const double *le = vle[e];
-      double dl[2] = {vle[e + 1][0] - le[0], vle[e + 1][1] - le[1]};
-      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      const double dl[2] = {edl[e][0], edl[e][1]};
+      const double dn = dln[e], rdn = dlni[e];
       double Rle[2], Rdl[2], Fdl_e[4], Fl_e[4];
       mat_vec(ego_R, le, Rle);
       mat_vec(ego_R, dl, Rdl);
@@ -580,50 +682,49 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, i
       f_matrix(le, Rle, Fl_e);
       double uu[2] = {-sp[0] + sigma[0] + Rle[0], -sp[1] + sigma[1] + Rle[1]};
       double FB[4], t1[2], FlB[4], FlBR[4], t2[2];
-      mat_mat(Fdl_e, B_h, FB);
+      times_bh(Fdl_e, FB);
       mat_vec(FB, uu, t1);
-      mat_mat(Fl_e, B_h, FlB);
+      times_bh(Fl_e, FlB);
       mat_mat(FlB, ego_R, FlBR);
       mat_vec(FlBR, dl, t2);
-      double pdU[2] = {(t1[0] - t2[0]) / dln, (t1[1] - t2[1]) / dln};
+      double pdU[2] = {div_rcp(t1[0] - t2[0], dn, rdn), div_rcp(t1[1] - t2[1], dn, rdn)};
       double FBT[4];
-      mat_mat(Fdl_e, B_hT, FBT);
+      times_bhT(Fdl_e, FBT);
       for (int o = 0; o < 4; o++) {
         double Rlo[2], q[2];
         mat_vec(sR, vle[o], Rlo);
         mat_vec(FBT, Rlo, q);
-        q[0] /= dln;
-        q[1] /= dln;
-        double w = dUo[e][o] / s2e_sum[e];
+        q[0] = div_rcp(q[0], dn, rdn);
+        q[1] = div_rcp(q[1], dn, rdn);
+        double w = dUo[e][o];
         pdU[0] += w * q[0];
         pdU[1] += w * q[1];
         DFTPAV_SCHED_FENCE();
       }
-      double w = d_test[e] / exp_sum_d;
+      double w = wd[e];
       pGds[0] -= w * pdU[0];
       pGds[1] -= w * pdU[1];
       DFTPAV_SCHED_FENCE();
     }
     for (int o = 0; o < 4; o++) {
-      const double *lo = vle[o];
-      double dl[2] = {vle[o + 1][0] - lo[0], vle[o + 1][1] - lo[1]};
-      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      const double dl[2] = {edl[o][0], edl[o][1]};
+      const double dn = dln[o], rdn = dlni[o];
       double pdE[2] = {0.0, 0.0};
       for (int e = 0; e < 4; e++) {
         double FB[4], FBR[4], q[2], Rle[2], Fl_e[4];
         mat_vec(ego_R, vle[e], Rle);
         f_matrix(vle[e], Rle, Fl_e);
-        mat_mat(Fl_e, B_h, FB);
+        times_bh(Fl_e, FB);
         mat_mat(FB, sR, FBR);
         mat_vec(FBR, dl, q);
-        q[0] /= dln;
-        q[1] /= dln;
-        double w = dEe[o][e] / e2s_sum[o];
+        q[0] = div_rcp(q[0], dn, rdn);
+        q[1] = div_rcp(q[1], dn, rdn);
+        double w = dEe[o][e];
         pdE[0] += w * q[0];
         pdE[1] += w * q[1];
         DFTPAV_SCHED_FENCE();
       }
-      double w = d_test[o + 4] / exp_sum_d;
+      double w = wd[o + 4];
       pGds[0] -= w * pdE[0];
       pGds[1] -= w * pdE[1];
       DFTPAV_SCHED_FENCE();
@@ -638,35 +739,34 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const DevSurround &S, i
       double HtRd[2] = {Hn[0] * Rud[0] + Hn[1] * Rud[2], Hn[0] * Rud[1] + Hn[1] * Rud[3]};
       for (int o = 0; o < 4; o++) {
         double ptv = HtRd[0] * vle[o][0] + HtRd[1] * vle[o][1];
-        acc += dUo[e][o] / s2e_sum[e] * ptv;
+        acc += dUo[e][o] * ptv;
       }
-      pGthat -= d_test[e] / exp_sum_d * acc;
+      pGthat -= wd[e] * acc;
       DFTPAV_SCHED_FENCE();
     }
     for (int o = 0; o < 4; o++) {
       const double *lo = vle[o];
-      double dl[2] = {vle[o + 1][0] - lo[0], vle[o + 1][1] - lo[1]};
-      double dln = sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
-      double BRd[4], BR[4], a1[2], a2[2], Rlo[2], Rdlo[2];
-      mat_mat(B_h, Rud, BRd);
-      mat_vec(BRd, dl, a1);
-      mat_mat(B_h, sR, BR);
-      mat_vec(BR, dl, a2);
+      const double dl[2] = {edl[o][0], edl[o][1]};
+      const double dn = dln[o], rdn = dlni[o];
+      double a1[2], a2[2], Rlo[2], Rdlo[2];
+      mat_vec(BRud, dl, a1);
+      mat_vec(BRsur, dl, a2);
       mat_vec(sR, lo, Rlo);
       mat_vec(Rud, lo, Rdlo);
       double w1[2] = {sigma[0] - sp[0] - Rlo[0], sigma[1] - sp[1] - Rlo[1]};
       double w2[2] = {-sv[0] - Rdlo[0], -sv[1] - Rdlo[1]};
-      double acc = ((a1[0] / dln) * w1[0] + (a1[1] / dln) * w1[1]) + ((a2[0] / dln) * w2[0] + (a2[1] / dln) * w2[1]);
+      double acc = (div_rcp(a1[0], dn, rdn) * w1[0] + div_rcp(a1[1], dn, rdn) * w1[1]) +
+                   (div_rcp(a2[0], dn, rdn) * w2[0] + div_rcp(a2[1], dn, rdn) * w2[1]);
       for (int e = 0; e < 4; e++) {
         double Rle[2];
         mat_vec(ego_R, vle[e], Rle);
-        double r1[2] = {Rle[0] * B_h[0] + Rle[1] * B_h[2], Rle[0] * B_h[1] + Rle[1] * B_h[3]};
+        double r1[2] = {Rle[1], -Rle[0]}; // Rle^T B_h
         double r2[2] = {r1[0] * Rud[0] + r1[1] * Rud[2], r1[0] * Rud[1] + r1[1] * Rud[3]};
-        double ptv = (r2[0] * dl[0] + r2[1] * dl[1]) / dln;
-        acc += dEe[o][e] / e2s_sum[o] * ptv;
+        double ptv = div_rcp(r2[0] * dl[0] + r2[1] * dl[1], dn, rdn);
+        acc += dEe[o][e] * ptv;
         DFTPAV_SCHED_FENCE();
       }
-      pGthat -= d_test[o + 4] / exp_sum_d * acc;
+      pGthat -= wd[o + 4] * acc;
       DFTPAV_SCHED_FENCE();
     }
 
@@ -1007,7 +1107,8 @@ DFTPAV_HD inline void dynamic_point_state(const SampleIn &in, DynPoint &q) {
   q.t = t + q.step * j;
 }
 // bit u set: obstacle u passes the distance gate at this point (no bits for a point the sample loop skips)
-DFTPAV_HD inline unsigned dynamic_gate_mask(const DevParams &P, const DevSurround &S, const SampleIn &in) {
+template <class SV>
+DFTPAV_HD inline unsigned dynamic_gate_mask(const DevParams &P, const SV &S, const SampleIn &in) {
   DynPoint q;
   dynamic_point_state(in, q);
   if (q.skip) return 0u;
@@ -1019,7 +1120,8 @@ DFTPAV_HD inline unsigned dynamic_gate_mask(const DevParams &P, const DevSurroun
   return mask;
 }
 // one (point, obstacle) pair that passed the gate
-DFTPAV_HD inline void dynamic_pair_math(const DevParams &P, const DevSurround &S, const SampleIn &in, int u, double out[8]) {
+template <class SV>
+DFTPAV_HD inline void dynamic_pair_math(const DevParams &P, const SV &S, const SampleIn &in, int u, double out[8]) {
   for (int k = 0; k < 8; k++) out[k] = 0.0;
   DynPoint q;
   dynamic_point_state(in, q);

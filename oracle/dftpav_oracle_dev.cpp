@@ -455,6 +455,7 @@ extern "C" void oracle_dev_init(oracle_ctx *c) {
     D->P.vec_le[k][0] = c->vec_le[k][0];
     D->P.vec_le[k][1] = c->vec_le[k][1];
   }
+  fill_footprint_edges(D->P);
   // moving obstacles
   std::memset(&D->S, 0, sizeof(D->S));
   if (c->S > 0) {
