@@ -306,6 +306,20 @@ static void build_piece_boxes(const std::vector<double> &dur, const std::vector<
     }
   }
 }
+// test hook (host only, no device): the tables the host derives from a set of moving obstacles -- theta [np] (zeros and
+// return value 0 if the walk has no threshold table) and the piece boxes [np][4]
+extern "C" int dftpav_debug_surround_tables(int S, const int *piece_offsets, const double *durations, const double *coeffs, double *theta,
+                                            double *boxes) {
+  if (S <= 0 || !piece_offsets || !durations || !coeffs) return DFTPAV_E_INVALID;
+  const int np = piece_offsets[S];
+  std::vector<int> off(piece_offsets, piece_offsets + S + 1);
+  std::vector<double> dur(durations, durations + np), coef(coeffs, coeffs + 12 * (size_t)np), th, box;
+  const bool ok = build_theta(off, dur, th);
+  build_piece_boxes(dur, coef, box);
+  if (theta) std::memcpy(theta, th.data(), sizeof(double) * np);
+  if (boxes) std::memcpy(boxes, box.data(), sizeof(double) * 4 * (size_t)np);
+  return ok ? 1 : 0;
+}
 static int upload_boxes(dftpav_handle *h, const std::vector<double> &dur, const std::vector<double> &coef) {
   for (double v : coef)
     if (!std::isfinite(v)) return DFTPAV_OK; // no table: nothing is skipped

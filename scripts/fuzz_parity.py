@@ -2,7 +2,7 @@
 
 Random layouts (1-3 gear segments of 2-12 pieces, sample resolutions 3-24, with and without moving obstacles),
 every launch shape, small batches; every field of the result must be bit-identical.
-  python scripts/fuzz_parity.py [n_cases] [first_seed]"""
+  python scripts/fuzz_parity.py [n_cases] [first_seed] [moving]     (a third argument: every case has moving obstacles)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +11,7 @@ from oracle import pyoracle as po
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+force_moving = len(sys.argv) > 3
 keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
 bad = 0
 t0 = time.time()
@@ -25,6 +26,10 @@ for c in range(n_cases):
     K = int(rng.integers(3, 25)); Kd = int(rng.integers(3, 25))
     B = int(rng.integers(1, 7))
     moving = bool(rng.uniform() < 0.2) and sum(pieces) <= 12
+    if force_moving:
+        while sum(pieces) > 12:
+            pieces[int(np.argmax(pieces))] -= 1
+        moving = True
     mode = int(rng.choice([0, 1, 2]))
     os.environ["DFTPAV_MODE"] = str(mode)
     p = capi.default_params()

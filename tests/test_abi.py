@@ -61,6 +61,42 @@ def test_minco_operator_bits_equal_oracle(hiplib, oracle, N):
     assert np.array_equal(out, ref)
 
 
+def test_host_tables_of_the_moving_obstacles(hiplib):
+    """The two tables the host derives from the obstacles' pieces (capi.cpp): theta reproduces the piece index of the
+    reference's walk t -= duration (poly_traj_utils.hpp:510-528) for every t, and the box of a piece contains the
+    obstacle over the whole piece (so skipping a pair that is farther from the box than the gate never changes the gate)."""
+    rng = np.random.default_rng(3)
+    S = 5
+    nps = rng.integers(1, 40, S)
+    off = np.concatenate([[0], np.cumsum(nps)]).astype(np.int32)
+    npz = int(off[-1])
+    dur = rng.uniform(0.05, 3.0, npz)
+    dur[: nps[0]] = 1.0                                    # one obstacle with equal pieces
+    coef = rng.normal(0, 1, (npz, 6, 2)) * np.array([0.01, 0.05, 0.2, 1.0, 3.0, 20.0])[None, :, None]   # col 0 multiplies t^5
+    theta = np.zeros(npz); box = np.zeros((npz, 4))
+    fn = hiplib.lib().dftpav_debug_surround_tables
+    fn.argtypes = [C.c_int, C.POINTER(C.c_int), pods.c_double_p, pods.c_double_p, pods.c_double_p, pods.c_double_p]
+    assert fn(S, off.ctypes.data_as(C.POINTER(C.c_int)), pods.dptr(dur), pods.dptr(coef), pods.dptr(theta), pods.dptr(box)) == 1
+    for u in range(S):
+        d = dur[off[u]:off[u + 1]]; th = theta[off[u]:off[u + 1]]
+        assert np.all(np.diff(th) >= 0)
+        ts = np.concatenate([rng.uniform(0, d.sum() * 1.1, 400), th, np.nextafter(th, np.inf), np.nextafter(th, -np.inf)])
+        for t in ts:
+            tt, idx = t, 0
+            while idx < len(d) and tt > d[idx]:             # the reference's walk
+                tt -= d[idx]; idx += 1
+            assert idx == int(np.sum(t > th))
+    s = np.linspace(0.0, 1.0, 257)
+    for k in range(npz):
+        t = s * dur[k]
+        pw = np.stack([t ** 5, t ** 4, t ** 3, t ** 2, t, np.ones_like(t)], axis=1)      # [257][6]
+        pos = pw @ coef[k]                                                                # [257][2]
+        assert pos[:, 0].min() >= box[k, 0] and pos[:, 0].max() <= box[k, 1]
+        assert pos[:, 1].min() >= box[k, 2] and pos[:, 1].max() <= box[k, 3]
+        # and it is a tight box, not a trivial one: within the hull of a quintic's control points
+        assert box[k, 1] - box[k, 0] <= 3.0 * (pos[:, 0].max() - pos[:, 0].min()) + 1e-3 + 2.5 * np.abs(coef[k, :5, 0] * dur[k] ** np.arange(5, 0, -1)).sum()
+
+
 def test_no_cpu_fallback(hiplib):
     """Without a usable HIP device the product must fail loudly, never compute on the CPU."""
     import torch
