@@ -66,6 +66,10 @@ struct DevSurround {
   // the accessors traj_math.h uses (the kernels have a second view of the same tables with pointers that carry the
   // LDS address space, solver.hip: SurLds)
   DFTPAV_HD bool has_theta() const { return theta != nullptr; }
+  DFTPAV_HD bool has_bbox() const { return bbox != nullptr; }
+  DFTPAV_HD void load_box(int k, double bb[4]) const {
+    for (int i = 0; i < 4; i++) bb[i] = bbox[4 * (size_t)k + i];
+  }
   DFTPAV_HD bool far_from_piece(int k, const double sigma[2], double r) const {
     if (bbox == nullptr) return false;
     const double *bb = bbox + 4 * (size_t)k;

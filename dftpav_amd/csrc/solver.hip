@@ -52,6 +52,7 @@ struct Smem {
   double *gsum;  // [e4_groups][16] the 14 per-piece sums of every group of constraint points (E4)
   double *lpart; // [14][e4_lcap + 2] contributions of the leftover points of one round
   double *dpart; // [14][T + 2] contributions of T (point, moving obstacle) pairs (kernels with moving obstacles only)
+  double *tpc;   // [Ntot] SampleIn::t_piece of the pieces (moving obstacles only)
   double *shead; // [kSurHead] per-obstacle scalars of the moving obstacles (see SurLds)
   double *sdur;  // [sur_np] piece durations of the moving obstacles: Trajectory::locatePieceIdx (poly_traj_utils.hpp:510-528)
                  // walks them one dependent load after the other -- from LDS that is ~100 cycles a step instead of an L2 round trip
@@ -106,6 +107,11 @@ struct SurLds {
   bool theta_on, coef_in_lds, bbox_on;
   __device__ __forceinline__ bool has_theta() const { return theta_on; }
   __device__ __forceinline__ double rate(int u) const { return rate_[u]; }
+  __device__ __forceinline__ bool has_bbox() const { return bbox_on; }
+  __device__ __forceinline__ void load_box(int k, double bb[4]) const {
+    const lds_cd_t q = bbox_ + 4 * k;
+    bb[0] = q[0]; bb[1] = q[1]; bb[2] = q[2]; bb[3] = q[3];
+  }
   __device__ __forceinline__ bool far_from_piece(int k, const double sigma[2], double r) const {
     if (!bbox_on) return false; // uniform
     const lds_cd_t bb = bbox_ + 4 * k;
@@ -144,7 +150,7 @@ __host__ __device__ inline size_t smem_doubles(const DevLayout &L, int mem, int 
     const size_t a = 16 * (size_t)groups + 14 * (size_t)(lcap + 2), b = sur ? 14 * (size_t)(T + 2) : 0;
     n += a > b ? a : b;
   }
-  if (sur) n += kSurHead + 6 * (size_t)sur_np + (sur_coef ? 12 * (size_t)sur_np : 0);
+  if (sur) n += kSurHead + 6 * (size_t)sur_np + (sur_coef ? 12 * (size_t)sur_np : 0) + (size_t)L.Ntot;
   n += 4 * (size_t)L.Ntot;
   n += (size_t)mem;
   n += sNUM;
@@ -221,6 +227,8 @@ __device__ inline void carve(Smem &s, double *base, const DevLayout &L, int mem,
   if (sur) p += kSurHead;
   s.sdur = p; // durations, their thresholds (DevSurround::theta), the piece boxes, then the coefficient blocks if they fit
   if (sur) p += 6 * sur_np + (sur_coef ? 12 * sur_np : 0);
+  s.tpc = p; // start time of every piece inside its segment (SampleIn::t_piece)
+  if (sur) p += L.Ntot;
   s.pE = p; p += L.Ntot;
   s.pGsm = p; p += L.Ntot;
   s.pGdT = p; p += L.Ntot;
@@ -851,6 +859,11 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
     surL.coef_lds = (lds_cd_t)(sm.sdur + 6 * D.sur_np);
     surL.coef_glb = (const double __attribute__((address_space(1))) *)D.sur.coeffs;
     surL.coef_in_lds = D.sur_coef_lds != 0;
+    for (int p = tid; p < Ntot; p += T) { // the pieces' start times: the reference's running sum, once per piece instead of per point
+      const int *pc = sm.pcinfo + 8 * p;
+      sm.tpc[p] = piece_start_time(sm.seg[pc[3] * 16 + 1], pc[4]);
+    }
+    __syncthreads();
     for (int r = 0; r < D.e4_rounds; r++) {
       const int wv_ = tid >> 6, nwv_ = T >> 6;
       const int info = e4_lane_point(sm, sm.wtab[(r * nwv_ + wv_) * 3], sm.wtab[(r * nwv_ + wv_) * 3 + 1], sm.wtab[(r * nwv_ + wv_) * 3 + 2], lane);
@@ -871,6 +884,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         in.H = L.H;
         in.trajid = sg;
         in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16];
+        in.t_piece = sm.tpc[p];
         in.t_now = D.t_now;
         sm.dinfo[pc[0] + in.j] = (int)(dynamic_gate_mask(P, surL, in) << 16);
       }
@@ -934,6 +948,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         in.H = L.H;
         in.trajid = sg;
         in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16];
+        in.t_piece = sm.tpc[p];
         in.t_now = D.t_now;
         double o[8], v[14];
         dynamic_pair_math(P, surL, in, u, o);

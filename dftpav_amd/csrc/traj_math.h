@@ -321,7 +321,7 @@ DFTPAV_HD inline void mat_mat(const double a[4], const double b[4], double o[4])
 // Piece evaluators, poly_traj_utils.hpp:77-112,179-211; locatePieceIdx :510-528.
 // The tables are reached through a view SV (DevSurround, or the kernels' SurLds whose pointers carry the LDS address
 // space): S, piece_off, durations, theta / has_theta(), total, start, rate(u), load_piece(k, c), end_state(u, ...),
-// far_from_piece(k, sigma, r).  The 2x6 block of the located
+// far_from_piece(k, sigma, r), has_bbox(), load_box(k, bb).  The 2x6 block of the located
 // piece is fetched into registers in one go (twelve independent loads, one wait) before any arithmetic touches it.
 struct SurEval {
   double c[12]; // 2x6 col-major, col 0 = t^5
@@ -796,6 +796,8 @@ struct SampleIn {
   int H;            // half-planes per point
   int trajid;       // segment index (moving obstacles only)
   double trajtime;  // trajtimes[trajid] (traj_optimizer.cpp:230-234,291)
+  double t_piece;   // start time of the piece inside its segment: t += getDt() for the lp pieces before it
+                    // (traj_optimizer.cpp:775), the sum formed in that order once per piece (moving obstacles only)
   double t_now;
 };
 
@@ -1061,6 +1063,12 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
 // waited for the few that had an obstacle near).  The point's state is formed again from the same expressions as in
 // sample_point_math; a pair's result has the layout of a point's, {d/dsigma (2), d/dsigma' (2), 0, 0, gdT, cost}, and is
 // added to the per-piece sums after the static part, pairs in (point, obstacle) order (solver.hip, E4).
+// SampleIn::t_piece: t += getDt() for the lp pieces before piece lp of a segment (traj_optimizer.cpp:775)
+DFTPAV_HD inline double piece_start_time(double dt, int lp) {
+  double t = 0.0;
+  for (int p = 0; p < lp; p++) t += dt;
+  return t;
+}
 struct DynPoint {
   double sigma[2], dsigma[2], ddsigma[2], ego_R[4];
   double omg, step, alpha, t;
@@ -1102,18 +1110,56 @@ DFTPAV_HD inline void dynamic_point_state(const SampleIn &in, DynPoint &q) {
     q.dsigma[d] = dsigma[d];
     q.ddsigma[d] = ddsigma[d];
   }
-  double t = 0.0;
-  for (int p = 0; p < lp; p++) t += dt; // t += getDt() per piece, traj_optimizer.cpp:775
-  q.t = t + q.step * j;
+  q.t = in.t_piece + q.step * j;
 }
-// bit u set: obstacle u passes the distance gate at this point (no bits for a point the sample loop skips)
+// bit u set: obstacle u passes the distance gate at this point (no bits for a point the sample loop skips).
+// Most (point, obstacle) combinations are rejected by the box of the piece the obstacle is on (dyn_obstacle_near).  That
+// decision is taken here first for four obstacles at a time in straight-line code -- the guessed piece index is checked
+// against its two thresholds, the box of that piece against the point -- so that the table reads of the four are in
+// flight together instead of one dependent round trip after the other; only what is not rejected this way (guess off,
+// obstacle past its end, point near the box) goes through dyn_obstacle_near, which takes the same decisions again.
 template <class SV>
 DFTPAV_HD inline unsigned dynamic_gate_mask(const DevParams &P, const SV &S, const SampleIn &in) {
   DynPoint q;
   dynamic_point_state(in, q);
   if (q.skip) return 0u;
+  const int ns = S.S;
+  unsigned need = ns >= 32 ? 0xffffffffu : (1u << ns) - 1u;
+  if (S.has_theta() && S.has_bbox()) {
+    const double r = P.veh_length_infl * 1.5 + 1e-6;
+    for (int u0 = 0; u0 < ns; u0 += 4) {
+      // three rounds of table reads for the four obstacles, each round's reads independent of one another; no branches
+      // (bitwise combinations of the comparisons, every read from an always-valid address)
+      int pz[4], gz[4];
+      double ptz[4], totz[4];
+      for (int i = 0; i < 4; i++) {
+        const int u = u0 + i < ns ? u0 + i : ns - 1;
+        ptz[i] = (in.t_now - S.start[u] + in.trajtime) + q.t; // as in dyn_obstacle_near
+        totz[i] = S.total[u];
+        const int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
+        int g = (int)(ptz[i] * S.rate(u));
+        g = g < 0 ? 0 : (g > np - 1 ? np - 1 : g);
+        pz[i] = p0;
+        gz[i] = g;
+      }
+      double taz[4], tbz[4], bbz[4][4];
+      for (int i = 0; i < 4; i++) {
+        taz[i] = S.theta[pz[i] + gz[i]];
+        tbz[i] = S.theta[pz[i] + (gz[i] > 0 ? gz[i] - 1 : 0)];
+        S.load_box(pz[i] + gz[i], bbz[i]);
+      }
+      for (int i = 0; i < 4; i++) {
+        const bool exact = (!(ptz[i] > taz[i])) & ((gz[i] == 0) | (ptz[i] > tbz[i])); // sur_index returns g
+        const bool far = (q.sigma[0] < bbz[i][0] - r) | (q.sigma[0] > bbz[i][1] + r) | (q.sigma[1] < bbz[i][2] - r) |
+                         (q.sigma[1] > bbz[i][3] + r); // far_from_piece
+        const bool rej = (u0 + i < ns) & (ptz[i] < totz[i]) & exact & far;
+        need &= ~((rej ? 1u : 0u) << (u0 + i));
+      }
+    }
+  }
   unsigned mask = 0u;
-  for (int u = 0; u < S.S; u++) {
+  for (int u = 0; u < ns; u++) {
+    if (!((need >> u) & 1u)) continue;
     DynObs ob;
     if (dyn_obstacle_near(P, S, u, in.t_now, q.t, in.trajtime, q.sigma, ob)) mask |= 1u << u;
   }

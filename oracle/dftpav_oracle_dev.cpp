@@ -243,6 +243,7 @@ double dev_eval(oracle_ctx *c, DevState &D, const double *x, double *g) {
           in.H = L.H;
           in.trajid = sg;
           in.trajtime = sg == 0 ? 0.0 : D.seg[(sg - 1) * 16];
+          in.t_piece = piece_start_time(in.dt, lp);
           in.t_now = c->t_now;
           HostPlanes pl{c->cfgHs + (size_t)pt * L.H * 4};
           double o[8];
