@@ -305,6 +305,15 @@ DFTPAV_HD inline void point_contributions(double s1, const double o[8], double v
   v[13] = o[7];
 }
 
+// The 6x2 coefficient block of a piece into registers, all twelve reads in flight before the first is used (left to
+// itself the compiler reads them pair by pair, each pair a round trip to LDS in front of the multiply-adds that want it).
+DFTPAV_HD inline void load_piece_coeffs(const double *cc, double c[12]) {
+  for (int k = 0; k < 12; k++) c[k] = cc[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int k = 0; k < 12; k++) asm volatile("" : "+v"(c[k]));
+#endif
+}
+
 // 2x2 helpers, m = {m00, m01, m10, m11}
 DFTPAV_HD inline void mat_vec(const double m[4], const double v[2], double o[2]) {
   o[0] = m[0] * v[0] + m[1] * v[1];
@@ -822,7 +831,8 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
   double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
   double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
   double alpha = rK * j;
-  const double *cc = in.cc;
+  double cc[12];
+  load_piece_coeffs(in.cc, cc);
   double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0};
   for (int k = 0; k < 6; k++) {
     double c0 = cc[2 * k], c1 = cc[2 * k + 1];
@@ -1000,8 +1010,8 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     double u1 = fma_(z_h4, ddsigma[1], -(z_h4 * z_h4 * dsigma[1]));
     double ddd0 = 0.0, ddd1 = 0.0;
     for (int k = 0; k < 6; k++) {
-      ddd0 = fma_(cc[2 * k], beta3[k], ddd0);
-      ddd1 = fma_(cc[2 * k + 1], beta3[k], ddd1);
+      ddd0 = fma_(in.cc[2 * k], beta3[k], ddd0);
+      ddd1 = fma_(in.cc[2 * k + 1], beta3[k], ddd1);
     }
     double z_h2 = fma_(ddd0, dsigma[0], ddd1 * dsigma[1]);
     double sqn = fma_(ddsigma[0], ddsigma[0], ddsigma[1] * ddsigma[1]);
@@ -1022,8 +1032,8 @@ DFTPAV_HD inline void sample_point_math(const DevParams &P, const DevSurround &S
     double kw1 = vel3_2_reci_e * dsigma[0];
     double ddd0 = 0.0, ddd1 = 0.0;
     for (int k = 0; k < 6; k++) {
-      ddd0 = fma_(cc[2 * k], beta3[k], ddd0);
-      ddd1 = fma_(cc[2 * k + 1], beta3[k], ddd1);
+      ddd0 = fma_(in.cc[2 * k], beta3[k], ddd0);
+      ddd1 = fma_(in.cc[2 * k + 1], beta3[k], ddd1);
     }
     double z1 = fma_(ddd1, dsigma[0], (-ddd0) * dsigma[1]);
     double kt = alpha * vel3_2_reci_e * fma_(-(3 * vel2_reci_e * z_h3), z_h1, z1);
@@ -1085,7 +1095,8 @@ DFTPAV_HD inline void dynamic_point_state(const SampleIn &in, DynPoint &q) {
   double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
   double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
   q.alpha = rK * j;
-  const double *cc = in.cc;
+  double cc[12];
+  load_piece_coeffs(in.cc, cc);
   double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0};
   for (int k = 0; k < 6; k++) {
     double c0 = cc[2 * k], c1 = cc[2 * k + 1];
