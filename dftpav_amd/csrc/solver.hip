@@ -398,12 +398,16 @@ __device__ inline double div_by_rcp(double a, double b, double y) {
 
 // optional in-kernel phase timer (thread 0, shader clock); D.prof == nullptr turns it off
 struct Prof {
-  long long acc[12];
+  // The twelve accumulators live in the trajectory's row of DevBatch::prof, not in registers: as a member array they
+  // were 24 VGPRs held through the whole kernel for a debugging feature.
+  long long *acc; // &prof[b][0], or anything when off
   long long last;
   bool on;
-  __device__ inline void start(bool enable) {
+  __device__ inline void start(bool enable, long long *row, bool resume) {
     on = enable && threadIdx.x == 0;
-    for (int i = 0; i < 12; i++) acc[i] = 0;
+    acc = row;
+    if (on && !resume)
+      for (int i = 0; i < 12; i++) acc[i] = 0;
     last = on ? clock64() : 0;
   }
   __device__ inline void tick(int i) {
@@ -513,14 +517,16 @@ template <class P> __device__ __forceinline__ double op_col_dot(P MT, const doub
       const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
       mv[j] = MT[r];
     }
-    int k = r0 % 6;
+    // the power of 1 / dt that goes with row r is tInv[r mod 6]; rows advance by 4, so a lane only ever meets three of them
+    // (r0 mod 6, +4, +2): three reads in front instead of one per row (the per-row reads came out as a chain of LDS
+    // round trips behind the operator loads)
+    const int k0 = r0 % 6;
+    const double t3[3] = {tInv[k0], tInv[k0 + 4 >= 6 ? k0 - 2 : k0 + 4], tInv[k0 + 2 >= 6 ? k0 - 4 : k0 + 2]};
 #pragma unroll
     for (int j = 0; j < kOpChunk; j++) {
       const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
       gv[j] = gc[2 * r];
-      tv[j] = tInv[k];
-      k += 4;
-      if (k >= 6) k -= 6;
+      tv[j] = t3[j % 3];
     }
 #pragma unroll
     for (int j = 0; j < kOpChunk; j++) {
@@ -542,15 +548,14 @@ __device__ __forceinline__ void op_col_dot2(P MT, const double *gc, const double
       const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
       mv[j] = MT[r];
     }
-    int k = r0 % 6;
+    const int k0 = r0 % 6; // see op_col_dot
+    const double t3[3] = {tInv[k0], tInv[k0 + 4 >= 6 ? k0 - 2 : k0 + 4], tInv[k0 + 2 >= 6 ? k0 - 4 : k0 + 2]};
 #pragma unroll
     for (int j = 0; j < kOpChunk; j++) {
       const int r = r0 + 4 * j < nrow ? r0 + 4 * j : q;
       g0[j] = gc[2 * r];
       g1[j] = gc[2 * r + 1];
-      tv[j] = tInv[k];
-      k += 4;
-      if (k >= 6) k -= 6;
+      tv[j] = t3[j % 3];
     }
 #pragma unroll
     for (int j = 0; j < kOpChunk; j++) {
@@ -777,6 +782,9 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
               if (L.H <= 4) sample_point_math<false, 4>(P, D.sur, in, pl, o);
               else sample_point_math<false, 0>(P, D.sur, in, pl, o);
             } else if (L.H <= 4) {
+              double ccl[12]; // the piece's coefficients first (LDS), then the half-planes (global memory)
+              load_piece_coeffs(in.cc, ccl);
+              in.cc = ccl;
               double cor[16]; // all half-plane loads issued up front (unconditionally: rows past 4 H re-read row 0 and
                               // are never used), consumed after the state evaluation
               const cor_g_t cg = (cor_g_t)cb;
@@ -2002,8 +2010,8 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
     double *hU_b = Db.histU + (size_t)b * D.P.mem_size * 8, *hV_b = Db.histV + (size_t)b * D.P.mem_size * 8;
     double *hR_b = Db.histR + (size_t)b * D.P.mem_size * 2;
     const long long tick0 = wall_clock64();
-    pr.start(Db.prof != nullptr && mode == kModeSolve);
     const bool resume = mode == kModeSolve && sched.source != 0 && Db.sflag[b] == 1;
+    pr.start(Db.prof != nullptr && mode == kModeSolve, Db.prof + (size_t)b * 12, resume);
     __syncthreads(); // everybody has read iCUR before the state is restored over it
 
     // ---- per-trajectory staging: decision vector (or the suspended state) and half-planes
@@ -2078,9 +2086,6 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
         int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
         if (fx >= D.P.fail_cost) ok = 0;
         Db.success[b] = ok;
-        if (pr.on) {
-          for (int i = 0; i < 12; i++) Db.prof[(size_t)b * 12 + i] = (resume ? Db.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
-        }
         if (sched.source != 0) {
           Db.sflag[b] = 2;
           atomicSub(&Db.qctl[3], 1u);
@@ -2091,9 +2096,6 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
       __syncthreads(); // all of the record is written (and fenced by thread 0 below) before the id is handed on
       if (tid == 0) {
         Db.ticks[b] = (resume ? Db.ticks[b] : 0) + spent;
-        if (pr.on) {
-          for (int i = 0; i < 12; i++) Db.prof[(size_t)b * 12 + i] = (resume ? Db.prof[(size_t)b * 12 + i] : 0) + pr.acc[i];
-        }
         Db.sflag[b] = 1;
         // the end game is decided by the launched batch's own unfinished count; an adopted trajectory caught by
         // it goes to its own batch's second list (finished by a list launch of that batch right after this one)
