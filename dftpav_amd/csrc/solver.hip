@@ -1998,7 +1998,9 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
       sm.ist[iCUR] = id;
     }
     __syncthreads();
-    const int cur = sm.ist[iCUR];
+    // the same word for every lane, and known to the compiler as such: everything derived from it -- the trajectory's
+    // base pointers, the fields of its batch descriptor -- lives in scalar registers and is fetched by scalar loads
+    const int cur = __builtin_amdgcn_readfirstlane(sm.ist[iCUR]);
     if (cur < 0) break;
     const bool adopted = (cur & kAltTag) != 0;
     const int b = cur & (kAltTag - 1);
