@@ -187,6 +187,60 @@ def occupancy_grid(obstacles, arena=80.0, centre=(0.0, 0.0), resolution=MAP_RESL
     return grid, origin
 
 
+def fill_polygons(grid, origin, resolution, poly_xy, poly_off, value=80):
+    """Polygons into an occupancy grid the way DataRenderer::GetObstacleMap does it (data_renderer.cc:206-231): the
+    vertices are snapped to cell coordinates (GridMapND::GetCoordUsingGlobalPosition: round((p - origin) / resolution),
+    semantics.h:498-506), the integer polygon is filled even-odd over the cell centres, and the cells its edges pass
+    through are set as well (cv::fillPoly draws the outline too).  OpenCV is not in this image; the rule is its documented
+    one, a cell on the outline of a polygon may differ from cv::fillPoly's choice by one cell."""
+    ny, nx = grid.shape
+    for k in range(len(poly_off) - 1):
+        pts = np.asarray(poly_xy[poly_off[k]:poly_off[k + 1]], dtype=np.float64)
+        cx = np.rint((pts[:, 0] - origin[0]) / resolution).astype(np.int64)
+        cy = np.rint((pts[:, 1] - origin[1]) / resolution).astype(np.int64)
+        if cx.max() < 0 or cy.max() < 0 or cx.min() >= nx or cy.min() >= ny:
+            continue
+        ex0, ey0 = cx, cy
+        ex1, ey1 = np.roll(cx, -1), np.roll(cy, -1)
+        y_lo, y_hi = max(int(cy.min()), 0), min(int(cy.max()), ny - 1)
+        for y in range(y_lo, y_hi + 1):                       # even-odd fill at the cell centres of row y
+            yc = y + 0.0
+            crossing = ((ey0 <= yc) & (ey1 > yc)) | ((ey1 <= yc) & (ey0 > yc))
+            if not crossing.any():
+                continue
+            t = (yc - ey0[crossing]) / (ey1[crossing] - ey0[crossing])
+            xs = np.sort(ex0[crossing] + t * (ex1[crossing] - ex0[crossing]))
+            for a, b in zip(xs[0::2], xs[1::2]):
+                i0, i1 = max(int(np.ceil(a)), 0), min(int(np.floor(b)), nx - 1)
+                if i1 >= i0:
+                    grid[y, i0:i1 + 1] = value
+        for a0, b0, a1, b1 in zip(ex0, ey0, ex1, ey1):        # the outline
+            n = int(max(abs(a1 - a0), abs(b1 - b0))) + 1
+            xi = np.rint(np.linspace(a0, a1, n)).astype(np.int64)
+            yi = np.rint(np.linspace(b0, b1, n)).astype(np.int64)
+            ok = (xi >= 0) & (xi < nx) & (yi >= 0) & (yi < ny)
+            grid[yi[ok], xi[ok]] = value
+    return grid
+
+
+def default_sim_map(fixture=None):
+    """The reference's default simulation arena (playgrounds/ring_exp_v1.0: 36 obstacle polygons, ego start pose, the
+    1500 x 1500 x 0.2 m obstacle map of agent 0) from tests/golden/default_map.npz (data only, written by
+    tests/golden/make_default_map.py), rasterised as DataRenderer::GetObstacleMap lays it out around the ego vehicle:
+    origin = round(ego - extent / 2) (data_renderer.cc:157-165).  Returns (grid [1500][1500] uint8, origin, resolution,
+    ego_init (x, y, yaw))."""
+    import os
+    if fixture is None:
+        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "default_map.npz")
+    z = np.load(fixture)
+    w, h, res = int(z["map_meta"][0]), int(z["map_meta"][1]), float(z["map_meta"][2])
+    ego = z["ego_init"]
+    origin = (float(np.round(ego[0] - h * res / 2.0)), float(np.round(ego[1] - w * res / 2.0)))
+    grid = np.full((h, w), 127, dtype=np.uint8)
+    fill_polygons(grid, origin, res, z["poly_xy"], z["poly_off"])
+    return grid, origin, res, ego.copy()
+
+
 def rectangle_corridor(px, py, yaw, obstacles, step=MAP_RESL, limit=LIMIT_BOUND):
     """One 4-plane rectangle per state (x, y, yaw): the growth rule of
     TrajPlanner::getRectangleConst (traj_manager.cpp:1296-1441) — sides

@@ -1,0 +1,113 @@
+"""BASELINE configs[0] -- "single forward-only goal ... default sim map" -- on the reference's default arena
+(playgrounds/ring_exp_v1.0: the 36 obstacle polygons, the ego vehicle's start pose and the 1500 x 1500 x 0.2 m obstacle
+map of agent 0, tests/golden/default_map.npz written by tests/golden/make_default_map.py).  The reference's front end
+(hybrid A*) is out of scope; the path from the start to the goal is its analytic shot (KinoAstar::computeShotTraj,
+kino_astar.cpp:304-345), which is what closes every searched path.  From there the reference's own sequence:
+getKinoNode resampling -> getRectangleConst on the map -> OptimizeTrajectory -> the CheckReplan collision loop."""
+import numpy as np
+import pytest
+
+from dftpav_amd import scenarios as sc
+from dftpav_amd.pods import FrontendParams, LayoutSpec
+from dftpav_amd.scenarios import Scenario
+
+GOAL = np.array([[-52.5, -14.0, -1.9]])   # a free pose 45 m down the arena from the start, reachable forwards
+MAX_CUR, CHECKL = 0.35, 0.2
+
+
+def _scene():
+    grid, origin, res, ego = sc.default_sim_map()
+    return grid, origin, res, ego[None].copy()
+
+
+def _chain(dev, start, goal, p, K, Kd):
+    """shot -> path -> resampling on `dev` (the HIP handle or the oracle module); returns (shot, frontend output)"""
+    shot = dev(start, goal)
+    npt = int(shot["n_samples"][0])
+    path = np.zeros((1, npt + 1, 3))
+    path[0, :npt] = shot["samples"][0, :npt]
+    path[0, npt] = goal[0]                                    # the goal closes the list, kino_astar.cpp:599
+    return shot, path, np.array([npt + 1], dtype=np.int32)
+
+
+def test_default_map_fixture_and_rasteriser():
+    grid, origin, res, start = _scene()
+    z = np.load(sc.__file__.replace("dftpav_amd/scenarios.py", "tests/golden/default_map.npz"))
+    assert grid.shape == (1500, 1500) and res == 0.2 and origin == (-202.0, -120.0)   # round(ego - 150 m), data_renderer.cc:157-165
+    assert len(z["poly_off"]) - 1 == 36 and 0.02 < (grid == 80).mean() < 0.10
+    cell = lambda x, y: grid[int(round((y - origin[1]) / res)), int(round((x - origin[0]) / res))]
+    for k in range(len(z["poly_off"]) - 1):                   # every vertex and every centroid of a convex outline is occupied
+        pts = z["poly_xy"][z["poly_off"][k]:z["poly_off"][k + 1]]
+        inside = (np.abs(pts[:, 0] - origin[0] - 150) < 149) & (np.abs(pts[:, 1] - origin[1] - 150) < 149)
+        for x, y in pts[inside]:
+            assert cell(x, y) == 80
+    assert cell(start[0, 0], start[0, 1]) == 127 and cell(GOAL[0, 0], GOAL[0, 1]) == 127
+    # a unit square rasterised alone: its cells, nothing else
+    g = np.full((20, 20), 127, np.uint8)
+    sc.fill_polygons(g, (0.0, 0.0), 0.5, np.array([[2.0, 2.0], [4.0, 2.0], [4.0, 4.0], [2.0, 4.0], [2.0, 2.0]]), np.array([0, 5]))
+    want = np.full((20, 20), 127, np.uint8)
+    want[4:9, 4:9] = 80
+    assert np.array_equal(g, want)
+
+
+def test_forward_goal_on_the_default_map_oracle(oracle):
+    """the chain on the CPU oracle alone (literal order): the shot is free and forward-only, the solve succeeds and its
+    trajectory stays clear of the map"""
+    grid, origin, res, start = _scene()
+    shot = oracle.reeds_shepp_shots(start, GOAL, max_cur=MAX_CUR, checkl=CHECKL, max_samples=512, grid=grid, resolution=res,
+                                    origin=origin, order=0)
+    assert shot["collides"][0] == 0 and (shot["seg"][0] >= 0).all() and 40.0 < shot["length"][0] < 50.0
+
+
+@pytest.mark.gpu
+def test_forward_goal_on_the_default_map(hiplib, oracle):
+    grid, origin, res, start = _scene()
+    K, Kd = 16, 32
+    p = hiplib.default_params()
+    p.traj_resolution, p.des_traj_resolution = K, Kd
+    h = hiplib.Handle(p)
+    h.set_grid_map(grid, res, origin)
+    shot, path, plen = _chain(lambda a, b: h.reeds_shepp_shots(a, b, max_cur=MAX_CUR, checkl=CHECKL, max_samples=512, check_collision=True),
+                              start, GOAL, p, K, Kd)
+    want = oracle.reeds_shepp_shots(start, GOAL, max_cur=MAX_CUR, checkl=CHECKL, max_samples=512, grid=grid, resolution=res,
+                                    origin=origin, order=1)
+    for k in ("length", "type", "seg", "samples", "n_samples", "collides"):
+        assert np.array_equal(shot[k], want[k]), k
+    assert shot["collides"][0] == 0 and (shot["seg"][0] >= 0).all()
+    fp = FrontendParams.default(K=K, Kd=Kd)
+    ss = np.array([[start[0, 0], start[0, 1], start[0, 2], 0.0]])     # at rest, as the vehicle set starts it
+    es = np.array([[GOAL[0, 0], GOAL[0, 1], GOAL[0, 2], 0.0]])
+    fe = h.frontend_resample(path, plen, ss, es, np.zeros((1, 2)), fp)
+    fo = oracle.frontend_resample(path, plen, ss, es, np.zeros((1, 2)), fp, order=1)
+    for k in fo:
+        assert np.array_equal(fe[k], fo[k]), k
+    M = int(fe["n_seg"][0])
+    assert M == 1 and int(fe["singul"][0, 0]) == 1                    # one forward segment
+    pn = [int(x) for x in fe["piece_nums"][0, :M]]
+    lay = LayoutSpec(pn, [1], 4)
+    npts = lay.n_points(K, Kd)
+    states = fe["states"][0, 0, :fe["n_states"][0, 0]]
+    assert states.shape[0] == npts
+    inner = fe["inner_pts"][0, 0, :pn[0] - 1].reshape(-1)
+    B = 8                                                             # the hypothesis and seven seeded restarts of it
+    durs = (fe["piece_dt"][0, :M] * fe["piece_nums"][0, :M])
+    rin, rT = h.sample_restarts(inner[None], durs[None], B, seed=5)
+    oin, oT = oracle.sample_restarts(inner[None], durs[None], B, seed=5)
+    assert np.array_equal(rin, oin) and np.array_equal(rT, oT)
+    s = Scenario("default-map", lay, K, Kd, B, np.repeat(fe["ini_states"][0:1, :M], B, 0).copy(), np.repeat(fe["fin_states"][0:1, :M], B, 0).copy(),
+                 rin.reshape(B, -1).copy(), rT.reshape(B, M).copy(), np.zeros((B, npts, 4, 4)))
+    bt = hiplib.Batch(h, lay, B)
+    bt.upload(s, with_corridor=False)
+    bt.corridor_from_states(np.repeat(states[None], B, 0))
+    r = bt.solve()
+    s.corridor = np.repeat(oracle.corridor_rectangles(grid, res, origin, states, order=1)[None], B, 0)
+    ro = oracle.solve_batch(p, s, nthreads=2, order=1)
+    for k in ("final_cost", "x", "status", "iters", "evals"):
+        assert np.array_equal(r[k], ro[k]), k
+    assert r["success"].all()
+    col, first = bt.validate()
+    co, dts = bt.coeffs()
+    oc, of = oracle.validate_trajectories(grid, res, origin, co, dts, lay.piece_nums, lay.singuls, order=1)
+    assert np.array_equal(col, oc) and np.array_equal(first, of) and not col.any()
+    bt.close()
+    h.close()
