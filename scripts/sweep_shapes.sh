@@ -1,3 +1,4 @@
+# Developer script (GPU box): the bench (8 steps) under overrides of the schedule.   bash scripts/sweep_shapes.sh
 export TMPDIR=/tmp
 run() { echo "== $*"; env "$@" timeout 300 python bench.py --steps 8 --warmup 2 --no-extras --cpu-sample 0 2>&1 | python -c "
 import sys, json
@@ -7,7 +8,10 @@ for l in sys.stdin:
     elif 'rror' in l: print(l.strip())
 "; }
 run A=0
-run DFTPAV_SLOTS=1792
-run DFTPAV_SLOTS=1536
-run DFTPAV_THREADS=128 DFTPAV_SLOTS=1024
+run DFTPAV_SLICE=64
 run DFTPAV_SLICE=96
+run DFTPAV_SLICE=192
+run DFTPAV_SLICE=256
+run DFTPAV_SLOTS=1792
+run DFTPAV_SLOTS=2304
+run A=1
