@@ -59,6 +59,52 @@ def test_forward_goal_on_the_default_map_oracle(oracle):
     assert shot["collides"][0] == 0 and (shot["seg"][0] >= 0).all() and 40.0 < shot["length"][0] < 50.0
 
 
+def _default_map_scenario(oracle, p, K, Kd, B):
+    """the chain of the GPU test on the CPU oracle (device-order helpers for the steps around the solve): a Scenario"""
+    grid, origin, res, start = _scene()
+    shot = oracle.reeds_shepp_shots(start, GOAL, max_cur=MAX_CUR, checkl=CHECKL, max_samples=512, grid=grid, resolution=res,
+                                    origin=origin, order=1)
+    npt = int(shot["n_samples"][0])
+    path = np.zeros((1, npt + 1, 3))
+    path[0, :npt] = shot["samples"][0, :npt]
+    path[0, npt] = GOAL[0]
+    fp = FrontendParams.default(K=K, Kd=Kd)
+    ss = np.array([[start[0, 0], start[0, 1], start[0, 2], 0.0]])
+    es = np.array([[GOAL[0, 0], GOAL[0, 1], GOAL[0, 2], 0.0]])
+    fo = oracle.frontend_resample(path, np.array([npt + 1], dtype=np.int32), ss, es, np.zeros((1, 2)), fp, order=1)
+    pn = [int(x) for x in fo["piece_nums"][0, :1]]
+    lay = LayoutSpec(pn, [1], 4)
+    npts = lay.n_points(K, Kd)
+    states = fo["states"][0, 0, :fo["n_states"][0, 0]]
+    inner = fo["inner_pts"][0, 0, :pn[0] - 1].reshape(-1)
+    durs = fo["piece_dt"][0, :1] * fo["piece_nums"][0, :1]
+    rin, rT = oracle.sample_restarts(inner[None], durs[None], B, seed=5)
+    cor = oracle.corridor_rectangles(grid, res, origin, states, order=1)
+    return Scenario("default-map", lay, K, Kd, B, np.repeat(fo["ini_states"][0:1, :1], B, 0).copy(),
+                    np.repeat(fo["fin_states"][0:1, :1], B, 0).copy(), rin.reshape(B, -1).copy(), rT.reshape(B, 1).copy(),
+                    np.repeat(cor[None], B, 0))
+
+
+def test_default_map_solve_is_bit_equal_to_the_reference_build(oracle):
+    """OptimizeTrajectory of the reference's own sources (oracle/_ref) and the literal oracle on the default-arena problem:
+    the same x, cost, status and counts, bit for bit (skips where oracle/_ref is absent)."""
+    import os
+    from oracle import pyref
+    if os.path.exists("/root/reference/src/Plan/traj_planner"):
+        pyref.build()
+    if not pyref.available():
+        pytest.skip("oracle/_ref is not built here and /root/reference is absent")
+    K, Kd, B = 16, 32, 3
+    p = oracle.default_params()
+    p.traj_resolution, p.des_traj_resolution = K, Kd
+    s = _default_map_scenario(oracle, p, K, Kd, B)
+    lit = oracle.solve_batch(p, s, nthreads=1, order=0)
+    for b in range(B):
+        r = pyref.RefProblem(p, s, b).optimize()
+        assert r["ok"] and r["final_cost"] == lit["final_cost"][b] and np.array_equal(r["x"], lit["x"][b])
+        assert r["status"] == lit["status"][b] and r["iters"] == lit["iters"][b] and r["evals"] == lit["evals"][b]
+
+
 @pytest.mark.gpu
 def test_forward_goal_on_the_default_map(hiplib, oracle):
     grid, origin, res, start = _scene()
