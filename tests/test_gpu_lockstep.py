@@ -20,12 +20,18 @@ def literal_evaluator(oracle, p, s, b):
     return o.eval, "literal oracle"
 
 
-@pytest.mark.parametrize("cfg,B,b", [(1, 2, 0), (2, 2, 1), (3, 4, 2), (5, 2, 0)])
+# cfg 0: BASELINE configs[0] on the reference's default arena (tests/test_default_map.py), corridor from its map
+@pytest.mark.parametrize("cfg,B,b", [(1, 2, 0), (2, 2, 1), (3, 4, 2), (5, 2, 0), (0, 2, 1)])
 def test_solve_is_in_lockstep_with_the_reference_lbfgs(hiplib, oracle, cfg, B, b):
     capi = hiplib
     p = capi.default_params()
-    s = sc.baseline_config(cfg, B=B)
-    s.apply_resolution(p)
+    if cfg == 0:
+        from test_default_map import _default_map_scenario
+        p.traj_resolution, p.des_traj_resolution = 16, 32
+        s = _default_map_scenario(oracle, p, 16, 32, B)
+    else:
+        s = sc.baseline_config(cfg, B=B)
+        s.apply_resolution(p)
     h = capi.Handle(p)
     h.set_surround(s.surround)
     bt = capi.Batch(h, s.layout, B)
