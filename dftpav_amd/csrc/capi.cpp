@@ -897,9 +897,25 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
       // (many pieces or points: BASELINE configs[4]) take two waves per trajectory and as many workgroups as their LDS allows
       const size_t l64 = solver_lds_bytes(L, b->P, kWave, false, false, 0) + 64;
       if (l64 > 20 * 1024 || L.Npts > 1024) {
-        b->threads = 2 * kWave;
-        const size_t l128 = solver_lds_bytes(L, b->P, b->threads, false, false, 0) + 64;
-        per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / l128));
+        // Two or four waves per trajectory, whichever keeps more waves resident on a CU with the obstacle set installed on
+        // the handle right now (its tables are part of a workgroup's LDS): BASELINE configs[4] holds 3 workgroups of 128
+        // threads (6 waves) or 2 of 256 (8 waves) per CU -- 415 against 355 ms per 1024.  Without obstacles both give 8
+        // waves and the narrower workgroup wastes less in the serial phases.
+        const int np = h->S > 0 ? h->sur_pieces : 0;
+        size_t best_waves = 0;
+        for (int waves = 2; waves <= 4; waves += 2) {
+          const int T = waves * kWave;
+          const size_t cap = 8 / (size_t)waves; // 256 VGPRs: two waves per SIMD
+          auto resident = [&](bool coef) {
+            return std::min<size_t>(cap, (160 * 1024) / (solver_lds_bytes(L, b->P, T, false, false, np, coef) + 64));
+          };
+          const size_t wg = std::max<size_t>(1, np > 0 && np <= kSurCoefLds && resident(true) == resident(false) ? resident(true) : resident(false));
+          if (wg * waves > best_waves) {
+            best_waves = wg * waves;
+            b->threads = T;
+            per_cu = (int)wg;
+          }
+        }
       }
     }
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
@@ -920,7 +936,7 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
     b->slots = n_cu * per_cu;
     // iterations per slice: long slices cost fewer suspensions, short ones balance the end of a solve better; layouts with
     // many constraint points (costly iterations, few trajectories per slot) take the short ones (measured)
-    b->slice = L.Npts > 1024 ? 48 : 128;
+    b->slice = L.Npts > 1024 ? (b->threads >= 4 * kWave ? 32 : 48) : 128;
     b->hand_over = n_cu;
     if (const char *e = std::getenv("DFTPAV_SLOTS")) b->slots = std::atoi(e);
     if (const char *e = std::getenv("DFTPAV_SLICE")) b->slice = std::atoi(e);
