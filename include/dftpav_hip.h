@@ -251,7 +251,10 @@ int dftpav_corridor_rectangles(dftpav_handle *h, const double *states, int n_sta
 /* Duration of the last corridor kernel on the device (HIP events), without the copies. */
 int dftpav_corridor_last_ms(dftpav_handle *h, float *ms);
 
-/* Device-resident batch of B trajectories with a common layout. */
+/* Device-resident batch of B trajectories with a common layout.  The launch shape (threads per trajectory, workgroups per
+ * CU, what is staged in LDS) is chosen here, for layouts with many constraint points with the obstacle set that is
+ * installed on the handle at this moment (dftpav_set_surround / dftpav_fit_surround before dftpav_batch_create); a set
+ * installed later still works, with the shape chosen without it. */
 int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out);
 /* The same with the residency plan chosen by the caller instead of by B: 0 = one workgroup per CU, the trajectory's
  * half-planes and the MINCO operators staged in LDS (lowest latency of one solve; the default for B <= #CUs), 1 = two per
