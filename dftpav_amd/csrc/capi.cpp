@@ -916,6 +916,16 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
             per_cu = (int)wg;
           }
         }
+      } else if (residency < 0 && B < 2 * n_cu * per_cu) {
+        // Fewer trajectories than two per one-wave slot: an isolated batch of this size ends with most of the device idle
+        // behind its longest solves.  Two waves per trajectory on half as many slots finish each solve sooner and keep the
+        // time-sliced queue busy: 14.7 k against 13.5 k solves/s at B = 1024, 17.2 k against 12.8 k at 1536, 17.6 k against
+        // 15.0 k at 2048, 21.3 k against 19.8 k at 3072; equal at 4096, where the one-wave shape is 12 % ahead as soon as
+        // batches follow one another on two streams (the bench).  A caller that streams smaller batches asks for the
+        // one-wave shape with dftpav_batch_create_shaped(..., 2, ...).
+        b->threads = 2 * kWave;
+        const size_t l128 = solver_lds_bytes(L, b->P, b->threads, false, false, 0) + 64;
+        per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / l128));
       }
     }
     if (const char *e = std::getenv("DFTPAV_THREADS")) b->threads = std::atoi(e);
