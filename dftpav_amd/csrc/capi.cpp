@@ -700,7 +700,9 @@ extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   h->sur_version++;
   if (!s || s->S <= 0) return DFTPAV_OK;
   int S = s->S, np = s->piece_offsets[S];
-  if (np <= 0) return DFTPAV_E_INVALID;
+  if (np <= 0 || s->piece_offsets[0] != 0) return DFTPAV_E_INVALID;
+  for (int u = 0; u < S; u++) // every obstacle is a trajectory of at least one piece (Trajectory::locatePieceIdx has no empty case)
+    if (s->piece_offsets[u + 1] <= s->piece_offsets[u]) return DFTPAV_E_INVALID;
   HIPCHK(h, hipMalloc(&h->d_sur_off, sizeof(int) * (S + 1)));
   HIPCHK(h, hipMalloc(&h->d_sur_dur, sizeof(double) * np));
   HIPCHK(h, hipMalloc(&h->d_sur_coef, sizeof(double) * 12 * np));
