@@ -43,14 +43,22 @@ class DftpavError(RuntimeError):
 
 def build(force=False):
     """Compile libdftpav_hip.so for gfx950 (hipcc cross-compiles without a GPU).  Always goes through make: the
-    Makefile tracks every source and header, so a stale library cannot pass for a fresh one."""
+    Makefile tracks every source and header, so a stale library cannot pass for a fresh one.  The build is serialised
+    with a file lock: several ranks of one job (the gloo / RCCL tests, torchrun) call this at the same moment, and two
+    makes rewriting the same objects could leave one of them loading a half-written library."""
     src_dir = os.path.join(_HERE, "csrc")
-    if force:
-        subprocess.check_call(["make", "-C", src_dir, "-s", "clean"])
-    if os.environ.get("DFTPAV_LIB"):
+    if os.environ.get("DFTPAV_LIB"):   # a prebuilt library was named: nothing of the tree is built or cleaned
         return LIB_PATH
-    if os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", src_dir, "-s"])
+    import fcntl
+    with open(os.path.join(src_dir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force:
+                subprocess.check_call(["make", "-C", src_dir, "-s", "clean"])
+            if os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(LIB_PATH):
+                subprocess.check_call(["make", "-C", src_dir, "-s"])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -320,6 +320,29 @@ extern "C" int dftpav_debug_surround_tables(int S, const int *piece_offsets, con
   if (boxes) std::memcpy(boxes, box.data(), sizeof(double) * 4 * (size_t)np);
   return ok ? 1 : 0;
 }
+// test hook (host only, no device): the distance gate of traj_optimizer.cpp:1393 for `npts` ego positions `sigma` [npts][2] at
+// local times `t` [npts] against obstacle u, decided twice by the code the kernels run -- with the host's tables (threshold
+// search + piece boxes) and without them (the reference's walk).  out_with / out_without [npts]: 1 = the pair passes the gate.
+extern "C" int dftpav_debug_gate(int S, const int *piece_offsets, const double *durations, const double *coeffs, const double *total,
+                                 const double *start, int u, double t_now, double trajtime, double veh_length_infl, int npts,
+                                 const double *sigma, const double *t, int *out_with, int *out_without) {
+  if (S <= 0 || u < 0 || u >= S || !piece_offsets || !durations || !coeffs || !total || !start) return DFTPAV_E_INVALID;
+  const int np = piece_offsets[S];
+  std::vector<int> off(piece_offsets, piece_offsets + S + 1);
+  std::vector<double> dur(durations, durations + np), coef(coeffs, coeffs + 12 * (size_t)np), th, box;
+  if (!build_theta(off, dur, th)) return 0;
+  build_piece_boxes(dur, coef, box);
+  dftpav::DevParams P{};
+  P.veh_length_infl = veh_length_infl;
+  dftpav::DevSurround A{S, piece_offsets, durations, coeffs, total, start, th.data(), box.data()};
+  dftpav::DevSurround W{S, piece_offsets, durations, coeffs, total, start, nullptr, nullptr};
+  for (int i = 0; i < npts; i++) {
+    dftpav::DynObs ob;
+    out_with[i] = dftpav::dyn_obstacle_near(P, A, u, t_now, t[i], trajtime, sigma + 2 * i, ob) ? 1 : 0;
+    out_without[i] = dftpav::dyn_obstacle_near(P, W, u, t_now, t[i], trajtime, sigma + 2 * i, ob) ? 1 : 0;
+  }
+  return 1;
+}
 static int upload_boxes(dftpav_handle *h, const std::vector<double> &dur, const std::vector<double> &coef) {
   for (double v : coef)
     if (!std::isfinite(v)) return DFTPAV_OK; // no table: nothing is skipped
@@ -472,8 +495,18 @@ extern "C" int dftpav_frontend_resample(dftpav_handle *h, const dftpav_frontend_
   return rc;
 }
 
+// The solver numbers (constraint point, obstacle) pairs with 16 bits and keeps a 16-bit mask of obstacles per point; its
+// tables of the obstacles' pieces live in LDS.  A set beyond that is refused where it is installed, not at the first solve.
+static int check_surround_limits(dftpav_handle *h, int S, long long pieces) {
+  if (S > DFTPAV_MAX_SURROUND || pieces > DFTPAV_MAX_SURROUND_PIECES) {
+    h->err = "too many moving obstacles (at most DFTPAV_MAX_SURROUND = 16 with DFTPAV_MAX_SURROUND_PIECES = 512 pieces in all)";
+    return DFTPAV_E_UNSUPPORTED;
+  }
+  return DFTPAV_OK;
+}
 extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S, int n_states) {
   if (!h || (S > 0 && !states) || S < 0 || (S > 0 && n_states < 3)) return DFTPAV_E_INVALID;
+  if (int rc = check_surround_limits(h, S, (long long)S * (n_states - 1))) return rc; // the installed set stays as it is
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_batches_of(h)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -693,6 +726,10 @@ extern "C" int dftpav_corridor_rectangles(dftpav_handle *h, const double *states
 
 extern "C" int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s) {
   if (!h) return DFTPAV_E_INVALID;
+  if (s && s->S > 0) {
+    if (!s->piece_offsets) return DFTPAV_E_INVALID;
+    if (int rc = check_surround_limits(h, s->S, s->piece_offsets[s->S])) return rc; // the installed set stays as it is
+  }
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_batches_of(h)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));

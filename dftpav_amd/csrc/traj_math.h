@@ -489,8 +489,11 @@ DFTPAV_HD inline bool dyn_obstacle_near(const DevParams &P, const SV &S, int u, 
     if (S.has_theta()) {
       // Before anything is evaluated: if the point is farther than the gate's radius from the box that holds the whole
       // piece the obstacle is on (DevSurround::bbox, with a margin far above rounding), the distance test below fails.
+      // (only for pt_time >= 0: an obstacle whose trajectory starts after t_now is extrapolated backwards along the first
+      // piece's quintic, Trajectory::locatePieceIdx returns piece 0 with a negative local time, traj_optimizer.cpp:1374-1378 --
+      // that position is outside the hull box of the piece)
       const int idx = sur_index(S, u, pt_time);
-      if (idx < S.piece_off[u + 1] - S.piece_off[u] && S.far_from_piece(S.piece_off[u] + idx, sigma, P.veh_length_infl * 1.5 + 1e-6))
+      if (pt_time >= 0.0 && idx < S.piece_off[u + 1] - S.piece_off[u] && S.far_from_piece(S.piece_off[u] + idx, sigma, P.veh_length_infl * 1.5 + 1e-6))
         return false;
       sur_local(S, u, idx, pt_time, e);
     } else {
@@ -1163,7 +1166,7 @@ DFTPAV_HD inline unsigned dynamic_gate_mask(const DevParams &P, const SV &S, con
         const bool exact = (!(ptz[i] > taz[i])) & ((gz[i] == 0) | (ptz[i] > tbz[i])); // sur_index returns g
         const bool far = (q.sigma[0] < bbz[i][0] - r) | (q.sigma[0] > bbz[i][1] + r) | (q.sigma[1] < bbz[i][2] - r) |
                          (q.sigma[1] > bbz[i][3] + r); // far_from_piece
-        const bool rej = (u0 + i < ns) & (ptz[i] < totz[i]) & exact & far;
+        const bool rej = (u0 + i < ns) & (ptz[i] >= 0.0) & (ptz[i] < totz[i]) & exact & far; // a negative local time leaves the box
         need &= ~((rej ? 1u : 0u) << (u0 + i));
       }
     }

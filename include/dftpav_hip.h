@@ -166,7 +166,13 @@ void dftpav_destroy(dftpav_handle *h);
 const char *dftpav_last_error(const dftpav_handle *h);
 
 /* Replaces setSurroundTrajs (traj_optimizer.h:108). s==NULL or s->S==0 clears
- * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied. */
+ * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied.
+ * Limits (the reference loops over surround_trajs_->size() without one): at most DFTPAV_MAX_SURROUND obstacles with
+ * DFTPAV_MAX_SURROUND_PIECES pieces in all -- a larger set is refused here (DFTPAV_E_UNSUPPORTED, the installed set is
+ * kept), also by dftpav_fit_surround and dftpav_set_surround_wire; and (constraint points of the layout) x S <= 65535,
+ * which only a solve / eval / validation of a batch can check (DFTPAV_E_UNSUPPORTED there). */
+#define DFTPAV_MAX_SURROUND 16
+#define DFTPAV_MAX_SURROUND_PIECES 512
 int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s);
 
 /* ---- front-end resampling: from a searched path to the solver's arguments ----
@@ -273,7 +279,10 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  * (traj_manager.cpp:569-610) without the rectangles leaving the device: the
  * corridor of every trajectory of the batch is generated from its constraint-
  * point poses, states [B][Npts][3] (x, y, yaw), straight into the solver's own
- * layout.  Use with dftpav_batch_upload(d) where d->corridor == NULL.  H must be 4. */
+ * layout.  Use with dftpav_batch_upload(d) where d->corridor == NULL.  H must be 4.
+ * ORDER: dftpav_batch_upload first, then this call, then solve / eval.  Every upload with d->corridor == NULL
+ * invalidates the half-planes of the previous cycle on purpose (they belong to the previous poses): a solve that
+ * follows an upload without a new corridor returns DFTPAV_E_INVALID rather than using stale half-planes. */
 int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states);
 /* The same when the batch is n_restarts restarts of each hypothesis (trajectory
  * t = hypothesis * n_restarts + restart, as dftpav_sample_restarts lays them out)

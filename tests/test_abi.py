@@ -97,6 +97,48 @@ def test_host_tables_of_the_moving_obstacles(hiplib):
         assert box[k, 1] - box[k, 0] <= 3.0 * (pos[:, 0].max() - pos[:, 0].min()) + 1e-3 + 2.5 * np.abs(coef[k, :5, 0] * dur[k] ** np.arange(5, 0, -1)).sum()
 
 
+def test_gate_with_tables_equals_the_walk_also_before_the_obstacle_starts(hiplib):
+    """The distance gate of traj_optimizer.cpp:1393 as the kernels decide it with the host's tables (threshold search,
+    piece boxes) against the reference's walk -- including obstacles whose trajectory starts after t_now: piece 0 is then
+    extrapolated backwards (negative local time, traj_optimizer.cpp:1374-1378), outside its hull box.  Round-2 advisor
+    repro: one piece x = 10 + 2 t, start 3, t_now 0, t = 1, ego at the origin -> the obstacle is at (6, 0), inside the gate."""
+    fn = hiplib.lib().dftpav_debug_gate
+    ip = C.POINTER(C.c_int)
+    fn.argtypes = [C.c_int, ip, pods.c_double_p, pods.c_double_p, pods.c_double_p, pods.c_double_p, C.c_int, C.c_double, C.c_double,
+                   C.c_double, C.c_int, pods.c_double_p, pods.c_double_p, ip, ip]
+
+    def gate(off, dur, coef, total, start, u, t_now, trajtime, infl, sig, t):
+        off = np.ascontiguousarray(off, dtype=np.int32); sig = np.ascontiguousarray(sig, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        a = np.zeros(len(t), dtype=np.int32); w = np.zeros(len(t), dtype=np.int32)
+        rc = fn(len(total), off.ctypes.data_as(ip), pods.dptr(dur), pods.dptr(coef), pods.dptr(total), pods.dptr(start), u, t_now, trajtime,
+                infl, len(t), pods.dptr(sig), pods.dptr(t), a.ctypes.data_as(ip), w.ctypes.data_as(ip))
+        assert rc == 1
+        return a, w
+
+    coef = np.zeros((1, 6, 2)); coef[0, 4, 0] = 2.0; coef[0, 5, 0] = 10.0        # column 0 multiplies t^5: x = 10 + 2 t, y = 0
+    a, w = gate([0, 1], np.array([5.0]), coef, np.array([5.0]), np.array([3.0]), 0, 0.0, 0.0, 5.0, np.zeros((1, 2)), np.array([1.0]))
+    assert w[0] == 1 and a[0] == 1
+    rng = np.random.default_rng(8)
+    S = 4
+    nps = rng.integers(1, 12, S)
+    off = np.concatenate([[0], np.cumsum(nps)])
+    npz = int(off[-1])
+    dur = rng.uniform(0.3, 2.0, npz)
+    coef = rng.normal(0, 1, (npz, 6, 2)) * np.array([0.002, 0.01, 0.05, 0.3, 2.0, 8.0])[None, :, None]
+    total = np.array([dur[off[u]:off[u + 1]].sum() for u in range(S)])
+    start = np.array([6.0, 0.0, 2.5, -1.0])
+    npts = 4000
+    sig = rng.normal(0, 12, (npts, 2)); t = rng.uniform(0, 12, npts)
+    seen_neg = 0
+    for u in range(S):
+        a, w = gate(off, dur, coef, total, start, u, 0.5, 1.0, 4.0, sig, t)
+        assert np.array_equal(a, w), u
+        neg = (0.5 - start[u] + 1.0) + t < 0
+        seen_neg += int((w[neg] == 1).sum())
+    assert seen_neg > 0      # pairs that pass the gate while the obstacle has not started yet do occur
+
+
 def test_no_cpu_fallback(hiplib):
     """Without a usable HIP device the product must fail loudly, never compute on the CPU."""
     import torch

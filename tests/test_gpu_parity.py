@@ -51,6 +51,40 @@ def test_eval_matches_oracle(hiplib, oracle, cfg, B):
     h.close()
 
 
+def test_moving_obstacles_that_start_after_t_now(hiplib, oracle):
+    """An obstacle whose predicted trajectory starts later than the ego's clock (surround start_time > t_now, the normal
+    swarm situation) is extrapolated BACKWARDS along its first piece (Trajectory::locatePieceIdx returns piece 0 with a
+    negative local time, traj_optimizer.cpp:1374-1378): such a position lies outside the piece's hull box, so the box
+    rejection of the gate must not be applied there.  The device-order oracle has no box table (it walks the pieces)."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(5, B=3)
+    s.apply_resolution(p)
+    s.surround.start_time[:] = [4.0, 1.5, 0.0, 9.0]      # three of the four cars start after t_now = 0
+    s.t_now = 0.25
+    h, bt = _batch(hiplib, s, p)
+    x0 = bt.x0()
+    rng = np.random.default_rng(11)
+    npairs = 0
+    for scale in (0.0, 0.3):
+        x = x0 + rng.normal(0, scale, x0.shape) if scale else x0
+        f, g = bt.eval(x)
+        for b in range(s.B):
+            dev = oracle.OracleProblem(p, s, b, order=1)
+            fd, gd = dev.eval(x[b])
+            assert f[b] == fd and np.array_equal(g[b], gd)
+            lit = oracle.OracleProblem(p, s, b, order=0)
+            fl, gl = lit.eval(x[b])
+            assert abs(f[b] - fl) <= 1e-11 * abs(fl)
+            npairs += lit.cost_terms()[3] > 0.0
+    assert npairs > 0        # the moving-obstacle term is active somewhere, or this test checks nothing
+    r = bt.solve()
+    ro = oracle.solve_batch(p, s, nthreads=3, order=1)
+    assert np.array_equal(r["final_cost"], ro["final_cost"]) and np.array_equal(r["x"], ro["x"])
+    assert np.array_equal(r["iters"], ro["iters"]) and np.array_equal(r["evals"], ro["evals"])
+    bt.close()
+    h.close()
+
+
 @pytest.mark.parametrize("cfg,B", [(1, 4), (2, 4), (3, 32), (5, 2)])
 def test_solve_matches_oracle(hiplib, oracle, cfg, B):
     """L2 cut: the whole lbfgs_optimize run (lbfgs.hpp:440-751), every trajectory of the batch."""
