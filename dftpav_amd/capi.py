@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("DFTPAV_LIB") or os.path.join(_HERE, "libdftpav_hip.so
 _LIB = None
 
 OK = 0
+ORDER_DEVICE, ORDER_REFERENCE = 0, 1
 E_INVALID, E_MINI_T, E_ONE_PIECE, E_NO_DEVICE, E_HIP, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 
 # every symbol include/dftpav_hip.h declares
@@ -32,6 +33,7 @@ EXPORTS = [
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
     "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
     "dftpav_batch_trace", "dftpav_batch_get_trace", "dftpav_plan_cycle", "dftpav_plan_cycle_fetch", "dftpav_batch_create_shaped",
+    "dftpav_batch_set_order", "dftpav_batch_get_order",
 ]
 
 
@@ -302,6 +304,13 @@ class Batch:
         if rc != OK:
             self._b = None
             handle._check(rc, "batch_create")
+
+    def set_order(self, order):
+        """ORDER_DEVICE (default, the throughput kernels) or ORDER_REFERENCE: every sum in the order PolyTrajOptimizer
+        executes it, whole solves bit-equal to OptimizeTrajectory's (dftpav_batch_set_order)."""
+        fn = lib().dftpav_batch_set_order
+        fn.argtypes = [C.c_void_p, C.c_int]
+        self.handle._check(fn(self._b, int(order)), "batch_set_order")
 
     def upload(self, scen_or_data, with_corridor=True):
         """with_corridor=False: everything but the half-planes (they come from corridor_from_states)."""

@@ -47,6 +47,11 @@ hipError_t launch_shots(const double *from, const double *to, int n, double rho,
 hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 hipError_t launch_corridor_layout(const double *raw, double *out, int B, int Npts, int H, int NptsPad, hipStream_t stream);
 hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream);
+// solver_ref.hip: the same path in the reference's own floating-point order
+bool reference_order_supported(const DevLayout &L, const DevParams &P, int S);
+size_t reference_order_scratch_doubles(const DevLayout &L, int B);
+size_t reference_order_table_doubles(int N);
+hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream);
 }
 using namespace dftpav;
 
@@ -115,6 +120,9 @@ struct dftpav_batch {
   double *d_f_eval = nullptr; // costs of dftpav_batch_eval (kept apart from the solve's final costs)
   double *d_trace = nullptr;  // dftpav_batch_trace
   double *d_cor_raw = nullptr; // the caller's hPoly columns as uploaded (normalised and laid out on the device)
+  // dftpav_batch_set_order(DFTPAV_ORDER_REFERENCE): the substitution tables of the band system and the term records (solver_ref.hip)
+  int order = DFTPAV_ORDER_DEVICE;
+  double *d_ref_tab = nullptr, *d_ref_scratch = nullptr;
   // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
   struct PlanCycle {
     double *d_poses = nullptr, *d_t = nullptr, *d_v = nullptr, *d_rd = nullptr;
@@ -506,7 +514,8 @@ static int check_surround_limits(dftpav_handle *h, int S, long long pieces) {
 }
 extern "C" int dftpav_fit_surround(dftpav_handle *h, const double *states, int S, int n_states) {
   if (!h || (S > 0 && !states) || S < 0 || (S > 0 && n_states < 3)) return DFTPAV_E_INVALID;
-  if (int rc = check_surround_limits(h, S, (long long)S * (n_states - 1))) return rc; // the installed set stays as it is
+  // (no limit here: the fit is also a service of its own, its result read back with dftpav_get_surround; a fitted set beyond
+  // the solver's limits makes solve / eval / validate of a batch return DFTPAV_E_UNSUPPORTED, as the header says)
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_batches_of(h)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -841,7 +850,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
                   b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
-                  b->d_f_eval, b->d_trace, b->d_cor_raw, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
+                  b->d_f_eval, b->d_trace, b->d_cor_raw, b->d_ref_tab, b->d_ref_scratch, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
                   b->pc.d_valid};
   {
     auto &v = b->h->batches;
@@ -1397,6 +1406,69 @@ extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals
   return DFTPAV_OK;
 }
 
+// every launch of the solve kernel for a batch goes through here: the reference-order kernel when the batch asks for it
+static hipError_t launch_for(dftpav_batch *b, const DevBatch &D, int mode) {
+  if (b->order == DFTPAV_ORDER_REFERENCE) return launch_solver_ref(D, b->d_dev, mode, b->d_ref_tab, b->d_ref_scratch, b->h->stream);
+  return launch_solver(D, b->d_dev, mode, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, b->h->stream);
+}
+
+// The coefficient tables of the four substitution sweeps of BandedSystem::solve / solveAdj (poly_traj_utils.hpp:805-852) for
+// a segment of N pieces, row-oriented: row i of a sweep takes tab[i][0..5] against its six predecessors in the order the
+// reference's column loops reach it (solver_ref.hip, sweep).  From the reference's own LU (banded_factorize, traj_math.h).
+//   [0] solve, forward:     L(i, i-6+k)      [1] solve, backward:    U(i, i+6-k), then / U(i,i)
+//   [2] solveAdj, forward:  U(i-6+k, i), then / U(i,i)               [3] solveAdj, backward: L(i+6-k, i)
+//   then (U(i,i), 1 / U(i,i)) per row
+static void reference_order_tables(int N, std::vector<double> &out) {
+  const int n6 = 6 * N;
+  std::vector<double> band((size_t)n6 * 13, 0.0);
+  BandedLU A{n6, 6, 6, band.data()};
+  minco_fill(A, N);
+  banded_factorize(A);
+  out.assign(reference_order_table_doubles(N), 0.0);
+  double *t0 = out.data(), *t1 = t0 + 6 * (size_t)n6, *t2 = t1 + 6 * (size_t)n6, *t3 = t2 + 6 * (size_t)n6, *dg = t3 + 6 * (size_t)n6;
+  for (int i = 0; i < n6; i++) {
+    for (int k = 0; k < 6; k++) {
+      const int jl = i - 6 + k, jh = i + 6 - k;
+      if (jl >= 0) {
+        t0[6 * i + k] = A.at(i, jl);
+        t2[6 * i + k] = A.at(jl, i);
+      }
+      if (jh <= n6 - 1) {
+        t1[6 * i + k] = A.at(i, jh);
+        t3[6 * i + k] = A.at(jh, i);
+      }
+    }
+    dg[2 * i] = A.at(i, i);
+    dg[2 * i + 1] = 1.0 / A.at(i, i);
+  }
+}
+
+extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
+  if (!b || (order != DFTPAV_ORDER_DEVICE && order != DFTPAV_ORDER_REFERENCE)) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (order == b->order) return DFTPAV_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_pending(b)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (order == DFTPAV_ORDER_REFERENCE) {
+    if (!reference_order_supported(b->L, b->P, h->S)) {
+      h->err = "reference order: one gear segment, no moving obstacles, n <= 64, H <= 5 (libm inside the loop otherwise)";
+      return DFTPAV_E_UNSUPPORTED;
+    }
+    if (!b->d_ref_tab) {
+      std::vector<double> tab;
+      reference_order_tables(b->L.piece_nums[0], tab);
+      HIPCHK(h, hipMalloc(&b->d_ref_tab, sizeof(double) * tab.size()));
+      HIPCHK(h, hipMemcpy(b->d_ref_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+      HIPCHK(h, hipMalloc(&b->d_ref_scratch, sizeof(double) * reference_order_scratch_doubles(b->L, b->B)));
+    }
+  }
+  b->order = order;
+  b->solved = false;
+  return DFTPAV_OK;
+}
+extern "C" int dftpav_batch_get_order(const dftpav_batch *b) { return b ? b->order : DFTPAV_E_INVALID; }
+
 extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g) {
   if (!b || !x || !b->uploaded || !b->have_corridor) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
@@ -1405,7 +1477,7 @@ extern "C" int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, do
   HIPCHK(h, hipMemcpyAsync(b->d_x_in, x, sizeof(double) * nb, hipMemcpyHostToDevice, h->stream));
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeEval, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  HIPCHK(h, launch_for(b, D, kModeEval));
   if (f) HIPCHK(h, hipMemcpyAsync(f, b->d_f_eval, sizeof(double) * b->B, hipMemcpyDeviceToHost, h->stream));
   if (g) HIPCHK(h, hipMemcpyAsync(g, b->d_g, sizeof(double) * nb, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1464,7 +1536,13 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
-  if (!b->sched) {
+  if (b->order == DFTPAV_ORDER_REFERENCE) {
+    if (h->S > 0) { // obstacles were installed after the order was chosen
+      h->err = "reference order: no moving obstacles";
+      return DFTPAV_E_UNSUPPORTED;
+    }
+    HIPCHK(h, launch_for(b, D, kModeSolve)); // one workgroup per trajectory, no scheduling: the verification / latency mode
+  } else if (!b->sched) {
     HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, h->stream));
   } else {
     // queue = all trajectories, flags cleared, counters reset: device-to-device, nothing waits on the host
@@ -1596,7 +1674,7 @@ extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piec
   if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  HIPCHK(h, launch_for(b, D, kModeCoeffs));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (coeffs)
     HIPCHK(h, hipMemcpy(coeffs, b->d_coef, sizeof(double) * (size_t)b->B * 12 * b->L.Ntot, hipMemcpyDeviceToHost));
@@ -1613,7 +1691,7 @@ extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double v
   if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  HIPCHK(h, launch_for(b, D, kModeCoeffs));
   // the two running sums of the reference, tabulated: sample times (traj_server_ros.cpp:387) and the spacing of the
   // outline points (shapes.cc:128)
   std::vector<double> tt, vv;
@@ -1663,7 +1741,7 @@ extern "C" int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sam
   if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  HIPCHK(h, launch_for(b, D, kModeCoeffs));
   double *d_states = nullptr;
   int *d_valid = nullptr;
   int rc = DFTPAV_OK;
@@ -1740,7 +1818,7 @@ extern "C" int dftpav_plan_cycle(dftpav_batch *b, const dftpav_batch_data *d, co
   if (int rc = solve_impl(b, nullptr, false)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_solver(D, b->d_dev, kModeCoeffs, b->threads, b->B, SchedArgs{0, 0, 0}, h->stream));
+  HIPCHK(h, launch_for(b, D, kModeCoeffs));
   // the two running sums of the reference, tabulated (as dftpav_batch_validate)
   pc.tt.clear();
   pc.vv.clear();

@@ -1,0 +1,1069 @@
+// solver_ref.hip — the solve path in the REFERENCE'S OWN floating-point order (gfx950).
+//
+// solver.hip reassociates three things of the reference to run fast: the per-piece sums of the penalty gradient (cross-lane
+// trees), the MINCO solves (dense operator instead of the banded substitution) and the dot products of L-BFGS (butterflies,
+// blocked two-loop recursion).  Its results therefore equal the reference's only to rounding per evaluation, and the solver
+// being chaotic whole solves equal the reference's only statistically.  This kernel keeps every sum in the
+// order the reference executes it, so that a whole solve -- final x, cost, status, iterations, evaluations -- has the
+// reference's BITS (tests/test_gpu_reference_order.py compares with oracle/_ref, the reference's sources compiled here):
+//
+//   * MinJerkOpt::generate / calGrads_PT: the banded forward / backward substitutions of BandedSystem::solve / solveAdj
+//     (poly_traj_utils.hpp:805-852) row by row, each row's updates in the reference's order (a row is the unit: its six
+//     multiply-subtract pairs are those the reference's column loops apply to it, in that order);
+//   * addPVAGradCost2CT (traj_optimizer.cpp:486-705): every constraint point is evaluated by its own lane, term by term
+//     (vertex x half-plane, velocity, acceleration, curvature left / right) exactly as written; what an ACTIVE term adds to
+//     gdC (12 entries), gdT and the cost is parked in a record, and chain lanes -- one per (piece, entry), one for gdT, one
+//     per cost -- add the records in the reference's sample -> vertex -> plane order;
+//   * lbfgs_optimize / line_search_lewisoverton (lbfgs.hpp:276-390, 440-751): sequential dot products (the products are
+//     formed by the lanes, the sum is one chain from the first element) and the plain two-loop recursion (:716-739);
+//   * no fused multiply-add anywhere except inside a division by a stored reciprocal (div_by_rcp: the correctly rounded
+//     quotient, i.e. the bits of a / b); contraction is off for the file.
+//
+// Scope: one gear segment (M == 1), no moving obstacles, n <= 64 decision variables, H <= 5 half-planes per point.  With a
+// gear shift the reference calls libm's sin / cos inside the loop, with moving obstacles exp / log: glibc's results are not
+// correctly rounded and cannot be reproduced on the device without its tables, so those layouts stay with solver.hip
+// (DESIGN.md §2.5).  One workgroup per trajectory; this is a latency / verification mode, not the throughput path.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#include "device_types.h"
+
+namespace dftpav {
+namespace reford {
+
+// ------------------------------------------------------------------ helpers
+typedef double __attribute__((address_space(3))) *ldsd_t;
+typedef const double __attribute__((address_space(3))) *ldscd_t;
+typedef int __attribute__((address_space(3))) *ldsi_t;
+typedef const double __attribute__((address_space(1))) *gcd_t;
+typedef double __attribute__((address_space(1))) *gd_t;
+
+// a / b from y = 1 / b (Markstein): the correctly rounded quotient, i.e. the bits of a / b (solver.hip: checked on 2^31
+// pairs on gfx950 against the division)
+__device__ __forceinline__ double div_by_rcp(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, y, q0);
+}
+template <int CTRL> __device__ __forceinline__ double mov_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// max over the 64 lanes (order-free: the maximum has no rounding), the same value in every lane
+__device__ __forceinline__ double wave_max64(double v) {
+  v = fmax(v, mov_dpp<0xB1>(v));
+  v = fmax(v, mov_dpp<0x4E>(v));
+  v = fmax(v, mov_dpp<0x141>(v));
+  v = fmax(v, mov_dpp<0x140>(v));
+  {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+  }
+  {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+  }
+  int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// scalar solver state (as solver.hip keeps it)
+enum { sFX = 0, sFINIT, sDGINIT, sDGTEST, sDSTEST, sMU, sNU, sSTP, sSTEP, sF, sPF0 /* ..+7 */, sGDT = 18, sCOST0, sCOST2, sENERGY, sNUM = 24 };
+enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iNUM = 16 };
+enum { kActEval = 0, kActDone = 1 };
+
+constexpr int kRec = 16;        // doubles per term record: 12 entries of gdC, gdT, cost, 2 unused
+constexpr int kListCap = 4096;  // active terms chained per window
+
+struct Sm {
+  ldsd_t x, xp, g, gp, d;   // [npad]
+  ldsd_t bnd;               // [12] iniS, finS
+  ldsd_t seg;               // [16] 0:T 1:dt 2..7:t^k 8..13:t^-k
+  ldsd_t spow;              // [2][Kmax+1] the running sample offsets (s1 += step) for K and Kd
+  ldsd_t b, c, gdC, adj;    // [6N][2]
+  ldsd_t pE, pG, pA;        // [N] per-piece energy, d(energy)/dT, chain-rule term of calGrads_PT
+  ldsd_t tab;               // [4][6N][6] coefficients of the four substitution sweeps, then [6N][2] (diagonal, 1 / diagonal)
+  ldsd_t dot;               // [4][64] products of up to four sequential dot products
+  ldsd_t alpha;             // [mem]
+  ldsd_t st;                // [sNUM]
+  ldsi_t ist;               // [iNUM]
+  ldsi_t pmask;             // [Npts] active terms of a constraint point (bit t = term t)
+  ldsi_t pfirst;            // [Npts + 1] index of a point's first active term in (point, term) order
+  ldsi_t list;              // [kListCap] (point << 5 | term) of the active terms of the current window
+};
+
+__host__ __device__ inline size_t lds_doubles(const DevLayout &L, int mem) {
+  const int N = L.piece_nums[0];
+  return 5 * (size_t)L.npad + 12 + 16 + 2 * (size_t)(L.Kmax + 1) + 4 * 12 * (size_t)N + 3 * (size_t)N + (size_t)(4 * 36 + 12) * N + 4 * 64 +
+         (size_t)mem + sNUM;
+}
+__host__ __device__ inline size_t lds_ints(const DevLayout &L) { return iNUM + 2 * (size_t)L.Npts + 1 + kListCap; }
+
+__device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
+  const int N = L.piece_nums[0];
+  ldsd_t p = (ldsd_t)base;
+  s.x = p; p += L.npad;
+  s.xp = p; p += L.npad;
+  s.g = p; p += L.npad;
+  s.gp = p; p += L.npad;
+  s.d = p; p += L.npad;
+  s.bnd = p; p += 12;
+  s.seg = p; p += 16;
+  s.spow = p; p += 2 * (L.Kmax + 1);
+  s.b = p; p += 12 * N;
+  s.c = p; p += 12 * N;
+  s.gdC = p; p += 12 * N;
+  s.adj = p; p += 12 * N;
+  s.pE = p; p += N;
+  s.pG = p; p += N;
+  s.pA = p; p += N;
+  s.tab = p; p += (4 * 36 + 12) * N;
+  s.dot = p; p += 4 * 64;
+  s.alpha = p; p += mem;
+  s.st = p; p += sNUM;
+  ldsi_t q = (ldsi_t)p;
+  s.ist = q; q += iNUM;
+  s.pmask = q; q += L.Npts;
+  s.pfirst = q; q += L.Npts + 1;
+  s.list = q;
+}
+
+// One lane, one dimension: a substitution sweep over the 6N rows of the band system, row by row.  Row i (ascending
+// sweeps: i = 0, 1, ...; descending: i = 6N-1, ...) takes its six updates  acc -= tab[i][k] * b[row k of its window]  in
+// the order the reference's column loops apply them to it (k = 0..5; ascending: rows i-6 .. i-1, descending: rows i+6 ..
+// i+1), skipping exact zeros as the reference does (`if (a != 0.0)`), then -- DIV -- divides by the diagonal.  The six
+// previous results live in registers (rows are taken six at a time, so the window is indexed statically).
+template <bool DESC, bool DIV>
+__device__ __forceinline__ void sweep(ldscd_t tab, ldscd_t dg, ldsd_t b, int n6, int d) {
+  double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i0 = 0; i0 < n6; i0 += 6) {
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
+      ldscd_t a = tab + 6 * i;
+      double acc = b[2 * i + d];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const double ak = a[k];
+        const double t = ak * w[(r + k) % 6];
+        acc = ak != 0.0 ? acc - t : acc;
+      }
+      if (DIV) acc = div_by_rcp(acc, dg[2 * i], dg[2 * i + 1]);
+      w[r] = acc;
+      b[2 * i + d] = acc;
+    }
+  }
+}
+
+// positiveSmoothedL1, traj_optimizer.cpp:783-806
+__device__ __forceinline__ void smoothed_l1(double x, double &f, double &df) {
+  const double pe = 1.0e-4;
+  const double half = 0.5 * pe;
+  const double f3c = 1.0 / (pe * pe);
+  const double f4c = -0.5 * f3c / pe;
+  const double d2c = 3.0 * f3c;
+  const double d3c = 4.0 * f4c;
+  if (x < pe) {
+    f = (f4c * x + f3c) * x * x * x;
+    df = (d3c * x + d2c) * x * x;
+  } else {
+    f = x - half;
+    df = 1.0;
+  }
+}
+
+// ------------------------------------------------ one constraint point (traj_optimizer.cpp:499-705)
+// Point j of piece i (K intervals, offset s1 = the running sum of traj_optimizer.cpp:513, taken from the table).  Writes a
+// record for every active term and returns the mask of active terms.  cor: &corridor[b][0][pt] (component-major, pitch
+// NptsPad); rec: &scratch[pt][0][0].
+__device__ __noinline__ unsigned point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
+                                             int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec) {
+  double cc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) cc[k] = cc_[k];
+  const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+  const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  const double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+  const double beta3[6] = {0.0, 0.0, 0.0, 6.0, 24.0 * s1, 60.0 * s2};
+  const double alpha = 1.0 / K * j;
+  double sigma[2] = {0, 0}, dsigma[2] = {0, 0}, ddsigma[2] = {0, 0}, dddsigma[2] = {0, 0};
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      sigma[d] += cc[2 * k + d] * beta0[k];
+      dsigma[d] += cc[2 * k + d] * beta1[k];
+      ddsigma[d] += cc[2 * k + d] * beta2[k];
+      dddsigma[d] += cc[2 * k + d] * beta3[k];
+    }
+  const double omg = (j == 0 || j == K) ? 0.5 : 1.0;
+  double z_h0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
+  const double z_h1 = ddsigma[0] * dsigma[0] + ddsigma[1] * dsigma[1];
+  const double z_h2 = dddsigma[0] * dsigma[0] + dddsigma[1] * dsigma[1];
+  const double z_h3 = ddsigma[1] * dsigma[0] + (-ddsigma[0]) * dsigma[1];  // ddsigma^T B_h dsigma, :529
+  const double z1 = dddsigma[1] * dsigma[0] + (-dddsigma[0]) * dsigma[1];  // :538
+  if (z_h0 < 1e-4 || (j == 0 && i == 0) || (i == N - 1 && j == K)) return 0u; // :550-553
+
+  const double max_vel = singul_ > 0 ? P.max_vel[0] : P.max_vel[1];
+  const double max_acc = singul_ > 0 ? P.max_acc[0] : P.max_acc[1];
+  const double max_cur = singul_ > 0 ? P.max_cur[0] : P.max_cur[1];
+  const double sg = (double)singul_;
+
+  const double vel2_reci = 1.0 / (z_h0 * z_h0);
+  const double vel2_reci_e = 1.0 / (z_h0 * z_h0 + epis);
+  const double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);
+  z_h0 = 1.0 / z_h0;
+  const double z_h4 = z_h1 * vel2_reci;
+  const double violaVel = 1.0 / vel2_reci - max_vel * max_vel;
+  const double acc2 = z_h1 * z_h1 * vel2_reci;
+  const double cur = z_h3 * vel3_2_reci_e;
+  const double violaAcc = acc2 - max_acc * max_acc;
+  const double violaCurL = cur - max_cur;
+  const double violaCurR = -cur - max_cur;
+
+  const double ego_R[4] = {sg * dsigma[0] * z_h0, sg * -dsigma[1] * z_h0, sg * dsigma[1] * z_h0, sg * dsigma[0] * z_h0}; // :581-583
+  const double temp_a[4] = {ddsigma[0], -ddsigma[1], ddsigma[1], ddsigma[0]};
+  const double temp_v[4] = {dsigma[0], -dsigma[1], dsigma[1], dsigma[0]};
+  double R_dot[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) R_dot[k] = sg * (temp_a[k] * z_h0 - temp_v[k] * vel2_reci * z_h0 * z_h1);
+
+  unsigned mask = 0u;
+  // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634
+#pragma unroll 1
+  for (int v = 0; v < 5; v++) {
+    const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
+    const double Rle0 = ego_R[0] * le0 + ego_R[1] * le1, Rle1 = ego_R[2] * le0 + ego_R[3] * le1;
+    const double bpt0 = sigma[0] + Rle0, bpt1 = sigma[1] + Rle1;
+    const double tl[4] = {le0, -le1, le1, le0};
+#pragma unroll 1
+    for (int k = 0; k < H; k++) {
+      const double on0 = cor[(size_t)(4 * k + 0) * pitch], on1 = cor[(size_t)(4 * k + 1) * pitch];
+      const double q0 = cor[(size_t)(4 * k + 2) * pitch], q1 = cor[(size_t)(4 * k + 3) * pitch];
+      const double violaPos = on0 * (bpt0 - q0) + on1 * (bpt1 - q1);
+      if (violaPos > 0) {
+        double pena, penaD;
+        smoothed_l1(violaPos, pena, penaD);
+        double Mm[4];
+        Mm[0] = sg * tl[0] * z_h0 - Rle0 * dsigma[0] * vel2_reci;
+        Mm[1] = sg * tl[1] * z_h0 - Rle0 * dsigma[1] * vel2_reci;
+        Mm[2] = sg * tl[2] * z_h0 - Rle1 * dsigma[0] * vel2_reci;
+        Mm[3] = sg * tl[3] * z_h0 - Rle1 * dsigma[1] * vel2_reci;
+        const double w0 = dsigma[0] + (R_dot[0] * le0 + R_dot[1] * le1);
+        const double w1 = dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1);
+        const double gradViolaPt = (alpha * on0) * w0 + (alpha * on1) * w1;
+        const double sc = omg * step * P.wei_obs * penaD;
+        const int t = v * H + k;
+        gd_t r_ = rec + (size_t)t * kRec;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const double b1n0 = beta1[r] * on0, b1n1 = beta1[r] * on1;
+          const double g0 = beta0[r] * on0 + (b1n0 * Mm[0] + b1n1 * Mm[2]);
+          const double g1 = beta0[r] * on1 + (b1n0 * Mm[1] + b1n1 * Mm[3]);
+          r_[2 * r + 0] = sc * g0;
+          r_[2 * r + 1] = sc * g1;
+        }
+        r_[12] = omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
+        r_[13] = omg * step * P.wei_obs * pena;
+        mask |= 1u << t;
+      }
+    }
+  }
+  const int t0 = 5 * H;
+  if (violaVel > 0.0) { // :642-653
+    double pena, penaD;
+    smoothed_l1(violaVel, pena, penaD);
+    const double gradViolaVt = 2.0 * alpha * z_h1;
+    const double sc = omg * step * P.wei_feas * penaD;
+    gd_t r_ = rec + (size_t)t0 * kRec;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      r_[2 * r + 0] = sc * (2.0 * beta1[r] * dsigma[0]);
+      r_[2 * r + 1] = sc * (2.0 * beta1[r] * dsigma[1]);
+    }
+    r_[12] = omg * P.wei_feas * (penaD * gradViolaVt * step + pena / K);
+    r_[13] = omg * step * P.wei_feas * pena;
+    mask |= 1u << t0;
+  }
+  if (violaAcc > 0.0) { // :655-665
+    double pena, penaD;
+    smoothed_l1(violaAcc, pena, penaD);
+    const double u0 = z_h4 * ddsigma[0] - z_h4 * z_h4 * dsigma[0], u1 = z_h4 * ddsigma[1] - z_h4 * z_h4 * dsigma[1];
+    const double sqn = ddsigma[0] * ddsigma[0] + ddsigma[1] * ddsigma[1];
+    const double gradViolaAt = 2.0 * alpha * (z_h4 * (sqn + z_h2) - z_h4 * z_h4 * z_h1);
+    const double sc = omg * step * P.wei_feas * penaD;
+    gd_t r_ = rec + (size_t)(t0 + 1) * kRec;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      r_[2 * r + 0] = sc * (2.0 * beta1[r] * u0 + 2.0 * beta2[r] * z_h4 * dsigma[0]);
+      r_[2 * r + 1] = sc * (2.0 * beta1[r] * u1 + 2.0 * beta2[r] * z_h4 * dsigma[1]);
+    }
+    r_[12] = omg * P.wei_feas * (penaD * gradViolaAt * step + pena / K);
+    r_[13] = omg * step * P.wei_feas * pena;
+    mask |= 1u << (t0 + 1);
+  }
+  // ---- curvature, :684-705
+  const double ku0 = vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0];
+  const double ku1 = vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1];
+  const double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
+  if (violaCurL > 0.0) {
+    double pena, penaD;
+    smoothed_l1(violaCurL, pena, penaD);
+    const double sc = omg * step * P.wei_feas * 10.0 * penaD;
+    gd_t r_ = rec + (size_t)(t0 + 2) * kRec;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double kw0 = -((beta2[r] * vel3_2_reci_e) * dsigma[1]), kw1 = (beta2[r] * vel3_2_reci_e) * dsigma[0];
+      r_[2 * r + 0] = sc * (beta1[r] * ku0 + kw0);
+      r_[2 * r + 1] = sc * (beta1[r] * ku1 + kw1);
+    }
+    r_[12] = omg * P.wei_feas * 10.0 * (penaD * kt * step + pena / K);
+    r_[13] = omg * step * P.wei_feas * 10.0 * pena;
+    mask |= 1u << (t0 + 2);
+  }
+  if (violaCurR > 0.0) {
+    double pena, penaD;
+    smoothed_l1(violaCurR, pena, penaD);
+    const double sc = omg * step * P.wei_feas * 10.0 * penaD;
+    gd_t r_ = rec + (size_t)(t0 + 3) * kRec;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double kw0 = -((beta2[r] * vel3_2_reci_e) * dsigma[1]), kw1 = (beta2[r] * vel3_2_reci_e) * dsigma[0];
+      r_[2 * r + 0] = sc * -(beta1[r] * ku0 + kw0);
+      r_[2 * r + 1] = sc * -(beta1[r] * ku1 + kw1);
+    }
+    r_[12] = omg * P.wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
+    r_[13] = omg * step * P.wei_feas * 10.0 * pena;
+    mask |= 1u << (t0 + 3);
+  }
+  return mask;
+}
+
+// first constraint point of piece lp and its interval count: pieces are [Kd+1, K+1, ..., K+1, Kd+1] points long
+__device__ __forceinline__ int piece_pt0(const DevLayout &L, int lp) { return lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1); }
+__device__ __forceinline__ int piece_K(const DevLayout &L, int lp, int N) { return (lp == 0 || lp == N - 1) ? L.Kd : L.K; }
+
+// ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350), M == 1
+// x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].
+__device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g) {
+  const DevLayout &L = D.L;
+  const DevParams &P = D.P;
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int N = L.piece_nums[0], n6 = 6 * N, Npts = L.Npts, H = L.H, nterm = 5 * H + 4, Kmax1 = L.Kmax + 1;
+  const int singul_ = L.singuls[0];
+  ldscd_t iniS = sm.bnd, finS = sm.bnd + 6;
+
+  // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966), right-hand side (:968-977)
+  if (tid == 0) {
+    const double vt = x[L.x_tau0];
+    const double Tr = vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + P.mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + P.mini_T;
+    const double t1 = Tr / N, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+    sm.seg[0] = Tr;
+    sm.seg[1] = t1;
+    sm.seg[2] = 1.0; sm.seg[3] = t1; sm.seg[4] = t2; sm.seg[5] = t3; sm.seg[6] = t4; sm.seg[7] = t5;
+    sm.seg[8] = 1.0 / 1.0; sm.seg[9] = 1.0 / t1; sm.seg[10] = 1.0 / t2; sm.seg[11] = 1.0 / t3; sm.seg[12] = 1.0 / t4; sm.seg[13] = 1.0 / t5;
+  }
+  __syncthreads();
+  {
+    const double t1 = sm.seg[3], t2 = sm.seg[4];
+    for (int w = tid; w < 2 * n6; w += T) {
+      const int row = w >> 1, d = w & 1;
+      double v = 0.0;
+      if (row < 3) v = row == 0 ? iniS[d] : (row == 1 ? iniS[2 + d] * t1 : iniS[4 + d] * t2);
+      else if (row >= n6 - 3) v = row == n6 - 3 ? finS[d] : (row == n6 - 2 ? finS[2 + d] * t1 : finS[4 + d] * t2);
+      else if (row % 6 == 5) v = x[2 * (row / 6) + d];
+      sm.b[w] = v;
+    }
+  }
+  __syncthreads();
+  // ---- wave 0: BandedSystem::solve (poly_traj_utils.hpp:805-826), one lane per dimension; wave 1 (or wave 0 after it):
+  // the running sample offsets s1 += step (traj_optimizer.cpp:513), one lane per table
+  if (tid < 2) {
+    sweep<false, false>(sm.tab, sm.tab + 144 * N, sm.b, n6, tid);
+    sweep<true, true>(sm.tab + 36 * N, sm.tab + 144 * N, sm.b, n6, tid);
+  }
+  {
+    const int w0 = T > 64 ? 64 : 2;
+    if (tid >= w0 && tid < w0 + 2) {
+      const int which = tid - w0;
+      const int K = which ? L.Kd : L.K;
+      const double step = sm.seg[1] / K;
+      ldsd_t tab = sm.spow + which * Kmax1;
+      double s1 = 0.0;
+      for (int j = 0; j <= K; j++) {
+        tab[j] = s1;
+        s1 += step;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- c = b * tInv (:979-984)
+  for (int w = tid; w < 2 * n6; w += T) {
+    const int row = w >> 1;
+    sm.c[w] = sm.b[w] * sm.seg[8 + row % 6];
+  }
+  __syncthreads();
+  // ---- initSmGradCost / getTrajJerkCost per piece (poly_traj_utils.hpp:998-1035); the sums over the pieces are chained below
+  for (int i = tid; i < N; i += T) {
+    ldscd_t c = sm.c + 12 * i;
+    ldscd_t t = sm.seg + 2;
+    const double n33 = c[6] * c[6] + c[7] * c[7], n44 = c[8] * c[8] + c[9] * c[9], n55 = c[10] * c[10] + c[11] * c[11];
+    const double d43 = c[8] * c[6] + c[9] * c[7], d53 = c[10] * c[6] + c[11] * c[7], d54 = c[10] * c[8] + c[11] * c[9];
+    sm.pE[i] = 36.0 * n33 * t[1] + 144.0 * d43 * t[2] + 192.0 * n44 * t[3] + 240.0 * d53 * t[3] + 720.0 * d54 * t[4] + 720.0 * n55 * t[5];
+    sm.pG[i] = 36.0 * n33 + 288.0 * d43 * t[1] + 576.0 * n44 * t[2] + 720.0 * d53 * t[2] + 2880.0 * d54 * t[3] + 3600.0 * n55 * t[4];
+    ldsd_t gc = sm.gdC + 12 * i;
+    for (int d = 0; d < 2; d++) {
+      const double c3 = c[6 + d], c4 = c[8 + d], c5 = c[10 + d];
+      gc[10 + d] = 240.0 * c3 * t[3] + 720.0 * c4 * t[4] + 1440.0 * c5 * t[5];
+      gc[8 + d] = 144.0 * c3 * t[2] + 384.0 * c4 * t[3] + 720.0 * c5 * t[4];
+      gc[6 + d] = 72.0 * c3 * t[1] + 144.0 * c4 * t[2] + 240.0 * c5 * t[3];
+      gc[d] = 0.0;
+      gc[2 + d] = 0.0;
+      gc[4 + d] = 0.0;
+    }
+  }
+  // ---- the constraint points, each on a lane of its own
+  for (int pt = tid; pt < Npts; pt += T) {
+    // piece of the point: edge pieces hold Kd + 1 points, the others K + 1
+    int lp, j;
+    if (pt < L.Kd + 1) {
+      lp = 0;
+      j = pt;
+    } else {
+      const int q = pt - (L.Kd + 1);
+      lp = 1 + q / (L.K + 1);
+      j = q - (lp - 1) * (L.K + 1);
+      if (lp > N - 1) { // (only when N == 2: both pieces are edge pieces)
+        lp = N - 1;
+        j = pt - piece_pt0(L, lp);
+      }
+    }
+    const int K = piece_K(L, lp, N);
+    const bool edge = lp == 0 || lp == N - 1;
+    double cc[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * lp + k];
+    const double step = sm.seg[1] / K;
+    const double s1 = sm.spow[(edge ? 1 : 0) * Kmax1 + j];
+    sm.pmask[pt] = (int)point_terms(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
+                                    rec_b + (size_t)pt * nterm * kRec);
+  }
+  __threadfence_block(); // the records are read back by other threads of this workgroup
+  __syncthreads();
+  // ---- number the active terms in (point, term) order: exclusive prefix sum of the counts (wave 0)
+  if (tid < 64) {
+    const int per = (Npts + 63) >> 6, start = tid * per;
+    int sum = 0;
+    for (int i = start; i < start + per && i < Npts; i++) sum += __builtin_popcount((unsigned)sm.pmask[i]);
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      if (tid >= o) incl += up;
+    }
+    int run = incl - sum;
+    for (int i = start; i < start + per && i < Npts; i++) {
+      sm.pfirst[i] = run;
+      run += __builtin_popcount((unsigned)sm.pmask[i]);
+    }
+    if (tid == 63) sm.pfirst[Npts] = incl;
+  } else if (tid == 64 || (T <= 64 && tid == 0)) {
+    // gdT and the energy start from the sums over the pieces (`gdT +=`, `energy +=` in piece order, from 0.0)
+    double gdT = 0.0, en = 0.0;
+    for (int i = 0; i < N; i++) {
+      gdT += sm.pG[i];
+      en += sm.pE[i];
+    }
+    sm.st[sGDT] = gdT;
+    sm.st[sENERGY] = en;
+    sm.st[sCOST0] = 0.0;
+    sm.st[sCOST2] = 0.0;
+  }
+  if (T <= 64) { // (one-wave workgroups: the branch above could not run beside the prefix sum)
+    __syncthreads();
+    if (tid == 0) {
+      double gdT = 0.0, en = 0.0;
+      for (int i = 0; i < N; i++) {
+        gdT += sm.pG[i];
+        en += sm.pE[i];
+      }
+      sm.st[sGDT] = gdT;
+      sm.st[sENERGY] = en;
+      sm.st[sCOST0] = 0.0;
+      sm.st[sCOST2] = 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- chains: the active terms in windows of kListCap; lane (piece, entry) adds its piece's records in order, three more
+  // lanes walk all of them for gdT, the corridor cost and the feasibility cost
+  const int n_act = sm.pfirst[Npts];
+  const int n_chain = 12 * N + 3;
+  for (int c0 = 0; c0 < n_act; c0 += kListCap) {
+    const int c1 = c0 + kListCap < n_act ? c0 + kListCap : n_act;
+    for (int pt = tid; pt < Npts; pt += T) {
+      unsigned m = (unsigned)sm.pmask[pt];
+      int e = sm.pfirst[pt];
+      while (m) {
+        const int t = __builtin_ctz(m);
+        m &= m - 1;
+        if (e >= c0 && e < c1) sm.list[e - c0] = (pt << 5) | t;
+        e++;
+      }
+    }
+    __syncthreads();
+    for (int w = tid; w < n_chain; w += T) {
+      int e0, e1, q;
+      ldsd_t dst;
+      bool corridor_only = false, feas_only = false;
+      if (w < 12 * N) {
+        const int p = w / 12;
+        q = w - 12 * p;
+        const int pt0 = piece_pt0(L, p), pt1 = pt0 + piece_K(L, p, N) + 1;
+        e0 = sm.pfirst[pt0];
+        e1 = sm.pfirst[pt1];
+        dst = sm.gdC + w;
+      } else {
+        const int s = w - 12 * N;
+        e0 = 0;
+        e1 = n_act;
+        q = s == 0 ? 12 : 13;
+        dst = sm.st + (s == 0 ? sGDT : (s == 1 ? sCOST0 : sCOST2));
+        corridor_only = s == 1;
+        feas_only = s == 2;
+      }
+      e0 = e0 > c0 ? e0 : c0;
+      e1 = e1 < c1 ? e1 : c1;
+      if (e1 <= e0) continue;
+      double acc = *dst;
+      int e = e0;
+      for (; e + 8 <= e1; e += 8) {
+        int id[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) id[u] = sm.list[e + u - c0];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = rec_b[((size_t)(id[u] >> 5) * nterm + (id[u] & 31)) * kRec + q];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const bool cor_term = (id[u] & 31) < 5 * H;
+          const bool take = !(corridor_only && !cor_term) && !(feas_only && cor_term);
+          acc = take ? acc + v[u] : acc;
+        }
+      }
+      for (; e < e1; e++) {
+        const int id = sm.list[e - c0];
+        const double v = rec_b[((size_t)(id >> 5) * nterm + (id & 31)) * kRec + q];
+        const bool cor_term = (id & 31) < 5 * H;
+        const bool take = !(corridor_only && !cor_term) && !(feas_only && cor_term);
+        acc = take ? acc + v : acc;
+      }
+      *dst = acc;
+    }
+    __syncthreads();
+  }
+  // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
+  for (int w = tid; w < 2 * n6; w += T) {
+    const int row = w >> 1;
+    sm.adj[w] = sm.gdC[w] * sm.seg[8 + row % 6];
+  }
+  __syncthreads();
+  if (tid < 2) {
+    sweep<false, true>(sm.tab + 72 * N, sm.tab + 144 * N, sm.adj, n6, tid);
+    sweep<true, false>(sm.tab + 108 * N, sm.tab + 144 * N, sm.adj, n6, tid);
+  } else if (tid >= 64 && tid < 64 + N) { // the per-piece chain-rule terms (they only need gdC and b)
+    const int i = tid - 64;
+    ldscd_t tInv = sm.seg + 8;
+    const double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double gdcol = sm.gdC[12 * i + 2 * k] * sm.b[12 * i + 2 * k] + sm.gdC[12 * i + 2 * k + 1] * sm.b[12 * i + 2 * k + 1];
+      acc += gdtInv[k] * gdcol;
+    }
+    sm.pA[i] = acc;
+  }
+  __syncthreads();
+  if (T <= 64 + N) { // narrow workgroups: the branch above did not cover every piece
+    for (int i = tid; i < N; i += T) {
+      ldscd_t tInv = sm.seg + 8;
+      const double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const double gdcol = sm.gdC[12 * i + 2 * k] * sm.b[12 * i + 2 * k] + sm.gdC[12 * i + 2 * k + 1] * sm.b[12 * i + 2 * k + 1];
+        acc += gdtInv[k] * gdcol;
+      }
+      sm.pA[i] = acc;
+    }
+    __syncthreads();
+  }
+  // ---- gradient and cost (traj_optimizer.cpp:299-344)
+  for (int e = tid; e < 2 * (N - 1); e += T) g[e] = sm.adj[2 * (6 * (e >> 1) + 5) + (e & 1)]; // gdP
+  if (tid == 0) {
+    ldscd_t adj = sm.adj;
+    const double t1 = sm.seg[3];
+    double gdT = sm.st[sGDT];
+    gdT += iniS[2] * adj[2 * 1] + iniS[3] * adj[2 * 1 + 1];
+    gdT += (iniS[4] * adj[2 * 2] + iniS[5] * adj[2 * 2 + 1]) * 2.0 * t1;
+    gdT += finS[2] * adj[2 * (n6 - 2)] + finS[3] * adj[2 * (n6 - 2) + 1];
+    gdT += (finS[4] * adj[2 * (n6 - 1)] + finS[5] * adj[2 * (n6 - 1) + 1]) * 2.0 * t1;
+    for (int i = 0; i < N; i++) gdT += sm.pA[i];
+    // VirtualTGradCost, :405-419
+    const double VT = x[L.x_tau0], RT = sm.seg[0];
+    double gdVT2Rt;
+    if (VT > 0) {
+      gdVT2Rt = VT + 1.0;
+    } else {
+      const double denSqrt = (0.5 * VT - 1.0) * VT + 1.0;
+      gdVT2Rt = (1.0 - VT) / (denSqrt * denSqrt);
+    }
+    g[L.x_tau0] = (gdT / N + P.wei_time) * gdVT2Rt;
+    const double time_cost = RT * P.wei_time;
+    double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
+    total_smcost += sm.st[sENERGY];
+    penalty_cost += (sm.st[sCOST0] + 0.0) + sm.st[sCOST2];
+    total_timecost += time_cost;
+    sm.st[sF] = total_smcost + total_timecost + penalty_cost;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------ sequential sums on wave 0
+// The products sit one per lane (lanes >= n hold anything); the sum is the chain 0.0 + p[0] + p[1] + ... every lane forms
+// for itself from the LDS copy (broadcast reads), so all lanes end with the same bits.
+__device__ __forceinline__ double seq_sum(double p, int n, ldsd_t buf, int lane) {
+  buf[lane] = p;
+  __threadfence_block();
+  double s = 0.0;
+  int e = 0;
+  for (; e + 8 <= n; e += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = buf[e + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += v[u];
+  }
+  for (; e < n; e++) s += buf[e];
+  __threadfence_block(); // the buffer is free again
+  return s;
+}
+
+// Start of an outer iteration (lbfgs.hpp:559-574, 290-315): xp = x, gp = g, dginit = gp . d, first trial point
+__device__ __forceinline__ bool begin_iteration(const DevParams &P, const Sm &sm, int n, int lane) {
+  double pr = 0.0;
+  if (lane < n) {
+    sm.xp[lane] = sm.x[lane];
+    const double gv = sm.g[lane];
+    sm.gp[lane] = gv;
+    pr = gv * sm.d[lane];
+  }
+  const double dginit = seq_sum(pr, n, sm.dot, lane);
+  const double step = sm.st[sSTEP];
+  if (!(step > 0.0)) {
+    if (lane == 0) sm.ist[iRET] = -1006;
+    return false;
+  }
+  if (0.0 < dginit) {
+    if (lane == 0) sm.ist[iRET] = -1005;
+    return false;
+  }
+  if (lane == 0) {
+    sm.st[sFINIT] = sm.st[sFX];
+    sm.st[sDGINIT] = dginit;
+    sm.st[sDGTEST] = P.f_dec_coeff * dginit;
+    sm.st[sDSTEST] = P.s_curv_coeff * dginit;
+    sm.st[sMU] = 0.0;
+    sm.st[sNU] = P.max_step;
+    sm.st[sSTP] = step;
+    sm.ist[iCOUNT] = 0;
+    sm.ist[iBRACKT] = 0;
+    sm.ist[iTOUCHED] = 0;
+  }
+  if (lane < n) sm.x[lane] = sm.xp[lane] + step * sm.d[lane];
+  return true;
+}
+
+// Everything lbfgs_optimize does between two evaluations (lbfgs.hpp:524-745 with the line search of :312-389 unrolled into
+// it), on wave 0, one decision variable per lane (n <= 64); sets iACTION.
+__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, gd_t hS, gd_t hR, int lane) {
+  const DevParams &P = D.P;
+  const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
+  const double f = sm.st[sF];
+  int action = kActEval;
+  if (sm.ist[iPHASE] == 0) { // after the first evaluation: lbfgs.hpp:524-551
+    double gv = 0.0, xv = 0.0;
+    if (lane < n) {
+      gv = sm.g[lane];
+      xv = sm.x[lane];
+      sm.d[lane] = -gv;
+    }
+    const double gmax = wave_max64(lane < n ? fabs(gv) : 0.0), xmax = wave_max64(lane < n ? fabs(xv) : 0.0);
+    const double dd = seq_sum((-gv) * (-gv), n, sm.dot, lane);
+    if (lane == 0) {
+      sm.st[sFX] = f;
+      sm.st[sPF0] = f;
+      sm.ist[iEVALS] = 1;
+      sm.ist[iEND] = 0;
+      sm.ist[iBOUND] = 0;
+      sm.ist[iHISTLO] = 0;
+      sm.ist[iHISTHI] = 0;
+      sm.ist[iPHASE] = 1;
+    }
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      if (lane == 0) {
+        sm.ist[iRET] = 0;
+        sm.ist[iK] = 0;
+      }
+      action = kActDone;
+    } else {
+      if (lane == 0) {
+        sm.st[sSTEP] = 1.0 / sqrt(dd);
+        sm.ist[iK] = 1;
+      }
+      __threadfence_block();
+      if (!begin_iteration(P, sm, n, lane)) action = kActDone;
+    }
+    if (lane == 0) sm.ist[iACTION] = action;
+    return;
+  }
+
+  // ---- after a line-search trial: lbfgs.hpp:317-389
+  const double fx = f;
+  const double finit = sm.st[sFINIT];
+  double stp = sm.st[sSTP];
+  const int count = sm.ist[iCOUNT] + 1;
+  int ls = 0;
+  bool decided = false;
+  const int evals_before = sm.ist[iEVALS];
+  __threadfence_block();
+  if (lane == 0) {
+    sm.st[sFX] = fx;
+    sm.ist[iEVALS] = evals_before + 1;
+    sm.ist[iCOUNT] = count;
+  }
+  if (isinf(fx) || isnan(fx)) {
+    ls = -1012;
+    decided = true;
+  } else if (P.past > 0 && fabs(finit - fx) / (fabs(finit) + 1.0) < P.delta / P.past) { // lbfgs.hpp:326-329
+    ls = count;
+    decided = true;
+  } else {
+    double mu = sm.st[sMU], nu = sm.st[sNU];
+    bool brackt = sm.ist[iBRACKT] != 0;
+    const int touched = sm.ist[iTOUCHED];
+    if (fx > finit + stp * sm.st[sDGTEST]) {
+      nu = stp;
+      brackt = true;
+    } else {
+      const double gs = seq_sum(lane < n ? sm.g[lane] * sm.d[lane] : 0.0, n, sm.dot, lane);
+      if (gs < sm.st[sDSTEST]) {
+        mu = stp;
+      } else {
+        ls = count;
+        decided = true;
+      }
+    }
+    bool touch_now = false;
+    if (!decided) {
+      if (P.max_linesearch <= count) {
+        ls = -1009;
+        decided = true;
+      } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+        ls = -1007;
+        decided = true;
+      } else {
+        if (brackt) stp = 0.5 * (mu + nu);
+        else stp *= 2.0;
+        if (stp < P.min_step) {
+          ls = -1011;
+          decided = true;
+        } else if (stp > P.max_step) {
+          if (touched) {
+            ls = -1010;
+            decided = true;
+          } else {
+            touch_now = true;
+            stp = P.max_step;
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    if (lane == 0) {
+      sm.st[sMU] = mu;
+      sm.st[sNU] = nu;
+      sm.ist[iBRACKT] = brackt ? 1 : 0;
+      sm.st[sSTP] = stp;
+      if (touch_now) sm.ist[iTOUCHED] = 1;
+    }
+    if (!decided) {
+      if (lane < n) sm.x[lane] = sm.xp[lane] + stp * sm.d[lane];
+      if (lane == 0) sm.ist[iACTION] = kActEval;
+      return;
+    }
+  }
+  if (lane == 0) sm.st[sSTEP] = stp; // lbfgs.hpp:574 passes `step` by reference
+  if (ls < 0) { // lbfgs.hpp:604-611: x, g reverted; fx is not
+    if (lane < n) {
+      sm.x[lane] = sm.xp[lane];
+      sm.g[lane] = sm.gp[lane];
+    }
+    if (lane == 0) {
+      sm.ist[iRET] = ls;
+      sm.ist[iACTION] = kActDone;
+    }
+    return;
+  }
+
+  // ---- convergence / stopping tests (lbfgs.hpp:628-666)
+  int k = sm.ist[iK];
+  {
+    const double gmax = wave_max64(lane < n ? fabs(sm.g[lane]) : 0.0), xmax = wave_max64(lane < n ? fabs(sm.x[lane]) : 0.0);
+    const int kGoOn = 12345;
+    int ret = kGoOn;
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      ret = 0;
+    } else {
+      if (0 < P.past) {
+        const int slot = k % P.past;
+        const double pf = sm.st[sPF0 + slot];
+        __threadfence_block();
+        if (P.past <= k) {
+          const double rate = fabs(pf - fx) / fmax(1.0, fabs(fx));
+          if (rate < P.delta) ret = 1;
+        }
+        if (ret == kGoOn && lane == 0) sm.st[sPF0 + slot] = fx;
+      }
+      if (ret == kGoOn && P.max_iterations != 0 && P.max_iterations <= k) ret = -1008;
+    }
+    if (ret != kGoOn) {
+      if (lane == 0) {
+        sm.ist[iRET] = ret;
+        sm.ist[iACTION] = kActDone;
+      }
+      return;
+    }
+  }
+  ++k;
+  const int end = sm.ist[iEND];
+  int bound = sm.ist[iBOUND];
+  __threadfence_block();
+  if (lane == 0) sm.ist[iK] = k;
+
+  // ---- history update + two-loop recursion (lbfgs.hpp:676-740); (s, y) interleaved per element as solver.hip stores them
+  typedef double __attribute__((ext_vector_type(2))) d2_t;
+  typedef const d2_t __attribute__((address_space(1))) *gcd2_t;
+  typedef d2_t __attribute__((address_space(1))) *gd2_t;
+  double sv = 0.0, yv = 0.0, gpv = 0.0;
+  if (lane < n) {
+    sv = sm.x[lane] - sm.xp[lane];
+    yv = sm.g[lane] - sm.gp[lane];
+    gpv = sm.gp[lane];
+    d2_t sy;
+    sy.x = sv;
+    sy.y = yv;
+    ((gd2_t)hS)[(size_t)end * npad + lane] = sy;
+    sm.d[lane] = -sm.g[lane];
+  }
+  // the four dot products of lbfgs.hpp:683-694, their chains side by side
+  double ys, yy, ss, gpgp;
+  {
+    sm.dot[lane] = yv * sv;
+    sm.dot[64 + lane] = yv * yv;
+    sm.dot[128 + lane] = sv * sv;
+    sm.dot[192 + lane] = gpv * gpv;
+    __threadfence_block();
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int e = 0; e < n; e++) {
+      a0 += sm.dot[e];
+      a1 += sm.dot[64 + e];
+      a2 += sm.dot[128 + e];
+      a3 += sm.dot[192 + e];
+    }
+    __threadfence_block();
+    ys = a0; yy = a1; ss = a2; gpgp = a3;
+  }
+  if (lane == 0) {
+    d2_t yr;
+    yr.x = ys;
+    yr.y = 1.0 / ys;
+    ((gd2_t)hR)[end] = yr;
+  }
+  const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+  if (ys > cau) {
+    ++bound;
+    bound = m < bound ? m : bound;
+    const int ne = end + 1 == m ? 0 : end + 1;
+    __threadfence_block(); // lane 0's (ys, 1 / ys) of the newest pair is read by every lane below
+    double dreg = lane < n ? -sm.g[lane] : 0.0;
+    const int ln = lane < n ? lane : 0;
+    int j = ne;
+    // first loop: newest -> oldest.  The (s, y) rows and (ys, 1 / ys) of the next steps are requested ahead of the chain.
+    constexpr int PF = 4;
+    d2_t ring[PF], rr[PF];
+    {
+      int jj = j;
+      for (int u = 0; u < PF; u++) {
+        jj = jj == 0 ? m - 1 : jj - 1;
+        ring[u] = ((gcd2_t)hS)[(size_t)jj * npad + ln];
+        rr[u] = ((gcd2_t)hR)[jj];
+      }
+    }
+    int jpf = j; // slot the ring's next refill comes from
+    for (int u = 0; u < PF; u++) jpf = jpf == 0 ? m - 1 : jpf - 1;
+    for (int i0 = 0; i0 < bound; i0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        if (i0 + u < bound) { // uniform
+          j = j == 0 ? m - 1 : j - 1;
+          const d2_t sy = ring[u], yr = rr[u];
+          jpf = jpf == 0 ? m - 1 : jpf - 1;
+          ring[u] = ((gcd2_t)hS)[(size_t)jpf * npad + ln];
+          rr[u] = ((gcd2_t)hR)[jpf];
+          const double dot = seq_sum(lane < n ? sy.x * dreg : 0.0, n, sm.dot, lane);
+          const double a = div_by_rcp(dot, yr.x, yr.y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
+          if (lane == 0) sm.alpha[j] = a;
+          const double na = -a;
+          dreg = dreg + na * sy.y; // d += (-alpha) * lm_y.col(j)
+        }
+      }
+    }
+    const double sc0 = ys / yy;
+    dreg = dreg * sc0;
+    __threadfence_block(); // alpha written by lane 0, read by all below
+    // second loop: oldest -> newest, from the slot the first loop ended on
+    {
+      int jj = j;
+      for (int u = 0; u < PF; u++) {
+        ring[u] = ((gcd2_t)hS)[(size_t)jj * npad + ln];
+        rr[u] = ((gcd2_t)hR)[jj];
+        jj = jj == m - 1 ? 0 : jj + 1;
+      }
+      jpf = jj;
+    }
+    for (int i0 = 0; i0 < bound; i0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        if (i0 + u < bound) { // uniform
+          const d2_t sy = ring[u], yr = rr[u];
+          ring[u] = ((gcd2_t)hS)[(size_t)jpf * npad + ln];
+          rr[u] = ((gcd2_t)hR)[jpf];
+          jpf = jpf == m - 1 ? 0 : jpf + 1;
+          const double al = sm.alpha[j];
+          const double dot = seq_sum(lane < n ? sy.y * dreg : 0.0, n, sm.dot, lane);
+          const double beta = div_by_rcp(dot, yr.x, yr.y);
+          const double cf = al - beta;
+          dreg = dreg + cf * sy.x; // d += (alpha - beta) * lm_s.col(j)
+          j = j == m - 1 ? 0 : j + 1;
+        }
+      }
+    }
+    if (lane < n) sm.d[lane] = dreg;
+    if (lane == 0) {
+      sm.ist[iEND] = ne;
+      sm.ist[iBOUND] = bound;
+      long long hs = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+      hs += bound;
+      sm.ist[iHISTLO] = (int)(hs & 0xffffffffLL);
+      sm.ist[iHISTHI] = (int)(hs >> 32);
+    }
+  }
+  if (lane == 0) sm.st[sSTEP] = 1.0; // lbfgs.hpp:743
+  __threadfence_block();
+  const bool ok = begin_iteration(P, sm, n, lane);
+  if (lane == 0) sm.ist[iACTION] = ok ? kActEval : kActDone;
+}
+
+// ------------------------------------------------ the kernel
+__global__ void __launch_bounds__(256) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
+  extern __shared__ double lds_raw[];
+  const DevBatch &D = *Dp;
+  const DevLayout &L = D.L;
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
+  const int n = L.n, N = L.piece_nums[0], b = blockIdx.x;
+  Sm sm;
+  carve(sm, lds_raw, L, D.P.mem_size);
+  for (int i = tid; i < (4 * 36 + 12) * N; i += T) sm.tab[i] = tabs[i];
+  for (int e = tid; e < L.npad; e += T) {
+    const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
+    sm.x[e] = e < n ? xsrc[(size_t)b * n + e] : 0.0;
+    sm.xp[e] = 0.0;
+    sm.g[e] = 0.0;
+    sm.gp[e] = 0.0;
+    sm.d[e] = 0.0;
+  }
+  if (tid < iNUM) sm.ist[tid] = 0;
+  if (tid < 12) sm.bnd[tid] = tid < 6 ? D.iniS[(size_t)b * 6 + tid] : D.finS[(size_t)b * 6 + (tid - 6)];
+  const gcd_t cor_b = (gcd_t)(D.corridor + (size_t)b * L.H * 4 * D.NptsPad);
+  const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * (5 * L.H + 4) * kRec);
+  const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
+  const gd_t hR = (gd_t)(D.histR + (size_t)b * D.P.mem_size * 2);
+  const long long tick0 = wall_clock64();
+  __syncthreads();
+
+  ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g);
+
+  if (mode == kModeEval) {
+    for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
+    if (tid == 0) D.f_eval[b] = sm.st[sF];
+    return;
+  }
+  if (mode == kModeCoeffs) {
+    for (int w = tid; w < 12 * N; w += T) D.coef_out[(size_t)b * 12 * N + w] = sm.c[w];
+    if (tid == 0) D.dt_out[b] = sm.seg[1];
+    return;
+  }
+  while (true) {
+    if (tid < 64) lbfgs_advance(D, sm, hS, hR, lane);
+    __syncthreads();
+    if (sm.ist[iACTION] == kActDone) break;
+    ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g);
+  }
+  for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
+  if (tid == 0) {
+    const double fx = sm.st[sFX];
+    const int ret = sm.ist[iRET];
+    D.f_out[b] = fx;
+    D.status[b] = ret;
+    D.iters[b] = sm.ist[iK];
+    D.evals[b] = sm.ist[iEVALS];
+    D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+    D.ticks[b] = wall_clock64() - tick0;
+    int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
+    if (fx >= D.P.fail_cost) ok = 0;
+    D.success[b] = ok;
+  }
+}
+
+} // namespace reford
+
+// ---- host side
+// what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
+bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
+  if (S > 0 || L.M != 1 || L.n > 64 || L.H > 5 || L.piece_nums[0] < 2) return false;
+  const size_t lds = reford::lds_doubles(L, P.mem_size) * sizeof(double) + reford::lds_ints(L) * sizeof(int);
+  return lds <= 160 * 1024 - 1024;
+}
+// doubles of term records a batch of B trajectories needs
+size_t reference_order_scratch_doubles(const DevLayout &L, int B) { return (size_t)B * L.Npts * (5 * L.H + 4) * reford::kRec; }
+// doubles of the sweep tables of a segment of N pieces
+size_t reference_order_table_doubles(int N) { return (size_t)(4 * 36 + 12) * N; }
+
+hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream) {
+  const size_t lds = reford::lds_doubles(D.L, D.P.mem_size) * sizeof(double) + reford::lds_ints(D.L) * sizeof(int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reford::ref_kernel, dim3(D.B), dim3(256), lds, stream, d_dev, mode, tabs, scratch);
+  return hipGetLastError();
+}
+
+} // namespace dftpav

@@ -168,9 +168,11 @@ const char *dftpav_last_error(const dftpav_handle *h);
 /* Replaces setSurroundTrajs (traj_optimizer.h:108). s==NULL or s->S==0 clears
  * it (surround_trajs_ == NULL, traj_optimizer.cpp:636). Data is copied.
  * Limits (the reference loops over surround_trajs_->size() without one): at most DFTPAV_MAX_SURROUND obstacles with
- * DFTPAV_MAX_SURROUND_PIECES pieces in all -- a larger set is refused here (DFTPAV_E_UNSUPPORTED, the installed set is
- * kept), also by dftpav_fit_surround and dftpav_set_surround_wire; and (constraint points of the layout) x S <= 65535,
- * which only a solve / eval / validation of a batch can check (DFTPAV_E_UNSUPPORTED there). */
+ * DFTPAV_MAX_SURROUND_PIECES pieces in all -- a larger set is refused here and by dftpav_set_surround_wire
+ * (DFTPAV_E_UNSUPPORTED, the installed set is kept); and (constraint points of the layout) x S <= 65535, which only a
+ * solve / eval / validation of a batch can check (DFTPAV_E_UNSUPPORTED there).  dftpav_fit_surround fits and installs
+ * a set of any size (its result can be read back with dftpav_get_surround); beyond the limits above the solver refuses
+ * it in the same way. */
 #define DFTPAV_MAX_SURROUND 16
 #define DFTPAV_MAX_SURROUND_PIECES 512
 int dftpav_set_surround(dftpav_handle *h, const dftpav_surround *s);
@@ -273,6 +275,24 @@ void dftpav_batch_destroy(dftpav_batch *b);
  * normalises corridor normals, clamps boundary |v|,|a|, packs x0, uploads to
  * HBM.  After this call the batch is resident; solve/eval touch no host data. */
 int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
+
+/* The floating-point order of the solve path for this batch (eval, solve, coeffs; default DFTPAV_ORDER_DEVICE).
+ *
+ * DFTPAV_ORDER_DEVICE: the throughput kernels.  They reassociate three sums of the reference -- the per-piece sums of the
+ *   penalty gradient, the MINCO solves (a dense operator for the banded substitution) and the dot products of L-BFGS --
+ *   so a single evaluation equals the reference's to rounding (<= 1e-11) and, the solver being chaotic, a whole solve
+ *   equals it statistically.
+ * DFTPAV_ORDER_REFERENCE: every sum in the order PolyTrajOptimizer executes it (traj_optimizer.cpp:486-705 sample ->
+ *   vertex -> plane accumulation, poly_traj_utils.hpp:805-852 banded substitutions, lbfgs.hpp:716-739 two-loop with
+ *   sequential dot products), no fused multiply-adds: final x, cost, status, iterations and evaluations are BIT-EQUAL
+ *   to OptimizeTrajectory's on the same inputs.  One workgroup per trajectory, slower per iteration: the mode of a
+ *   drop-in that must reproduce the CPU planner's decision exactly, and the parity proof of the other one.
+ *   Supported for one gear segment without moving obstacles, n <= 64, H <= 5 (with a gear shift or obstacles the
+ *   reference calls libm's sin / cos / exp / log inside the loop): DFTPAV_E_UNSUPPORTED otherwise, order unchanged. */
+#define DFTPAV_ORDER_DEVICE 0
+#define DFTPAV_ORDER_REFERENCE 1
+int dftpav_batch_set_order(dftpav_batch *b, int order);
+int dftpav_batch_get_order(const dftpav_batch *b);
 
 /* Decision vectors x0 packed by upload ([B][n], host copy). */
 /* RunMINCOParking's pair getRectangleConst(statelist) -> OptimizeTrajectory(..., hPoly_container, ...)

@@ -493,6 +493,12 @@ def test_fit_surround_matches_oracle_and_feeds_the_solver(hiplib, oracle):
         g2, w2 = h.get_surround(), oracle.fit_surround(sub, order=1)
         assert np.array_equal(g2["coeffs"].reshape(w2["coeffs"].shape), w2["coeffs"])
         assert np.array_equal(g2["total"], w2["total"])
+    # a ready-made set beyond the solver's limits is refused where it is installed, and the installed one stays
+    g37 = h.get_surround()
+    from dftpav_amd.pods import SurroundSet as _SS
+    with pytest.raises(hiplib.DftpavError) as e37:
+        h.set_surround(_SS(g37["offsets"], g37["durations"], g37["coeffs"], g37["total"], g37["start"]))
+    assert e37.value.code == hiplib.E_UNSUPPORTED and h.get_surround()["total"].size == 37
     h.fit_surround(np.zeros((0, 0, 7)))
     assert h.get_surround()["total"].size == 0
     # cfg 5 with obstacles fitted on the device == cfg 5 with the same fit uploaded through dftpav_set_surround

@@ -1,0 +1,128 @@
+"""The reference-order device mode (dftpav_batch_set_order(DFTPAV_ORDER_REFERENCE), dftpav_amd/csrc/solver_ref.hip) against
+the reference ITSELF: oracle/_ref is the reference's own traj_optimizer.cpp / poly_traj_utils.hpp / lbfgs.hpp compiled
+unmodified (oracle/Makefile.ref; the .so travels to the GPU box), the literal oracle its statement-by-statement restatement
+(bit-equal to it, tests/test_ref_pin.py).
+
+Bar: BIT-EQUAL -- every evaluation (cost, gradient) and every whole solve (final x, final cost, status, iterations,
+evaluations, flag_success) -- on the single-segment static configurations: BASELINE configs[0] (default arena), the tests'
+cfg 1 (8 pieces forward) and cfg 3 (configs[2]: 16 pieces, 32 points per piece), 32 trajectories each.  north_star's
+"final cost within 1e-5 relative of CPU" is met with 0.0.
+"""
+import numpy as np
+import pytest
+
+from dftpav_amd import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref():
+    from oracle import pyref
+    return pyref if pyref.available() else None
+
+
+def _scenario(oracle, hiplib, name, B):
+    p = hiplib.default_params()
+    if name == "default_arena":
+        from test_default_map import _default_map_scenario
+        p.traj_resolution, p.des_traj_resolution = 16, 32
+        return p, _default_map_scenario(oracle, p, 16, 32, B)
+    s = sc.baseline_config({"cfg1": 1, "cfg3": 3}[name], B=B)
+    s.apply_resolution(p)
+    return p, s
+
+
+def _batch(hiplib, s, p):
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    return h, bt
+
+
+@pytest.mark.parametrize("name,B", [("cfg1", 6), ("cfg3", 6), ("default_arena", 4)])
+def test_every_evaluation_has_the_reference_bits(hiplib, oracle, name, B):
+    """costFunctionCallback (traj_optimizer.cpp:206-350) at x0, at perturbed points (many active penalty terms) and at
+    the solution: cost and gradient bit for bit."""
+    p, s = _scenario(oracle, hiplib, name, B)
+    h, bt = _batch(hiplib, s, p)
+    x0 = bt.x0()
+    rng = np.random.default_rng(5)
+    pyref = _ref()
+    lits = [oracle.OracleProblem(p, s, b, order=0) for b in range(B)]
+    refs = [pyref.RefProblem(p, s, b) for b in range(min(B, 2))] if pyref else []
+    xs = [x0, x0 + rng.normal(0, 0.05, x0.shape), x0 + rng.normal(0, 0.7, x0.shape)]
+    xs.append(np.stack([oracle.solve_batch(p, s, nthreads=4, order=0)["x"][b] for b in range(B)]))
+    for x in xs:
+        f, g = bt.eval(x)
+        for b in range(B):
+            fl, gl = lits[b].eval(x[b])
+            assert f[b] == fl, (name, b, f[b], fl)
+            assert np.array_equal(g[b], gl), (name, b, np.abs(g[b] - gl).max())
+        for b, r in enumerate(refs):
+            fr, gr = r.eval(x[b])
+            assert f[b] == fr and np.array_equal(g[b], gr)
+    bt.close()
+    h.close()
+
+
+@pytest.mark.parametrize("name,B", [("cfg1", 32), ("cfg3", 32), ("default_arena", 32)])
+def test_whole_solves_are_bit_equal_to_the_reference(hiplib, oracle, name, B):
+    """OptimizeTrajectory (traj_optimizer.cpp:7-202) of the reference build, trajectory by trajectory, against one
+    reference-order solve of the batch on the device."""
+    p, s = _scenario(oracle, hiplib, name, B)
+    h, bt = _batch(hiplib, s, p)
+    r = bt.solve()
+    pyref = _ref()
+    lit = oracle.solve_batch(p, s, nthreads=8, order=0)
+    for k in ("final_cost", "x", "status", "iters", "evals", "success", "hist_sum"):
+        assert np.array_equal(r[k], lit[k]), (name, k)
+    if pyref:
+        for b in range(B):
+            rr = pyref.RefProblem(p, s, b).optimize()
+            assert rr["final_cost"] == r["final_cost"][b] and np.array_equal(rr["x"], r["x"][b]), (name, b)
+            assert rr["status"] == r["status"][b] and rr["iters"] == r["iters"][b] and rr["evals"] == r["evals"][b]
+            assert bool(rr["ok"]) == bool(r["success"][b])
+    assert r["success"].all()
+    # the coefficients handed back for the solution (getMinJerkOptPtr()[i].getTraj(), traj_manager.cpp:618-625)
+    c, dt = bt.coeffs()
+    for b in range(min(B, 3)):
+        lp = oracle.OracleProblem(p, s, b, order=0)
+        lp.eval(r["x"][b])
+        co, dto = lp.coeffs()
+        assert np.array_equal(c[b], co) and np.array_equal(dt[b], dto)
+    # and the device-order kernels on the same batch object still give their own (different, equally valid) answer
+    bt.set_order(hiplib.ORDER_DEVICE)
+    rd = bt.solve()
+    ro = oracle.solve_batch(p, s, nthreads=8, order=1)
+    assert np.array_equal(rd["final_cost"], ro["final_cost"]) and np.array_equal(rd["x"], ro["x"])
+    bt.close()
+    h.close()
+
+
+def test_reference_order_is_refused_where_libm_sits_in_the_loop(hiplib):
+    """gear shifts (sin / cos of the junction angle per evaluation) and moving obstacles (exp / log per pair) keep the device order"""
+    p = hiplib.default_params()
+    s = sc.baseline_config(2, B=2)
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    with pytest.raises(hiplib.DftpavError) as e:
+        bt.set_order(hiplib.ORDER_REFERENCE)
+    assert e.value.code == hiplib.E_UNSUPPORTED
+    r = bt.solve()      # the batch is still usable, in device order
+    assert r["success"].all()
+    bt.close()
+    h.close()
+    s5 = sc.baseline_config(5, B=2)
+    p5 = hiplib.default_params()
+    s5.apply_resolution(p5)
+    h5 = hiplib.Handle(p5)
+    h5.set_surround(s5.surround)
+    b5 = hiplib.Batch(h5, s5.layout, s5.B)
+    b5.upload(s5)
+    with pytest.raises(hiplib.DftpavError):
+        b5.set_order(hiplib.ORDER_REFERENCE)
+    b5.close()
+    h5.close()
