@@ -51,6 +51,7 @@ hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t str
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S);
 size_t reference_order_scratch_doubles(const DevLayout &L, int B);
 size_t reference_order_table_doubles(int N);
+int reference_order_interior_mask(int sweep, int row_mod_6);
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream);
 }
 using namespace dftpav;
@@ -1417,30 +1418,48 @@ static hipError_t launch_for(dftpav_batch *b, const DevBatch &D, int mode) {
 // reference's column loops reach it (solver_ref.hip, sweep).  From the reference's own LU (banded_factorize, traj_math.h).
 //   [0] solve, forward:     L(i, i-6+k)      [1] solve, backward:    U(i, i+6-k), then / U(i,i)
 //   [2] solveAdj, forward:  U(i-6+k, i), then / U(i,i)               [3] solveAdj, backward: L(i+6-k, i)
-//   then (U(i,i), 1 / U(i,i)) per row
-static void reference_order_tables(int N, std::vector<double> &out) {
+//   each row 8 doubles: the six coefficients, U(i,i), 1 / U(i,i).
+// Returns false if a row of a middle block (rows 6 .. 6N-7) has another non-zero pattern than the kernel assumes there.
+static bool reference_order_tables(int N, std::vector<double> &out) {
   const int n6 = 6 * N;
   std::vector<double> band((size_t)n6 * 13, 0.0);
   BandedLU A{n6, 6, 6, band.data()};
   minco_fill(A, N);
   banded_factorize(A);
   out.assign(reference_order_table_doubles(N), 0.0);
-  double *t0 = out.data(), *t1 = t0 + 6 * (size_t)n6, *t2 = t1 + 6 * (size_t)n6, *t3 = t2 + 6 * (size_t)n6, *dg = t3 + 6 * (size_t)n6;
+  double *t[4];
+  for (int q = 0; q < 4; q++) t[q] = out.data() + (size_t)q * 8 * n6;
+  bool ok = true;
   for (int i = 0; i < n6; i++) {
     for (int k = 0; k < 6; k++) {
       const int jl = i - 6 + k, jh = i + 6 - k;
       if (jl >= 0) {
-        t0[6 * i + k] = A.at(i, jl);
-        t2[6 * i + k] = A.at(jl, i);
+        t[0][8 * i + k] = A.at(i, jl);
+        t[2][8 * i + k] = A.at(jl, i);
       }
       if (jh <= n6 - 1) {
-        t1[6 * i + k] = A.at(i, jh);
-        t3[6 * i + k] = A.at(jh, i);
+        t[1][8 * i + k] = A.at(i, jh);
+        t[3][8 * i + k] = A.at(jh, i);
       }
     }
-    dg[2 * i] = A.at(i, i);
-    dg[2 * i + 1] = 1.0 / A.at(i, i);
+    for (int q = 0; q < 4; q++) {
+      int m = 0;
+      for (int k = 0; k < 6; k++)
+        if (t[q][8 * i + k] != 0.0) m |= 1 << k;
+      if (i >= 6 && i < n6 - 6 && m != reference_order_interior_mask(q, i % 6)) ok = false;
+      t[q][8 * i + 6] = A.at(i, i);
+      t[q][8 * i + 7] = 1.0 / A.at(i, i);
+    }
   }
+  return ok;
+}
+// test hook (host only): the sweep tables of a segment of N pieces, [4][6N][8]; returns 1 if the middle blocks have the assumed pattern
+extern "C" int dftpav_debug_reference_tables(int N, double *out) {
+  if (N < 2) return DFTPAV_E_INVALID;
+  std::vector<double> tab;
+  const bool ok = reference_order_tables(N, tab);
+  if (out) std::memcpy(out, tab.data(), sizeof(double) * tab.size());
+  return ok ? 1 : 0;
 }
 
 extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
@@ -1457,7 +1476,10 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
     }
     if (!b->d_ref_tab) {
       std::vector<double> tab;
-      reference_order_tables(b->L.piece_nums[0], tab);
+      if (!reference_order_tables(b->L.piece_nums[0], tab)) {
+        h->err = "reference order: the LU factors of this band system do not have the pattern the kernel assumes";
+        return DFTPAV_E_UNSUPPORTED;
+      }
       HIPCHK(h, hipMalloc(&b->d_ref_tab, sizeof(double) * tab.size()));
       HIPCHK(h, hipMemcpy(b->d_ref_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
       HIPCHK(h, hipMalloc(&b->d_ref_scratch, sizeof(double) * reference_order_scratch_doubles(b->L, b->B)));

@@ -80,6 +80,29 @@ enum { sFX = 0, sFINIT, sDGINIT, sDGTEST, sDSTEST, sMU, sNU, sSTP, sSTEP, sF, sP
 enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iNUM = 16 };
 enum { kActEval = 0, kActDone = 1 };
 
+// optional in-kernel phase timer (thread 0, shader clock; DevBatch::prof == nullptr turns it off), slots as solver.hip's:
+// 0 right-hand side + BandedSystem::solve, 1 coefficients + jerk terms, 2 constraint points, 3 numbering + chains,
+// 4 calGrads_PT (solveAdj), 5 gradient assembly, 6 line search, 7 history update, 8 two-loop recursion
+struct Prof {
+  long long *acc;
+  long long last;
+  bool on;
+  __device__ inline void start(bool enable, long long *row) {
+    on = enable && threadIdx.x == 0;
+    acc = row;
+    if (on)
+      for (int i = 0; i < 12; i++) acc[i] = 0;
+    last = on ? clock64() : 0;
+  }
+  __device__ inline void tick(int i) {
+    if (on) {
+      const long long t = clock64();
+      acc[i] += t - last;
+      last = t;
+    }
+  }
+};
+
 constexpr int kRec = 16;        // doubles per term record: 12 entries of gdC, gdT, cost, 2 unused
 constexpr int kListCap = 4096;  // active terms chained per window
 
@@ -90,7 +113,7 @@ struct Sm {
   ldsd_t spow;              // [2][Kmax+1] the running sample offsets (s1 += step) for K and Kd
   ldsd_t b, c, gdC, adj;    // [6N][2]
   ldsd_t pE, pG, pA;        // [N] per-piece energy, d(energy)/dT, chain-rule term of calGrads_PT
-  ldsd_t tab;               // [4][6N][6] coefficients of the four substitution sweeps, then [6N][2] (diagonal, 1 / diagonal)
+  ldsd_t tab;               // [4][6N][8] rows of the four substitution sweeps: six coefficients, diagonal, 1 / diagonal (sweep())
   ldsd_t dot;               // [4][64] products of up to four sequential dot products
   ldsd_t alpha;             // [mem]
   ldsd_t st;                // [sNUM]
@@ -102,7 +125,7 @@ struct Sm {
 
 __host__ __device__ inline size_t lds_doubles(const DevLayout &L, int mem) {
   const int N = L.piece_nums[0];
-  return 5 * (size_t)L.npad + 12 + 16 + 2 * (size_t)(L.Kmax + 1) + 4 * 12 * (size_t)N + 3 * (size_t)N + (size_t)(4 * 36 + 12) * N + 4 * 64 +
+  return 5 * (size_t)L.npad + 12 + 16 + 2 * (size_t)(L.Kmax + 1) + 4 * 12 * (size_t)N + 3 * (size_t)N + (size_t)(4 * 48) * N + 4 * 64 +
          (size_t)mem + sNUM;
 }
 __host__ __device__ inline size_t lds_ints(const DevLayout &L) { return iNUM + 2 * (size_t)L.Npts + 1 + kListCap; }
@@ -125,7 +148,7 @@ __device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
   s.pE = p; p += N;
   s.pG = p; p += N;
   s.pA = p; p += N;
-  s.tab = p; p += (4 * 36 + 12) * N;
+  s.tab = p; p += (4 * 48) * N;
   s.dot = p; p += 4 * 64;
   s.alpha = p; p += mem;
   s.st = p; p += sNUM;
@@ -137,30 +160,61 @@ __device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
 }
 
 // One lane, one dimension: a substitution sweep over the 6N rows of the band system, row by row.  Row i (ascending
-// sweeps: i = 0, 1, ...; descending: i = 6N-1, ...) takes its six updates  acc -= tab[i][k] * b[row k of its window]  in
-// the order the reference's column loops apply them to it (k = 0..5; ascending: rows i-6 .. i-1, descending: rows i+6 ..
-// i+1), skipping exact zeros as the reference does (`if (a != 0.0)`), then -- DIV -- divides by the diagonal.  The six
-// previous results live in registers (rows are taken six at a time, so the window is indexed statically).
-template <bool DESC, bool DIV>
-__device__ __forceinline__ void sweep(ldscd_t tab, ldscd_t dg, ldsd_t b, int n6, int d) {
-  double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i0 = 0; i0 < n6; i0 += 6) {
+// sweeps: i = 0, 1, ...; descending: i = 6N-1, ...) takes its updates  acc -= c[k] * (result of the k-th row of its
+// window)  in the order the reference's column loops apply them to it (k = 0..5; ascending: rows i-6 .. i-1, descending:
+// rows i+6 .. i+1), skipping exact zeros as the reference does (`if (a != 0.0)`), then -- sweeps 1 and 2 -- divides by the
+// diagonal.  The six previous results live in registers (rows are taken six at a time, so the window is indexed
+// statically).  The LU factors of the MINCO band are sparse (3.2 non-zeros per row of L, 1.75 of U) and away from the two
+// ends of the system the pattern repeats with the pieces: kInterior[sweep][i mod 6] below (the host checks it against the
+// factors it uploads, capi.cpp: reference_order_tables), so the rows of the middle blocks compute their non-zero terms only,
+// without a test; the first and the last block test every coefficient.
+// Table row of a sweep: the six coefficients, then (diagonal, 1 / diagonal).
+//   sweep 0: solve, forward (L)   1: solve, backward (U, / diagonal)   2: solveAdj, forward (U^T, / diagonal)   3: solveAdj, backward (L^T)
+__device__ constexpr int kInterior[4][6] = {{0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e},
+                                            {0x00, 0x18, 0x30, 0x31, 0x21, 0x06},
+                                            {0x00, 0x00, 0x00, 0x35, 0x3b, 0x30},
+                                            {0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38}};
+template <int Q, bool GENERIC>
+__device__ __forceinline__ void sweep_block(ldscd_t tab, ldsd_t b, int n6, int d, int i0, double (&w)[6]) {
+  constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
+  double c[6][6], bi[6], dv[6], dr[6];
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
-      ldscd_t a = tab + 6 * i;
-      double acc = b[2 * i + d];
+  for (int r = 0; r < 6; r++) { // everything the block reads, requested together
+    const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
+    const int mask = GENERIC ? 0x3f : kInterior[Q][DESC ? 5 - r : r];
+    ldscd_t a = tab + 8 * i;
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double ak = a[k];
-        const double t = ak * w[(r + k) % 6];
-        acc = ak != 0.0 ? acc - t : acc;
-      }
-      if (DIV) acc = div_by_rcp(acc, dg[2 * i], dg[2 * i + 1]);
-      w[r] = acc;
-      b[2 * i + d] = acc;
+    for (int k = 0; k < 6; k++)
+      if (mask & (1 << k)) c[r][k] = a[k];
+    bi[r] = b[2 * i + d];
+    if (DIV) {
+      dv[r] = a[6];
+      dr[r] = a[7];
     }
   }
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
+    const int mask = GENERIC ? 0x3f : kInterior[Q][DESC ? 5 - r : r];
+    double acc = bi[r];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (mask & (1 << k)) {
+        const double t = c[r][k] * w[(r + k) % 6];
+        if (GENERIC) acc = c[r][k] != 0.0 ? acc - t : acc;
+        else acc = acc - t;
+      }
+    if (DIV) acc = div_by_rcp(acc, dv[r], dr[r]);
+    w[r] = acc;
+    b[2 * i + d] = acc;
+  }
+}
+template <int Q>
+__device__ __forceinline__ void sweep(ldscd_t tab, ldsd_t b, int n6, int d) {
+  double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  sweep_block<Q, true>(tab, b, n6, d, 0, w);
+  for (int i0 = 6; i0 < n6 - 6; i0 += 6) sweep_block<Q, false>(tab, b, n6, d, i0, w);
+  sweep_block<Q, true>(tab, b, n6, d, n6 - 6, w); // (N >= 2)
 }
 
 // positiveSmoothedL1, traj_optimizer.cpp:783-806
@@ -184,7 +238,7 @@ __device__ __forceinline__ void smoothed_l1(double x, double &f, double &df) {
 // Point j of piece i (K intervals, offset s1 = the running sum of traj_optimizer.cpp:513, taken from the table).  Writes a
 // record for every active term and returns the mask of active terms.  cor: &corridor[b][0][pt] (component-major, pitch
 // NptsPad); rec: &scratch[pt][0][0].
-__device__ __noinline__ unsigned point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
+__device__ __forceinline__ unsigned point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
                                              int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec) {
   double cc[12];
 #pragma unroll
@@ -354,7 +408,7 @@ __device__ __forceinline__ int piece_K(const DevLayout &L, int lp, int N) { retu
 
 // ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350), M == 1
 // x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].
-__device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g) {
+__device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
   const int tid = threadIdx.x, T = blockDim.x;
@@ -388,8 +442,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   // ---- wave 0: BandedSystem::solve (poly_traj_utils.hpp:805-826), one lane per dimension; wave 1 (or wave 0 after it):
   // the running sample offsets s1 += step (traj_optimizer.cpp:513), one lane per table
   if (tid < 2) {
-    sweep<false, false>(sm.tab, sm.tab + 144 * N, sm.b, n6, tid);
-    sweep<true, true>(sm.tab + 36 * N, sm.tab + 144 * N, sm.b, n6, tid);
+    sweep<0>(sm.tab, sm.b, n6, tid);
+    sweep<1>(sm.tab + 48 * N, sm.b, n6, tid);
   }
   {
     const int w0 = T > 64 ? 64 : 2;
@@ -406,6 +460,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     }
   }
   __syncthreads();
+  pr.tick(0);
   // ---- c = b * tInv (:979-984)
   for (int w = tid; w < 2 * n6; w += T) {
     const int row = w >> 1;
@@ -431,6 +486,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       gc[4 + d] = 0.0;
     }
   }
+  pr.tick(1);
   // ---- the constraint points, each on a lane of its own
   for (int pt = tid; pt < Npts; pt += T) {
     // piece of the point: edge pieces hold Kd + 1 points, the others K + 1
@@ -459,6 +515,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   }
   __threadfence_block(); // the records are read back by other threads of this workgroup
   __syncthreads();
+  pr.tick(2);
   // ---- number the active terms in (point, term) order: exclusive prefix sum of the counts (wave 0)
   if (tid < 64) {
     const int per = (Npts + 63) >> 6, start = tid * per;
@@ -570,6 +627,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     }
     __syncthreads();
   }
+  pr.tick(3);
   // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
   for (int w = tid; w < 2 * n6; w += T) {
     const int row = w >> 1;
@@ -577,8 +635,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   }
   __syncthreads();
   if (tid < 2) {
-    sweep<false, true>(sm.tab + 72 * N, sm.tab + 144 * N, sm.adj, n6, tid);
-    sweep<true, false>(sm.tab + 108 * N, sm.tab + 144 * N, sm.adj, n6, tid);
+    sweep<2>(sm.tab + 96 * N, sm.adj, n6, tid);
+    sweep<3>(sm.tab + 144 * N, sm.adj, n6, tid);
   } else if (tid >= 64 && tid < 64 + N) { // the per-piece chain-rule terms (they only need gdC and b)
     const int i = tid - 64;
     ldscd_t tInv = sm.seg + 8;
@@ -606,6 +664,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     }
     __syncthreads();
   }
+  pr.tick(4);
   // ---- gradient and cost (traj_optimizer.cpp:299-344)
   for (int e = tid; e < 2 * (N - 1); e += T) g[e] = sm.adj[2 * (6 * (e >> 1) + 5) + (e & 1)]; // gdP
   if (tid == 0) {
@@ -635,29 +694,101 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     sm.st[sF] = total_smcost + total_timecost + penalty_cost;
   }
   __syncthreads();
+  pr.tick(5);
 }
 
 // ------------------------------------------------ sequential sums on wave 0
 // The products sit one per lane (lanes >= n hold anything); the sum is the chain 0.0 + p[0] + p[1] + ... every lane forms
 // for itself from the LDS copy (broadcast reads), so all lanes end with the same bits.
+// (LDS operations of one wave execute in order: the reads below see the writes above them without waiting for anything
+// else -- a workgroup-scope fence here would also wait for the history rows that are in flight from global memory)
+__device__ __forceinline__ void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+// CAP = 16 / 32 / 64 >= n values are fetched in one go (the reads go out together, the chain starts when the first
+// arrives); lanes from n on contribute -0.0, and x + (-0.0) == x for EVERY x (both zeros included), so the chain may
+// simply run to CAP.
+template <int CAP>
 __device__ __forceinline__ double seq_sum(double p, int n, ldsd_t buf, int lane) {
-  buf[lane] = p;
-  __threadfence_block();
+  buf[lane] = lane < n ? p : -0.0;
+  wave_lds_order();
+  double v[CAP];
+#pragma unroll
+  for (int u = 0; u < CAP; u++) v[u] = buf[u];
   double s = 0.0;
-  int e = 0;
-  for (; e + 8 <= n; e += 8) {
-    double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = buf[e + u];
-#pragma unroll
-    for (int u = 0; u < 8; u++) s += v[u];
-  }
-  for (; e < n; e++) s += buf[e];
-  __threadfence_block(); // the buffer is free again
+  for (int u = 0; u < CAP; u++) s += v[u];
+  wave_lds_order(); // the buffer is free again
   return s;
 }
 
+// ---- the two-loop recursion's view of the history: blocks of kPB stored pairs in registers, the next block in flight while
+// one is worked on
+constexpr int kPB = 8;
+typedef double __attribute__((ext_vector_type(2))) d2_t;
+typedef const d2_t __attribute__((address_space(1))) *gcd2_t;
+typedef d2_t __attribute__((address_space(1))) *gd2_t;
+struct HistBlk {
+  d2_t sy[kPB]; // (s, y) element of this lane
+  d2_t yr[kPB]; // (ys, 1 / ys) of the pair
+};
+template <int DIR>
+__device__ __forceinline__ void load_blk(HistBlk &R, gcd2_t hS, gcd2_t hR, int npad, int m, int ln, int &jl) {
+#pragma unroll
+  for (int q = 0; q < kPB; q++) {
+    R.sy[q] = hS[(size_t)jl * npad + ln];
+    R.yr[q] = hR[jl];
+    if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
+    else jl = jl == m - 1 ? 0 : jl + 1;
+  }
+}
+// makes every register of the block a use: the wait for its loads lands here, before the next block's loads are issued,
+// so it is a wait for this block only (solver.hip: pin_block)
+__device__ __forceinline__ void pin_blk(HistBlk &R) {
+#pragma unroll
+  for (int q = 0; q < kPB; q++) {
+    asm volatile("" : "+v"(R.sy[q].x), "+v"(R.sy[q].y), "+v"(R.yr[q].x), "+v"(R.yr[q].y));
+  }
+}
+// kPB steps of the first loop (lbfgs.hpp:722-726): alpha_j = s_j . d / ys_j ; d -= alpha_j y_j
+template <int CAP>
+__device__ __forceinline__ void first_steps(const HistBlk &R, const Sm &sm, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
+#pragma unroll
+  for (int u = 0; u < kPB; u++) {
+    if (i0 + u < bound) { // uniform
+      j = j == 0 ? m - 1 : j - 1;
+      const double dot = seq_sum<CAP>(R.sy[u].x * dreg, n, sm.dot, lane);
+      const double a = div_by_rcp(dot, R.yr[u].x, R.yr[u].y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
+      if (lane == 0) sm.alpha[j] = a;
+      const double na = -a;
+      dreg = dreg + na * R.sy[u].y; // d += (-alpha) * lm_y.col(j)
+    }
+  }
+}
+// kPB steps of the second loop (lbfgs.hpp:732-738): beta = y_j . d / ys_j ; d += (alpha_j - beta) s_j
+template <int CAP>
+__device__ __forceinline__ void second_steps(const HistBlk &R, const Sm &sm, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
+  double al[kPB];
+  {
+    int jj = j;
+#pragma unroll
+    for (int u = 0; u < kPB; u++) {
+      al[u] = sm.alpha[jj];
+      jj = jj == m - 1 ? 0 : jj + 1;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kPB; u++) {
+    if (i0 + u < bound) { // uniform
+      const double dot = seq_sum<CAP>(R.sy[u].y * dreg, n, sm.dot, lane);
+      const double beta = div_by_rcp(dot, R.yr[u].x, R.yr[u].y);
+      const double cf = al[u] - beta;
+      dreg = dreg + cf * R.sy[u].x; // d += (alpha - beta) * lm_s.col(j)
+      j = j == m - 1 ? 0 : j + 1;
+    }
+  }
+}
+
 // Start of an outer iteration (lbfgs.hpp:559-574, 290-315): xp = x, gp = g, dginit = gp . d, first trial point
+template <int CAP>
 __device__ __forceinline__ bool begin_iteration(const DevParams &P, const Sm &sm, int n, int lane) {
   double pr = 0.0;
   if (lane < n) {
@@ -666,7 +797,7 @@ __device__ __forceinline__ bool begin_iteration(const DevParams &P, const Sm &sm
     sm.gp[lane] = gv;
     pr = gv * sm.d[lane];
   }
-  const double dginit = seq_sum(pr, n, sm.dot, lane);
+  const double dginit = seq_sum<CAP>(pr, n, sm.dot, lane);
   const double step = sm.st[sSTEP];
   if (!(step > 0.0)) {
     if (lane == 0) sm.ist[iRET] = -1006;
@@ -694,7 +825,8 @@ __device__ __forceinline__ bool begin_iteration(const DevParams &P, const Sm &sm
 
 // Everything lbfgs_optimize does between two evaluations (lbfgs.hpp:524-745 with the line search of :312-389 unrolled into
 // it), on wave 0, one decision variable per lane (n <= 64); sets iACTION.
-__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, gd_t hS, gd_t hR, int lane) {
+template <int CAP>
+__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, gd_t hS, gd_t hR, int lane, Prof &pr) {
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
   const double f = sm.st[sF];
@@ -707,7 +839,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
       sm.d[lane] = -gv;
     }
     const double gmax = wave_max64(lane < n ? fabs(gv) : 0.0), xmax = wave_max64(lane < n ? fabs(xv) : 0.0);
-    const double dd = seq_sum((-gv) * (-gv), n, sm.dot, lane);
+    const double dd = seq_sum<CAP>((-gv) * (-gv), n, sm.dot, lane);
     if (lane == 0) {
       sm.st[sFX] = f;
       sm.st[sPF0] = f;
@@ -730,7 +862,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
         sm.ist[iK] = 1;
       }
       __threadfence_block();
-      if (!begin_iteration(P, sm, n, lane)) action = kActDone;
+      if (!begin_iteration<CAP>(P, sm, n, lane)) action = kActDone;
     }
     if (lane == 0) sm.ist[iACTION] = action;
     return;
@@ -764,7 +896,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
       nu = stp;
       brackt = true;
     } else {
-      const double gs = seq_sum(lane < n ? sm.g[lane] * sm.d[lane] : 0.0, n, sm.dot, lane);
+      const double gs = seq_sum<CAP>(lane < n ? sm.g[lane] * sm.d[lane] : 0.0, n, sm.dot, lane);
       if (gs < sm.st[sDSTEST]) {
         mu = stp;
       } else {
@@ -808,6 +940,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     if (!decided) {
       if (lane < n) sm.x[lane] = sm.xp[lane] + stp * sm.d[lane];
       if (lane == 0) sm.ist[iACTION] = kActEval;
+      pr.tick(6);
       return;
     }
   }
@@ -854,15 +987,13 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     }
   }
   ++k;
+  pr.tick(6);
   const int end = sm.ist[iEND];
   int bound = sm.ist[iBOUND];
   __threadfence_block();
   if (lane == 0) sm.ist[iK] = k;
 
   // ---- history update + two-loop recursion (lbfgs.hpp:676-740); (s, y) interleaved per element as solver.hip stores them
-  typedef double __attribute__((ext_vector_type(2))) d2_t;
-  typedef const d2_t __attribute__((address_space(1))) *gcd2_t;
-  typedef d2_t __attribute__((address_space(1))) *gd2_t;
   double sv = 0.0, yv = 0.0, gpv = 0.0;
   if (lane < n) {
     sv = sm.x[lane] - sm.xp[lane];
@@ -881,15 +1012,16 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     sm.dot[64 + lane] = yv * yv;
     sm.dot[128 + lane] = sv * sv;
     sm.dot[192 + lane] = gpv * gpv;
-    __threadfence_block();
+    wave_lds_order();
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
     for (int e = 0; e < n; e++) {
       a0 += sm.dot[e];
       a1 += sm.dot[64 + e];
       a2 += sm.dot[128 + e];
       a3 += sm.dot[192 + e];
     }
-    __threadfence_block();
+    wave_lds_order();
     ys = a0; yy = a1; ss = a2; gpgp = a3;
   }
   if (lane == 0) {
@@ -899,6 +1031,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     ((gd2_t)hR)[end] = yr;
   }
   const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+  pr.tick(7);
   if (ys > cau) {
     ++bound;
     bound = m < bound ? m : bound;
@@ -906,66 +1039,33 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     __threadfence_block(); // lane 0's (ys, 1 / ys) of the newest pair is read by every lane below
     double dreg = lane < n ? -sm.g[lane] : 0.0;
     const int ln = lane < n ? lane : 0;
+    const gcd2_t cS = (gcd2_t)hS, cR = (gcd2_t)hR;
+    HistBlk A, B;
+    // first loop: newest -> oldest (slots ne-1, ne-2, ...)
     int j = ne;
-    // first loop: newest -> oldest.  The (s, y) rows and (ys, 1 / ys) of the next steps are requested ahead of the chain.
-    constexpr int PF = 4;
-    d2_t ring[PF], rr[PF];
-    {
-      int jj = j;
-      for (int u = 0; u < PF; u++) {
-        jj = jj == 0 ? m - 1 : jj - 1;
-        ring[u] = ((gcd2_t)hS)[(size_t)jj * npad + ln];
-        rr[u] = ((gcd2_t)hR)[jj];
-      }
-    }
-    int jpf = j; // slot the ring's next refill comes from
-    for (int u = 0; u < PF; u++) jpf = jpf == 0 ? m - 1 : jpf - 1;
-    for (int i0 = 0; i0 < bound; i0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; u++) {
-        if (i0 + u < bound) { // uniform
-          j = j == 0 ? m - 1 : j - 1;
-          const d2_t sy = ring[u], yr = rr[u];
-          jpf = jpf == 0 ? m - 1 : jpf - 1;
-          ring[u] = ((gcd2_t)hS)[(size_t)jpf * npad + ln];
-          rr[u] = ((gcd2_t)hR)[jpf];
-          const double dot = seq_sum(lane < n ? sy.x * dreg : 0.0, n, sm.dot, lane);
-          const double a = div_by_rcp(dot, yr.x, yr.y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
-          if (lane == 0) sm.alpha[j] = a;
-          const double na = -a;
-          dreg = dreg + na * sy.y; // d += (-alpha) * lm_y.col(j)
-        }
-      }
+    int jl = ne == 0 ? m - 1 : ne - 1;
+    load_blk<-1>(A, cS, cR, npad, m, ln, jl);
+    for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
+      pin_blk(A);
+      load_blk<-1>(B, cS, cR, npad, m, ln, jl);
+      first_steps<CAP>(A, sm, i0, bound, m, n, lane, j, dreg);
+      pin_blk(B);
+      load_blk<-1>(A, cS, cR, npad, m, ln, jl);
+      first_steps<CAP>(B, sm, i0 + kPB, bound, m, n, lane, j, dreg);
     }
     const double sc0 = ys / yy;
     dreg = dreg * sc0;
-    __threadfence_block(); // alpha written by lane 0, read by all below
+    wave_lds_order(); // alpha written by lane 0, read by all below
     // second loop: oldest -> newest, from the slot the first loop ended on
-    {
-      int jj = j;
-      for (int u = 0; u < PF; u++) {
-        ring[u] = ((gcd2_t)hS)[(size_t)jj * npad + ln];
-        rr[u] = ((gcd2_t)hR)[jj];
-        jj = jj == m - 1 ? 0 : jj + 1;
-      }
-      jpf = jj;
-    }
-    for (int i0 = 0; i0 < bound; i0 += PF) {
-#pragma unroll
-      for (int u = 0; u < PF; u++) {
-        if (i0 + u < bound) { // uniform
-          const d2_t sy = ring[u], yr = rr[u];
-          ring[u] = ((gcd2_t)hS)[(size_t)jpf * npad + ln];
-          rr[u] = ((gcd2_t)hR)[jpf];
-          jpf = jpf == m - 1 ? 0 : jpf + 1;
-          const double al = sm.alpha[j];
-          const double dot = seq_sum(lane < n ? sy.y * dreg : 0.0, n, sm.dot, lane);
-          const double beta = div_by_rcp(dot, yr.x, yr.y);
-          const double cf = al - beta;
-          dreg = dreg + cf * sy.x; // d += (alpha - beta) * lm_s.col(j)
-          j = j == m - 1 ? 0 : j + 1;
-        }
-      }
+    jl = j;
+    load_blk<+1>(A, cS, cR, npad, m, ln, jl);
+    for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
+      pin_blk(A);
+      load_blk<+1>(B, cS, cR, npad, m, ln, jl);
+      second_steps<CAP>(A, sm, i0, bound, m, n, lane, j, dreg);
+      pin_blk(B);
+      load_blk<+1>(A, cS, cR, npad, m, ln, jl);
+      second_steps<CAP>(B, sm, i0 + kPB, bound, m, n, lane, j, dreg);
     }
     if (lane < n) sm.d[lane] = dreg;
     if (lane == 0) {
@@ -978,12 +1078,15 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     }
   }
   if (lane == 0) sm.st[sSTEP] = 1.0; // lbfgs.hpp:743
+  pr.tick(8);
   __threadfence_block();
-  const bool ok = begin_iteration(P, sm, n, lane);
+  const bool ok = begin_iteration<CAP>(P, sm, n, lane);
   if (lane == 0) sm.ist[iACTION] = ok ? kActEval : kActDone;
+  pr.tick(6);
 }
 
 // ------------------------------------------------ the kernel
+template <int CAP>
 __global__ void __launch_bounds__(256) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
@@ -992,7 +1095,7 @@ __global__ void __launch_bounds__(256) ref_kernel(const DevBatch *__restrict__ D
   const int n = L.n, N = L.piece_nums[0], b = blockIdx.x;
   Sm sm;
   carve(sm, lds_raw, L, D.P.mem_size);
-  for (int i = tid; i < (4 * 36 + 12) * N; i += T) sm.tab[i] = tabs[i];
+  for (int i = tid; i < 4 * 48 * N; i += T) sm.tab[i] = tabs[i];
   for (int e = tid; e < L.npad; e += T) {
     const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
     sm.x[e] = e < n ? xsrc[(size_t)b * n + e] : 0.0;
@@ -1008,9 +1111,11 @@ __global__ void __launch_bounds__(256) ref_kernel(const DevBatch *__restrict__ D
   const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
   const gd_t hR = (gd_t)(D.histR + (size_t)b * D.P.mem_size * 2);
   const long long tick0 = wall_clock64();
+  Prof pr;
+  pr.start(D.prof != nullptr && mode == kModeSolve, D.prof + (size_t)b * 12);
   __syncthreads();
 
-  ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g);
+  ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
 
   if (mode == kModeEval) {
     for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
@@ -1023,10 +1128,10 @@ __global__ void __launch_bounds__(256) ref_kernel(const DevBatch *__restrict__ D
     return;
   }
   while (true) {
-    if (tid < 64) lbfgs_advance(D, sm, hS, hR, lane);
+    if (tid < 64) lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
     __syncthreads();
     if (sm.ist[iACTION] == kActDone) break;
-    ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g);
+    ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
   }
   for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
   if (tid == 0) {
@@ -1056,14 +1161,22 @@ bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
 // doubles of term records a batch of B trajectories needs
 size_t reference_order_scratch_doubles(const DevLayout &L, int B) { return (size_t)B * L.Npts * (5 * L.H + 4) * reford::kRec; }
 // doubles of the sweep tables of a segment of N pieces
-size_t reference_order_table_doubles(int N) { return (size_t)(4 * 36 + 12) * N; }
+size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
+// the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
+int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior[sweep][row_mod_6]; }
 
+template <int CAP>
+static hipError_t launch_ref_cap(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reford::ref_kernel<CAP>, dim3(D.B), dim3(256), lds, stream, d_dev, mode, tabs, scratch);
+  return hipGetLastError();
+}
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream) {
   const size_t lds = reford::lds_doubles(D.L, D.P.mem_size) * sizeof(double) + reford::lds_ints(D.L) * sizeof(int);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reford::ref_kernel, dim3(D.B), dim3(256), lds, stream, d_dev, mode, tabs, scratch);
-  return hipGetLastError();
+  if (D.L.n <= 16) return launch_ref_cap<16>(D, d_dev, mode, tabs, scratch, lds, stream);
+  if (D.L.n <= 32) return launch_ref_cap<32>(D, d_dev, mode, tabs, scratch, lds, stream);
+  return launch_ref_cap<64>(D, d_dev, mode, tabs, scratch, lds, stream);
 }
 
 } // namespace dftpav

@@ -12,6 +12,8 @@ p = capi.default_params()
 s = sc.baseline_config(cfg, B=B); s.apply_resolution(p)
 h = capi.Handle(p); h.set_surround(s.surround)
 bt = capi.Batch(h, s.layout, B); bt.upload(s)
+if os.environ.get("ORDER") == "ref":   # the reference-order kernel (solver_ref.hip): slots 0..8 as its Prof says
+    bt.set_order(capi.ORDER_REFERENCE)
 bt.solve_async(); bt.sync()
 ms0 = []
 for _ in range(3):

@@ -188,3 +188,62 @@ def test_oracle_lbfgs_and_minco_reproduce_the_reference_builds_vectors(oracle):
         f, df = C.c_double(0), C.c_double(0)
         oracle.lib().oracle_smoothed_l1(float(x), C.byref(f), C.byref(df))
         assert (f.value, df.value) == (f0, d0)
+
+
+# ---- the reference-order device mode's substitution tables (dftpav_amd/csrc/solver_ref.hip: sweep)
+_INTERIOR = [[0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e], [0x00, 0x18, 0x30, 0x31, 0x21, 0x06],
+             [0x00, 0x00, 0x00, 0x35, 0x3b, 0x30], [0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38]]
+
+
+def _row_sweep(tab, q, b):
+    """the kernel's row-oriented sweep q over one right-hand side, in Python's IEEE doubles (multiply, then subtract;
+    the division is the one the kernel reproduces with its stored reciprocal)"""
+    n6 = tab.shape[1]
+    desc, div = q in (1, 3), q in (1, 2)
+    b = b.copy()
+    for idx in range(n6):
+        i = n6 - 1 - idx if desc else idx
+        generic = idx < 6 or idx >= n6 - 6
+        acc = b[i]
+        for k in range(6):
+            c = tab[q, i, k]
+            src = i + 6 - k if desc else i - 6 + k
+            if generic:
+                if c != 0.0 and 0 <= src < n6:
+                    acc = acc - c * b[src]
+            elif _INTERIOR[q][i % 6] >> k & 1:
+                acc = acc - c * b[src]
+        if div:
+            acc = acc / tab[q, i, 6]
+        b[i] = acc
+    return b
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 8, 10, 16, 31, 32])
+def test_row_sweeps_of_the_reference_order_kernel_equal_banded_solve(ref, hiplib, N):
+    """BandedSystem::solve / solveAdj (poly_traj_utils.hpp:805-852) are column loops; the reference-order kernel runs them
+    row by row from tables the host derives from the same LU (capi.cpp: reference_order_tables), the middle blocks with a
+    fixed non-zero pattern.  Row form == column form, bit for bit, on random right-hand sides; the stored reciprocal of
+    the diagonal is the correctly rounded one."""
+    import ctypes as C
+    from dftpav_amd import pods
+    fn = hiplib.lib().dftpav_debug_reference_tables
+    fn.argtypes = [C.c_int, pods.c_double_p]
+    tab = np.zeros((4, 6 * N, 8))
+    assert fn(N, pods.dptr(tab)) == 1          # the middle blocks have the pattern the kernel assumes
+    assert np.array_equal(tab[:, :, 7], 1.0 / tab[:, :, 6])
+    A = sc.minco_matrix(N)
+    rng = np.random.default_rng(N)
+    for trial in range(3):
+        b = rng.normal(0, 10.0 ** rng.integers(-2, 3), 6 * N)
+        if trial == 0:                          # the sparsity of a real right-hand side (poly_traj_utils.hpp:968-977)
+            keep = [0, 1, 2] + [6 * i + 5 for i in range(N - 1)] + [6 * N - 3, 6 * N - 2, 6 * N - 1]
+            z = np.zeros_like(b)
+            z[keep] = b[keep]
+            b = z
+        want = ref.banded_solve(A, 6, 6, b)[:, 0]
+        got = _row_sweep(tab, 1, _row_sweep(tab, 0, b))
+        assert np.array_equal(got, want)
+        want_adj = ref.banded_solve(A, 6, 6, b, adjoint=True)[:, 0]
+        got_adj = _row_sweep(tab, 3, _row_sweep(tab, 2, b))
+        assert np.array_equal(got_adj, want_adj)
