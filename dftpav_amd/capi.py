@@ -19,7 +19,7 @@ _LIB = None
 
 OK = 0
 ORDER_DEVICE, ORDER_REFERENCE = 0, 1
-E_INVALID, E_MINI_T, E_ONE_PIECE, E_NO_DEVICE, E_HIP, E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+E_INVALID, E_MINI_T, E_ONE_PIECE, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/dftpav_hip.h declares
 EXPORTS = [
@@ -33,8 +33,31 @@ EXPORTS = [
     "dftpav_sample_restarts", "dftpav_batch_corridor_from_hypotheses", "dftpav_batch_sample_states",
     "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
     "dftpav_batch_trace", "dftpav_batch_get_trace", "dftpav_plan_cycle", "dftpav_plan_cycle_fetch", "dftpav_batch_create_shaped",
-    "dftpav_batch_set_order", "dftpav_batch_get_order",
+    "dftpav_batch_set_order", "dftpav_batch_get_order", "dftpav_batch_trace_range", "dftpav_batch_get_trace_of",
+    "dftpav_comm_unique_id", "dftpav_comm_create", "dftpav_comm_destroy", "dftpav_comm_layout", "dftpav_batch_allgather_results",
 ]
+
+
+def comm_unique_id():
+    """the 128-byte id of a new RCCL communicator (ncclGetUniqueId through the C-ABI): rank 0 makes it, the host hands it round"""
+    fn = lib().dftpav_comm_unique_id
+    fn.argtypes = [C.c_void_p]
+    buf = np.zeros(128, dtype=np.uint8)
+    rc = fn(buf.ctypes.data_as(C.c_void_p))
+    if rc != OK:
+        raise DftpavError(rc, "comm_unique_id: RCCL is not loadable")
+    return buf
+
+
+def comm_layout(global_B, nranks, rank):
+    """(first, count, block) of dftpav_comm_layout"""
+    fn = lib().dftpav_comm_layout
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p]
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = fn(int(global_B), int(nranks), int(rank), C.byref(a), C.byref(b), C.byref(c))
+    if rc != OK:
+        raise DftpavError(rc, "comm_layout")
+    return a.value, b.value, c.value
 
 
 class DftpavError(RuntimeError):
@@ -153,6 +176,20 @@ class Handle:
                        ptr(out["length"]), ptr(out["type"]), ptr(out["seg"]), ptr(out["samples"]), ptr(out["n_samples"]),
                        ptr(out["collides"])), "reeds_shepp_shots")
         return out
+
+    def comm_create(self, nranks, rank, unique_id):
+        """ncclCommInitRank on this handle's device, collectively (dftpav_comm_create); unique_id: the 128 bytes of comm_unique_id()
+        of rank 0, distributed by the host."""
+        fn = lib().dftpav_comm_create
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        buf = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        assert buf.size == 128
+        self._check(fn(self._h, int(nranks), int(rank), buf.ctypes.data_as(C.c_void_p)), "comm_create")
+
+    def comm_destroy(self):
+        fn = lib().dftpav_comm_destroy
+        fn.argtypes = [C.c_void_p]
+        self._check(fn(self._h), "comm_destroy")
 
     def mark(self, slot=0):
         """Records one of the handle's two marker events on its stream (dftpav_mark)."""
@@ -438,21 +475,22 @@ class Batch:
                               iptr(r["collision"]), iptr(r["first_sample"]), dptr(r["states"]), iptr(r["n_valid"])), "plan_cycle_fetch")
         return r
 
-    def trace(self, traj, max_evals=4096):
-        """Record every evaluation of trajectory `traj` during the following solves (dftpav_batch_trace); 0 = off."""
-        fn = lib().dftpav_batch_trace
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int]
-        self.handle._check(fn(self._b, int(traj), int(max_evals)), "batch_trace")
-        self._trace_cap = int(max_evals)
+    def trace(self, traj, max_evals=4096, count=1):
+        """Record every evaluation of trajectories traj .. traj + count - 1 during the following solves
+        (dftpav_batch_trace_range); max_evals = 0 switches it off."""
+        fn = lib().dftpav_batch_trace_range
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self.handle._check(fn(self._b, int(traj), int(count), int(max_evals)), "batch_trace")
+        self._trace_cap, self._trace_first = int(max_evals), int(traj)
 
-    def get_trace(self):
-        """-> dict(x [E][n], g [E][n], d [E][n], f [E], stp [E], k [E], count [E]) of the traced trajectory"""
-        fn = lib().dftpav_batch_get_trace
-        fn.argtypes = [C.c_void_p, c_double_p, c_int_p]
+    def get_trace(self, traj=None):
+        """-> dict(x [E][n], g [E][n], d [E][n], f [E], stp [E], k [E], count [E]) of a traced trajectory (default: the first)"""
+        fn = lib().dftpav_batch_get_trace_of
+        fn.argtypes = [C.c_void_p, C.c_int, c_double_p, c_int_p]
         n = self.layout.n_vars
         rows = np.zeros((self._trace_cap, 3 * n + 4))
         cnt = C.c_int(0)
-        self.handle._check(fn(self._b, dptr(rows), C.byref(cnt)), "batch_get_trace")
+        self.handle._check(fn(self._b, self._trace_first if traj is None else int(traj), dptr(rows), C.byref(cnt)), "batch_get_trace")
         r = rows[:cnt.value]
         return dict(x=r[:, :n].copy(), g=r[:, n:2 * n].copy(), d=r[:, 2 * n:3 * n].copy(), f=r[:, 3 * n].copy(),
                     stp=r[:, 3 * n + 1].copy(), k=r[:, 3 * n + 2].astype(np.int64), count=r[:, 3 * n + 3].astype(np.int64))
@@ -469,6 +507,13 @@ class Batch:
         out = np.zeros((self.B, 12), dtype=np.int64)
         self.handle._check(fn(self._b, 1, llptr(out)), "read_profile")
         return out
+
+    def allgather_results(self, global_B, device_ptr):
+        """packs this rank's 16-byte records and all-gathers them over RCCL into device memory of nranks * block * 16 bytes
+        (dftpav_batch_allgather_results; asynchronous on the handle's stream)"""
+        fn = lib().dftpav_batch_allgather_results
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.handle._check(fn(self._b, int(global_B), C.c_void_p(device_ptr)), "batch_allgather_results")
 
     def pack_results(self, device_ptr):
         """16-byte {f64 cost, i32 status, i32 iters} records into device memory (async on the handle's stream)."""

@@ -7,6 +7,8 @@
 // There is deliberately no CPU fallback: without a usable HIP device every
 // entry point that needs one fails with DFTPAV_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <mutex>
 
 #include <cmath>
 #include <cstdio>
@@ -77,6 +79,11 @@ struct dftpav_handle {
   hipEvent_t mark[2] = {nullptr, nullptr};   // dftpav_mark
   bool ctimed = false;
   std::vector<struct dftpav_batch *> batches; // every live batch of this handle (obstacle changes finish their chained stragglers)
+  // RCCL communicator of dftpav_comm_create (one rank per handle = per GPU), and the staging block of this rank's records
+  void *comm = nullptr;
+  int comm_ranks = 0, comm_rank = 0;
+  unsigned char *d_comm_send = nullptr;
+  size_t comm_send_bytes = 0;
 };
 
 struct dftpav_batch {
@@ -133,7 +140,7 @@ struct dftpav_batch {
     int n_samples = 0;
     bool in_flight = false;
   } pc;
-  int trace_b = -1, trace_cap = 0;
+  int trace_b = -1, trace_cap = 0, trace_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;  // a solve was enqueued: ev0 / ev1 are recorded
   bool solved = false; // results of a solve of the CURRENT inputs exist (cleared by dftpav_batch_upload)
@@ -147,6 +154,8 @@ struct dftpav_batch {
       return DFTPAV_E_HIP;                                                               \
     }                                                                                    \
   } while (0)
+
+extern "C" int dftpav_comm_destroy(dftpav_handle *h);
 
 // ------------------------------------------------------------------ params
 extern "C" void dftpav_default_params(dftpav_params *p) {
@@ -386,6 +395,7 @@ static void free_surround(dftpav_handle *h) {
 
 extern "C" void dftpav_destroy(dftpav_handle *h) {
   if (!h) return;
+  (void)dftpav_comm_destroy(h);
   (void)hipSetDevice(h->device);
   free_surround(h);
   if (h->d_cells) (void)hipFree(h->d_cells);
@@ -1309,6 +1319,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.trace = b->d_trace;
   D.trace_b = b->trace_b;
   D.trace_cap = b->trace_cap;
+  D.trace_n = b->trace_n;
   return D;
 }
 
@@ -1359,8 +1370,8 @@ extern "C" int dftpav_debug_profile(dftpav_batch *b, int enable, long long *out)
 
 // Records every evaluation of one trajectory during the following solves (what lbfgs_optimize shows its progress callback,
 // lbfgs.hpp:242-249,617-624, but per evaluation): used by the lockstep parity test against the reference's line search.
-extern "C" int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals) {
-  if (!b || max_evals < 0 || (max_evals > 0 && (traj < 0 || traj >= b->B))) return DFTPAV_E_INVALID;
+extern "C" int dftpav_batch_trace_range(dftpav_batch *b, int first, int count, int max_evals) {
+  if (!b || max_evals < 0 || (max_evals > 0 && (first < 0 || count < 1 || first + count > b->B))) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
@@ -1371,27 +1382,31 @@ extern "C" int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals) {
   }
   b->trace_b = -1;
   b->trace_cap = 0;
+  b->trace_n = 0;
   if (max_evals > 0) {
-    const size_t nd = 8 + (size_t)max_evals * (3 * (size_t)b->L.npad + 8);
+    const size_t nd = (size_t)count * (8 + (size_t)max_evals * (3 * (size_t)b->L.npad + 8));
     HIPCHK(h, hipMalloc(&b->d_trace, sizeof(double) * nd));
     HIPCHK(h, hipMemset(b->d_trace, 0, sizeof(double) * nd));
-    b->trace_b = traj;
+    b->trace_b = first;
+    b->trace_n = count;
     b->trace_cap = max_evals;
   }
   b->dev_version = -1;
   return DFTPAV_OK;
 }
+extern "C" int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals) { return dftpav_batch_trace_range(b, traj, 1, max_evals); }
 
-extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals) {
-  if (!b || !n_evals || !b->d_trace) return DFTPAV_E_INVALID;
+extern "C" int dftpav_batch_get_trace_of(dftpav_batch *b, int traj, double *out, int *n_evals) {
+  if (!b || !n_evals || !b->d_trace || traj < b->trace_b || traj >= b->trace_b + b->trace_n) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const int n = b->L.n, npad = b->L.npad;
   const size_t stride = 3 * (size_t)npad + 8;
-  std::vector<double> raw(8 + (size_t)b->trace_cap * stride);
-  HIPCHK(h, hipMemcpy(raw.data(), b->d_trace, sizeof(double) * raw.size(), hipMemcpyDeviceToHost));
+  const size_t block = 8 + (size_t)b->trace_cap * stride;
+  std::vector<double> raw(block);
+  HIPCHK(h, hipMemcpy(raw.data(), b->d_trace + (size_t)(traj - b->trace_b) * block, sizeof(double) * block, hipMemcpyDeviceToHost));
   int cnt = (int)raw[0];
   if (cnt > b->trace_cap) cnt = b->trace_cap;
   *n_evals = cnt;
@@ -1405,6 +1420,10 @@ extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals
       std::memcpy(o + 3 * n, r + 3 * npad, sizeof(double) * 4);
     }
   return DFTPAV_OK;
+}
+extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals) {
+  if (!b) return DFTPAV_E_INVALID;
+  return dftpav_batch_get_trace_of(b, b->trace_b, out, n_evals);
 }
 
 // every launch of the solve kernel for a batch goes through here: the reference-order kernel when the batch asks for it
@@ -1676,6 +1695,126 @@ extern "C" int dftpav_batch_results(dftpav_batch *b, double *x, double *final_co
     HIPCHK(h, hipMemcpy(t.data(), b->d_ticks, sizeof(long long) * B, hipMemcpyDeviceToHost));
     for (int i = 0; i < B; i++) latency_us[i] = (double)t[i] * 0.01; // wall_clock64: 100 MHz
   }
+  return DFTPAV_OK;
+}
+
+// ------------------------------------------------------------------ RCCL behind the C-ABI
+// The one collective of the path: an all-gather of 16-byte result records over xGMI.  RCCL is loaded at the first use
+// (dlopen by its soname: inside a process that already holds an RCCL -- PyTorch ships one -- this is that same copy, so a
+// process never runs two), which keeps the library loadable where no RCCL is installed: only these entry points fail there.
+namespace {
+struct RcclUniqueId {
+  char internal[DFTPAV_UNIQUE_ID_BYTES];
+};
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+RcclApi &rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (!api.lib) return;
+    api.GetUniqueId = reinterpret_cast<int (*)(RcclUniqueId *)>(dlsym(api.lib, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<int (*)(void **, int, RcclUniqueId, int)>(dlsym(api.lib, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(api.lib, "ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(api.lib, "ncclAllGather"));
+    api.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(api.lib, "ncclGetErrorString"));
+    api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather;
+  });
+  return api;
+}
+constexpr int kNcclUint8 = 1; // ncclUint8 == ncclChar + 1 (rccl.h)
+} // namespace
+#define RCCLCHK(h, call)                                                                                        \
+  do {                                                                                                          \
+    int e_ = (call);                                                                                            \
+    if (e_ != 0) {                                                                                              \
+      (h)->err = std::string(#call) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e_) : "rccl error"); \
+      return DFTPAV_E_COMM;                                                                                     \
+    }                                                                                                           \
+  } while (0)
+
+extern "C" int dftpav_comm_unique_id(void *id) {
+  if (!id) return DFTPAV_E_INVALID;
+  if (!rccl().ok) return DFTPAV_E_COMM;
+  RcclUniqueId u;
+  if (rccl().GetUniqueId(&u) != 0) return DFTPAV_E_COMM;
+  std::memcpy(id, u.internal, DFTPAV_UNIQUE_ID_BYTES);
+  return DFTPAV_OK;
+}
+extern "C" int dftpav_comm_destroy(dftpav_handle *h) {
+  if (!h) return DFTPAV_E_INVALID;
+  if (h->comm) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)rccl().CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  if (h->d_comm_send) (void)hipFree(h->d_comm_send);
+  h->d_comm_send = nullptr;
+  h->comm_send_bytes = 0;
+  h->comm_ranks = 0;
+  return DFTPAV_OK;
+}
+extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const void *unique_id) {
+  if (!h || nranks < 1 || rank < 0 || rank >= nranks || !unique_id) return DFTPAV_E_INVALID;
+  if (!rccl().ok) {
+    h->err = "RCCL (librccl.so.1) is not loadable";
+    return DFTPAV_E_COMM;
+  }
+  if (int rc = dftpav_comm_destroy(h)) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  RcclUniqueId u;
+  std::memcpy(u.internal, unique_id, DFTPAV_UNIQUE_ID_BYTES);
+  RCCLCHK(h, rccl().CommInitRank(&h->comm, nranks, u, rank));
+  h->comm_ranks = nranks;
+  h->comm_rank = rank;
+  return DFTPAV_OK;
+}
+extern "C" int dftpav_comm_layout(int global_B, int nranks, int rank, int *first, int *count, int *block) {
+  if (global_B < 1 || nranks < 1 || rank < 0 || rank >= nranks) return DFTPAV_E_INVALID;
+  const long long lo = (long long)global_B * rank / nranks, hi = (long long)global_B * (rank + 1) / nranks;
+  if (first) *first = (int)lo;
+  if (count) *count = (int)(hi - lo);
+  if (block) *block = (global_B + nranks - 1) / nranks; // the largest shard: every rank's block in the gathered buffer
+  return DFTPAV_OK;
+}
+extern "C" int dftpav_batch_allgather_results(dftpav_batch *b, int global_B, void *all_records) {
+  if (!b || !all_records || !b->uploaded || !b->solved) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (!h->comm) {
+    h->err = "dftpav_comm_create first";
+    return DFTPAV_E_INVALID;
+  }
+  int first = 0, count = 0, block = 0;
+  if (int rc = dftpav_comm_layout(global_B, h->comm_ranks, h->comm_rank, &first, &count, &block)) return rc;
+  if (count != b->B) {
+    h->err = "this batch is not the shard dftpav_comm_layout assigns to the rank";
+    return DFTPAV_E_INVALID;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = finish_pending(b)) return rc;
+  const size_t bytes = (size_t)block * 16;
+  if (h->comm_send_bytes < bytes) {
+    if (h->d_comm_send) (void)hipFree(h->d_comm_send);
+    h->d_comm_send = nullptr;
+    HIPCHK(h, hipMalloc(&h->d_comm_send, bytes));
+    h->comm_send_bytes = bytes;
+  }
+  if ((size_t)count * 16 < bytes) HIPCHK(h, hipMemsetAsync(h->d_comm_send + (size_t)count * 16, 0, bytes - (size_t)count * 16, h->stream));
+  DevBatch D = make_dev(b);
+  HIPCHK(h, launch_pack(D, h->d_comm_send, h->stream));
+  RCCLCHK(h, rccl().AllGather(h->d_comm_send, all_records, bytes, kNcclUint8, h->comm, h->stream));
   return DFTPAV_OK;
 }
 

@@ -151,10 +151,11 @@ struct DevBatch {
   long long *prof;  // optional [B][12] shader-clock phase profile (nullptr = off)
   double *coef_out; // [B][Ntot][6][2]
   double *dt_out;   // [B][M]
-  // optional record of every evaluation of one trajectory (dftpav_batch_trace; nullptr = off):
-  // 8 doubles of header ([0] = records written), then records of 3 npad + 8 doubles: x, g, d, {f, stp, k, count}
+  // optional record of every evaluation of trajectories trace_b .. trace_b + trace_n - 1 (dftpav_batch_trace_range; nullptr =
+  // off), per trajectory: 8 doubles of header ([0] = records written), then trace_cap records of 3 npad + 8 doubles: x, g, d,
+  // {f, stp, k, count}
   double *trace;
-  int trace_b, trace_cap;
+  int trace_b, trace_cap, trace_n;
 };
 
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };

@@ -2,13 +2,93 @@
 // looks like against the drop-in; doubles as the compile/link check of the C++ host mirror and as a
 // tiny end-to-end run when a GPU is present (exit 0 either way; prints what happened).
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include <hip/hip_runtime_api.h>
 
 #include "poly_traj_optimizer.hpp"
 #include "traj_planner_steps.hpp"
 
 using namespace plan_manage;
 
-int main() {
+// `host_example --ranks N`: the multi-GPU hand-off of SURVEY 8(e) from a C++ host, through the C-ABI only -- N ranks (one
+// thread and one dftpav_handle per GPU here; one process per GPU works the same way, the 128-byte id then travels over the
+// host's own channel), a batch of restarts sharded contiguously, every rank solves its shard, ONE RCCL all-gather of the
+// 16-byte records, every rank ends with every result.  Needs N GPUs (RCCL ranks cannot share a device).
+static int run_ranks(int nranks) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < nranks) {
+    std::printf("--ranks %d: %d HIP device(s) here, nothing run\n", nranks, ndev);
+    return 0;
+  }
+  const int N = 3, B = 8 * nranks + 3; // uneven shards on purpose
+  dftpav_params p;
+  dftpav_default_params(&p);
+  p.traj_resolution = 4;
+  p.des_traj_resolution = 6;
+  const int pn[1] = {N}, sg[1] = {1};
+  dftpav_layout lay{1, pn, sg, 4};
+  const int npts = dftpav_num_points(&p, &lay);
+  unsigned char id[DFTPAV_UNIQUE_ID_BYTES];
+  if (dftpav_comm_unique_id(id) != DFTPAV_OK) {
+    std::printf("--ranks: RCCL is not loadable here, nothing run\n");
+    return 0;
+  }
+  std::vector<int> ok(nranks, 0);
+  std::vector<std::vector<unsigned char>> gathered(nranks);
+  std::vector<std::thread> th;
+  for (int r = 0; r < nranks; r++)
+    th.emplace_back([&, r] {
+      int first = 0, count = 0, block = 0;
+      dftpav_comm_layout(B, nranks, r, &first, &count, &block);
+      dftpav_handle *h = nullptr;
+      dftpav_batch *b = nullptr;
+      if (dftpav_create(&p, r, &h) != DFTPAV_OK) return;
+      bool good = dftpav_comm_create(h, nranks, r, id) == DFTPAV_OK && dftpav_batch_create(h, &lay, count, &b) == DFTPAV_OK;
+      // trajectory g of the global batch: the straight run of main() with its middle waypoints moved by g centimetres
+      std::vector<double> ini((size_t)count * 6, 0.0), fin((size_t)count * 6, 0.0), inner((size_t)count * 2 * (N - 1)), Ts(count, 3.0),
+          cor((size_t)count * npts * 16);
+      for (int i = 0; i < count; i++) {
+        const int g = first + i;
+        ini[6 * i + 2] = 2.0; fin[6 * i + 0] = 6.0; fin[6 * i + 2] = 2.0;
+        inner[4 * i + 0] = 2.0; inner[4 * i + 1] = 0.01 * g; inner[4 * i + 2] = 4.0; inner[4 * i + 3] = -0.01 * g;
+        for (int k = 0; k < npts; k++) {
+          const double hp[16] = {0, 1, 0, 10, 1, 0, 30, 0, 0, -1, 0, -10, -1, 0, -20, 0};
+          std::memcpy(&cor[((size_t)i * npts + k) * 16], hp, sizeof(hp));
+        }
+      }
+      dftpav_batch_data d{};
+      d.ini_states = ini.data(); d.fin_states = fin.data(); d.inner_pts = inner.data(); d.init_Ts = Ts.data(); d.corridor = cor.data();
+      void *all = nullptr;
+      good = good && dftpav_batch_upload(b, &d) == DFTPAV_OK && dftpav_batch_solve_async(b) == DFTPAV_OK;
+      good = good && hipSetDevice(r) == hipSuccess && hipMalloc(&all, (size_t)nranks * block * 16) == hipSuccess;
+      good = good && dftpav_batch_allgather_results(b, B, all) == DFTPAV_OK && dftpav_batch_sync(b) == DFTPAV_OK;
+      gathered[r].resize((size_t)nranks * block * 16);
+      good = good && hipMemcpy(gathered[r].data(), all, gathered[r].size(), hipMemcpyDeviceToHost) == hipSuccess;
+      std::vector<double> cost(count);
+      good = good && dftpav_batch_results(b, nullptr, cost.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == DFTPAV_OK;
+      for (int i = 0; good && i < count; i++) { // this rank's own block of the gathered buffer holds its own results
+        double c;
+        std::memcpy(&c, &gathered[r][((size_t)r * block + i) * 16], 8);
+        good = c == cost[i];
+      }
+      if (!good) std::printf("rank %d: %s\n", r, dftpav_last_error(h));
+      ok[r] = good;
+      if (all) (void)hipFree(all);
+      dftpav_batch_destroy(b);
+      dftpav_destroy(h);
+    });
+  for (auto &t : th) t.join();
+  bool all_ok = true;
+  for (int r = 0; r < nranks; r++) all_ok = all_ok && ok[r] && gathered[r] == gathered[0]; // every rank sees every result
+  std::printf("--ranks %d: %d trajectories sharded, solved, one all-gather of 16-byte records -> %s\n", nranks, B, all_ok ? "identical on every rank" : "FAILED");
+  return all_ok ? 0 : 1;
+}
+
+int main(int argc, char **argv) {
+  if (argc >= 3 && std::strcmp(argv[1], "--ranks") == 0) return run_ranks(std::atoi(argv[2]));
   PolyTrajOptimizer opt;
   dftpav_params p;
   dftpav_default_params(&p);

@@ -1835,11 +1835,12 @@ __device__ inline void queue_push(unsigned *ctl, int *ring, int cap, int id) {
 
 // dftpav_batch_trace: the evaluation that just finished (x, g in LDS, f in st[sF]) of the traced trajectory
 __device__ inline void trace_eval(const DevBatch &Db, const Smem &sm, int b, int tid, int T) {
-  if (Db.trace == nullptr || b != Db.trace_b) return; // uniform
+  if (Db.trace == nullptr || b < Db.trace_b || b >= Db.trace_b + Db.trace_n) return; // uniform
   const int idx = sm.ist[iPHASE] == 0 ? 0 : sm.ist[iEVALS];
   if (idx >= Db.trace_cap) return;
   const int n = Db.L.n, npad = Db.L.npad;
-  double *rec = Db.trace + 8 + (size_t)idx * (3 * npad + 8);
+  double *tr0 = Db.trace + (size_t)(b - Db.trace_b) * (8 + (size_t)Db.trace_cap * (3 * npad + 8)); // this trajectory's block
+  double *rec = tr0 + 8 + (size_t)idx * (3 * npad + 8);
   for (int e = tid; e < n; e += T) {
     rec[e] = sm.x[e];
     rec[npad + e] = sm.g[e];
@@ -1850,7 +1851,7 @@ __device__ inline void trace_eval(const DevBatch &Db, const Smem &sm, int b, int
     rec[3 * npad + 1] = idx == 0 ? 0.0 : sm.st[sSTP];
     rec[3 * npad + 2] = (double)sm.ist[iK];
     rec[3 * npad + 3] = idx == 0 ? 0.0 : (double)(sm.ist[iCOUNT] + 1);
-    Db.trace[0] = (double)(idx + 1);
+    tr0[0] = (double)(idx + 1);
   }
   __syncthreads(); // wave 0 rewrites x / g / d next (every condition above is uniform)
 }

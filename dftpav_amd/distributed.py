@@ -58,6 +58,43 @@ def allgather_records(local_rec, B, group=None):
     return torch.cat([recv[r, :sizes[r]] for r in range(world)], dim=0)
 
 
+class RcclComm:
+    """The communicator of the C-ABI (dftpav_comm_create) for one handle, set up from a torch.distributed job: rank 0 makes the
+    128-byte id through the library, torch.distributed only carries those bytes to the other ranks; the all-gather itself
+    is the library's (ncclAllGather on the handle's stream), so a C++ host without PyTorch runs the identical path
+    (dftpav_amd/csrc/host/host_example.cpp --ranks N)."""
+
+    def __init__(self, handle, group=None):
+        from . import capi
+        self.handle = handle
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = capi.comm_unique_id() if self.rank == 0 else np.zeros(128, dtype=np.uint8)
+        if self.world > 1:
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.from_numpy(uid).to(dev)
+            dist.broadcast(t, src=0, group=group)
+            uid = t.cpu().numpy()
+        handle.comm_create(self.world, self.rank, uid)
+        self._recv = None
+
+    def allgather(self, batch, B):
+        """-> uint8 tensor [B][16] on the device, identical on every rank, valid once the handle's stream is synchronised"""
+        from . import capi
+        _, count, block = capi.comm_layout(B, self.world, self.rank)
+        assert count == batch.B
+        if self._recv is None or self._recv.shape[0] != self.world * block:
+            self._recv = torch.zeros((self.world * block, RECORD_BYTES), dtype=torch.uint8, device="cuda")
+        batch.allgather_results(B, self._recv.data_ptr())
+        batch.sync()
+        sizes = [shard_range(B, r, self.world)[1] - shard_range(B, r, self.world)[0] for r in range(self.world)]
+        blocks = self._recv.view(self.world, block, RECORD_BYTES)
+        return torch.cat([blocks[r, :sizes[r]] for r in range(self.world)], dim=0)
+
+    def close(self):
+        self.handle.comm_destroy()
+
+
 def best_of(cost, status):
     """Host-side argmin over successful restarts (status as lbfgs.hpp:135-184;
     success rule of traj_optimizer.cpp:176-201 without the cost cap)."""

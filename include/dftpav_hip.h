@@ -35,6 +35,7 @@ extern "C" {
 #define DFTPAV_E_NO_DEVICE (-4)   /* no HIP device / kernel image not loadable: never falls back to CPU */
 #define DFTPAV_E_HIP (-5)         /* a HIP runtime call failed (see dftpav_last_error) */
 #define DFTPAV_E_UNSUPPORTED (-6) /* layout exceeds a compiled limit */
+#define DFTPAV_E_COMM (-7)        /* RCCL is not loadable, or one of its calls failed (see dftpav_last_error) */
 
 /* ---- per-trajectory solver status: values of lbfgs.hpp:135-184 ----------- */
 enum {
@@ -329,6 +330,10 @@ int dftpav_batch_eval(dftpav_batch *b, const double *x, double *f, double *g);
  * test against the reference's line search and two-loop recursion. */
 int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals);
 int dftpav_batch_get_trace(dftpav_batch *b, double *rows, int *n_evals);
+/* The same for `count` consecutive trajectories from `first` at once (one block of records each), and the read-out of one
+ * of them.  Device-order solves only (a reference-order solve needs no such check: it is the reference's sequence). */
+int dftpav_batch_trace_range(dftpav_batch *b, int first, int count, int max_evals);
+int dftpav_batch_get_trace_of(dftpav_batch *b, int traj, double *rows, int *n_evals);
 
 /* L2 cut (production) == lbfgs::lbfgs_optimize driven from
  * OptimizeTrajectory (traj_optimizer.cpp:159-166, lbfgs.hpp:440-751): one
@@ -383,6 +388,25 @@ int dftpav_batch_set_hand_over(dftpav_batch *b, int hand_over);
  * per trajectory into caller-owned DEVICE memory (asynchronously, on the handle's
  * stream) — the send buffer of the single all-gather of SURVEY §8(e). */
 int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst);
+
+/* The collective itself behind the C-ABI, for a C++ host (the reference's caller is one: TrajPlanner::RunMINCOParking,
+ * traj_manager.cpp:608-610) that shards its restarts / hypotheses over the GPUs of a node, one process (or thread) and one
+ * dftpav_handle per GPU: ONE RCCL all-gather of the 16-byte records over xGMI, enqueued on the handle's stream.
+ *   dftpav_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands the bytes to the other ranks by whatever
+ *                           channel the host has (MPI, a socket, torch.distributed ...)
+ *   dftpav_comm_create      every rank, collectively: ncclCommInitRank on the handle's device
+ *   dftpav_comm_layout      the contiguous shard [first, first + count) of a rank out of global_B trajectories, and `block` =
+ *                           the largest shard: the gathered buffer holds nranks blocks of `block` records, rank r's shard at
+ *                           the start of block r (the pad, at most one record, is zero)
+ *   dftpav_batch_allgather_results   packs this rank's records and all-gathers them into all_records (DEVICE memory,
+ *                           nranks * block * 16 bytes); asynchronous: the caller synchronises the handle's stream (dftpav_batch_sync)
+ * RCCL is loaded on first use (librccl.so.1); DFTPAV_E_COMM where it is absent or a call fails. */
+#define DFTPAV_UNIQUE_ID_BYTES 128
+int dftpav_comm_unique_id(void *id128);
+int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const void *id128);
+int dftpav_comm_destroy(dftpav_handle *h);
+int dftpav_comm_layout(int global_B, int nranks, int rank, int *first, int *count, int *block);
+int dftpav_batch_allgather_results(dftpav_batch *b, int global_B, void *all_records);
 
 /* Replaces getMinJerkOptPtr()[i].getCoeffs()/getDt() (traj_optimizer.h:112,
  * poly_traj_utils.hpp:1069-1074): regenerates the piece coefficients from the

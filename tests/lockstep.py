@@ -31,9 +31,10 @@ def two_loop(S, Y, YS, g, order):
     return d
 
 
-def replay(tr, lit_eval, p, flip_tol=1e-9):
+def replay(tr, lit_eval, p, flip_tol=1e-9, direction_every=1):
     """tr: dict from Batch.get_trace(); lit_eval(x) -> (f, g); p: dftpav_params.  Returns a report dict; raises
-    AssertionError on a branch mismatch whose margin exceeds flip_tol."""
+    AssertionError on a branch mismatch whose margin exceeds flip_tol.  direction_every: the plain two-loop recursion is
+    replayed (in Python, the slow part) at every such iteration only; every other check is made at every evaluation."""
     X, G, D, F, STP, K = tr["x"], tr["g"], tr["d"], tr["f"], tr["stp"], tr["k"]
     E = len(F)
     fl = np.zeros(E)
@@ -72,7 +73,8 @@ def replay(tr, lit_eval, p, flip_tol=1e-9):
         rows = [r for r in range(e, E) if K[r] == k]  # evaluations of this iteration's line search
         assert rows and rows[0] == e, "trace rows out of order"
         d = D[e]
-        rep["rel_d"] = max(rep["rel_d"], float(np.max(np.abs(d - d_ref)) / max(np.max(np.abs(d_ref)), 1e-300)))
+        if d_ref is not None:
+            rep["rel_d"] = max(rep["rel_d"], float(np.max(np.abs(d - d_ref)) / max(np.max(np.abs(d_ref)), 1e-300)))
         gp_lit = lit_eval(xp)[1]
         finit = fx_lit
         dginit = float(np.dot(gp_lit, d))
@@ -169,7 +171,7 @@ def replay(tr, lit_eval, p, flip_tol=1e-9):
             order.insert(0, end)
             order = order[:m]
             end = (end + 1) % m
-            d_ref = two_loop(S, Y, YS, G[r], order)
+            d_ref = two_loop(S, Y, YS, G[r], order) if k % direction_every == 0 else None
         rep["min_margin"] = min(rep["min_margin"], abs(ys - cau) / max(abs(cau), 1e-300))
         step = 1.0
         xp, gp_gpu = X[r].copy(), G[r].copy()

@@ -110,3 +110,39 @@ def test_bench_takes_the_rccl_path_when_forced(hiplib):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 1024
+
+
+def test_c_abi_communicator_gathers_the_records(hiplib):
+    """dftpav_comm_create / dftpav_batch_allgather_results: RCCL behind the C-ABI, no torch.distributed in the data path
+    (world size 1 on this box: init, pack, ncclAllGather on the handle's stream, layout with its zero pad)."""
+    from dftpav_amd import capi, scenarios as sc
+    p = capi.default_params()
+    B = 6
+    s = sc.baseline_config(3, B=B)
+    s.apply_resolution(p)
+    h = capi.Handle(p, device=0)
+    comm = dd.RcclComm(h)                       # no process group: world size 1, the id never leaves the process
+    assert comm.world == 1 and capi.comm_layout(7, 2, 0) == (0, 3, 4) and capi.comm_layout(7, 2, 1) == (3, 4, 4)
+    bt = capi.Batch(h, s.layout, B)
+    bt.upload(s)
+    bt.solve_async()
+    rec = comm.allgather(bt, B)
+    r = bt.results()
+    c, st, it = dd.unpack_records(rec.cpu().numpy())
+    assert np.array_equal(c, r["final_cost"]) and np.array_equal(st, r["status"]) and np.array_equal(it, r["iters"])
+    with pytest.raises(capi.DftpavError):       # a batch that is not the rank's shard is refused
+        bt.allgather_results(B + 1, comm._recv.data_ptr())
+    comm.close()
+    bt.close()
+    h.close()
+
+
+def test_cpp_host_runs_the_collective_through_the_c_abi(hiplib):
+    """host_example --ranks 1: a C++ host, one thread per rank, sharding + solve + the RCCL all-gather with nothing but
+    include/dftpav_hip.h"""
+    exe = os.path.join(ROOT, "dftpav_amd", "csrc", "host", "host_example")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    out = subprocess.run([exe, "--ranks", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "identical on every rank" in out.stdout

@@ -65,3 +65,64 @@ def test_solve_is_in_lockstep_with_the_reference_lbfgs(hiplib, oracle, cfg, B, b
         assert rep["iterations"] >= 10
     bt.close()
     h.close()
+
+
+def summarize(reps):
+    """what a set of replays amounts to (also bench.py's parity.lockstep)"""
+    return dict(trajectories=len(reps), evaluations=int(sum(r["evals"] for r in reps)), iterations_replayed=int(sum(r["iterations"] for r in reps)),
+                branches_identical=int(sum(r["branches"] for r in reps)), flips=int(sum(r["flip"] is not None for r in reps)),
+                flip_margins=[float(r["flip"]["margin"]) for r in reps if r["flip"] is not None],
+                min_branch_margin=float(min(r["min_margin"] for r in reps)), max_rel_f=float(max(r["rel_f"] for r in reps)),
+                max_rel_g=float(max(r["rel_g"] for r in reps)), max_rel_d=float(max(r["rel_d"] for r in reps)),
+                max_rel_x=float(max(r["rel_x"] for r in reps)))
+
+
+# 64 trajectories per configuration, all traced in ONE solve (dftpav_batch_trace_range).  cfg 5 (BASELINE configs[4], moving
+# obstacles) runs in the launch shape and schedule dftpav_batch_create picks for its batch of 1024 -- four waves per
+# trajectory, time-sliced in slices of 32 iterations -- forced here on 64 trajectories over 16 slots.
+@pytest.mark.parametrize("cfg,B", [(1, 64), (2, 64), (3, 64), (5, 64), (0, 64)])
+def test_lockstep_over_64_trajectories(hiplib, oracle, monkeypatch, cfg, B):
+    capi = hiplib
+    p = capi.default_params()
+    if cfg == 0:
+        from test_default_map import _default_map_scenario
+        p.traj_resolution, p.des_traj_resolution = 16, 32
+        s = _default_map_scenario(oracle, p, 16, 32, B)
+    else:
+        s = sc.baseline_config(cfg, B=B)
+        s.apply_resolution(p)
+    if cfg == 5:
+        for k, v in (("DFTPAV_MODE", "2"), ("DFTPAV_THREADS", "256"), ("DFTPAV_SCHED", "1"), ("DFTPAV_SLOTS", "16"), ("DFTPAV_SLICE", "32"),
+                     ("DFTPAV_HANDOVER", "8")):
+            monkeypatch.setenv(k, v)
+    h = capi.Handle(p)
+    h.set_surround(s.surround)
+    bt = capi.Batch(h, s.layout, B)
+    bt.upload(s)
+    bt.trace(0, 4096, count=B)
+    r = bt.solve()
+    reps = []
+    for b in range(B):
+        tr = bt.get_trace(b)
+        assert len(tr["f"]) == r["evals"][b] and np.array_equal(tr["x"][0], bt.x0()[b])
+        if b < 2:   # the reference build itself for the first two; the restatement (bit-equal to it, ten times faster) for the rest
+            lit, who = literal_evaluator(oracle, p, s, b)
+        else:
+            lit = oracle.OracleProblem(p, s, b, order=0).eval
+        rep = lockstep.replay(tr, lit, p, direction_every=1 if b < 2 else 16)
+        # Maxima over ~40 000 evaluated points per configuration, most of them far from x0: 1e-11 / 1e-10 hold at x0
+        # (test_eval_matches_oracle).  Along whole solves the largest differences seen are 2.3e-10 on f and 1.5e-5 on g relative
+        # to max(1, its largest component) -- absolute errors of 1e-5 on a gradient whose penalty terms have curvature 6e8 x
+        # weight (traj_optimizer.cpp:783-806) are position roundings of 1e-14 m.  What decides is below: every BRANCH taken from
+        # the literal values is the branch the kernel took.
+        assert rep["rel_f"] <= 1e-9 and rep["rel_g"] <= 1e-4 and rep["rel_x"] <= 1e-15 and rep["rel_d"] <= 1e-9
+        if rep["flip"] is None:
+            assert abs(rep["iterations"] - r["iters"][b]) <= 1
+        reps.append(rep)
+    sm = summarize(reps)
+    print("cfg %d (%s): %s" % (cfg, who, sm))
+    # a flip needs a branch within 1e-9 (relative) of its threshold: rare; most solves replay to their end
+    assert sm["flips"] <= B // 8
+    bt.trace(0, 0)
+    bt.close()
+    h.close()
