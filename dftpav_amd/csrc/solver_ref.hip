@@ -29,6 +29,10 @@
 
 #include "device_types.h"
 
+#ifndef DFTPAV_REF_SUM_ALL_LANES
+#define DFTPAV_REF_SUM_ALL_LANES 1 // measured: the chain on one lane + broadcast costs 637 cycles per history step against 546
+#endif
+
 namespace dftpav {
 namespace reford {
 
@@ -174,37 +178,42 @@ __device__ constexpr int kInterior[4][6] = {{0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e}
                                             {0x00, 0x18, 0x30, 0x31, 0x21, 0x06},
                                             {0x00, 0x00, 0x00, 0x35, 0x3b, 0x30},
                                             {0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38}};
-template <int Q, bool GENERIC>
-__device__ __forceinline__ void sweep_block(ldscd_t tab, ldsd_t b, int n6, int d, int i0, double (&w)[6]) {
-  constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
-  double c[6][6], bi[6], dv[6], dr[6];
+typedef double __attribute__((ext_vector_type(2))) v2d_t;
+typedef const v2d_t __attribute__((address_space(3))) *ldscv2_t;
+struct SweepBlk {
+  v2d_t c[6][4]; // rows of the table: (c0,c1) (c2,c3) (c4,c5) (diagonal, 1 / diagonal)
+  double bi[6];
+};
+template <int Q>
+__device__ __forceinline__ void sweep_load(SweepBlk &R, ldscd_t tab, ldscd_t b, int n6, int d, int i0) {
+  constexpr bool DESC = Q == 1 || Q == 3;
+  i0 = i0 < n6 ? i0 : n6 - 6; // a block past the end re-reads the last one (never used)
 #pragma unroll
-  for (int r = 0; r < 6; r++) { // everything the block reads, requested together
+  for (int r = 0; r < 6; r++) {
     const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
-    const int mask = GENERIC ? 0x3f : kInterior[Q][DESC ? 5 - r : r];
-    ldscd_t a = tab + 8 * i;
+    const ldscv2_t a = (ldscv2_t)(tab + 8 * i);
 #pragma unroll
-    for (int k = 0; k < 6; k++)
-      if (mask & (1 << k)) c[r][k] = a[k];
-    bi[r] = b[2 * i + d];
-    if (DIV) {
-      dv[r] = a[6];
-      dr[r] = a[7];
-    }
+    for (int q = 0; q < 4; q++) R.c[r][q] = a[q];
+    R.bi[r] = b[2 * i + d];
   }
+}
+template <int Q, bool GENERIC>
+__device__ __forceinline__ void sweep_rows(const SweepBlk &R, ldsd_t b, int n6, int d, int i0, double (&w)[6]) {
+  constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
     const int mask = GENERIC ? 0x3f : kInterior[Q][DESC ? 5 - r : r];
-    double acc = bi[r];
+    double acc = R.bi[r];
 #pragma unroll
     for (int k = 0; k < 6; k++)
       if (mask & (1 << k)) {
-        const double t = c[r][k] * w[(r + k) % 6];
-        if (GENERIC) acc = c[r][k] != 0.0 ? acc - t : acc;
+        const double ck = (k & 1) ? R.c[r][k >> 1].y : R.c[r][k >> 1].x;
+        const double t = ck * w[(r + k) % 6];
+        if (GENERIC) acc = ck != 0.0 ? acc - t : acc;
         else acc = acc - t;
       }
-    if (DIV) acc = div_by_rcp(acc, dv[r], dr[r]);
+    if (DIV) acc = div_by_rcp(acc, R.c[r][3].x, R.c[r][3].y);
     w[r] = acc;
     b[2 * i + d] = acc;
   }
@@ -212,9 +221,25 @@ __device__ __forceinline__ void sweep_block(ldscd_t tab, ldsd_t b, int n6, int d
 template <int Q>
 __device__ __forceinline__ void sweep(ldscd_t tab, ldsd_t b, int n6, int d) {
   double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  sweep_block<Q, true>(tab, b, n6, d, 0, w);
-  for (int i0 = 6; i0 < n6 - 6; i0 += 6) sweep_block<Q, false>(tab, b, n6, d, i0, w);
-  sweep_block<Q, true>(tab, b, n6, d, n6 - 6, w); // (N >= 2)
+  SweepBlk A, B;
+  sweep_load<Q>(A, tab, b, n6, d, 0);
+  sweep_load<Q>(B, tab, b, n6, d, 6);
+  sweep_rows<Q, true>(A, b, n6, d, 0, w); // the first block tests every coefficient
+  // middle blocks 6 .. n6-12, two per turn; the block after the next is requested before a block is worked on
+  int i0 = 6;
+  for (; i0 + 6 < n6 - 6; i0 += 12) {
+    sweep_load<Q>(A, tab, b, n6, d, i0 + 6);
+    sweep_rows<Q, false>(B, b, n6, d, i0, w);
+    sweep_load<Q>(B, tab, b, n6, d, i0 + 12);
+    sweep_rows<Q, false>(A, b, n6, d, i0 + 6, w);
+  }
+  if (i0 < n6 - 6) { // one middle block left (B holds it); then the last block
+    sweep_load<Q>(A, tab, b, n6, d, i0 + 6);
+    sweep_rows<Q, false>(B, b, n6, d, i0, w);
+    sweep_rows<Q, true>(A, b, n6, d, n6 - 6, w);
+  } else {
+    sweep_rows<Q, true>(B, b, n6, d, n6 - 6, w); // B holds the last block
+  }
 }
 
 // positiveSmoothedL1, traj_optimizer.cpp:783-806
@@ -292,45 +317,75 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
   for (int k = 0; k < 4; k++) R_dot[k] = sg * (temp_a[k] * z_h0 - temp_v[k] * vel2_reci * z_h0 * z_h1);
 
   unsigned mask = 0u;
-  // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634
-#pragma unroll 1
+  // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634.  The 5 H tests first (term v H + k:
+  // the order of the reference's nested loops), collected in the mask; then one pass over the set bits, so that a lane spends
+  // time on its own violated half-planes only (as nested loops every body ran for the whole wave if a single lane needed it).
+  double pn0[5], pn1[5], pq0[5], pq1[5], rl0[5], rl1[5];
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const int kk = k < H ? k : 0; // rows past H re-read plane 0 and are never used
+    pn0[k] = cor[(size_t)(4 * kk + 0) * pitch];
+    pn1[k] = cor[(size_t)(4 * kk + 1) * pitch];
+    pq0[k] = cor[(size_t)(4 * kk + 2) * pitch];
+    pq1[k] = cor[(size_t)(4 * kk + 3) * pitch];
+  }
+#pragma unroll
   for (int v = 0; v < 5; v++) {
     const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
-    const double Rle0 = ego_R[0] * le0 + ego_R[1] * le1, Rle1 = ego_R[2] * le0 + ego_R[3] * le1;
-    const double bpt0 = sigma[0] + Rle0, bpt1 = sigma[1] + Rle1;
-    const double tl[4] = {le0, -le1, le1, le0};
-#pragma unroll 1
-    for (int k = 0; k < H; k++) {
-      const double on0 = cor[(size_t)(4 * k + 0) * pitch], on1 = cor[(size_t)(4 * k + 1) * pitch];
-      const double q0 = cor[(size_t)(4 * k + 2) * pitch], q1 = cor[(size_t)(4 * k + 3) * pitch];
-      const double violaPos = on0 * (bpt0 - q0) + on1 * (bpt1 - q1);
-      if (violaPos > 0) {
-        double pena, penaD;
-        smoothed_l1(violaPos, pena, penaD);
-        double Mm[4];
-        Mm[0] = sg * tl[0] * z_h0 - Rle0 * dsigma[0] * vel2_reci;
-        Mm[1] = sg * tl[1] * z_h0 - Rle0 * dsigma[1] * vel2_reci;
-        Mm[2] = sg * tl[2] * z_h0 - Rle1 * dsigma[0] * vel2_reci;
-        Mm[3] = sg * tl[3] * z_h0 - Rle1 * dsigma[1] * vel2_reci;
-        const double w0 = dsigma[0] + (R_dot[0] * le0 + R_dot[1] * le1);
-        const double w1 = dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1);
-        const double gradViolaPt = (alpha * on0) * w0 + (alpha * on1) * w1;
-        const double sc = omg * step * P.wei_obs * penaD;
-        const int t = v * H + k;
-        gd_t r_ = rec + (size_t)t * kRec;
+    rl0[v] = ego_R[0] * le0 + ego_R[1] * le1;
+    rl1[v] = ego_R[2] * le0 + ego_R[3] * le1;
+    const double bpt0 = sigma[0] + rl0[v], bpt1 = sigma[1] + rl1[v];
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-          const double b1n0 = beta1[r] * on0, b1n1 = beta1[r] * on1;
-          const double g0 = beta0[r] * on0 + (b1n0 * Mm[0] + b1n1 * Mm[2]);
-          const double g1 = beta0[r] * on1 + (b1n0 * Mm[1] + b1n1 * Mm[3]);
-          r_[2 * r + 0] = sc * g0;
-          r_[2 * r + 1] = sc * g1;
-        }
-        r_[12] = omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
-        r_[13] = omg * step * P.wei_obs * pena;
-        mask |= 1u << t;
-      }
+    for (int k = 0; k < 5; k++) {
+      const double violaPos = pn0[k] * (bpt0 - pq0[k]) + pn1[k] * (bpt1 - pq1[k]);
+      if (k < H && violaPos > 0) mask |= 1u << (v * H + k);
     }
+  }
+  for (unsigned m = mask; m;) {
+    const int t = __builtin_ctz(m);
+    m &= m - 1;
+    int v = 0;
+#pragma unroll
+    for (int q = 1; q < 5; q++) v += t >= q * H ? 1 : 0;
+    const int k = t - v * H;
+    double on0 = pn0[0], on1 = pn1[0], q0 = pq0[0], q1 = pq1[0];
+    double Rle0 = rl0[0], Rle1 = rl1[0], le0 = P.vec_le[0][0], le1 = P.vec_le[0][1];
+#pragma unroll
+    for (int q = 1; q < 5; q++) {
+      on0 = k == q ? pn0[q] : on0;
+      on1 = k == q ? pn1[q] : on1;
+      q0 = k == q ? pq0[q] : q0;
+      q1 = k == q ? pq1[q] : q1;
+      Rle0 = v == q ? rl0[q] : Rle0;
+      Rle1 = v == q ? rl1[q] : Rle1;
+      le0 = v == q ? P.vec_le[q][0] : le0;
+      le1 = v == q ? P.vec_le[q][1] : le1;
+    }
+    const double bpt0 = sigma[0] + Rle0, bpt1 = sigma[1] + Rle1;
+    const double violaPos = on0 * (bpt0 - q0) + on1 * (bpt1 - q1); // the expression of the test: > 0 here
+    const double tl[4] = {le0, -le1, le1, le0};
+    double pena, penaD;
+    smoothed_l1(violaPos, pena, penaD);
+    double Mm[4];
+    Mm[0] = sg * tl[0] * z_h0 - Rle0 * dsigma[0] * vel2_reci;
+    Mm[1] = sg * tl[1] * z_h0 - Rle0 * dsigma[1] * vel2_reci;
+    Mm[2] = sg * tl[2] * z_h0 - Rle1 * dsigma[0] * vel2_reci;
+    Mm[3] = sg * tl[3] * z_h0 - Rle1 * dsigma[1] * vel2_reci;
+    const double w0 = dsigma[0] + (R_dot[0] * le0 + R_dot[1] * le1);
+    const double w1 = dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1);
+    const double gradViolaPt = (alpha * on0) * w0 + (alpha * on1) * w1;
+    const double sc = omg * step * P.wei_obs * penaD;
+    gd_t r_ = rec + (size_t)t * kRec;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double b1n0 = beta1[r] * on0, b1n1 = beta1[r] * on1;
+      const double g0 = beta0[r] * on0 + (b1n0 * Mm[0] + b1n1 * Mm[2]);
+      const double g1 = beta0[r] * on1 + (b1n0 * Mm[1] + b1n1 * Mm[3]);
+      r_[2 * r + 0] = sc * g0;
+      r_[2 * r + 1] = sc * g1;
+    }
+    r_[12] = omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
+    r_[13] = omg * step * P.wei_obs * pena;
   }
   const int t0 = 5 * H;
   if (violaVel > 0.0) { // :642-653
@@ -710,13 +765,25 @@ template <int CAP>
 __device__ __forceinline__ double seq_sum(double p, int n, ldsd_t buf, int lane) {
   buf[lane] = lane < n ? p : -0.0;
   wave_lds_order();
-  double v[CAP];
-#pragma unroll
-  for (int u = 0; u < CAP; u++) v[u] = buf[u];
   double s = 0.0;
+#if DFTPAV_REF_SUM_ALL_LANES
+  {
+#else
+  if (lane == 0) { // one lane reads and chains (an LDS read costs by the lanes it serves), the others take its result
+#endif
+    double v[CAP];
 #pragma unroll
-  for (int u = 0; u < CAP; u++) s += v[u];
+    for (int u = 0; u < CAP; u++) v[u] = buf[u];
+#pragma unroll
+    for (int u = 0; u < CAP; u++) s += v[u];
+  }
   wave_lds_order(); // the buffer is free again
+#if !DFTPAV_REF_SUM_ALL_LANES
+  {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(s)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(s));
+    s = __hiloint2double(hi, lo);
+  }
+#endif
   return s;
 }
 
@@ -1086,8 +1153,10 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
 }
 
 // ------------------------------------------------ the kernel
+// (two workgroups per CU = two waves per SIMD where the registers allow it: a second trajectory fills the issue slots the
+// dependent chains of the first leave empty)
 template <int CAP>
-__global__ void __launch_bounds__(256) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
+__global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
   const DevLayout &L = D.L;
