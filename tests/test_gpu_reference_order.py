@@ -126,3 +126,57 @@ def test_reference_order_is_refused_where_libm_sits_in_the_loop(hiplib):
         b5.set_order(hiplib.ORDER_REFERENCE)
     b5.close()
     h5.close()
+
+
+def test_random_layouts_in_reference_order(hiplib, oracle):
+    """Randomly shaped single-segment problems -- 2 to 32 pieces (n = 3 .. 63: the three widths of the sequential sums), sample
+    resolutions 3-24, forward and reverse gears, 0-60 obstacles, L-BFGS memories from 3 pairs (the ring wraps after three
+    iterations) to 300, other `past` / `delta` settings: every field of every solve bit-equal to the reference's restatement,
+    and to the reference build itself where it is there."""
+    pyref = _ref()
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    for c in range(20):
+        rng = np.random.default_rng(12000 + c)
+        N = int([2, 3, 5, 9, 12, 17, 24, 32, 8, 16][c % 10])
+        K, Kd, B = int(rng.integers(3, 25)), int(rng.integers(3, 25)), int(rng.integers(1, 4))
+        p = hiplib.default_params()
+        s = sc.make_scenario([N], [int(rng.choice([1, -1]))], K, Kd, B, seed=13000 + c, n_obs=int(rng.integers(0, 60)))
+        s.apply_resolution(p)
+        if c % 2 == 0:
+            p.lbfgs_mem_size = [3, 8, 5, 300, 17, 64, 9, 33, 4, 128][c // 2]
+        if c % 5 == 1:
+            p.lbfgs_past, p.lbfgs_delta = int(rng.integers(1, 7)), float(10.0 ** rng.uniform(-6, -3))
+        if c % 7 == 3:
+            s.help_eps = 1e-3       # the second reciprocal of the curvature term (traj_optimizer.cpp:556-558) differs from the first
+        h, bt = _batch(hiplib, s, p)
+        x = bt.x0() + rng.normal(0, 0.2, bt.x0().shape)
+        f, g = bt.eval(x)
+        for b in range(B):
+            fl, gl = oracle.OracleProblem(p, s, b, order=0).eval(x[b])
+            assert f[b] == fl and np.array_equal(g[b], gl), (c, N, K, Kd, b)
+        r = bt.solve()
+        lit = oracle.solve_batch(p, s, nthreads=2, order=0)
+        for k in keys:
+            assert np.array_equal(r[k], lit[k]), (c, N, K, Kd, B, p.lbfgs_mem_size, p.lbfgs_past, k)
+        if pyref and c % 4 == 0:
+            rr = pyref.RefProblem(p, s, 0).optimize()
+            assert rr["final_cost"] == r["final_cost"][0] and np.array_equal(rr["x"], r["x"][0]) and rr["iters"] == r["iters"][0]
+        bt.close()
+        h.close()
+
+
+def test_six_half_planes_and_wide_layouts_are_refused_cleanly(hiplib):
+    """H > 5 (the term mask has 32 bits) and n > 64 stay with the device order"""
+    p = hiplib.default_params()
+    from dftpav_amd.pods import LayoutSpec
+    s = sc.make_scenario([40], [1], 8, 8, 1, seed=5)       # n = 79
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, 1)
+    bt.upload(s)
+    with pytest.raises(hiplib.DftpavError) as e:
+        bt.set_order(hiplib.ORDER_REFERENCE)
+    assert e.value.code == hiplib.E_UNSUPPORTED
+    assert bt.solve()["success"].all()
+    bt.close()
+    h.close()
