@@ -276,12 +276,13 @@ def main():
         ebytes_steps = sum(eb[(state["k"] - args.steps + j) % 2] for j in range(args.steps))  # the batches the timed steps solved
         kms = gpu_ms / args.steps  # device time of the timed region (marker events on the library's streams) per step
         achieved = ebytes_steps / args.steps / (kms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu_per_solve = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 traffic = pj.get("hbm_bytes_per_launch")
+                valu_per_solve = pj.get("valu_instructions_per_solve")
                 traffic_source = "profiles/pmc_latest.json: separate rocprofv3 --pmc passes of `%s` (%s)" % (
                     pj.get("command", "bench.py --steps 3 --no-extras"), pj.get("collected", "round 1"))
             except Exception:
@@ -316,6 +317,16 @@ def main():
             "mean_hist_depth": float(r["hist_sum"].sum() / max(1, r["iters"].sum())),
             "success_rate": float(r["success"].mean()),
         }
+        if valu_per_solve:
+            # the roof that actually binds: VALU issue.  SQ_INSTS_VALU per solve (the --pmc pass named in traffic_source) x solves/s
+            # against one wave64 VALU instruction per SIMD every 4 cycles (fp64 FMA / add / mul issue at that rate on CDNA4)
+            clk = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
+            peak_i = n_cu * 4 * clk / 4.0
+            out["roofline"]["valu"] = {"instructions_per_solve": valu_per_solve, "achieved_instr_per_s": valu_per_solve * value / world,
+                                       "peak_instr_per_s": peak_i, "frac": valu_per_solve * value / world / peak_i,
+                                       "clock_hz": clk, "simds": n_cu * 4,
+                                       "note": "wave64 VALU instructions issued per second over (SIMDs x clock / 4); the kernel is bound "
+                                               "here and by dependent latency at two waves per SIMD, not by bytes"}
         if other is not None:
             out["other_scaling"] = other
         if strong_shard is not None:

@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: everything profiles/ is summarised from, for one tag (default r02).  rocprofv3 runs from /tmp with TMPDIR=/tmp;
+# GPU box: everything profiles/ is summarised from, for one tag (default r03).  rocprofv3 runs from /tmp with TMPDIR=/tmp;
 # the counter passes are separate runs with --pmc only (never combined with trace domains).
-#   scripts/collect_profiles.sh r02      then, here:  python scripts/summarize_profiles.py r02
-tag=${1:-r02}
+#   scripts/collect_profiles.sh r03      then, here:  python scripts/summarize_profiles.py r03
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 4 --warmup 1 --no-extras --cpu-sample 0"

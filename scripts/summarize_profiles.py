@@ -102,7 +102,8 @@ if sq:
     if "SQC_ICACHE_REQ" in sq:
         d["icache_miss_rate"] = sq.get("SQC_ICACHE_MISSES", 0.0) / sq["SQC_ICACHE_REQ"]
     if "SQ_INSTS_VALU" in sq:
-        d["valu_instructions_per_solve"] = sq["SQ_INSTS_VALU"] / (steps * (gmax // wg if False else 1)) / 4096.0
+        d["valu_instructions_per_solve"] = sq["SQ_INSTS_VALU"] / steps / 4096.0
+        rec["valu_instructions_per_solve"] = d["valu_instructions_per_solve"]   # bench.py: roofline.valu
     json.dump(d, open(os.path.join(out, "%s_sq.json" % tag), "w"), indent=1)
     print(json.dumps(d.get("fractions_of_wave_cycles")), d.get("icache_miss_rate"))
 bl = os.path.join(root, "gpurun_out", "bench_line_%s.json" % tag)
