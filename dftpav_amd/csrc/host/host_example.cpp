@@ -120,6 +120,14 @@ int main(int argc, char **argv) {
   std::printf("OptimizeTrajectory -> %d, status %d, cost %.6f, %d iterations, %zu segments, dt %.4f\n", (int)ok,
               opt.last_status(), opt.last_cost(), opt.last_iterations(), opt.getMinJerkOptPtr()->size(),
               ok ? (*opt.getMinJerkOptPtr())[0].getDt() : 0.0);
+  // the same call in the reference's own floating-point order (the bits of the CPU planner)
+  opt.setReferenceOrder(true);
+  const bool ok_ref = opt.OptimizeTrajectory(ini, fin, inner, Ts, polys, {1}, 0.0, 0.0);
+  std::printf("  in reference order -> %d (order %d), status %d, cost %.6f, %d iterations\n", (int)ok_ref, opt.last_order(), opt.last_status(),
+              opt.last_cost(), opt.last_iterations());
+  ok = ok && ok_ref && opt.last_order() == DFTPAV_ORDER_REFERENCE;
+  opt.setReferenceOrder(false);
+  ok = ok && opt.OptimizeTrajectory(ini, fin, inner, Ts, polys, {1}, 0.0, 0.0);
   // ---- the read-out of the plan the way the server publishes it, and the plan as bytes
   bool ok3 = ok;
   if (ok) {

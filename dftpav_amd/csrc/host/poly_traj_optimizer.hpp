@@ -94,7 +94,12 @@ class PolyTrajOptimizer {
   int get_traj_resolution_() const { return params_.traj_resolution; }        // traj_optimizer.h:113
   int get_destraj_resolution_() const { return params_.des_traj_resolution; } // traj_optimizer.h:114
   const std::vector<MinJerkOptView> *getMinJerkOptPtr() const { return &mjo_; } // traj_optimizer.h:112
-  // extras of the new build: status of the last solve
+  // extras of the new build.  setReferenceOrder(true): solves run with every sum in the order the reference executes it and
+  // return OptimizeTrajectory's own bits (one gear segment, no moving obstacles; include/dftpav_hip.h:
+  // dftpav_batch_set_order); where the layout does not allow it the throughput order runs and last_order() says so
+  void setReferenceOrder(bool on) { want_reference_order_ = on; }
+  int last_order() const { return order_; } // DFTPAV_ORDER_* of the last solve
+  // status of the last solve
   int last_status() const { return status_; }
   double last_cost() const { return cost_; }
   int last_iterations() const { return iters_; }
@@ -173,6 +178,8 @@ class PolyTrajOptimizer {
     int rc = dftpav_batch_create(h_, &lay, 1, &b);
     if (rc != DFTPAV_OK) return fail(rc);
     rc = dftpav_batch_upload(b, &d);
+    order_ = DFTPAV_ORDER_DEVICE;
+    if (rc == DFTPAV_OK && want_reference_order_ && dftpav_batch_set_order(b, DFTPAV_ORDER_REFERENCE) == DFTPAV_OK) order_ = DFTPAV_ORDER_REFERENCE;
     if (rc == DFTPAV_OK) rc = dftpav_batch_solve_async(b);
     int success = 0;
     if (rc == DFTPAV_OK) rc = dftpav_batch_results(b, nullptr, &cost_, &status_, &success, &iters_, nullptr, nullptr, nullptr);
@@ -211,7 +218,8 @@ class PolyTrajOptimizer {
   dftpav_handle *h_ = nullptr;
   const SurroundSet *surround_ = nullptr;
   std::vector<MinJerkOptView> mjo_;
-  int status_ = 0, iters_ = 0, err_ = 0;
+  int status_ = 0, iters_ = 0, err_ = 0, order_ = DFTPAV_ORDER_DEVICE;
+  bool want_reference_order_ = false;
   double cost_ = 0.0;
 };
 

@@ -31,8 +31,12 @@ class MinJerkOptView:
 
 
 class PolyTrajOptimizer:
-    def __init__(self, device=0):
+    def __init__(self, device=0, reference_order=False):
+        """reference_order: solve with every sum in the order the reference executes it -- OptimizeTrajectory's own bits
+        (one gear segment, no moving obstacles; dftpav_batch_set_order).  Where the layout does not allow it the
+        throughput order runs; `last["order"]` says which one did."""
         self._device = device
+        self._reference_order = bool(reference_order)
         self._params = capi.default_params()
         self._handle = None
         self._surround = None
@@ -128,7 +132,16 @@ class PolyTrajOptimizer:
             if rc in (capi.E_MINI_T, capi.E_INVALID, capi.E_ONE_PIECE):
                 return dict(success=np.zeros(B, dtype=np.int32))
             h._check(rc, "upload")
+        order = capi.ORDER_DEVICE
+        if self._reference_order:
+            try:
+                bt.set_order(capi.ORDER_REFERENCE)
+                order = capi.ORDER_REFERENCE
+            except capi.DftpavError as ex:
+                if ex.code != capi.E_UNSUPPORTED:
+                    raise
         r = bt.solve()
+        r["order"] = order
         c, dt = bt.coeffs()
         # results stay inside the optimiser until the next call (traj_optimizer.h:91,112); B=1 view for the ROS path
         off = 0

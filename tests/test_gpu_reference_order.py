@@ -180,3 +180,47 @@ def test_six_half_planes_and_wide_layouts_are_refused_cleanly(hiplib):
     assert bt.solve()["success"].all()
     bt.close()
     h.close()
+
+
+def test_class_mirror_in_reference_order_returns_the_reference_answer(hiplib, oracle):
+    """PolyTrajOptimizer(reference_order=True).OptimizeTrajectory with the containers traj_manager.cpp:608-610 passes: the
+    reference's own answer for a single-segment problem (bit-equal to the reference build / its restatement), and the
+    throughput order -- reported as such -- where the layout has a gear shift."""
+    from dftpav_amd.optimizer import PolyTrajOptimizer
+
+    def containers(s):
+        lay = s.layout
+        ini = [s.ini_states[0, i].reshape(3, 2).T for i in range(lay.M)]
+        fin = [s.fin_states[0, i].reshape(3, 2).T for i in range(lay.M)]
+        inner, off, polys, pt = [], 0, [], 0
+        for N in lay.piece_nums:
+            inner.append(s.inner_pts[0, off:off + 2 * (N - 1)].reshape(N - 1, 2).T)
+            off += 2 * (N - 1)
+            cnt = (N - 2) * (s.K + 1) + 2 * (s.Kd + 1)
+            polys.append([s.corridor[0, pt + k].T for k in range(cnt)])
+            pt += cnt
+        return ini, fin, inner, polys
+
+    p = hiplib.default_params()
+    s = sc.baseline_config(1, B=1)
+    s.apply_resolution(p)
+    opt = PolyTrajOptimizer(reference_order=True)
+    opt.setParam(p)
+    ini, fin, inner, polys = containers(s)
+    assert opt.OptimizeTrajectory(ini, fin, inner, s.init_Ts[0], polys, list(s.layout.singuls), 0.0, 0.0) is True
+    assert opt.last["order"] == hiplib.ORDER_REFERENCE
+    lit = oracle.solve_batch(p, s, nthreads=1, order=0)
+    assert opt.last["final_cost"][0] == lit["final_cost"][0] and np.array_equal(opt.last["x"][0], lit["x"][0])
+    assert opt.last["iters"][0] == lit["iters"][0] and opt.last["evals"][0] == lit["evals"][0]
+    pyref = _ref()
+    if pyref:
+        rr = pyref.RefProblem(p, s, 0).optimize()
+        assert rr["final_cost"] == opt.last["final_cost"][0] and np.array_equal(rr["x"], opt.last["x"][0])
+    s2 = sc.baseline_config(2, B=1)
+    p2 = hiplib.default_params()
+    s2.apply_resolution(p2)
+    opt2 = PolyTrajOptimizer(reference_order=True)
+    opt2.setParam(p2)
+    ini, fin, inner, polys = containers(s2)
+    assert opt2.OptimizeTrajectory(ini, fin, inner, s2.init_Ts[0], polys, list(s2.layout.singuls), 0.0, 0.0) is True
+    assert opt2.last["order"] == hiplib.ORDER_DEVICE      # gear shift: libm inside the loop
