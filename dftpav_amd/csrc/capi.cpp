@@ -22,6 +22,7 @@
 #include "device_types.h"
 #include "e4_plan.h"
 #include "traj_math.h"
+#include "cr_trig.h"
 
 namespace dftpav {
 hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int threads, int grid, SchedArgs sched,
@@ -1472,6 +1473,13 @@ static bool reference_order_tables(int N, std::vector<double> &out) {
   }
   return ok;
 }
+// test hook (host only): the correctly rounded sin / cos the reference-order kernel uses for the junction angles (cr_trig.h),
+// run on the host for n arguments
+extern "C" int dftpav_debug_cr_sincos(int n, const double *x, double *s, double *c) {
+  if (n < 0 || !x || !s || !c) return DFTPAV_E_INVALID;
+  for (int i = 0; i < n; i++) dftpav::crt::sincos(x[i], s[i], c[i]);
+  return DFTPAV_OK;
+}
 // test hook (host only): the sweep tables of a segment of N pieces, [4][6N][8]; returns 1 if the middle blocks have the assumed pattern
 extern "C" int dftpav_debug_reference_tables(int N, double *out) {
   if (N < 2) return DFTPAV_E_INVALID;
@@ -1490,14 +1498,18 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (order == DFTPAV_ORDER_REFERENCE) {
     if (!reference_order_supported(b->L, b->P, h->S)) {
-      h->err = "reference order: one gear segment, no moving obstacles, n <= 64, H <= 5 (libm inside the loop otherwise)";
+      h->err = "reference order: no moving obstacles (libm's exp / log inside the loop), n <= 64, H <= 5";
       return DFTPAV_E_UNSUPPORTED;
     }
     if (!b->d_ref_tab) {
-      std::vector<double> tab;
-      if (!reference_order_tables(b->L.piece_nums[0], tab)) {
-        h->err = "reference order: the LU factors of this band system do not have the pattern the kernel assumes";
-        return DFTPAV_E_UNSUPPORTED;
+      std::vector<double> tab; // the tables of the segments, one after the other
+      for (int sg = 0; sg < b->L.M; sg++) {
+        std::vector<double> one;
+        if (!reference_order_tables(b->L.piece_nums[sg], one)) {
+          h->err = "reference order: the LU factors of this band system do not have the pattern the kernel assumes";
+          return DFTPAV_E_UNSUPPORTED;
+        }
+        tab.insert(tab.end(), one.begin(), one.end());
       }
       HIPCHK(h, hipMalloc(&b->d_ref_tab, sizeof(double) * tab.size()));
       HIPCHK(h, hipMemcpy(b->d_ref_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));

@@ -1,0 +1,125 @@
+// cr_trig.h — correctly rounded sin and cos in fp64, for host and device.
+//
+// The reference-order kernel (solver_ref.hip) runs the reference's floating-point program.  With a gear shift that program
+// calls libm's cos / sin of the junction angle in every evaluation (traj_optimizer.cpp:273-282, 311-318), and libm's
+// results are a property of the host: glibc's sin / cos are not correctly rounded (on this image's glibc 2.35 they differ
+// from the correctly rounded value for 1 argument in 1 000) and are IFUNC symbols whose variant -- SSE2 or AVX2+FMA, with
+// different roundings -- is picked by the CPU.  The device therefore uses the one sin / cos that is DEFINED rather than
+// implemented: the correctly rounded one.  Any correctly rounded libm (CORE-MATH, LLVM libc) gives these bits; glibc
+// gives them for 999 arguments in 1 000.
+//
+// Method: x - k pi/2 with pi/2 in three 33-bit chunks and a tail (152 bits; k p_i exact for |k| < 2^20, i.e. |x| < 1.6e6),
+// carried in double-double; Taylor series of sin / cos on |r| <= pi/4 in double-double arithmetic (error-free sums and
+// FMA products) with the coefficients 1 / n! as double-double constants, to ~2^-100; the high word of the normalised
+// result is the correctly rounded value unless the true value lies within ~2^-100 relative of a rounding boundary
+// (probability ~2^-47 per call; the known hardest cases of sin / cos in double need 2^-126).
+// tests/test_cr_trig.py checks it against binary128 (libquadmath) on millions of arguments.
+#pragma once
+#include "device_types.h"
+
+namespace dftpav {
+namespace crt {
+
+struct dd {
+  double hi, lo;
+};
+DFTPAV_HD inline dd two_sum(double a, double b) { // error-free a + b
+  const double s = a + b;
+  const double bb = s - a;
+  return dd{s, (a - (s - bb)) + (b - bb)};
+}
+DFTPAV_HD inline dd fast_two_sum(double a, double b) { // |a| >= |b|
+  const double s = a + b;
+  return dd{s, b - (s - a)};
+}
+DFTPAV_HD inline dd two_prod(double a, double b) { // error-free a b
+  const double p = a * b;
+  return dd{p, __builtin_fma(a, b, -p)};
+}
+DFTPAV_HD inline dd dd_add(dd a, dd b) {
+  dd s = two_sum(a.hi, b.hi);
+  const dd t = two_sum(a.lo, b.lo);
+  s.lo += t.hi;
+  s = fast_two_sum(s.hi, s.lo);
+  s.lo += t.lo;
+  return fast_two_sum(s.hi, s.lo);
+}
+DFTPAV_HD inline dd dd_add_d(dd a, double b) {
+  dd s = two_sum(a.hi, b);
+  s.lo += a.lo;
+  return fast_two_sum(s.hi, s.lo);
+}
+DFTPAV_HD inline dd dd_mul(dd a, dd b) {
+  dd p = two_prod(a.hi, b.hi);
+  p.lo += a.hi * b.lo + a.lo * b.hi;
+  return fast_two_sum(p.hi, p.lo);
+}
+DFTPAV_HD inline dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+
+// 1 / n!, n = 2 .. 31 (index n - 2)
+DFTPAV_HD inline dd inv_fact(int n) {
+  const double t[30][2] = {
+      {0x1.0000000000000p-1, 0x0.0p+0},           {0x1.5555555555555p-3, 0x1.5555555555555p-57},   {0x1.5555555555555p-5, 0x1.5555555555555p-59},
+      {0x1.1111111111111p-7, 0x1.1111111111111p-63}, {0x1.6c16c16c16c17p-10, -0x1.f49f49f49f49fp-65}, {0x1.a01a01a01a01ap-13, 0x1.a01a01a01a01ap-73},
+      {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76}, {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73}, {0x1.27e4fb7789f5cp-22, 0x1.cbbc05b4fa99ap-76},
+      {0x1.ae64567f544e4p-26, -0x1.c062e06d1f209p-80}, {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83}, {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
+      {0x1.93974a8c07c9dp-37, 0x1.05d6f8a2efd1fp-92}, {0x1.ae7f3e733b81fp-41, 0x1.1d8656b0ee8cbp-97}, {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
+      {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103}, {0x1.6827863b97d97p-53, 0x1.eec01221a8b0bp-107}, {0x1.2f49b46814157p-57, 0x1.2650f61dbdcb4p-112},
+      {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120}, {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120}, {0x1.0ce396db7f853p-70, -0x1.aebcdbd20331cp-124},
+      {0x1.761b41316381ap-75, -0x1.3423c7d91404fp-130}, {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135}, {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139},
+      {0x1.88e85fc6a4e5ap-89, -0x1.71c37ebd16540p-143}, {0x1.d1ab1c2dccea3p-94, 0x1.054d0c78aea14p-149}, {0x1.0a18a2635085dp-98, 0x1.b9e2e28e1aa54p-153},
+      {0x1.259f98b4358adp-103, 0x1.eaf8c39dd9bc5p-157}, {0x1.3932c5047d60ep-108, 0x1.832b7b530a627p-162}, {0x1.434d2e783f5bcp-113, 0x1.0b87b91be9affp-167}};
+  return dd{t[n - 2][0], t[n - 2][1]};
+}
+
+// r = x - k pi/2 as a double-double, k = nearest integer to x 2/pi (|x| < 1.6e6); returns k
+DFTPAV_HD inline int reduce(double x, dd &r) {
+  const double two_over_pi = 0x1.45f306dc9c883p-1;
+  const double p1 = 0x1.921fb54400000p+0, p2 = 0x1.0b4611a600000p-34, p3 = 0x1.3198a2e000000p-69, p4 = 0x1.b839a252049c1p-104;
+  const double fk = x * two_over_pi;
+  const int k = (int)(fk < 0.0 ? fk - 0.5 : fk + 0.5);
+  const double kd = (double)k;
+  dd a = two_sum(x, -(kd * p1)); // kd p1, kd p2, kd p3 are exact (33-bit chunks, |k| < 2^20)
+  a = dd_add_d(a, -(kd * p2));
+  a = dd_add_d(a, -(kd * p3));
+  const dd t = two_prod(kd, p4);
+  r = dd_add(a, dd_neg(t));
+  return k;
+}
+// sin and cos of a double-double |r| <= ~pi/4 by their Taylor series in double-double (Horner in r^2)
+DFTPAV_HD inline dd sin_dd(dd r) {
+  const dd r2 = dd_mul(r, r);
+  dd acc = inv_fact(31);
+  for (int n = 29; n >= 3; n -= 2) acc = dd_add(inv_fact(n), dd_neg(dd_mul(acc, r2))); // 1/n! - r^2 (1/(n+2)! - ...)
+  // sin r = r - r^3 (1/3! - r^2 (...)) = r (1 - r^2 acc)
+  const dd t = dd_mul(dd_mul(acc, r2), r);
+  return dd_add(r, dd_neg(t));
+}
+DFTPAV_HD inline dd cos_dd(dd r) {
+  const dd r2 = dd_mul(r, r);
+  dd acc = inv_fact(30);
+  for (int n = 28; n >= 2; n -= 2) acc = dd_add(inv_fact(n), dd_neg(dd_mul(acc, r2))); // 1/n! - r^2 (1/(n+2)! - ...)
+  // cos r = 1 - r^2 (1/2! - r^2 (...))
+  return dd_add_d(dd_neg(dd_mul(acc, r2)), 1.0);
+}
+
+// correctly rounded sin x and cos x
+DFTPAV_HD inline void sincos(double x, double &s, double &c) {
+  if (x == 0.0) { // sin keeps the sign of zero
+    s = x;
+    c = 1.0;
+    return;
+  }
+  dd r;
+  const int k = reduce(x, r);
+  const dd sr = sin_dd(r), cr = cos_dd(r);
+  switch (k & 3) {
+    case 0: s = sr.hi; c = cr.hi; break;
+    case 1: s = cr.hi; c = -sr.hi; break;
+    case 2: s = -sr.hi; c = -cr.hi; break;
+    default: s = -cr.hi; c = sr.hi; break;
+  }
+}
+
+} // namespace crt
+} // namespace dftpav

@@ -19,15 +19,19 @@
 //   * no fused multiply-add anywhere except inside a division by a stored reciprocal (div_by_rcp: the correctly rounded
 //     quotient, i.e. the bits of a / b); contraction is off for the file.
 //
-// Scope: one gear segment (M == 1), no moving obstacles, n <= 64 decision variables, H <= 5 half-planes per point.  With a
-// gear shift the reference calls libm's sin / cos inside the loop, with moving obstacles exp / log: glibc's results are not
-// correctly rounded and cannot be reproduced on the device without its tables, so those layouts stay with solver.hip
-// (DESIGN.md §2.5).  One workgroup per trajectory; this is a latency / verification mode, not the throughput path.
+// Scope: no moving obstacles, n <= 64 decision variables, H <= 5 half-planes per point.  With ONE gear segment the
+// reference's program has no libm call inside the loop and the device reproduces its bits.  With gear shifts the reference
+// calls libm's cos / sin of the junction angles in every evaluation -- bits that belong to the host (glibc's sin / cos are
+// not correctly rounded and IFUNC-dispatched by CPU model): the kernel uses the correctly rounded cos / sin (cr_trig.h), i.e.
+// runs the reference's program with those two calls defined instead of implemented (oracle order 2 is that program on the
+// CPU).  With moving obstacles the reference calls exp / log per (point, obstacle) pair: those layouts stay with solver.hip
+// (DESIGN.md section 2.3).  One workgroup per trajectory; a latency / verification mode, not the throughput path.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 
 #include "device_types.h"
+#include "cr_trig.h"
 
 #ifndef DFTPAV_REF_SUM_ALL_LANES
 #define DFTPAV_REF_SUM_ALL_LANES 1 // measured: the chain on one lane + broadcast costs 637 cycles per history step against 546
@@ -112,52 +116,60 @@ constexpr int kListCap = 4096;  // active terms chained per window
 
 struct Sm {
   ldsd_t x, xp, g, gp, d;   // [npad]
-  ldsd_t bnd;               // [12] iniS, finS
-  ldsd_t seg;               // [16] 0:T 1:dt 2..7:t^k 8..13:t^-k
-  ldsd_t spow;              // [2][Kmax+1] the running sample offsets (s1 += step) for K and Kd
-  ldsd_t b, c, gdC, adj;    // [6N][2]
-  ldsd_t pE, pG, pA;        // [N] per-piece energy, d(energy)/dT, chain-rule term of calGrads_PT
-  ldsd_t tab;               // [4][6N][8] rows of the four substitution sweeps: six coefficients, diagonal, 1 / diagonal (sweep())
+  ldsd_t bnd;               // [M][12] iniS [6], finS [6] of each gear segment as uploaded (clamped)
+  ldsd_t pva;               // [M][12] head / tail position, velocity, acceleration in force for this x (junction overrides, traj_optimizer.cpp:273-282)
+  ldsd_t trig;              // [M][2] cos, sin of the junction angles (M - 1 of them)
+  ldsd_t seg;               // [M][16] 0:T 1:dt 2..7:t^k 8..13:t^-k
+  ldsd_t spow;              // [M][2][Kmax+1] the running sample offsets (s1 += step) for K and Kd
+  ldsd_t b, c, gdC, adj;    // [6 Ntot][2]
+  ldsd_t pE, pG, pA;        // [Ntot] per-piece energy, d(energy)/dT, chain-rule term of calGrads_PT
+  ldsd_t tab;               // per segment [4][6N][8]: rows of the four substitution sweeps (six coefficients, diagonal, 1 / diagonal)
+  ldsd_t segsum;            // [M][4] per segment: gdT, corridor cost, feasibility cost, jerk energy
   ldsd_t dot;               // [4][64] products of up to four sequential dot products
   ldsd_t alpha;             // [mem]
   ldsd_t st;                // [sNUM]
   ldsi_t ist;               // [iNUM]
+  ldsi_t pinfo;             // [Ntot][4] segment, piece index inside it, first constraint point, intervals K
   ldsi_t pmask;             // [Npts] active terms of a constraint point (bit t = term t)
   ldsi_t pfirst;            // [Npts + 1] index of a point's first active term in (point, term) order
   ldsi_t list;              // [kListCap] (point << 5 | term) of the active terms of the current window
 };
+enum { gGDT = 0, gCOST0, gCOST2, gENERGY };
 
 __host__ __device__ inline size_t lds_doubles(const DevLayout &L, int mem) {
-  const int N = L.piece_nums[0];
-  return 5 * (size_t)L.npad + 12 + 16 + 2 * (size_t)(L.Kmax + 1) + 4 * 12 * (size_t)N + 3 * (size_t)N + (size_t)(4 * 48) * N + 4 * 64 +
+  return 5 * (size_t)L.npad + (size_t)L.M * (12 + 12 + 2 + 16 + 4) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3 + 4 * 48) * (size_t)L.Ntot + 4 * 64 +
          (size_t)mem + sNUM;
 }
-__host__ __device__ inline size_t lds_ints(const DevLayout &L) { return iNUM + 2 * (size_t)L.Npts + 1 + kListCap; }
+__host__ __device__ inline size_t lds_ints(const DevLayout &L) { return iNUM + 4 * (size_t)L.Ntot + 2 * (size_t)L.Npts + 1 + kListCap; }
 
 __device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
-  const int N = L.piece_nums[0];
+  const int M = L.M, Ntot = L.Ntot;
   ldsd_t p = (ldsd_t)base;
   s.x = p; p += L.npad;
   s.xp = p; p += L.npad;
   s.g = p; p += L.npad;
   s.gp = p; p += L.npad;
   s.d = p; p += L.npad;
-  s.bnd = p; p += 12;
-  s.seg = p; p += 16;
-  s.spow = p; p += 2 * (L.Kmax + 1);
-  s.b = p; p += 12 * N;
-  s.c = p; p += 12 * N;
-  s.gdC = p; p += 12 * N;
-  s.adj = p; p += 12 * N;
-  s.pE = p; p += N;
-  s.pG = p; p += N;
-  s.pA = p; p += N;
-  s.tab = p; p += (4 * 48) * N;
+  s.bnd = p; p += 12 * M;
+  s.pva = p; p += 12 * M;
+  s.trig = p; p += 2 * M;
+  s.seg = p; p += 16 * M;
+  s.spow = p; p += 2 * M * (L.Kmax + 1);
+  s.b = p; p += 12 * Ntot;
+  s.c = p; p += 12 * Ntot;
+  s.gdC = p; p += 12 * Ntot;
+  s.adj = p; p += 12 * Ntot;
+  s.pE = p; p += Ntot;
+  s.pG = p; p += Ntot;
+  s.pA = p; p += Ntot;
+  s.tab = p; p += (4 * 48) * Ntot;
+  s.segsum = p; p += 4 * M;
   s.dot = p; p += 4 * 64;
   s.alpha = p; p += mem;
   s.st = p; p += sNUM;
   ldsi_t q = (ldsi_t)p;
   s.ist = q; q += iNUM;
+  s.pinfo = q; q += 4 * Ntot;
   s.pmask = q; q += L.Npts;
   s.pfirst = q; q += L.Npts + 1;
   s.list = q;
@@ -457,75 +469,112 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
   return mask;
 }
 
-// first constraint point of piece lp and its interval count: pieces are [Kd+1, K+1, ..., K+1, Kd+1] points long
-__device__ __forceinline__ int piece_pt0(const DevLayout &L, int lp) { return lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1); }
-__device__ __forceinline__ int piece_K(const DevLayout &L, int lp, int N) { return (lp == 0 || lp == N - 1) ? L.Kd : L.K; }
-
-// ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350), M == 1
-// x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].
+// ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350)
+// x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].  The gear segments are independent
+// up to the sums of :292-297 and the junction variables' gradients (:307-320), so every stage runs them side by side.
 __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
   const int tid = threadIdx.x, T = blockDim.x;
-  const int N = L.piece_nums[0], n6 = 6 * N, Npts = L.Npts, H = L.H, nterm = 5 * H + 4, Kmax1 = L.Kmax + 1;
-  const int singul_ = L.singuls[0];
-  ldscd_t iniS = sm.bnd, finS = sm.bnd + 6;
+  const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, H = L.H, nterm = 5 * H + 4, Kmax1 = L.Kmax + 1;
 
-  // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966), right-hand side (:968-977)
-  if (tid == 0) {
-    const double vt = x[L.x_tau0];
+  // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966); cos / sin of the junction angles
+  if (tid < M) {
+    const int sg = tid;
+    const double vt = x[L.x_tau0 + sg];
     const double Tr = vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + P.mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + P.mini_T;
+    int N = 0;
+    for (int q = 0; q < M; q++) N = q == sg ? L.piece_nums[q] : N;
     const double t1 = Tr / N, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
-    sm.seg[0] = Tr;
-    sm.seg[1] = t1;
-    sm.seg[2] = 1.0; sm.seg[3] = t1; sm.seg[4] = t2; sm.seg[5] = t3; sm.seg[6] = t4; sm.seg[7] = t5;
-    sm.seg[8] = 1.0 / 1.0; sm.seg[9] = 1.0 / t1; sm.seg[10] = 1.0 / t2; sm.seg[11] = 1.0 / t3; sm.seg[12] = 1.0 / t4; sm.seg[13] = 1.0 / t5;
+    ldsd_t se = sm.seg + 16 * sg;
+    se[0] = Tr;
+    se[1] = t1;
+    se[2] = 1.0; se[3] = t1; se[4] = t2; se[5] = t3; se[6] = t4; se[7] = t5;
+    se[8] = 1.0 / 1.0; se[9] = 1.0 / t1; se[10] = 1.0 / t2; se[11] = 1.0 / t3; se[12] = 1.0 / t4; se[13] = 1.0 / t5;
+  } else if (tid >= 64 && tid < 64 + M - 1) {
+    const int i = tid - 64;
+    double sn, cs;
+    crt::sincos(x[L.x_ang0 + i], sn, cs); // the reference: libm's cos / sin (host-dependent bits); here the correctly rounded ones
+    sm.trig[2 * i] = cs;
+    sm.trig[2 * i + 1] = sn;
   }
   __syncthreads();
-  {
-    const double t1 = sm.seg[3], t2 = sm.seg[4];
-    for (int w = tid; w < 2 * n6; w += T) {
-      const int row = w >> 1, d = w & 1;
-      double v = 0.0;
-      if (row < 3) v = row == 0 ? iniS[d] : (row == 1 ? iniS[2 + d] * t1 : iniS[4 + d] * t2);
-      else if (row >= n6 - 3) v = row == n6 - 3 ? finS[d] : (row == n6 - 2 ? finS[2 + d] * t1 : finS[4 + d] * t2);
-      else if (row % 6 == 5) v = x[2 * (row / 6) + d];
-      sm.b[w] = v;
+  // ---- boundary states in force (IniS / FinS of :270-282): junction position from x, junction velocity from the angle
+  if (tid < M) {
+    const int sg = tid;
+    ldscd_t ini = sm.bnd + 12 * sg, fin = ini + 6;
+    ldsd_t hv = sm.pva + 12 * sg, tv = hv + 6;
+    for (int q = 0; q < 6; q++) {
+      hv[q] = ini[q];
+      tv[q] = fin[q];
+    }
+    if (sg > 0) {
+      hv[0] = x[L.x_gear0 + 2 * (sg - 1)];
+      hv[1] = x[L.x_gear0 + 2 * (sg - 1) + 1];
+      hv[2] = -P.non_sinv * sm.trig[2 * (sg - 1)];
+      hv[3] = -P.non_sinv * sm.trig[2 * (sg - 1) + 1];
+    }
+    if (sg < M - 1) {
+      tv[0] = x[L.x_gear0 + 2 * sg];
+      tv[1] = x[L.x_gear0 + 2 * sg + 1];
+      tv[2] = P.non_sinv * sm.trig[2 * sg];
+      tv[3] = P.non_sinv * sm.trig[2 * sg + 1];
     }
   }
   __syncthreads();
-  // ---- wave 0: BandedSystem::solve (poly_traj_utils.hpp:805-826), one lane per dimension; wave 1 (or wave 0 after it):
-  // the running sample offsets s1 += step (traj_optimizer.cpp:513), one lane per table
-  if (tid < 2) {
-    sweep<0>(sm.tab, sm.b, n6, tid);
-    sweep<1>(sm.tab + 48 * N, sm.b, n6, tid);
+  // ---- right-hand sides (poly_traj_utils.hpp:968-977)
+  for (int w = tid; w < 12 * Ntot; w += T) {
+    const int p = w / 12, q = w - 12 * p, k = q >> 1, d = q & 1;
+    const int sg = sm.pinfo[4 * p], lp = sm.pinfo[4 * p + 1];
+    int N = 0, x0 = 0;
+    for (int q2 = 0; q2 < M; q2++) {
+      N = q2 == sg ? L.piece_nums[q2] : N;
+      x0 = q2 == sg ? L.seg_x0[q2] : x0;
+    }
+    const double t1 = sm.seg[16 * sg + 3], t2 = sm.seg[16 * sg + 4];
+    ldscd_t hv = sm.pva + 12 * sg, tv = hv + 6;
+    double v = 0.0;
+    if (lp == 0 && k < 3) v = k == 0 ? hv[d] : (k == 1 ? hv[2 + d] * t1 : hv[4 + d] * t2);
+    else if (lp == N - 1 && k >= 3) v = k == 3 ? tv[d] : (k == 4 ? tv[2 + d] * t1 : tv[4 + d] * t2);
+    else if (k == 5) v = x[x0 + 2 * lp + d];
+    sm.b[w] = v;
   }
-  {
-    const int w0 = T > 64 ? 64 : 2;
-    if (tid >= w0 && tid < w0 + 2) {
-      const int which = tid - w0;
-      const int K = which ? L.Kd : L.K;
-      const double step = sm.seg[1] / K;
-      ldsd_t tab = sm.spow + which * Kmax1;
-      double s1 = 0.0;
-      for (int j = 0; j <= K; j++) {
-        tab[j] = s1;
-        s1 += step;
-      }
+  __syncthreads();
+  // ---- wave 0: BandedSystem::solve (poly_traj_utils.hpp:805-826), one lane per (segment, dimension); wave 1: the running sample
+  // offsets s1 += step (traj_optimizer.cpp:513), one lane per table
+  if (tid < 2 * M) {
+    const int sg = tid >> 1, d = tid & 1;
+    int N = 0, p0 = 0;
+    for (int q = 0; q < M; q++) {
+      N = q == sg ? L.piece_nums[q] : N;
+      p0 = q == sg ? L.seg_piece0[q] : p0;
+    }
+    ldscd_t tb = sm.tab + 192 * p0;
+    sweep<0>(tb, sm.b + 12 * p0, 6 * N, d);
+    sweep<1>(tb + 48 * N, sm.b + 12 * p0, 6 * N, d);
+  } else if (tid >= 64 && tid < 64 + 2 * M) {
+    const int sg = (tid - 64) >> 1, which = (tid - 64) & 1;
+    const int K = which ? L.Kd : L.K;
+    const double step = sm.seg[16 * sg + 1] / K;
+    ldsd_t tab = sm.spow + (2 * sg + which) * Kmax1;
+    double s1 = 0.0;
+    for (int j = 0; j <= K; j++) {
+      tab[j] = s1;
+      s1 += step;
     }
   }
   __syncthreads();
   pr.tick(0);
   // ---- c = b * tInv (:979-984)
-  for (int w = tid; w < 2 * n6; w += T) {
-    const int row = w >> 1;
-    sm.c[w] = sm.b[w] * sm.seg[8 + row % 6];
+  for (int w = tid; w < 12 * Ntot; w += T) {
+    const int p = w / 12, k = (w - 12 * p) >> 1;
+    sm.c[w] = sm.b[w] * sm.seg[16 * sm.pinfo[4 * p] + 8 + k];
   }
   __syncthreads();
   // ---- initSmGradCost / getTrajJerkCost per piece (poly_traj_utils.hpp:998-1035); the sums over the pieces are chained below
-  for (int i = tid; i < N; i += T) {
+  for (int i = tid; i < Ntot; i += T) {
     ldscd_t c = sm.c + 12 * i;
-    ldscd_t t = sm.seg + 2;
+    ldscd_t t = sm.seg + 16 * sm.pinfo[4 * i] + 2;
     const double n33 = c[6] * c[6] + c[7] * c[7], n44 = c[8] * c[8] + c[9] * c[9], n55 = c[10] * c[10] + c[11] * c[11];
     const double d43 = c[8] * c[6] + c[9] * c[7], d53 = c[10] * c[6] + c[11] * c[7], d54 = c[10] * c[8] + c[11] * c[9];
     sm.pE[i] = 36.0 * n33 * t[1] + 144.0 * d43 * t[2] + 192.0 * n44 * t[3] + 240.0 * d53 * t[3] + 720.0 * d54 * t[4] + 720.0 * n55 * t[5];
@@ -544,34 +593,27 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   pr.tick(1);
   // ---- the constraint points, each on a lane of its own
   for (int pt = tid; pt < Npts; pt += T) {
-    // piece of the point: edge pieces hold Kd + 1 points, the others K + 1
-    int lp, j;
-    if (pt < L.Kd + 1) {
-      lp = 0;
-      j = pt;
-    } else {
-      const int q = pt - (L.Kd + 1);
-      lp = 1 + q / (L.K + 1);
-      j = q - (lp - 1) * (L.K + 1);
-      if (lp > N - 1) { // (only when N == 2: both pieces are edge pieces)
-        lp = N - 1;
-        j = pt - piece_pt0(L, lp);
-      }
+    const int p = D.pt_piece[pt], j = D.pt_j[pt];
+    const int sg = sm.pinfo[4 * p], lp = sm.pinfo[4 * p + 1], K = sm.pinfo[4 * p + 3];
+    int N = 0, singul_ = 1;
+    for (int q = 0; q < M; q++) {
+      N = q == sg ? L.piece_nums[q] : N;
+      singul_ = q == sg ? L.singuls[q] : singul_;
     }
-    const int K = piece_K(L, lp, N);
     const bool edge = lp == 0 || lp == N - 1;
     double cc[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * lp + k];
-    const double step = sm.seg[1] / K;
-    const double s1 = sm.spow[(edge ? 1 : 0) * Kmax1 + j];
+    for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * p + k];
+    const double step = sm.seg[16 * sg + 1] / K;
+    const double s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
     sm.pmask[pt] = (int)point_terms(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
                                     rec_b + (size_t)pt * nterm * kRec);
   }
   __threadfence_block(); // the records are read back by other threads of this workgroup
   __syncthreads();
   pr.tick(2);
-  // ---- number the active terms in (point, term) order: exclusive prefix sum of the counts (wave 0)
+  // ---- number the active terms in (point, term) order: exclusive prefix sum of the counts (wave 0); wave 1: the start values
+  // of the per-segment chains (`gdT +=`, `energy +=` over the pieces in order, from 0.0)
   if (tid < 64) {
     const int per = (Npts + 63) >> 6, start = tid * per;
     int sum = 0;
@@ -588,37 +630,28 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       run += __builtin_popcount((unsigned)sm.pmask[i]);
     }
     if (tid == 63) sm.pfirst[Npts] = incl;
-  } else if (tid == 64 || (T <= 64 && tid == 0)) {
-    // gdT and the energy start from the sums over the pieces (`gdT +=`, `energy +=` in piece order, from 0.0)
+  } else if (tid < 64 + M) {
+    const int sg = tid - 64;
+    int p0 = 0, p1 = 0;
+    for (int q = 0; q < M; q++) {
+      p0 = q == sg ? L.seg_piece0[q] : p0;
+      p1 = q == sg ? L.seg_piece0[q + 1] : p1;
+    }
     double gdT = 0.0, en = 0.0;
-    for (int i = 0; i < N; i++) {
+    for (int i = p0; i < p1; i++) {
       gdT += sm.pG[i];
       en += sm.pE[i];
     }
-    sm.st[sGDT] = gdT;
-    sm.st[sENERGY] = en;
-    sm.st[sCOST0] = 0.0;
-    sm.st[sCOST2] = 0.0;
-  }
-  if (T <= 64) { // (one-wave workgroups: the branch above could not run beside the prefix sum)
-    __syncthreads();
-    if (tid == 0) {
-      double gdT = 0.0, en = 0.0;
-      for (int i = 0; i < N; i++) {
-        gdT += sm.pG[i];
-        en += sm.pE[i];
-      }
-      sm.st[sGDT] = gdT;
-      sm.st[sENERGY] = en;
-      sm.st[sCOST0] = 0.0;
-      sm.st[sCOST2] = 0.0;
-    }
+    sm.segsum[4 * sg + gGDT] = gdT;
+    sm.segsum[4 * sg + gENERGY] = en;
+    sm.segsum[4 * sg + gCOST0] = 0.0;
+    sm.segsum[4 * sg + gCOST2] = 0.0;
   }
   __syncthreads();
   // ---- chains: the active terms in windows of kListCap; lane (piece, entry) adds its piece's records in order, three more
-  // lanes walk all of them for gdT, the corridor cost and the feasibility cost
+  // lanes per segment walk all of the segment's for gdT, the corridor cost and the feasibility cost
   const int n_act = sm.pfirst[Npts];
-  const int n_chain = 12 * N + 3;
+  const int n_chain = 12 * Ntot + 3 * M;
   for (int c0 = 0; c0 < n_act; c0 += kListCap) {
     const int c1 = c0 + kListCap < n_act ? c0 + kListCap : n_act;
     for (int pt = tid; pt < Npts; pt += T) {
@@ -636,21 +669,26 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       int e0, e1, q;
       ldsd_t dst;
       bool corridor_only = false, feas_only = false;
-      if (w < 12 * N) {
+      if (w < 12 * Ntot) {
         const int p = w / 12;
         q = w - 12 * p;
-        const int pt0 = piece_pt0(L, p), pt1 = pt0 + piece_K(L, p, N) + 1;
+        const int pt0 = sm.pinfo[4 * p + 2], pt1 = pt0 + sm.pinfo[4 * p + 3] + 1;
         e0 = sm.pfirst[pt0];
         e1 = sm.pfirst[pt1];
         dst = sm.gdC + w;
       } else {
-        const int s = w - 12 * N;
-        e0 = 0;
-        e1 = n_act;
-        q = s == 0 ? 12 : 13;
-        dst = sm.st + (s == 0 ? sGDT : (s == 1 ? sCOST0 : sCOST2));
-        corridor_only = s == 1;
-        feas_only = s == 2;
+        const int v = w - 12 * Ntot, sg = v / 3, kind = v - 3 * sg;
+        int a0 = 0, a1 = 0;
+        for (int q2 = 0; q2 < M; q2++) {
+          a0 = q2 == sg ? L.seg_pt0[q2] : a0;
+          a1 = q2 == sg ? L.seg_pt0[q2 + 1] : a1;
+        }
+        e0 = sm.pfirst[a0];
+        e1 = sm.pfirst[a1];
+        q = kind == 0 ? 12 : 13;
+        dst = sm.segsum + 4 * sg + (kind == 0 ? gGDT : (kind == 1 ? gCOST0 : gCOST2));
+        corridor_only = kind == 1;
+        feas_only = kind == 2;
       }
       e0 = e0 > c0 ? e0 : c0;
       e1 = e1 < c1 ? e1 : c1;
@@ -684,17 +722,24 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   }
   pr.tick(3);
   // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
-  for (int w = tid; w < 2 * n6; w += T) {
-    const int row = w >> 1;
-    sm.adj[w] = sm.gdC[w] * sm.seg[8 + row % 6];
+  for (int w = tid; w < 12 * Ntot; w += T) {
+    const int p = w / 12, k = (w - 12 * p) >> 1;
+    sm.adj[w] = sm.gdC[w] * sm.seg[16 * sm.pinfo[4 * p] + 8 + k];
   }
   __syncthreads();
-  if (tid < 2) {
-    sweep<2>(sm.tab + 96 * N, sm.adj, n6, tid);
-    sweep<3>(sm.tab + 144 * N, sm.adj, n6, tid);
-  } else if (tid >= 64 && tid < 64 + N) { // the per-piece chain-rule terms (they only need gdC and b)
+  if (tid < 2 * M) {
+    const int sg = tid >> 1, d = tid & 1;
+    int N = 0, p0 = 0;
+    for (int q = 0; q < M; q++) {
+      N = q == sg ? L.piece_nums[q] : N;
+      p0 = q == sg ? L.seg_piece0[q] : p0;
+    }
+    ldscd_t tb = sm.tab + 192 * p0;
+    sweep<2>(tb + 96 * N, sm.adj + 12 * p0, 6 * N, d);
+    sweep<3>(tb + 144 * N, sm.adj + 12 * p0, 6 * N, d);
+  } else if (tid >= 64 && tid < 64 + Ntot) { // the per-piece chain-rule terms (they only need gdC and b)
     const int i = tid - 64;
-    ldscd_t tInv = sm.seg + 8;
+    ldscd_t tInv = sm.seg + 16 * sm.pinfo[4 * i] + 8;
     const double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
     double acc = 0.0;
 #pragma unroll
@@ -705,34 +750,37 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     sm.pA[i] = acc;
   }
   __syncthreads();
-  if (T <= 64 + N) { // narrow workgroups: the branch above did not cover every piece
-    for (int i = tid; i < N; i += T) {
-      ldscd_t tInv = sm.seg + 8;
-      const double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const double gdcol = sm.gdC[12 * i + 2 * k] * sm.b[12 * i + 2 * k] + sm.gdC[12 * i + 2 * k + 1] * sm.b[12 * i + 2 * k + 1];
-        acc += gdtInv[k] * gdcol;
-      }
-      sm.pA[i] = acc;
-    }
-    __syncthreads();
-  }
   pr.tick(4);
   // ---- gradient and cost (traj_optimizer.cpp:299-344)
-  for (int e = tid; e < 2 * (N - 1); e += T) g[e] = sm.adj[2 * (6 * (e >> 1) + 5) + (e & 1)]; // gdP
-  if (tid == 0) {
-    ldscd_t adj = sm.adj;
-    const double t1 = sm.seg[3];
-    double gdT = sm.st[sGDT];
-    gdT += iniS[2] * adj[2 * 1] + iniS[3] * adj[2 * 1 + 1];
-    gdT += (iniS[4] * adj[2 * 2] + iniS[5] * adj[2 * 2 + 1]) * 2.0 * t1;
-    gdT += finS[2] * adj[2 * (n6 - 2)] + finS[3] * adj[2 * (n6 - 2) + 1];
-    gdT += (finS[4] * adj[2 * (n6 - 1)] + finS[5] * adj[2 * (n6 - 1) + 1]) * 2.0 * t1;
-    for (int i = 0; i < N; i++) gdT += sm.pA[i];
-    // VirtualTGradCost, :405-419
-    const double VT = x[L.x_tau0], RT = sm.seg[0];
+  for (int e = tid; e < L.x_tau0; e += T) { // gdP of every segment: rows 6 i + 5 of its adjoint
+    int sg = 0, x0 = 0, p0 = 0;
+    for (int q = 0; q < M; q++) {
+      const bool in = e >= L.seg_x0[q];
+      sg = in ? q : sg;
+      x0 = in ? L.seg_x0[q] : x0;
+      p0 = in ? L.seg_piece0[q] : p0;
+    }
+    const int w = e - x0;
+    g[e] = sm.adj[12 * p0 + 2 * (6 * (w >> 1) + 5) + (w & 1)];
+  }
+  if (tid < M) { // the duration gradient of segment tid (poly_traj_utils.hpp:1050-1064, VirtualTGradCost :405-419)
+    const int sg = tid;
+    int N = 0, p0 = 0;
+    for (int q = 0; q < M; q++) {
+      N = q == sg ? L.piece_nums[q] : N;
+      p0 = q == sg ? L.seg_piece0[q] : p0;
+    }
+    ldscd_t adj = sm.adj + 12 * p0;
+    ldscd_t hv = sm.pva + 12 * sg, tv = hv + 6;
+    const int n6 = 6 * N;
+    const double t1 = sm.seg[16 * sg + 3];
+    double gdT = sm.segsum[4 * sg + gGDT];
+    gdT += hv[2] * adj[2 * 1] + hv[3] * adj[2 * 1 + 1];
+    gdT += (hv[4] * adj[2 * 2] + hv[5] * adj[2 * 2 + 1]) * 2.0 * t1;
+    gdT += tv[2] * adj[2 * (n6 - 2)] + tv[3] * adj[2 * (n6 - 2) + 1];
+    gdT += (tv[4] * adj[2 * (n6 - 1)] + tv[5] * adj[2 * (n6 - 1) + 1]) * 2.0 * t1;
+    for (int i = 0; i < N; i++) gdT += sm.pA[p0 + i];
+    const double VT = x[L.x_tau0 + sg];
     double gdVT2Rt;
     if (VT > 0) {
       gdVT2Rt = VT + 1.0;
@@ -740,12 +788,46 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       const double denSqrt = (0.5 * VT - 1.0) * VT + 1.0;
       gdVT2Rt = (1.0 - VT) / (denSqrt * denSqrt);
     }
-    g[L.x_tau0] = (gdT / N + P.wei_time) * gdVT2Rt;
-    const double time_cost = RT * P.wei_time;
+    g[L.x_tau0 + sg] = (gdT / N + P.wei_time) * gdVT2Rt;
+  } else if (tid >= 64 && tid < 64 + M - 1 && P.gear_opt) { // junction i: position and angle (traj_optimizer.cpp:307-320)
+    const int i = tid - 64;
+    int Ni = 0, p0i = 0, p0n = 0;
+    for (int q = 0; q < M; q++) {
+      Ni = q == i ? L.piece_nums[q] : Ni;
+      p0i = q == i ? L.seg_piece0[q] : p0i;
+      p0n = q == i + 1 ? L.seg_piece0[q] : p0n;
+    }
+    ldscd_t adji = sm.adj + 12 * p0i, adjn = sm.adj + 12 * p0n;
+    const int r3 = 6 * Ni - 3;
+    const double t1i = sm.seg[16 * i + 3], t1n = sm.seg[16 * (i + 1) + 3];
+    // gdTail of segment i and gdHead of segment i + 1 (poly_traj_utils.hpp:1045-1049: adj row * t^k)
+    const double fin0[2] = {adji[2 * r3] * 1.0, adji[2 * r3 + 1] * 1.0}, fin1[2] = {adji[2 * (r3 + 1)] * t1i, adji[2 * (r3 + 1) + 1] * t1i};
+    const double ini0[2] = {adjn[0] * 1.0, adjn[1] * 1.0}, ini1[2] = {adjn[2] * t1n, adjn[3] * t1n};
+    const double cs = sm.trig[2 * i], sn = sm.trig[2 * i + 1];
+    // grad is zeroed, then segment i adds its tail term, then segment i + 1 its head term (trajid ascending)
+    for (int d = 0; d < 2; d++) {
+      double v = 0.0;
+      v += fin0[d];
+      v += ini0[d];
+      g[L.x_gear0 + 2 * i + d] = v;
+    }
+    double va = 0.0;
+    va += fin1[0] * (-P.non_sinv * sn) + fin1[1] * (P.non_sinv * cs);
+    va += ini1[0] * (P.non_sinv * sn) + ini1[1] * (-P.non_sinv * cs);
+    g[L.x_ang0 + i] = va;
+  } else if (tid >= 64 && tid < 64 + M - 1) { // gear_opt off: the junction variables keep a zero gradient
+    const int i = tid - 64;
+    g[L.x_gear0 + 2 * i] = 0.0;
+    g[L.x_gear0 + 2 * i + 1] = 0.0;
+    g[L.x_ang0 + i] = 0.0;
+  }
+  if (tid == 128 || (T <= 128 && tid == 0)) { // the cost: sums over the segments in order (:292-297, :328-330)
     double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
-    total_smcost += sm.st[sENERGY];
-    penalty_cost += (sm.st[sCOST0] + 0.0) + sm.st[sCOST2];
-    total_timecost += time_cost;
+    for (int sg = 0; sg < M; sg++) {
+      total_smcost += sm.segsum[4 * sg + gENERGY];
+      penalty_cost += (sm.segsum[4 * sg + gCOST0] + 0.0) + sm.segsum[4 * sg + gCOST2];
+    }
+    for (int sg = 0; sg < M; sg++) total_timecost += sm.seg[16 * sg] * P.wei_time;
     sm.st[sF] = total_smcost + total_timecost + penalty_cost;
   }
   __syncthreads();
@@ -1161,10 +1243,25 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
   const DevBatch &D = *Dp;
   const DevLayout &L = D.L;
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
-  const int n = L.n, N = L.piece_nums[0], b = blockIdx.x;
+  const int n = L.n, b = blockIdx.x;
   Sm sm;
   carve(sm, lds_raw, L, D.P.mem_size);
-  for (int i = tid; i < 4 * 48 * N; i += T) sm.tab[i] = tabs[i];
+  for (int i = tid; i < 4 * 48 * L.Ntot; i += T) sm.tab[i] = tabs[i];
+  for (int p = tid; p < L.Ntot; p += T) { // piece -> segment, index inside it, first constraint point, intervals
+    int sg = 0, p0 = 0, N = 0, pt0s = 0;
+    for (int q = 0; q < L.M; q++) {
+      const bool in = p >= L.seg_piece0[q];
+      sg = in ? q : sg;
+      p0 = in ? L.seg_piece0[q] : p0;
+      N = in ? L.piece_nums[q] : N;
+      pt0s = in ? L.seg_pt0[q] : pt0s;
+    }
+    const int lp = p - p0;
+    sm.pinfo[4 * p] = sg;
+    sm.pinfo[4 * p + 1] = lp;
+    sm.pinfo[4 * p + 2] = pt0s + (lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1)); // pieces of a segment are [Kd+1, K+1, ..., K+1, Kd+1] points long
+    sm.pinfo[4 * p + 3] = (lp == 0 || lp == N - 1) ? L.Kd : L.K;
+  }
   for (int e = tid; e < L.npad; e += T) {
     const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
     sm.x[e] = e < n ? xsrc[(size_t)b * n + e] : 0.0;
@@ -1174,7 +1271,10 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
     sm.d[e] = 0.0;
   }
   if (tid < iNUM) sm.ist[tid] = 0;
-  if (tid < 12) sm.bnd[tid] = tid < 6 ? D.iniS[(size_t)b * 6 + tid] : D.finS[(size_t)b * 6 + (tid - 6)];
+  for (int w = tid; w < 12 * L.M; w += T) {
+    const int sg = w / 12, q = w - 12 * sg;
+    sm.bnd[w] = q < 6 ? D.iniS[((size_t)b * L.M + sg) * 6 + q] : D.finS[((size_t)b * L.M + sg) * 6 + (q - 6)];
+  }
   const gcd_t cor_b = (gcd_t)(D.corridor + (size_t)b * L.H * 4 * D.NptsPad);
   const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * (5 * L.H + 4) * kRec);
   const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
@@ -1192,8 +1292,8 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
     return;
   }
   if (mode == kModeCoeffs) {
-    for (int w = tid; w < 12 * N; w += T) D.coef_out[(size_t)b * 12 * N + w] = sm.c[w];
-    if (tid == 0) D.dt_out[b] = sm.seg[1];
+    for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
+    for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[16 * sg + 1];
     return;
   }
   while (true) {
@@ -1223,13 +1323,15 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
 // ---- host side
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
-  if (S > 0 || L.M != 1 || L.n > 64 || L.H > 5 || L.piece_nums[0] < 2) return false;
+  if (S > 0 || L.M < 1 || L.n > 64 || L.H > 5 || L.Npts >= (1 << 26)) return false;
+  for (int i = 0; i < L.M; i++)
+    if (L.piece_nums[i] < 2) return false;
   const size_t lds = reford::lds_doubles(L, P.mem_size) * sizeof(double) + reford::lds_ints(L) * sizeof(int);
   return lds <= 160 * 1024 - 1024;
 }
 // doubles of term records a batch of B trajectories needs
 size_t reference_order_scratch_doubles(const DevLayout &L, int B) { return (size_t)B * L.Npts * (5 * L.H + 4) * reford::kRec; }
-// doubles of the sweep tables of a segment of N pieces
+// doubles of the sweep tables of a segment of N pieces (the tables of a layout's segments follow one another)
 size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
 int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior[sweep][row_mod_6]; }

@@ -285,11 +285,16 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *   equals it statistically.
  * DFTPAV_ORDER_REFERENCE: every sum in the order PolyTrajOptimizer executes it (traj_optimizer.cpp:486-705 sample ->
  *   vertex -> plane accumulation, poly_traj_utils.hpp:805-852 banded substitutions, lbfgs.hpp:716-739 two-loop with
- *   sequential dot products), no fused multiply-adds: final x, cost, status, iterations and evaluations are BIT-EQUAL
- *   to OptimizeTrajectory's on the same inputs.  One workgroup per trajectory, slower per iteration: the mode of a
+ *   sequential dot products), no fused multiply-adds.  One workgroup per trajectory, slower per iteration: the mode of a
  *   drop-in that must reproduce the CPU planner's decision exactly, and the parity proof of the other one.
- *   Supported for one gear segment without moving obstacles, n <= 64, H <= 5 (with a gear shift or obstacles the
- *   reference calls libm's sin / cos / exp / log inside the loop): DFTPAV_E_UNSUPPORTED otherwise, order unchanged. */
+ *     - one gear segment: final x, cost, status, iterations and evaluations are BIT-EQUAL to OptimizeTrajectory's on the
+ *       same inputs (the reference's program has no libm call inside the loop there);
+ *     - with gear shifts the reference calls libm's cos / sin of every junction angle per evaluation
+ *       (traj_optimizer.cpp:273-282, 311-318), whose bits depend on the host (glibc's are not correctly rounded and are
+ *       IFUNC-dispatched by CPU model): this mode uses the CORRECTLY ROUNDED cos / sin instead (cr_trig.h) -- the
+ *       reference's program with those two calls defined rather than implemented; it equals the reference's own result
+ *       whenever the host's libm rounded every junction angle's cos / sin correctly (glibc: 999 arguments in 1 000);
+ *     - moving obstacles (exp / log per point and obstacle), n > 64 or H > 5: DFTPAV_E_UNSUPPORTED, order unchanged. */
 #define DFTPAV_ORDER_DEVICE 0
 #define DFTPAV_ORDER_REFERENCE 1
 int dftpav_batch_set_order(dftpav_batch *b, int order);

@@ -20,6 +20,7 @@
 
 #include <alloca.h>
 #include <math.h>
+#include <quadmath.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -1214,6 +1215,13 @@ static void addPVAGradCost2CT(oracle_ctx *c, double costs[3], int trajid, double
   }
 }
 
+/* cos / sin of a junction angle (OPT:276-281, 312-317).  Order 0: libm's, as the reference calls them -- a property of the host
+ * (glibc's are not correctly rounded, and IFUNC-dispatched by CPU).  Order 2: the CORRECTLY ROUNDED values, here simply through
+ * binary128 (libquadmath; the double rounding binary128 -> double could differ from direct rounding in 1 case in 2^60): the
+ * definition the reference-order device kernel implements with double-double arithmetic (dftpav_amd/csrc/cr_trig.h). */
+static double o_cos(const oracle_ctx *c, double th) { return c->order == 2 ? (double)cosq((__float128)th) : cos(th); }
+static double o_sin(const oracle_ctx *c, double th) { return c->order == 2 ? (double)sinq((__float128)th) : sin(th); }
+
 /* ========================================================================= */
 /* costFunctionCallback, OPT:206-350                                           */
 /* ========================================================================= */
@@ -1256,15 +1264,15 @@ double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
       double theta = Angles[trajid - 1];
       IniS[0] = Gear[2 * (trajid - 1) + 0];
       IniS[1] = Gear[2 * (trajid - 1) + 1];
-      IniS[2] = -P->non_sinv * cos(theta);
-      IniS[3] = -P->non_sinv * sin(theta);
+      IniS[2] = -P->non_sinv * o_cos(c, theta);
+      IniS[3] = -P->non_sinv * o_sin(c, theta);
     }
     if (trajid < M - 1) { /* OPT:278-282 */
       double theta = Angles[trajid];
       FinS[0] = Gear[2 * trajid + 0];
       FinS[1] = Gear[2 * trajid + 1];
-      FinS[2] = P->non_sinv * cos(theta);
-      FinS[3] = P->non_sinv * sin(theta);
+      FinS[2] = P->non_sinv * o_cos(c, theta);
+      FinS[3] = P->non_sinv * o_sin(c, theta);
     }
     minjerk_t *mj = &c->mj[trajid];
     minjerk_generate(mj, x + Poff[trajid], T[trajid] / c->piece_nums[trajid], IniS, FinS);
@@ -1289,13 +1297,13 @@ double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
         double theta = Angles[trajid - 1];
         gradGear[2 * (trajid - 1) + 0] += gradIni[0];
         gradGear[2 * (trajid - 1) + 1] += gradIni[1];
-        gradAngles[trajid - 1] += gradIni[2] * (P->non_sinv * sin(theta)) + gradIni[3] * (-P->non_sinv * cos(theta));
+        gradAngles[trajid - 1] += gradIni[2] * (P->non_sinv * o_sin(c, theta)) + gradIni[3] * (-P->non_sinv * o_cos(c, theta));
       }
       if (trajid < M - 1) {
         double theta = Angles[trajid];
         gradGear[2 * trajid + 0] += gradFin[0];
         gradGear[2 * trajid + 1] += gradFin[1];
-        gradAngles[trajid] += gradFin[2] * (-P->non_sinv * sin(theta)) + gradFin[3] * (P->non_sinv * cos(theta));
+        gradAngles[trajid] += gradFin[2] * (-P->non_sinv * o_sin(c, theta)) + gradFin[3] * (P->non_sinv * o_cos(c, theta));
       }
     }
     virtualT_grad_cost(P, T[trajid], tvar[trajid], mj->gdT / c->piece_nums[trajid], &gradt[trajid], &time_cost);

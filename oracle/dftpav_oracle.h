@@ -69,7 +69,12 @@ void oracle_free(oracle_ctx *c);
  *       per-sample subtotals chained per piece, 64-lane butterfly dots,
  *       portable sin/cos/exp/log) — see dftpav_oracle_dev.cpp.  The kernel is
  *       required to match this mode BIT FOR BIT; mode 0 cross-checks mode 1 to
- *       rounding level on single evaluations. */
+ *       rounding level on single evaluations.
+ *   2 = LITERAL with CORRECTLY ROUNDED cos / sin of the junction angles
+ *       (OPT:276-281, 312-317) in place of libm's: the program the
+ *       reference-order device kernel runs on layouts with a gear shift, where
+ *       libm's own bits are a property of the host CPU.  Identical to mode 0 on
+ *       single-segment layouts (no such call). */
 void oracle_set_order(oracle_ctx *c, int order);
 /* x0 packing of traj_optimizer.cpp:96-115 */
 void oracle_pack_x0(const oracle_ctx *c, double *x0);

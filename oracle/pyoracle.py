@@ -135,7 +135,8 @@ class OracleProblem:
             self.set_order(order)
 
     def set_order(self, order):
-        """0 = literal reference statement order, 1 = device order (see dftpav_oracle.h)."""
+        """0 = literal reference statement order, 1 = device order, 2 = literal with correctly rounded cos / sin of the
+        junction angles (see dftpav_oracle.h)."""
         lib().oracle_set_order(self.ctx, order)
 
     def __del__(self):

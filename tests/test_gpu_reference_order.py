@@ -100,21 +100,8 @@ def test_whole_solves_are_bit_equal_to_the_reference(hiplib, oracle, name, B):
     h.close()
 
 
-def test_reference_order_is_refused_where_libm_sits_in_the_loop(hiplib):
-    """gear shifts (sin / cos of the junction angle per evaluation) and moving obstacles (exp / log per pair) keep the device order"""
-    p = hiplib.default_params()
-    s = sc.baseline_config(2, B=2)
-    s.apply_resolution(p)
-    h = hiplib.Handle(p)
-    bt = hiplib.Batch(h, s.layout, s.B)
-    bt.upload(s)
-    with pytest.raises(hiplib.DftpavError) as e:
-        bt.set_order(hiplib.ORDER_REFERENCE)
-    assert e.value.code == hiplib.E_UNSUPPORTED
-    r = bt.solve()      # the batch is still usable, in device order
-    assert r["success"].all()
-    bt.close()
-    h.close()
+def test_reference_order_is_refused_with_moving_obstacles(hiplib):
+    """moving obstacles (libm's exp / log per (point, obstacle) pair inside the loop) keep the device order; the batch stays usable"""
     s5 = sc.baseline_config(5, B=2)
     p5 = hiplib.default_params()
     s5.apply_resolution(p5)
@@ -122,10 +109,72 @@ def test_reference_order_is_refused_where_libm_sits_in_the_loop(hiplib):
     h5.set_surround(s5.surround)
     b5 = hiplib.Batch(h5, s5.layout, s5.B)
     b5.upload(s5)
-    with pytest.raises(hiplib.DftpavError):
+    with pytest.raises(hiplib.DftpavError) as e:
         b5.set_order(hiplib.ORDER_REFERENCE)
+    assert e.value.code == hiplib.E_UNSUPPORTED
+    assert b5.solve()["success"].all()
     b5.close()
     h5.close()
+
+
+def test_gear_shifts_in_reference_order(hiplib, oracle):
+    """With gear shifts the reference calls libm's cos / sin of the junction angles in every evaluation: bits of the HOST (glibc's
+    are not correctly rounded, and dispatched by CPU model).  The device runs the reference's program with the CORRECTLY ROUNDED
+    cos / sin (cr_trig.h); oracle order 2 is that same program on the CPU (its cos / sin through binary128).  Bar: bit-equal
+    to order 2 -- evaluations and whole solves -- on BASELINE configs[1] (8 + 8 pieces, forward + reverse) and on random
+    layouts with up to four segments; against the reference build itself the solves agree exactly where this host's libm
+    happened to round every angle correctly, which is reported, not asserted."""
+    pyref = _ref()
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    cases = [("cfg2", None)] + [("rand", c) for c in range(8)]
+    same_as_build = total_build = 0
+    for name, c in cases:
+        p = hiplib.default_params()
+        if name == "cfg2":
+            s = sc.baseline_config(2, B=32)
+        else:
+            rng = np.random.default_rng(15000 + c)
+            M = int(rng.integers(2, 5))
+            pieces = [int(rng.integers(2, 9)) for _ in range(M)]
+            while 2 * (sum(pieces) - M) + M + 3 * (M - 1) > 64:
+                pieces[int(np.argmax(pieces))] -= 1
+            sing = [int(rng.choice([1, -1]))]
+            for _ in range(M - 1):
+                sing.append(-sing[-1])
+            s = sc.make_scenario(pieces, sing, int(rng.integers(4, 20)), int(rng.integers(4, 20)), int(rng.integers(1, 4)), seed=16000 + c,
+                                 n_obs=int(rng.integers(0, 50)))
+            if c % 3 == 0:
+                p.lbfgs_mem_size = [6, 40, 11][c // 3]
+        s.apply_resolution(p)
+        h, bt = _batch(hiplib, s, p)
+        x0 = bt.x0()
+        rng2 = np.random.default_rng(3)
+        for x in (x0, x0 + rng2.normal(0, 0.3, x0.shape)):
+            f, g = bt.eval(x)
+            for b in range(min(s.B, 4)):
+                f2, g2 = oracle.OracleProblem(p, s, b, order=2).eval(x[b])
+                assert f[b] == f2 and np.array_equal(g[b], g2), (name, c, b)
+                f0, g0 = oracle.OracleProblem(p, s, b, order=0).eval(x[b])      # libm's cos / sin: the same to rounding
+                assert abs(f[b] - f0) <= 1e-13 * abs(f0) and np.abs(g[b] - g0).max() <= 1e-11 * max(1.0, np.abs(g0).max())
+        r = bt.solve()
+        o2 = oracle.solve_batch(p, s, nthreads=8, order=2)
+        for k in keys:
+            assert np.array_equal(r[k], o2[k]), (name, c, k)
+        assert r["success"].all()
+        cf, dt = bt.coeffs()
+        lp = oracle.OracleProblem(p, s, 0, order=2)
+        lp.eval(r["x"][0])
+        co, dto = lp.coeffs()
+        assert np.array_equal(cf[0], co) and np.array_equal(dt[0], dto)
+        if pyref and name == "cfg2":
+            for b in range(s.B):
+                rr = pyref.RefProblem(p, s, b).optimize()
+                total_build += 1
+                same_as_build += int(rr["final_cost"] == r["final_cost"][b] and np.array_equal(rr["x"], r["x"][b]) and rr["iters"] == r["iters"][b])
+        bt.close()
+        h.close()
+    print("gear-shift solves of configs[1] bit-equal to the reference build on this host (its libm rounded every junction angle "
+          "correctly): %d of %d" % (same_as_build, total_build))
 
 
 def test_random_layouts_in_reference_order(hiplib, oracle):
@@ -223,4 +272,15 @@ def test_class_mirror_in_reference_order_returns_the_reference_answer(hiplib, or
     opt2.setParam(p2)
     ini, fin, inner, polys = containers(s2)
     assert opt2.OptimizeTrajectory(ini, fin, inner, s2.init_Ts[0], polys, list(s2.layout.singuls), 0.0, 0.0) is True
-    assert opt2.last["order"] == hiplib.ORDER_DEVICE      # gear shift: libm inside the loop
+    assert opt2.last["order"] == hiplib.ORDER_REFERENCE   # gear shift: the reference's program with correctly rounded cos / sin
+    o2 = oracle.solve_batch(p2, s2, nthreads=1, order=2)
+    assert opt2.last["final_cost"][0] == o2["final_cost"][0] and np.array_equal(opt2.last["x"][0], o2["x"][0])
+    s5 = sc.baseline_config(5, B=1)
+    p5 = hiplib.default_params()
+    s5.apply_resolution(p5)
+    opt5 = PolyTrajOptimizer(reference_order=True)
+    opt5.setParam(p5)
+    opt5.setSurroundTrajs(s5.surround)
+    ini, fin, inner, polys = containers(s5)
+    assert opt5.OptimizeTrajectory(ini, fin, inner, s5.init_Ts[0], polys, list(s5.layout.singuls), 0.0, 0.0) is True
+    assert opt5.last["order"] == hiplib.ORDER_DEVICE      # moving obstacles: libm's exp / log inside the loop
