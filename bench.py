@@ -407,7 +407,8 @@ def main():
             # per-iteration time beside it
             def single(cfg, seeds):
                 p2 = capi.default_params()
-                ms, its, oks = [], [], []
+                ms, its, oks, ms_ref, its_ref, eq2, eqb = [], [], [], [], [], [], []
+                from oracle import pyref as _pr
                 for sd in seeds:
                     s2 = sc.baseline_config(cfg, B=1, seed=args.seed + 17 * sd)
                     s2.apply_resolution(p2)
@@ -419,11 +420,29 @@ def main():
                     r2 = b2.results()
                     ms.append(b2.last_solve_ms()); its.append(int(r2["iters"][0]))
                     oks.append(bit_check(p2, s2, r2, np.array([0])))
+                    # the same instance in reference order: the reference's program with the correctly rounded cos / sin of the
+                    # junction angle (oracle order 2 is that program on the CPU); equal to the reference build itself whenever this
+                    # host's libm rounded every angle correctly
+                    b2.set_order(capi.ORDER_REFERENCE)
+                    b2.solve_async(); b2.sync()
+                    b2.solve_async(); b2.sync()
+                    r3 = b2.results()
+                    ms_ref.append(b2.last_solve_ms()); its_ref.append(int(r3["iters"][0]))
+                    o2 = po.solve_batch(p2, s2, nthreads=1, order=2)
+                    eq2.append(bool(o2["final_cost"][0] == r3["final_cost"][0] and np.array_equal(o2["x"][0], r3["x"][0]) and o2["iters"][0] == r3["iters"][0]))
+                    if _pr.available():
+                        rr_ = _pr.RefProblem(p2, s2, 0).optimize()
+                        eqb.append(bool(rr_["final_cost"] == r3["final_cost"][0] and np.array_equal(rr_["x"], r3["x"][0])))
                     b2.close(); h2.close()
-                ms, its = np.array(ms), np.array(its)
+                ms, its, ms_ref, its_ref = np.array(ms), np.array(its), np.array(ms_ref), np.array(its_ref)
                 return {"batch": 1, "instances": len(seeds), "p50_ms_per_solve": float(np.median(ms)), "min_ms": float(ms.min()),
                         "max_ms": float(ms.max()), "median_iters": float(np.median(its)), "us_per_iteration": float(1e3 * ms.sum() / its.sum()),
-                        "solves_per_s": float(1e3 / np.median(ms)), "device_order_oracle_bit_exact_on_all": bool(all(oks))}
+                        "solves_per_s": float(1e3 / np.median(ms)), "device_order_oracle_bit_exact_on_all": bool(all(oks)),
+                        "reference_order": {"p50_ms_per_solve": float(np.median(ms_ref)), "us_per_iteration": float(1e3 * ms_ref.sum() / its_ref.sum()),
+                                            "median_iters": float(np.median(its_ref)),
+                                            "bit_equal_to_the_reference_program_with_correctly_rounded_cos_sin": int(sum(eq2)),
+                                            "bit_equal_to_the_reference_build_on_this_host": (int(sum(eqb)) if eqb else None),
+                                            "instances": len(seeds)}}
             out["single"] = single(2, range(9))
             out["moving_obstacles_1024"] = side(5, 1024, 1, 4)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
             # ---- the step before the solve: rectangle corridors of the shard's hypotheses on the device
