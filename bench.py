@@ -320,7 +320,7 @@ def main():
         if valu_per_solve:
             # the roof that actually binds: VALU issue.  SQ_INSTS_VALU per solve (the --pmc pass named in traffic_source) x solves/s
             # against one wave64 VALU instruction per SIMD every 4 cycles (fp64 FMA / add / mul issue at that rate on CDNA4)
-            clk = torch.cuda.get_device_properties(local_rank).clock_rate * 1e3
+            clk = 2.4e9  # MI355X engine clock (MI355X_MICROARCH.md; the in-kernel phase timer measures 2.39-2.40 GHz under this load)
             peak_i = n_cu * 4 * clk / 4.0
             out["roofline"]["valu"] = {"instructions_per_solve": valu_per_solve, "achieved_instr_per_s": valu_per_solve * value / world,
                                        "peak_instr_per_s": peak_i, "frac": valu_per_solve * value / world / peak_i,
