@@ -112,7 +112,7 @@ struct Prof {
 };
 
 constexpr int kRec = 16;        // doubles per term record: 12 entries of gdC, gdT, cost, 2 unused
-constexpr int kListCap = 4096;  // active terms chained per window
+constexpr int kListCap = 1024;  // active terms chained per window
 
 struct Sm {
   ldsd_t x, xp, g, gp, d;   // [npad]
@@ -1336,11 +1336,20 @@ size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
 int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior[sweep][row_mod_6]; }
 
+// Workgroup size: four waves per trajectory while the batch leaves CUs to spare (the parallel stages finish sooner: 70 against
+// 73 ms at batch 32, 133 against 140 at 256); two waves, i.e. four trajectories per CU instead of two, for batches that fill
+// the device -- most of a solve is its serial wave (two-loop recursion, sweeps), so more trajectories per CU is what pays:
+// 654 against 796 ms per 4096.  Same bits either way: no sum depends on the number of waves.
+static int ref_threads(int B) {
+  if (const char *e = std::getenv("DFTPAV_REF_THREADS")) return std::atoi(e);
+  return B > 768 ? 128 : 256;
+}
 template <int CAP>
 static hipError_t launch_ref_cap(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, size_t lds, hipStream_t stream) {
+  const int threads = ref_threads(D.B);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reford::ref_kernel<CAP>, dim3(D.B), dim3(256), lds, stream, d_dev, mode, tabs, scratch);
+  hipLaunchKernelGGL(reford::ref_kernel<CAP>, dim3(D.B), dim3(threads), lds, stream, d_dev, mode, tabs, scratch);
   return hipGetLastError();
 }
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream) {
