@@ -160,8 +160,12 @@ def main():
         def deliver(self, i):
             t1 = time.perf_counter()
             if self.comms is not None:
-                self.rec = (self.comms[i].allgather(self.bts[i], self.B_total), i)
-            else:
+                try:
+                    self.rec = (self.comms[i].allgather(self.bts[i], self.B_total), i)
+                except capi.DftpavError as ex:  # the collective behind the C-ABI failed: torch.distributed's from here on
+                    self.via = "torch.distributed all_gather_into_tensor (RCCL); the C-ABI collective failed: %s" % ex
+                    self.comms = None
+            if self.comms is None:
                 self.bts[i].pack_results(self.rec_dev[i].data_ptr())
                 self.bts[i].sync()
                 self.rec = (dd.allgather_records(self.rec_dev[i], self.B_total) if distributed else self.rec_dev[i], i)
