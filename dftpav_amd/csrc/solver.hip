@@ -976,7 +976,19 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         i1 = i1 < c0 + T ? i1 : c0 + T;
         if (i1 <= i0) continue;
         double acc = q < 12 ? sm.gdC[12 * p + q] : (q == 12 ? sm.pGdT[p] : sm.pCost[p]);
-        for (int i2 = i0; i2 < i1; i2++) acc += sm.dpart[q * dstride + (i2 - c0)];
+        {
+          // the chain itself is sequential by definition; its LDS reads are not: eight at a time in front of their additions
+          const double *src = sm.dpart + q * dstride - c0;
+          int i2 = i0;
+          for (; i2 + 8 <= i1; i2 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[i2 + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+          }
+          for (; i2 < i1; i2++) acc += src[i2];
+        }
         if (q < 12) sm.gdC[12 * p + q] = acc;
         else if (q == 12) sm.pGdT[p] = acc;
         else sm.pCost[p] = acc;
