@@ -124,6 +124,11 @@ struct dftpav_batch {
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
   DevBatch *d_dev = nullptr; // device copy of the launch descriptor
   int dev_version = -1;
+  // pinned host staging of the two descriptors and the event behind their last copy: refreshing the device copies then
+  // needs no stream synchronisation (dftpav_plan_cycle enqueues the corridor kernel in front of the solve and must not wait for it)
+  DevBatch *h_stage = nullptr;
+  hipEvent_t stage_ev = nullptr;
+  bool stage_busy = false;
   bool prof_on = false;
   double *d_coef = nullptr, *d_dt = nullptr;
   double *d_f_eval = nullptr; // costs of dftpav_batch_eval (kept apart from the solve's final costs)
@@ -877,6 +882,8 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
     if (b->d_opM[i]) (void)hipFree(b->d_opM[i]);
     if (b->d_opMT[i]) (void)hipFree(b->d_opMT[i]);
   }
+  if (b->h_stage) (void)hipHostFree(b->h_stage);
+  if (b->stage_ev) (void)hipEventDestroy(b->stage_ev);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   delete b;
@@ -1335,8 +1342,14 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
   D = make_dev(b);
   int version = h->sur_version * 4 + (b->prof_on ? 1 : 0) + (b->uploaded ? 2 : 0);
   if (version != b->dev_version) {
-    HIPCHK(h, hipMemcpyAsync(b->d_dev, &D, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
-    DevBatch D2 = D; // the same batch in the latency shape (follow-up launch of a scheduled solve)
+    if (!b->h_stage) {
+      HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), 2 * sizeof(DevBatch), hipHostMallocDefault));
+      HIPCHK(h, hipEventCreateWithFlags(&b->stage_ev, hipEventDisableTiming));
+    }
+    if (b->stage_busy) HIPCHK(h, hipEventSynchronize(b->stage_ev)); // the previous copies out of the staging area (long done)
+    b->h_stage[0] = D;
+    DevBatch &D2 = b->h_stage[1];
+    D2 = D; // the same batch in the latency shape (follow-up launch of a scheduled solve)
     D2.op_in_lds = b->op_in_lds2 ? 1 : 0;
     D2.cor_in_lds = b->cor_in_lds2 ? 1 : 0;
     D2.sur_coef_lds = sur_coef_in_lds(b, b->threads2, b->op_in_lds2, b->cor_in_lds2);
@@ -1349,8 +1362,10 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
     D2.e4_wave = b->d_e4[1][2];
     D2.e4_round = b->d_e4[1][3];
     D2.e4_piece = b->d_e4[1][4];
-    HIPCHK(h, hipMemcpyAsync(b->d_dev2, &D2, sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream)); // D, D2 live on this stack frame
+    HIPCHK(h, hipMemcpyAsync(b->d_dev, &b->h_stage[0], sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(b->d_dev2, &b->h_stage[1], sizeof(DevBatch), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipEventRecord(b->stage_ev, h->stream));
+    b->stage_busy = true;
     b->dev_version = version;
   }
   return DFTPAV_OK;
