@@ -1339,6 +1339,10 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
     h->err = "too many moving obstacles for this layout (S <= 16, Npts * S <= 65535, <= 512 pieces in all)";
     return DFTPAV_E_UNSUPPORTED;
   }
+  if (b->order == DFTPAV_ORDER_REFERENCE && h->S > 0) { // obstacles were installed after the order was chosen
+    h->err = "reference order: no moving obstacles (dftpav_batch_set_order(b, DFTPAV_ORDER_DEVICE) first)";
+    return DFTPAV_E_UNSUPPORTED;
+  }
   D = make_dev(b);
   int version = h->sur_version * 4 + (b->prof_on ? 1 : 0) + (b->uploaded ? 2 : 0);
   if (version != b->dev_version) {
@@ -1516,7 +1520,7 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
       h->err = "reference order: no moving obstacles (libm's exp / log inside the loop), n <= 64, H <= 5";
       return DFTPAV_E_UNSUPPORTED;
     }
-    if (!b->d_ref_tab) {
+    if (!b->d_ref_tab || !b->d_ref_scratch) {
       std::vector<double> tab; // the tables of the segments, one after the other
       for (int sg = 0; sg < b->L.M; sg++) {
         std::vector<double> one;
@@ -1526,9 +1530,20 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
         }
         tab.insert(tab.end(), one.begin(), one.end());
       }
-      HIPCHK(h, hipMalloc(&b->d_ref_tab, sizeof(double) * tab.size()));
-      HIPCHK(h, hipMemcpy(b->d_ref_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
-      HIPCHK(h, hipMalloc(&b->d_ref_scratch, sizeof(double) * reference_order_scratch_doubles(b->L, b->B)));
+      double *d_tab = nullptr, *d_scr = nullptr;
+      if (hipMalloc(&d_tab, sizeof(double) * tab.size()) != hipSuccess ||
+          hipMalloc(&d_scr, sizeof(double) * reference_order_scratch_doubles(b->L, b->B)) != hipSuccess ||
+          hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        if (d_tab) (void)hipFree(d_tab);
+        if (d_scr) (void)hipFree(d_scr);
+        (void)hipGetLastError();
+        h->err = "reference order: no device memory for the term records of this batch";
+        return DFTPAV_E_HIP; // the order stays as it was, the batch usable
+      }
+      if (b->d_ref_tab) (void)hipFree(b->d_ref_tab);
+      if (b->d_ref_scratch) (void)hipFree(b->d_ref_scratch);
+      b->d_ref_tab = d_tab;
+      b->d_ref_scratch = d_scr;
     }
   }
   b->order = order;
