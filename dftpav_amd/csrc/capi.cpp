@@ -1499,6 +1499,12 @@ extern "C" int dftpav_debug_cr_sincos(int n, const double *x, double *s, double 
   for (int i = 0; i < n; i++) dftpav::crt::sincos(x[i], s[i], c[i]);
   return DFTPAV_OK;
 }
+// test hook (host only): which = 0 exp, 1 log, 2 x^3 -- the correctly rounded functions of cr_trig.h for n arguments
+extern "C" int dftpav_debug_cr_fn(int which, int n, const double *x, double *y) {
+  if (n < 0 || !x || !y || which < 0 || which > 2) return DFTPAV_E_INVALID;
+  for (int i = 0; i < n; i++) y[i] = which == 0 ? dftpav::crt::exp_cr(x[i]) : (which == 1 ? dftpav::crt::log_cr(x[i]) : dftpav::crt::cube_cr(x[i]));
+  return DFTPAV_OK;
+}
 // test hook (host only): the sweep tables of a segment of N pieces, [4][6N][8]; returns 1 if the middle blocks have the assumed pattern
 extern "C" int dftpav_debug_reference_tables(int N, double *out) {
   if (N < 2) return DFTPAV_E_INVALID;

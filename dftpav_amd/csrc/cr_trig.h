@@ -121,5 +121,98 @@ DFTPAV_HD inline void sincos(double x, double &s, double &c) {
   }
 }
 
+
+// ---------------------------------------------------------------- exp, log, x^3 (the moving-obstacle term of the reference:
+// 40 exponentials and 9 logarithms per (constraint point, obstacle) pair, traj_optimizer.cpp:1686-1707; pow(|v|, 3) in
+// Piece::getRdot, poly_traj_utils.hpp:109) -- correctly rounded for the same reason as sin / cos above.
+DFTPAV_HD inline dd dd_mul_d(dd a, double b) {
+  dd p = two_prod(a.hi, b);
+  p.lo += a.lo * b;
+  return fast_two_sum(p.hi, p.lo);
+}
+DFTPAV_HD inline dd dd_div(dd a, dd b) { // a / b to ~2^-104
+  const double q0 = a.hi / b.hi;
+  dd r = dd_add(a, dd_neg(dd_mul_d(b, q0)));
+  const double q1 = r.hi / b.hi;
+  r = dd_add(r, dd_neg(dd_mul_d(b, q1)));
+  const double q2 = r.hi / b.hi;
+  dd q = fast_two_sum(q0, q1);
+  return dd_add_d(q, q2);
+}
+DFTPAV_HD inline double scale2(double v, int k) { // v 2^k, in two steps so that the multipliers stay normal
+  const int k1 = k / 2, k2 = k - k1;
+  union { double d; unsigned long long u; } a, b;
+  a.u = (unsigned long long)(1023 + k1) << 52;
+  b.u = (unsigned long long)(1023 + k2) << 52;
+  return (v * a.d) * b.d;
+}
+// exp x: x = k ln2 + r (ln2 in three 33-bit chunks and a tail), exp(r / 16) by its Taylor series in double-double, four squarings.
+// Results below the normal range (x < -708.4) go through a second rounding in scale2 (the reference's sums absorb them:
+// they are weights relative to a term that is exactly 1).
+DFTPAV_HD inline double exp_cr(double x) {
+  if (x < -745.2) return 0.0;
+  if (x > 709.8) return 1.0e308 * 1.0e308;
+  if (x == 0.0) return 1.0;
+  const double inv_ln2 = 0x1.71547652b82fep+0;
+  const double l1 = 0x1.62e42ff000000p-1, l2 = -0x1.718432a200000p-35, l3 = 0x1.3c76730000000p-69, l4 = 0x1.f97b57a079a19p-103;
+  const double fk = x * inv_ln2;
+  const int k = (int)(fk < 0.0 ? fk - 0.5 : fk + 0.5);
+  const double kd = (double)k;
+  dd r = two_sum(x, -(kd * l1)); // kd l1, kd l2, kd l3 are exact (|k| <= 1075)
+  r = dd_add_d(r, -(kd * l2));
+  r = dd_add_d(r, -(kd * l3));
+  r = dd_add(r, dd_neg(two_prod(kd, l4)));
+  r.hi *= 0.0625; // r / 16, exact
+  r.lo *= 0.0625;
+  dd p = inv_fact(14);
+  for (int n = 13; n >= 2; n--) p = dd_add(inv_fact(n), dd_mul(p, r));
+  p = dd_add_d(dd_mul(p, r), 1.0); // 1 + r (1/2! + ...)  -> coefficient of r^1
+  dd e = dd_add_d(dd_mul(p, r), 1.0);
+  for (int q = 0; q < 4; q++) e = dd_mul(e, e);
+  return scale2(e.hi, k);
+}
+// log x (x > 0, normal): x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh((m - 1) / (m + 1)) by its series in double-double
+DFTPAV_HD inline double log_cr(double x) {
+  const double t[21][2] = {
+      {0x1.5555555555555p-2, 0x1.5555555555555p-56},  {0x1.999999999999ap-3, -0x1.999999999999ap-57}, {0x1.2492492492492p-3, 0x1.2492492492492p-57},
+      {0x1.c71c71c71c71cp-4, 0x1.c71c71c71c71cp-58},  {0x1.745d1745d1746p-4, -0x1.745d1745d1746p-59}, {0x1.3b13b13b13b14p-4, -0x1.3b13b13b13b14p-58},
+      {0x1.1111111111111p-4, 0x1.1111111111111p-60},  {0x1.e1e1e1e1e1e1ep-5, 0x1.e1e1e1e1e1e1ep-61},  {0x1.af286bca1af28p-5, 0x1.af286bca1af28p-59},
+      {0x1.8618618618618p-5, 0x1.8618618618618p-59},  {0x1.642c8590b2164p-5, 0x1.642c8590b2164p-60},  {0x1.47ae147ae147bp-5, -0x1.eb851eb851eb8p-61},
+      {0x1.2f684bda12f68p-5, 0x1.2f684bda12f68p-59},  {0x1.1a7b9611a7b96p-5, 0x1.1a7b9611a7b96p-61},  {0x1.0842108421084p-5, 0x1.0842108421084p-60},
+      {0x1.f07c1f07c1f08p-6, -0x1.f07c1f07c1f08p-61}, {0x1.d41d41d41d41dp-6, 0x1.0750750750750p-60},  {0x1.bacf914c1bad0p-6, -0x1.bacf914c1bad0p-60},
+      {0x1.a41a41a41a41ap-6, 0x1.0690690690690p-60},  {0x1.8f9c18f9c18fap-6, -0x1.f3831f3831f38p-61}, {0x1.7d05f417d05f4p-6, 0x1.7d05f417d05f4p-62}};
+  const double l1 = 0x1.62e42ff000000p-1, l2 = -0x1.718432a200000p-35, l3 = 0x1.3c76730000000p-69, l4 = 0x1.f97b57a079a19p-103;
+  if (x == 1.0) return 0.0;
+  union { double d; unsigned long long u; } v;
+  v.d = x;
+  int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+  v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; // mantissa in [1, 2)
+  double m = v.d;
+  if (m > 0x1.6a09e667f3bcdp+0) { // sqrt(2)
+    m *= 0.5;
+    e += 1;
+  }
+  const dd num = dd{m - 1.0, 0.0};        // exact (m in [0.70, 1.42))
+  const dd den = two_sum(m, 1.0);         // exact as a double-double
+  const dd z = dd_div(num, den);
+  const dd w = dd_mul(z, z);
+  dd acc = dd{t[20][0], t[20][1]};
+  for (int n = 19; n >= 0; n--) acc = dd_add(dd{t[n][0], t[n][1]}, dd_mul(acc, w)); // 1/3 + w (1/5 + w (...))
+  dd sres = dd_add(z, dd_mul(dd_mul(acc, w), z)); // z + z^3 (1/3 + ...)
+  sres.hi *= 2.0;
+  sres.lo *= 2.0;
+  const double ed = (double)e;
+  dd r = two_sum(ed * l1, ed * l2); // exact products (|e| <= 1074)
+  r = dd_add_d(r, ed * l3);
+  r = dd_add(r, two_prod(ed, l4));
+  r = dd_add(r, sres);
+  return r.hi;
+}
+// x^3, correctly rounded (the reference: pow(x, 3))
+DFTPAV_HD inline double cube_cr(double x) {
+  const dd p = two_prod(x, x);
+  return dd_mul_d(p, x).hi;
+}
+
 } // namespace crt
 } // namespace dftpav
