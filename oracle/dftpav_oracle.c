@@ -456,7 +456,11 @@ static void virtualT_grad_cost(const dftpav_params *p, double RT, double VT, dou
 }
 
 /* log_sum_exp, OPT:1686-1707: mutates all_dists into the exp weights */
-static double log_sum_exp(double alpha, double *all_dists, int n, double *exp_sum) {
+/* libm's exp / log / pow as the reference calls them, or (order 2) the correctly rounded values through binary128 */
+static double o_exp(int cr, double x) { return cr ? (double)expq((__float128)x) : exp(x); }
+static double o_log(int cr, double x) { return cr ? (double)logq((__float128)x) : log(x); }
+static double o_pow3(int cr, double x) { return cr ? (double)((__float128)x * (__float128)x * (__float128)x) : pow(x, 3); }
+static double log_sum_exp(int cr, double alpha, double *all_dists, int n, double *exp_sum) {
   double d_0 = all_dists[0];
   if (alpha > 0) {
     for (int j = 1; j < n; j++)
@@ -467,10 +471,10 @@ static double log_sum_exp(double alpha, double *all_dists, int n, double *exp_su
   }
   *exp_sum = 0;
   for (int j = 0; j < n; j++) {
-    all_dists[j] = exp(alpha * (all_dists[j] - d_0));
+    all_dists[j] = o_exp(cr, alpha * (all_dists[j] - d_0));
     *exp_sum += all_dists[j];
   }
-  return log(*exp_sum) / alpha + d_0;
+  return o_log(cr, *exp_sum) / alpha + d_0;
 }
 
 /* ========================================================================= */
@@ -523,12 +527,12 @@ static void piece_getR(const double *cm, double t, double R[4]) { /* MINCO:89-98
   R[2] = singul * v[1] / nv;
   R[3] = singul * v[0] / nv;
 }
-static void piece_getRdot(const double *cm, double t, double Rd[4]) { /* MINCO:100-112 */
+static void piece_getRdot(int cr, const double *cm, double t, double Rd[4]) { /* MINCO:100-112 */
   double v[2], a[2];
   piece_getdSigma(cm, t, v);
   piece_getddSigma(cm, t, a);
   double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
-  double nv3 = pow(nv, 3);
+  double nv3 = o_pow3(cr, nv);
   double va = v[0] * a[0] + v[1] * a[1];
   const int singul = 1;
   double ta[4] = {a[0], -a[1], a[1], a[0]};
@@ -565,9 +569,9 @@ static void traj_getR(const sur_traj_t *s, double t, double R[4]) {
   int i = traj_locate(s->durs, s->n_pieces, &t);
   piece_getR(s->coeffs + 12 * i, t, R);
 }
-static void traj_getRdot(const sur_traj_t *s, double t, double R[4]) {
+static void traj_getRdot(int cr, const sur_traj_t *s, double t, double R[4]) {
   int i = traj_locate(s->durs, s->n_pieces, &t);
-  piece_getRdot(s->coeffs + 12 * i, t, R);
+  piece_getRdot(cr, s->coeffs + 12 * i, t, R);
 }
 
 /* ========================================================================= */
@@ -781,7 +785,7 @@ static double dynamicObsGradCostP(oracle_ctx *c, double omg, double step, double
   if (c->S < 1) return 0.0;
   minjerk_t *mj = &c->mj[trajid];
 
-  double alpha = 100.0, d_min = P->surround_clearance + log(8.0) / alpha; /* OPT:1336 */
+  double alpha = 100.0, d_min = P->surround_clearance + o_log(c->order == 2, 8.0) / alpha; /* OPT:1336 */
   double temp0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
   double temp0_reci = (temp0 != 0.0) ? 1.0 / temp0 : 0.0;
   double temp3 = temp0_reci * temp0_reci;
@@ -858,7 +862,7 @@ static double dynamicObsGradCostP(oracle_ctx *c, double omg, double step, double
         vec_d_Uo_e[e][o] = HtR[0] * lo[0] + HtR[1] * lo[1];
       }
       double exp_sum;
-      d_U[e] = log_sum_exp(-alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_e_tilde;
+      d_U[e] = log_sum_exp(c->order == 2, -alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_e_tilde;
       surround2ego_sum_exp_vec[e] = exp_sum;
     }
 
@@ -885,7 +889,7 @@ static double dynamicObsGradCostP(oracle_ctx *c, double omg, double step, double
         vec_d_Ee_o[o][e] = HtR[0] * le[0] + HtR[1] * le[1];
       }
       double exp_sum;
-      d_E[o] = log_sum_exp(-alpha, vec_d_Ee_o[o], nE, &exp_sum) + d_E_o_tilde;
+      d_E[o] = log_sum_exp(c->order == 2, -alpha, vec_d_Ee_o[o], nE, &exp_sum) + d_E_o_tilde;
       ego2surround_sum_exp_vec[o] = exp_sum;
     }
 
@@ -893,7 +897,7 @@ static double dynamicObsGradCostP(oracle_ctx *c, double omg, double step, double
     for (int e = 0; e < 4; e++) d_test[e] = d_U[e];
     for (int o = 0; o < 4; o++) d_test[4 + o] = d_E[o];
     double exp_sum_d = 0;
-    double d_value_test = d_min - log_sum_exp(alpha, d_test, 8, &exp_sum_d); /* OPT:1498-1502 */
+    double d_value_test = d_min - log_sum_exp(c->order == 2, alpha, d_test, 8, &exp_sum_d); /* OPT:1498-1502 */
     double costp = d_value_test;
     if (costp <= 0) continue;
     double pena, penaD;
@@ -978,7 +982,7 @@ static double dynamicObsGradCostP(oracle_ctx *c, double omg, double step, double
     /* dG/dt_hat, OPT:1586-1646 */
     double pGthat = 0.0;
     double Rud[4];
-    traj_getRdot(st, pt_time, Rud); /* OPT:1599 */
+    traj_getRdot(c->order == 2, st, pt_time, Rud); /* OPT:1599 */
     for (int e = 0; e < nE; e++) {
       double d_Uo_e_exp_sum = surround2ego_sum_exp_vec[e];
       const double *Hn = ego_normal[e];
@@ -1215,12 +1219,23 @@ static void addPVAGradCost2CT(oracle_ctx *c, double costs[3], int trajid, double
   }
 }
 
-/* cos / sin of a junction angle (OPT:276-281, 312-317).  Order 0: libm's, as the reference calls them -- a property of the host
- * (glibc's are not correctly rounded, and IFUNC-dispatched by CPU).  Order 2: the CORRECTLY ROUNDED values, here simply through
- * binary128 (libquadmath; the double rounding binary128 -> double could differ from direct rounding in 1 case in 2^60): the
- * definition the reference-order device kernel implements with double-double arithmetic (dftpav_amd/csrc/cr_trig.h). */
-static double o_cos(const oracle_ctx *c, double th) { return c->order == 2 ? (double)cosq((__float128)th) : cos(th); }
-static double o_sin(const oracle_ctx *c, double th) { return c->order == 2 ? (double)sinq((__float128)th) : sin(th); }
+/* cos / sin of a junction angle (OPT:276-281, 312-317).  Order 0: libm's, written as the reference writes them -- cos(theta)
+ * and sin(theta) side by side, which gcc -O2 turns into ONE call of sincos() in the reference build and here alike; glibc's
+ * sincos() differs from its own sin() / cos() for 1 argument in 1 600, so even that fusion is part of "the reference's bits"
+ * (they are a property of the host: not correctly rounded, IFUNC-dispatched by CPU).  Order 2: the CORRECTLY ROUNDED values,
+ * here simply through binary128 (libquadmath; the double rounding binary128 -> double could differ from direct rounding in
+ * 1 case in 2^60): the definition the reference-order device kernel implements with double-double arithmetic
+ * (dftpav_amd/csrc/cr_trig.h). */
+#define O_COS_SIN(c_, th_, cs_, sn_)                 \
+  do {                                               \
+    if ((c_)->order == 2) {                          \
+      (cs_) = (double)cosq((__float128)(th_));       \
+      (sn_) = (double)sinq((__float128)(th_));       \
+    } else {                                         \
+      (cs_) = cos(th_);                              \
+      (sn_) = sin(th_);                              \
+    }                                                \
+  } while (0)
 
 /* ========================================================================= */
 /* costFunctionCallback, OPT:206-350                                           */
@@ -1264,15 +1279,19 @@ double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
       double theta = Angles[trajid - 1];
       IniS[0] = Gear[2 * (trajid - 1) + 0];
       IniS[1] = Gear[2 * (trajid - 1) + 1];
-      IniS[2] = -P->non_sinv * o_cos(c, theta);
-      IniS[3] = -P->non_sinv * o_sin(c, theta);
+      double cs, sn;
+      O_COS_SIN(c, theta, cs, sn);
+      IniS[2] = -P->non_sinv * cs;
+      IniS[3] = -P->non_sinv * sn;
     }
     if (trajid < M - 1) { /* OPT:278-282 */
       double theta = Angles[trajid];
       FinS[0] = Gear[2 * trajid + 0];
       FinS[1] = Gear[2 * trajid + 1];
-      FinS[2] = P->non_sinv * o_cos(c, theta);
-      FinS[3] = P->non_sinv * o_sin(c, theta);
+      double cs, sn;
+      O_COS_SIN(c, theta, cs, sn);
+      FinS[2] = P->non_sinv * cs;
+      FinS[3] = P->non_sinv * sn;
     }
     minjerk_t *mj = &c->mj[trajid];
     minjerk_generate(mj, x + Poff[trajid], T[trajid] / c->piece_nums[trajid], IniS, FinS);
@@ -1297,13 +1316,17 @@ double oracle_eval(oracle_ctx *c, const double *x, double *grad) {
         double theta = Angles[trajid - 1];
         gradGear[2 * (trajid - 1) + 0] += gradIni[0];
         gradGear[2 * (trajid - 1) + 1] += gradIni[1];
-        gradAngles[trajid - 1] += gradIni[2] * (P->non_sinv * o_sin(c, theta)) + gradIni[3] * (-P->non_sinv * o_cos(c, theta));
+        double cs, sn;
+        O_COS_SIN(c, theta, cs, sn);
+        gradAngles[trajid - 1] += gradIni[2] * (P->non_sinv * sn) + gradIni[3] * (-P->non_sinv * cs);
       }
       if (trajid < M - 1) {
         double theta = Angles[trajid];
         gradGear[2 * trajid + 0] += gradFin[0];
         gradGear[2 * trajid + 1] += gradFin[1];
-        gradAngles[trajid] += gradFin[2] * (-P->non_sinv * o_sin(c, theta)) + gradFin[3] * (P->non_sinv * o_cos(c, theta));
+        double cs, sn;
+        O_COS_SIN(c, theta, cs, sn);
+        gradAngles[trajid] += gradFin[2] * (-P->non_sinv * sn) + gradFin[3] * (P->non_sinv * cs);
       }
     }
     virtualT_grad_cost(P, T[trajid], tvar[trajid], mj->gdT / c->piece_nums[trajid], &gradt[trajid], &time_cost);
