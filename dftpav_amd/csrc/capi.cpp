@@ -52,7 +52,7 @@ hipError_t launch_corridor_layout(const double *raw, double *out, int B, int Npt
 hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream);
 // solver_ref.hip: the same path in the reference's own floating-point order
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S);
-size_t reference_order_scratch_doubles(const DevLayout &L, int B);
+size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S);
 size_t reference_order_table_doubles(int N);
 int reference_order_interior_mask(int sweep, int row_mod_6);
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream);
@@ -136,6 +136,7 @@ struct dftpav_batch {
   double *d_cor_raw = nullptr; // the caller's hPoly columns as uploaded (normalised and laid out on the device)
   // dftpav_batch_set_order(DFTPAV_ORDER_REFERENCE): the substitution tables of the band system and the term records (solver_ref.hip)
   int order = DFTPAV_ORDER_DEVICE;
+  int ref_S = 0; // moving obstacles on the handle when the reference order was chosen (the term records are sized for them)
   double *d_ref_tab = nullptr, *d_ref_scratch = nullptr;
   // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
   struct PlanCycle {
@@ -1339,8 +1340,8 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
     h->err = "too many moving obstacles for this layout (S <= 16, Npts * S <= 65535, <= 512 pieces in all)";
     return DFTPAV_E_UNSUPPORTED;
   }
-  if (b->order == DFTPAV_ORDER_REFERENCE && h->S > 0) { // obstacles were installed after the order was chosen
-    h->err = "reference order: no moving obstacles (dftpav_batch_set_order(b, DFTPAV_ORDER_DEVICE) first)";
+  if (b->order == DFTPAV_ORDER_REFERENCE && h->S != b->ref_S) { // the obstacle set changed after the order was chosen
+    h->err = "reference order: the number of moving obstacles changed -- choose the order again (dftpav_batch_set_order)";
     return DFTPAV_E_UNSUPPORTED;
   }
   D = make_dev(b);
@@ -1517,16 +1518,16 @@ extern "C" int dftpav_debug_reference_tables(int N, double *out) {
 extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
   if (!b || (order != DFTPAV_ORDER_DEVICE && order != DFTPAV_ORDER_REFERENCE)) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
-  if (order == b->order) return DFTPAV_OK;
+  if (order == b->order && (order == DFTPAV_ORDER_DEVICE || b->ref_S == h->S)) return DFTPAV_OK;
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (order == DFTPAV_ORDER_REFERENCE) {
     if (!reference_order_supported(b->L, b->P, h->S)) {
-      h->err = "reference order: no moving obstacles (libm's exp / log inside the loop), n <= 64, H <= 5";
+      h->err = "reference order: n <= 64 variables, 5 H + S + 4 <= 32 terms per point, one gear segment with moving obstacles";
       return DFTPAV_E_UNSUPPORTED;
     }
-    if (!b->d_ref_tab || !b->d_ref_scratch) {
+    if (!b->d_ref_tab || !b->d_ref_scratch || b->ref_S != h->S) {
       std::vector<double> tab; // the tables of the segments, one after the other
       for (int sg = 0; sg < b->L.M; sg++) {
         std::vector<double> one;
@@ -1538,7 +1539,7 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
       }
       double *d_tab = nullptr, *d_scr = nullptr;
       if (hipMalloc(&d_tab, sizeof(double) * tab.size()) != hipSuccess ||
-          hipMalloc(&d_scr, sizeof(double) * reference_order_scratch_doubles(b->L, b->B)) != hipSuccess ||
+          hipMalloc(&d_scr, sizeof(double) * reference_order_scratch_doubles(b->L, b->B, h->S)) != hipSuccess ||
           hipMemcpy(d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
         if (d_tab) (void)hipFree(d_tab);
         if (d_scr) (void)hipFree(d_scr);
@@ -1550,6 +1551,7 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
       if (b->d_ref_scratch) (void)hipFree(b->d_ref_scratch);
       b->d_ref_tab = d_tab;
       b->d_ref_scratch = d_scr;
+      b->ref_S = h->S;
     }
   }
   b->order = order;
@@ -1626,10 +1628,6 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
   if (b->order == DFTPAV_ORDER_REFERENCE) {
-    if (h->S > 0) { // obstacles were installed after the order was chosen
-      h->err = "reference order: no moving obstacles";
-      return DFTPAV_E_UNSUPPORTED;
-    }
     HIPCHK(h, launch_for(b, D, kModeSolve)); // one workgroup per trajectory, no scheduling: the verification / latency mode
   } else if (!b->sched) {
     HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, h->stream));

@@ -124,7 +124,7 @@ struct Sm {
   ldsd_t b, c, gdC, adj;    // [6 Ntot][2]
   ldsd_t pE, pG, pA;        // [Ntot] per-piece energy, d(energy)/dT, chain-rule term of calGrads_PT
   ldsd_t tab;               // per segment [4][6N][8]: rows of the four substitution sweeps (six coefficients, diagonal, 1 / diagonal)
-  ldsd_t segsum;            // [M][4] per segment: gdT, corridor cost, feasibility cost, jerk energy
+  ldsd_t segsum;            // [M][gNUM] per segment: gdT, corridor cost, feasibility cost, jerk energy, moving-obstacle cost
   ldsd_t dot;               // [4][64] products of up to four sequential dot products
   ldsd_t alpha;             // [mem]
   ldsd_t st;                // [sNUM]
@@ -134,10 +134,10 @@ struct Sm {
   ldsi_t pfirst;            // [Npts + 1] index of a point's first active term in (point, term) order
   ldsi_t list;              // [kListCap] (point << 5 | term) of the active terms of the current window
 };
-enum { gGDT = 0, gCOST0, gCOST2, gENERGY };
+enum { gGDT = 0, gCOST0, gCOST2, gENERGY, gCOST1, gNUM = 6 };
 
 __host__ __device__ inline size_t lds_doubles(const DevLayout &L, int mem) {
-  return 5 * (size_t)L.npad + (size_t)L.M * (12 + 12 + 2 + 16 + 4) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3 + 4 * 48) * (size_t)L.Ntot + 4 * 64 +
+  return 5 * (size_t)L.npad + (size_t)L.M * (12 + 12 + 2 + 16 + gNUM) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3 + 4 * 48) * (size_t)L.Ntot + 4 * 64 +
          (size_t)mem + sNUM;
 }
 __host__ __device__ inline size_t lds_ints(const DevLayout &L) { return iNUM + 4 * (size_t)L.Ntot + 2 * (size_t)L.Npts + 1 + kListCap; }
@@ -163,7 +163,7 @@ __device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
   s.pG = p; p += Ntot;
   s.pA = p; p += Ntot;
   s.tab = p; p += (4 * 48) * Ntot;
-  s.segsum = p; p += 4 * M;
+  s.segsum = p; p += gNUM * M;
   s.dot = p; p += 4 * 64;
   s.alpha = p; p += mem;
   s.st = p; p += sNUM;
@@ -271,12 +271,406 @@ __device__ __forceinline__ void smoothed_l1(double x, double &f, double &df) {
   }
 }
 
+// ------------------------------------------------ moving obstacles: dynamicObsGradCostP (traj_optimizer.cpp:1311-1684)
+// Obstacle trajectories as the reference evaluates them (poly_traj_utils.hpp:77-112, 179-211, 510-528): the walk of
+// locatePieceIdx, Horner-free power sums, getR / getRdot.  coeffs: 2 x 6 column-major, column 0 multiplies t^5.
+struct SurTraj {
+  const double *durs, *coeffs;
+  int n_pieces;
+  double duration, start_time;
+};
+__device__ inline void piece_getPos(const double *cm, double t, double out[2]) {
+  out[0] = 0.0;
+  out[1] = 0.0;
+  double tn = 1.0;
+  for (int i = 5; i >= 0; i--) {
+    out[0] += tn * cm[2 * i + 0];
+    out[1] += tn * cm[2 * i + 1];
+    tn *= t;
+  }
+}
+__device__ inline void piece_getdSigma(const double *cm, double t, double out[2]) {
+  out[0] = 0.0;
+  out[1] = 0.0;
+  double tn = 1.0;
+  int n = 1;
+  for (int i = 4; i >= 0; i--) {
+    out[0] += n * tn * cm[2 * i + 0];
+    out[1] += n * tn * cm[2 * i + 1];
+    tn *= t;
+    n++;
+  }
+}
+__device__ inline void piece_getddSigma(const double *cm, double t, double out[2]) {
+  out[0] = 0.0;
+  out[1] = 0.0;
+  double tn = 1.0;
+  int m = 1, n = 2;
+  for (int i = 3; i >= 0; i--) {
+    out[0] += m * n * tn * cm[2 * i + 0];
+    out[1] += m * n * tn * cm[2 * i + 1];
+    tn *= t;
+    m++;
+    n++;
+  }
+}
+__device__ inline void piece_getR(const double *cm, double t, double R[4]) {
+  double v[2];
+  piece_getdSigma(cm, t, v);
+  const double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+  const int singul = 1; // obstacle trajectories are built with getTraj(1), traj_manager.cpp:775
+  R[0] = singul * v[0] / nv;
+  R[1] = singul * -v[1] / nv;
+  R[2] = singul * v[1] / nv;
+  R[3] = singul * v[0] / nv;
+}
+__device__ inline void piece_getRdot(const double *cm, double t, double Rd[4]) {
+  double v[2], a[2];
+  piece_getdSigma(cm, t, v);
+  piece_getddSigma(cm, t, a);
+  const double nv = sqrt(v[0] * v[0] + v[1] * v[1]);
+  const double nv3 = crt::cube_cr(nv); // the reference: pow(nv, 3)
+  const double va = v[0] * a[0] + v[1] * a[1];
+  const int singul = 1;
+  const double ta[4] = {a[0], -a[1], a[1], a[0]};
+  const double tv[4] = {v[0], -v[1], v[1], v[0]};
+  for (int k = 0; k < 4; k++) Rd[k] = singul * (ta[k] / nv - tv[k] / nv3 * va);
+}
+__device__ inline int traj_locate(const double *durs, int N, double &t) { // Trajectory::locatePieceIdx
+  int idx;
+  double dur;
+  for (idx = 0; idx < N && t > (dur = durs[idx]); idx++) t -= dur;
+  if (idx == N) {
+    idx--;
+    t += durs[idx];
+  }
+  return idx;
+}
+__device__ inline void traj_getPos(const SurTraj *s, double t, double o[2]) {
+  const int i = traj_locate(s->durs, s->n_pieces, t);
+  piece_getPos(s->coeffs + 12 * i, t, o);
+}
+__device__ inline void traj_getdSigma(const SurTraj *s, double t, double o[2]) {
+  const int i = traj_locate(s->durs, s->n_pieces, t);
+  piece_getdSigma(s->coeffs + 12 * i, t, o);
+}
+__device__ inline void traj_getddSigma(const SurTraj *s, double t, double o[2]) {
+  const int i = traj_locate(s->durs, s->n_pieces, t);
+  piece_getddSigma(s->coeffs + 12 * i, t, o);
+}
+__device__ inline void traj_getR(const SurTraj *s, double t, double R[4]) {
+  const int i = traj_locate(s->durs, s->n_pieces, t);
+  piece_getR(s->coeffs + 12 * i, t, R);
+}
+__device__ inline void traj_getRdot(const SurTraj *s, double t, double R[4]) {
+  const int i = traj_locate(s->durs, s->n_pieces, t);
+  piece_getRdot(s->coeffs + 12 * i, t, R);
+}
+// 2 x 2 helpers, m = {m00, m01, m10, m11}
+__device__ inline void mat_vec(const double m[4], const double v[2], double o[2]) {
+  o[0] = m[0] * v[0] + m[1] * v[1];
+  o[1] = m[2] * v[0] + m[3] * v[1];
+}
+__device__ inline void mat_mat(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[0] * b[0] + a[1] * b[2];
+  o[1] = a[0] * b[1] + a[1] * b[3];
+  o[2] = a[2] * b[0] + a[3] * b[2];
+  o[3] = a[2] * b[1] + a[3] * b[3];
+}
+// log_sum_exp, traj_optimizer.cpp:1686-1707 (mutates all_dists into the exp weights); exp / log correctly rounded
+__device__ inline double lse_cr(double alpha, double *all_dists, int n, double *exp_sum) {
+  double d_0 = all_dists[0];
+  if (alpha > 0) {
+    for (int j = 1; j < n; j++)
+      if (all_dists[j] > d_0) d_0 = all_dists[j];
+  } else {
+    for (int j = 1; j < n; j++)
+      if (all_dists[j] < d_0) d_0 = all_dists[j];
+  }
+  *exp_sum = 0;
+  for (int j = 0; j < n; j++) {
+    all_dists[j] = crt::exp_cr(alpha * (all_dists[j] - d_0));
+    *exp_sum += all_dists[j];
+  }
+  return crt::log_cr(*exp_sum) / alpha + d_0;
+}
+// The obstacle loop of dynamicObsGradCostP for one constraint point, statement by statement.  Every obstacle with a positive
+// penalty writes a record (term t_first + sur_id) and sets its bit in `mask`; the point's penalty -- the inner sum over the
+// obstacles, which the reference adds to costs(1) once per point -- goes into slot [13] of the first such record.
+__device__ __noinline__ unsigned surround_terms(const DevParams &P, const DevSurround &S, double t_now, double omg, double step, double t,
+                                                const double beta0[6], const double beta1[6], double gama, int pieceid, int trajres,
+                                                const double sigma[2], const double dsigma[2], const double ddsigma[2], const double ego_R[4],
+                                                int singul_, int trajid, double trajtime, int Nseg, int t_first, gd_t rec) {
+  const double B_h[4] = {0.0, -1.0, 1.0, 0.0}, B_hT[4] = {0.0, 1.0, -1.0, 0.0}; // traj_optimizer.cpp:1741-1742
+  unsigned mask = 0u;
+  int first_active = -1;
+  const double alpha = 100.0, d_min = P.surround_clearance + crt::log_cr(8.0) / alpha; // traj_optimizer.cpp:1336 (the reference: std::log(8.0))
+  double temp0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
+  double temp0_reci = (temp0 != 0.0) ? 1.0 / temp0 : 0.0;
+  double temp3 = temp0_reci * temp0_reci;
+  const int nE = 4, nO = 4;
+  double totalPenalty = 0.0;
+
+  for (int sur_id = 0; sur_id < S.S; sur_id++) {
+    const SurTraj st_{S.durations + S.piece_off[sur_id], S.coeffs + 12 * (size_t)S.piece_off[sur_id], S.piece_off[sur_id + 1] - S.piece_off[sur_id], S.total[sur_id], S.start[sur_id]};
+    const SurTraj *st = &st_;
+    double offsettime = t_now - st->start_time + trajtime; // OPT:1367-1369
+    double pt_time = offsettime + t;
+    double surround_p[2], surround_v[2], surround_a[2];
+    if (pt_time < st->duration) {
+      traj_getPos(st, pt_time, surround_p);
+      traj_getdSigma(st, pt_time, surround_v);
+      traj_getddSigma(st, pt_time, surround_a);
+    } else { // OPT:1379-1389
+      double vd[2], pd[2];
+      traj_getddSigma(st, st->duration, surround_a);
+      double exceed_time = pt_time - st->duration;
+      traj_getdSigma(st, st->duration, vd);
+      surround_v[0] = vd[0] + exceed_time * surround_a[0];
+      surround_v[1] = vd[1] + exceed_time * surround_a[1];
+      traj_getPos(st, st->duration, pd);
+      surround_p[0] = pd[0] + exceed_time * vd[0] + 0.5 * surround_a[0] * exceed_time * exceed_time;
+      surround_p[1] = pd[1] + exceed_time * vd[1] + 0.5 * surround_a[1] * exceed_time * exceed_time;
+    }
+    {
+      double dx = surround_p[0] - sigma[0], dy = surround_p[1] - sigma[1];
+      if (sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5) continue; // OPT:1393
+    }
+    double surround_R[4];
+    traj_getR(st, pt_time, surround_R); // OPT:1410
+
+    double surround2ego_sum_exp_vec[4], d_U[4];
+    double ego_normal[4][2], vec_d_Uo_e[4][4], F_delta_le_v[4][4], F_le_v[4][4];
+    for (int e = 0; e < nE; e++) { // OPT:1417-1461
+      const double *le = P.vec_le[e];
+      double delta_le[2] = {P.vec_le[e + 1][0] - le[0], P.vec_le[e + 1][1] - le[1]};
+      double delta_le_norm = sqrt(delta_le[0] * delta_le[0] + delta_le[1] * delta_le[1]);
+      double delta_le_norm_inverse = 1 / delta_le_norm;
+      double Rdl[2], Rle[2];
+      mat_vec(ego_R, delta_le, Rdl);
+      mat_vec(ego_R, le, Rle);
+      // F(l) = singul*[l,Bl]^T*temp0_reci - dsigma*(R l)^T*temp3
+      {
+        double LT[4] = {delta_le[0], delta_le[1], -delta_le[1], delta_le[0]};
+        double *F = F_delta_le_v[e];
+        F[0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rdl[0] * temp3;
+        F[1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rdl[1] * temp3;
+        F[2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rdl[0] * temp3;
+        F[3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rdl[1] * temp3;
+      }
+      {
+        double LT[4] = {le[0], le[1], -le[1], le[0]};
+        double *F = F_le_v[e];
+        F[0] = singul_ * LT[0] * temp0_reci - dsigma[0] * Rle[0] * temp3;
+        F[1] = singul_ * LT[1] * temp0_reci - dsigma[0] * Rle[1] * temp3;
+        F[2] = singul_ * LT[2] * temp0_reci - dsigma[1] * Rle[0] * temp3;
+        F[3] = singul_ * LT[3] * temp0_reci - dsigma[1] * Rle[1] * temp3;
+      }
+      double BR[4], H_tilde[2];
+      mat_mat(B_h, ego_R, BR);
+      mat_vec(BR, delta_le, H_tilde);
+      H_tilde[0] *= delta_le_norm_inverse;
+      H_tilde[1] *= delta_le_norm_inverse;
+      ego_normal[e][0] = H_tilde[0];
+      ego_normal[e][1] = H_tilde[1];
+      double w[2] = {surround_p[0] - sigma[0] - Rle[0], surround_p[1] - sigma[1] - Rle[1]};
+      double d_U_e_tilde = H_tilde[0] * w[0] + H_tilde[1] * w[1];
+      double HtR[2] = {H_tilde[0] * surround_R[0] + H_tilde[1] * surround_R[2],
+                       H_tilde[0] * surround_R[1] + H_tilde[1] * surround_R[3]};
+      for (int o = 0; o < nO; o++) {
+        const double *lo = P.vec_le[o];
+        vec_d_Uo_e[e][o] = HtR[0] * lo[0] + HtR[1] * lo[1];
+      }
+      double exp_sum;
+      d_U[e] = lse_cr(-alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_e_tilde;
+      surround2ego_sum_exp_vec[e] = exp_sum;
+    }
+
+    double ego2surround_sum_exp_vec[4], d_E[4];
+    double surround_normal[4][2], vec_d_Ee_o[4][4];
+    for (int o = 0; o < nO; o++) { // OPT:1464-1496
+      const double *lo = P.vec_le[o];
+      double delta_lo[2] = {P.vec_le[o + 1][0] - lo[0], P.vec_le[o + 1][1] - lo[1]};
+      double delta_lo_norm = sqrt(delta_lo[0] * delta_lo[0] + delta_lo[1] * delta_lo[1]);
+      double delta_lo_norm_inverse = 1 / delta_lo_norm;
+      double BR[4], H_tilde[2], Rlo[2];
+      mat_mat(B_h, surround_R, BR);
+      mat_vec(BR, delta_lo, H_tilde);
+      H_tilde[0] *= delta_lo_norm_inverse;
+      H_tilde[1] *= delta_lo_norm_inverse;
+      surround_normal[o][0] = H_tilde[0];
+      surround_normal[o][1] = H_tilde[1];
+      mat_vec(surround_R, lo, Rlo);
+      double w[2] = {sigma[0] - surround_p[0] - Rlo[0], sigma[1] - surround_p[1] - Rlo[1]};
+      double d_E_o_tilde = H_tilde[0] * w[0] + H_tilde[1] * w[1];
+      double HtR[2] = {H_tilde[0] * ego_R[0] + H_tilde[1] * ego_R[2], H_tilde[0] * ego_R[1] + H_tilde[1] * ego_R[3]};
+      for (int e = 0; e < nE; e++) {
+        const double *le = P.vec_le[e];
+        vec_d_Ee_o[o][e] = HtR[0] * le[0] + HtR[1] * le[1];
+      }
+      double exp_sum;
+      d_E[o] = lse_cr(-alpha, vec_d_Ee_o[o], nE, &exp_sum) + d_E_o_tilde;
+      ego2surround_sum_exp_vec[o] = exp_sum;
+    }
+
+    double d_test[8];
+    for (int e = 0; e < 4; e++) d_test[e] = d_U[e];
+    for (int o = 0; o < 4; o++) d_test[4 + o] = d_E[o];
+    double exp_sum_d = 0;
+    double d_value_test = d_min - lse_cr(alpha, d_test, 8, &exp_sum_d); // OPT:1498-1502
+    double costp = d_value_test;
+    if (costp <= 0) continue;
+    double pena, penaD;
+    smoothed_l1(costp, pena, penaD);
+    totalPenalty += omg * step * P.wei_surround * pena;
+
+    // dG/dsigma, OPT:1511-1523
+    double pGs[2] = {0.0, 0.0};
+    for (int e = 0; e < nE; e++) {
+      double w = d_test[e] / exp_sum_d;
+      pGs[0] -= w * (-ego_normal[e][0]);
+      pGs[1] -= w * (-ego_normal[e][1]);
+    }
+    for (int o = 0; o < nO; o++) {
+      double w = d_test[o + nE] / exp_sum_d;
+      pGs[0] -= w * surround_normal[o][0];
+      pGs[1] -= w * surround_normal[o][1];
+    }
+
+    // dG/dsigma', OPT:1528-1573
+    double pGds[2] = {0.0, 0.0};
+    for (int e = 0; e < nE; e++) {
+      const double *F_delta_le = F_delta_le_v[e], *F_le = F_le_v[e];
+      const double *le = P.vec_le[e];
+      double delta_le[2] = {P.vec_le[e + 1][0] - le[0], P.vec_le[e + 1][1] - le[1]};
+      double dln = sqrt(delta_le[0] * delta_le[0] + delta_le[1] * delta_le[1]);
+      double d_Uo_e_exp_sum = surround2ego_sum_exp_vec[e];
+      double Rle[2];
+      mat_vec(ego_R, le, Rle);
+      double u[2] = {-surround_p[0] + sigma[0] + Rle[0], -surround_p[1] + sigma[1] + Rle[1]};
+      double FB[4], t1[2], FlB[4], FlBR[4], t2[2];
+      mat_mat(F_delta_le, B_h, FB);
+      mat_vec(FB, u, t1);
+      mat_mat(F_le, B_h, FlB);
+      mat_mat(FlB, ego_R, FlBR);
+      mat_vec(FlBR, delta_le, t2);
+      double pdU[2] = {(t1[0] - t2[0]) / dln, (t1[1] - t2[1]) / dln};
+      double FBT[4];
+      mat_mat(F_delta_le, B_hT, FBT);
+      for (int o = 0; o < nO; o++) {
+        double d_Uo_e = vec_d_Uo_e[e][o];
+        double Rlo[2], q[2];
+        mat_vec(surround_R, P.vec_le[o], Rlo);
+        mat_vec(FBT, Rlo, q);
+        q[0] /= dln;
+        q[1] /= dln;
+        double w = d_Uo_e / d_Uo_e_exp_sum;
+        pdU[0] += w * q[0];
+        pdU[1] += w * q[1];
+      }
+      double w = d_test[e] / exp_sum_d;
+      pGds[0] -= w * pdU[0];
+      pGds[1] -= w * pdU[1];
+    }
+    for (int o = 0; o < nO; o++) {
+      const double *lo = P.vec_le[o];
+      double delta_lo[2] = {P.vec_le[o + 1][0] - lo[0], P.vec_le[o + 1][1] - lo[1]};
+      double dln = sqrt(delta_lo[0] * delta_lo[0] + delta_lo[1] * delta_lo[1]);
+      double d_Ee_o_exp_sum = ego2surround_sum_exp_vec[o];
+      double pdE[2] = {0.0, 0.0};
+      for (int e = 0; e < nE; e++) {
+        const double *F_le = F_le_v[e];
+        double d_Ee_o = vec_d_Ee_o[o][e];
+        double FB[4], FBR[4], q[2];
+        mat_mat(F_le, B_h, FB);
+        mat_mat(FB, surround_R, FBR);
+        mat_vec(FBR, delta_lo, q);
+        q[0] /= dln;
+        q[1] /= dln;
+        double w = d_Ee_o / d_Ee_o_exp_sum;
+        pdE[0] += w * q[0];
+        pdE[1] += w * q[1];
+      }
+      double w = d_test[o + nE] / exp_sum_d;
+      pGds[0] -= w * pdE[0];
+      pGds[1] -= w * pdE[1];
+    }
+
+    // dG/dt_bar, OPT:1578-1580
+    double pGtbar = (pGs[0] * dsigma[0] + pGs[1] * dsigma[1]) + (pGds[0] * ddsigma[0] + pGds[1] * ddsigma[1]);
+
+    // dG/dt_hat, OPT:1586-1646
+    double pGthat = 0.0;
+    double Rud[4];
+    traj_getRdot(st, pt_time, Rud); // OPT:1599
+    for (int e = 0; e < nE; e++) {
+      double d_Uo_e_exp_sum = surround2ego_sum_exp_vec[e];
+      const double *Hn = ego_normal[e];
+      double acc = Hn[0] * surround_v[0] + Hn[1] * surround_v[1];
+      double HtRd[2] = {Hn[0] * Rud[0] + Hn[1] * Rud[2], Hn[0] * Rud[1] + Hn[1] * Rud[3]};
+      for (int o = 0; o < nO; o++) {
+        const double *lo = P.vec_le[o];
+        double pt = HtRd[0] * lo[0] + HtRd[1] * lo[1];
+        double d_Uo_e = vec_d_Uo_e[e][o];
+        acc += d_Uo_e / d_Uo_e_exp_sum * pt;
+      }
+      pGthat -= d_test[e] / exp_sum_d * acc;
+    }
+    for (int o = 0; o < nO; o++) {
+      double d_Ee_o_exp_sum = ego2surround_sum_exp_vec[o];
+      const double *lo = P.vec_le[o];
+      double delta_lo[2] = {P.vec_le[o + 1][0] - lo[0], P.vec_le[o + 1][1] - lo[1]};
+      double dln = sqrt(delta_lo[0] * delta_lo[0] + delta_lo[1] * delta_lo[1]);
+      double BRd[4], BR[4], a1[2], a2[2], Rlo[2], Rdlo[2];
+      mat_mat(B_h, Rud, BRd);
+      mat_vec(BRd, delta_lo, a1);
+      mat_mat(B_h, surround_R, BR);
+      mat_vec(BR, delta_lo, a2);
+      mat_vec(surround_R, lo, Rlo);
+      mat_vec(Rud, lo, Rdlo);
+      double w1[2] = {sigma[0] - surround_p[0] - Rlo[0], sigma[1] - surround_p[1] - Rlo[1]};
+      double w2[2] = {-surround_v[0] - Rdlo[0], -surround_v[1] - Rdlo[1]};
+      double acc = ((a1[0] / dln) * w1[0] + (a1[1] / dln) * w1[1]) + ((a2[0] / dln) * w2[0] + (a2[1] / dln) * w2[1]);
+      for (int e = 0; e < nE; e++) {
+        double d_Ee_o = vec_d_Ee_o[o][e];
+        double Rle[2];
+        mat_vec(ego_R, P.vec_le[e], Rle);
+        double r1[2] = {Rle[0] * B_h[0] + Rle[1] * B_h[2], Rle[0] * B_h[1] + Rle[1] * B_h[3]};
+        double r2[2] = {r1[0] * Rud[0] + r1[1] * Rud[2], r1[0] * Rud[1] + r1[1] * Rud[3]};
+        double pt = (r2[0] * delta_lo[0] + r2[1] * delta_lo[1]) / dln;
+        acc += d_Ee_o / d_Ee_o_exp_sum * pt;
+      }
+      pGthat -= d_test[o + nE] / exp_sum_d * acc;
+    }
+
+    // accumulate, OPT:1649-1676
+    double gradViolaPt = gama * pGtbar;
+    double scale = omg * step * P.wei_surround * penaD;
+    gd_t r_ = rec + (size_t)(t_first + sur_id) * kRec;
+    for (int k = 0; k < 6; k++) {
+      r_[2 * k + 0] = scale * (beta0[k] * pGs[0] + beta1[k] * pGds[0]);
+      r_[2 * k + 1] = scale * (beta0[k] * pGs[1] + beta1[k] * pGds[1]);
+    }
+    // the three `gdT +=` of traj_optimizer.cpp:1663-1676, kept apart: the chain adds them one after the other
+    r_[12] = omg * P.wei_surround * (pena / trajres + penaD * gradViolaPt * step);
+    r_[14] = omg * step * P.wei_surround * pGthat * penaD * pieceid;
+    r_[15] = omg * step * P.wei_surround * gama * pGthat * penaD;
+    r_[13] = 0.0;
+    if (first_active < 0) first_active = sur_id;
+    mask |= 1u << (t_first + sur_id);
+  }
+  if (first_active >= 0) rec[(size_t)(t_first + first_active) * kRec + 13] = totalPenalty;
+  return mask;
+}
+
 // ------------------------------------------------ one constraint point (traj_optimizer.cpp:499-705)
 // Point j of piece i (K intervals, offset s1 = the running sum of traj_optimizer.cpp:513, taken from the table).  Writes a
 // record for every active term and returns the mask of active terms.  cor: &corridor[b][0][pt] (component-major, pitch
 // NptsPad); rec: &scratch[pt][0][0].
+template <bool SUR>
 __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
-                                             int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec) {
+                                             int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec, const DevSurround &S,
+                                             double t_now, double t_piece) {
   double cc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) cc[k] = cc_[k];
@@ -399,7 +793,11 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
     r_[12] = omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
     r_[13] = omg * step * P.wei_obs * pena;
   }
-  const int t0 = 5 * H;
+  // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1; one gear segment: trajid 0, trajtime 0)
+  if (SUR && S.S > 0)
+    mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, 0, 0.0, N,
+                           5 * H, rec);
+  const int t0 = 5 * H + (SUR ? S.S : 0);
   if (violaVel > 0.0) { // :642-653
     double pena, penaD;
     smoothed_l1(violaVel, pena, penaD);
@@ -472,11 +870,12 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
 // ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350)
 // x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].  The gear segments are independent
 // up to the sums of :292-297 and the junction variables' gradients (:307-320), so every stage runs them side by side.
+template <bool SUR>
 __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
   const int tid = threadIdx.x, T = blockDim.x;
-  const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, H = L.H, nterm = 5 * H + 4, Kmax1 = L.Kmax + 1;
+  const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, H = L.H, nS = SUR ? D.sur.S : 0, nterm = 5 * H + nS + 4, Kmax1 = L.Kmax + 1;
 
   // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966); cos / sin of the junction angles
   if (tid < M) {
@@ -562,6 +961,18 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       tab[j] = s1;
       s1 += step;
     }
+    if (which == 0 && nS > 0) { // start time of every piece: the running sum t += dt of traj_optimizer.cpp:775 (pA is free until calGrads_PT)
+      int p0 = 0, p1 = 0;
+      for (int q = 0; q < M; q++) {
+        p0 = q == sg ? L.seg_piece0[q] : p0;
+        p1 = q == sg ? L.seg_piece0[q + 1] : p1;
+      }
+      double tt = 0.0;
+      for (int i = p0; i < p1; i++) {
+        sm.pA[i] = tt;
+        tt += sm.seg[16 * sg + 1];
+      }
+    }
   }
   __syncthreads();
   pr.tick(0);
@@ -606,8 +1017,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * p + k];
     const double step = sm.seg[16 * sg + 1] / K;
     const double s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
-    sm.pmask[pt] = (int)point_terms(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
-                                    rec_b + (size_t)pt * nterm * kRec);
+    sm.pmask[pt] = (int)point_terms<SUR>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
+                                    rec_b + (size_t)pt * nterm * kRec, D.sur, D.t_now, sm.pA[p]);
   }
   __threadfence_block(); // the records are read back by other threads of this workgroup
   __syncthreads();
@@ -642,16 +1053,17 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       gdT += sm.pG[i];
       en += sm.pE[i];
     }
-    sm.segsum[4 * sg + gGDT] = gdT;
-    sm.segsum[4 * sg + gENERGY] = en;
-    sm.segsum[4 * sg + gCOST0] = 0.0;
-    sm.segsum[4 * sg + gCOST2] = 0.0;
+    sm.segsum[gNUM * sg + gGDT] = gdT;
+    sm.segsum[gNUM * sg + gENERGY] = en;
+    sm.segsum[gNUM * sg + gCOST0] = 0.0;
+    sm.segsum[gNUM * sg + gCOST2] = 0.0;
+    sm.segsum[gNUM * sg + gCOST1] = 0.0;
   }
   __syncthreads();
   // ---- chains: the active terms in windows of kListCap; lane (piece, entry) adds its piece's records in order, three more
   // lanes per segment walk all of the segment's for gdT, the corridor cost and the feasibility cost
   const int n_act = sm.pfirst[Npts];
-  const int n_chain = 12 * Ntot + 3 * M;
+  const int n_chain = 12 * Ntot + 4 * M;
   for (int c0 = 0; c0 < n_act; c0 += kListCap) {
     const int c1 = c0 + kListCap < n_act ? c0 + kListCap : n_act;
     for (int pt = tid; pt < Npts; pt += T) {
@@ -666,9 +1078,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     }
     __syncthreads();
     for (int w = tid; w < n_chain; w += T) {
-      int e0, e1, q;
+      int e0, e1, q, kind = -1;
       ldsd_t dst;
-      bool corridor_only = false, feas_only = false;
       if (w < 12 * Ntot) {
         const int p = w / 12;
         q = w - 12 * p;
@@ -677,7 +1088,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
         e1 = sm.pfirst[pt1];
         dst = sm.gdC + w;
       } else {
-        const int v = w - 12 * Ntot, sg = v / 3, kind = v - 3 * sg;
+        const int v = w - 12 * Ntot, sg = v >> 2, kd = v & 3; // per segment: 0 gdT, 1 corridor cost, 2 feasibility cost, 3 moving-obstacle cost
         int a0 = 0, a1 = 0;
         for (int q2 = 0; q2 < M; q2++) {
           a0 = q2 == sg ? L.seg_pt0[q2] : a0;
@@ -685,36 +1096,70 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
         }
         e0 = sm.pfirst[a0];
         e1 = sm.pfirst[a1];
-        q = kind == 0 ? 12 : 13;
-        dst = sm.segsum + 4 * sg + (kind == 0 ? gGDT : (kind == 1 ? gCOST0 : gCOST2));
-        corridor_only = kind == 1;
-        feas_only = kind == 2;
+        q = kd == 0 ? 12 : 13;
+        dst = sm.segsum + gNUM * sg + (kd == 0 ? gGDT : (kd == 1 ? gCOST0 : (kd == 2 ? gCOST2 : gCOST1)));
+        kind = kd;
       }
       e0 = e0 > c0 ? e0 : c0;
       e1 = e1 < c1 ? e1 : c1;
       if (e1 <= e0) continue;
       double acc = *dst;
-      int e = e0;
-      for (; e + 8 <= e1; e += 8) {
-        int id[8];
-        double v[8];
+      const int tS0 = 5 * H, tS1 = 5 * H + nS;
+      if (kind < 0) { // an entry of gdC: every term of the piece, in order
+        int e = e0;
+        for (; e + 8 <= e1; e += 8) {
+          int id[8];
+          double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) id[u] = sm.list[e + u - c0];
+          for (int u = 0; u < 8; u++) id[u] = sm.list[e + u - c0];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = rec_b[((size_t)(id[u] >> 5) * nterm + (id[u] & 31)) * kRec + q];
+          for (int u = 0; u < 8; u++) v[u] = rec_b[((size_t)(id[u] >> 5) * nterm + (id[u] & 31)) * kRec + q];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const bool cor_term = (id[u] & 31) < 5 * H;
-          const bool take = !(corridor_only && !cor_term) && !(feas_only && cor_term);
-          acc = take ? acc + v[u] : acc;
+          for (int u = 0; u < 8; u++) acc += v[u];
         }
-      }
-      for (; e < e1; e++) {
-        const int id = sm.list[e - c0];
-        const double v = rec_b[((size_t)(id >> 5) * nterm + (id & 31)) * kRec + q];
-        const bool cor_term = (id & 31) < 5 * H;
-        const bool take = !(corridor_only && !cor_term) && !(feas_only && cor_term);
-        acc = take ? acc + v : acc;
+        for (; e < e1; e++) {
+          const int id = sm.list[e - c0];
+          acc += rec_b[((size_t)(id >> 5) * nterm + (id & 31)) * kRec + q];
+        }
+      } else {
+        // the per-segment chains: what an entry adds depends on its kind of term; its values are requested eight entries at
+        // a time in front of the additions (slots 14 / 15 only mean something for a moving-obstacle term and are only used there)
+        const unsigned smask = nS > 0 ? (1u << nS) - 1u : 0u;
+        for (int e = e0; e < e1; e += 8) {
+          int id[8];
+          double va[8], vb[8], vc[8];
+          unsigned pm[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) id[u] = sm.list[(e + u < e1 ? e + u : e1 - 1) - c0];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            gcd_t r_ = (gcd_t)(rec_b + ((size_t)(id[u] >> 5) * nterm + (id[u] & 31)) * kRec);
+            va[u] = r_[kind == 0 ? 12 : 13];
+            vb[u] = r_[14];
+            vc[u] = r_[15];
+            pm[u] = (unsigned)sm.pmask[id[u] >> 5];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            if (e + u >= e1) break;
+            const int t = id[u] & 31;
+            const bool sur_term = t >= tS0 && t < tS1;
+            if (kind == 0) { // gdT: one `+=` per term, three for a moving-obstacle term (traj_optimizer.cpp:1663-1676)
+              acc += va[u];
+              if (sur_term) {
+                acc += vb[u];
+                acc += vc[u];
+              }
+            } else if (kind == 1) {
+              if (t < tS0) acc += va[u];
+            } else if (kind == 2) {
+              if (t >= tS1) acc += va[u];
+            } else if (sur_term) { // costs(1) += the point's penalty, once per point: carried by its first active obstacle term
+              const unsigned sb = (pm[u] >> tS0) & smask;
+              if ((int)__builtin_ctz(sb) == t - tS0) acc += va[u];
+            }
+          }
+        }
       }
       *dst = acc;
     }
@@ -774,7 +1219,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     ldscd_t hv = sm.pva + 12 * sg, tv = hv + 6;
     const int n6 = 6 * N;
     const double t1 = sm.seg[16 * sg + 3];
-    double gdT = sm.segsum[4 * sg + gGDT];
+    double gdT = sm.segsum[gNUM * sg + gGDT];
     gdT += hv[2] * adj[2 * 1] + hv[3] * adj[2 * 1 + 1];
     gdT += (hv[4] * adj[2 * 2] + hv[5] * adj[2 * 2 + 1]) * 2.0 * t1;
     gdT += tv[2] * adj[2 * (n6 - 2)] + tv[3] * adj[2 * (n6 - 2) + 1];
@@ -824,8 +1269,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   if (tid == 128 || (T <= 128 && tid == 0)) { // the cost: sums over the segments in order (:292-297, :328-330)
     double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
     for (int sg = 0; sg < M; sg++) {
-      total_smcost += sm.segsum[4 * sg + gENERGY];
-      penalty_cost += (sm.segsum[4 * sg + gCOST0] + 0.0) + sm.segsum[4 * sg + gCOST2];
+      total_smcost += sm.segsum[gNUM * sg + gENERGY];
+      penalty_cost += (sm.segsum[gNUM * sg + gCOST0] + sm.segsum[gNUM * sg + gCOST1]) + sm.segsum[gNUM * sg + gCOST2];
     }
     for (int sg = 0; sg < M; sg++) total_timecost += sm.seg[16 * sg] * P.wei_time;
     sm.st[sF] = total_smcost + total_timecost + penalty_cost;
@@ -1237,8 +1682,8 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
 // ------------------------------------------------ the kernel
 // (two workgroups per CU = two waves per SIMD where the registers allow it: a second trajectory fills the issue slots the
 // dependent chains of the first leave empty)
-template <int CAP>
-__global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
+template <int CAP, bool SUR>
+__global__ void __launch_bounds__(256, (CAP <= 32 && !SUR) ? 2 : 1) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
   const DevLayout &L = D.L;
@@ -1276,7 +1721,7 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
     sm.bnd[w] = q < 6 ? D.iniS[((size_t)b * L.M + sg) * 6 + q] : D.finS[((size_t)b * L.M + sg) * 6 + (q - 6)];
   }
   const gcd_t cor_b = (gcd_t)(D.corridor + (size_t)b * L.H * 4 * D.NptsPad);
-  const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * (5 * L.H + 4) * kRec);
+  const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * (5 * L.H + (SUR ? D.sur.S : 0) + 4) * kRec);
   const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
   const gd_t hR = (gd_t)(D.histR + (size_t)b * D.P.mem_size * 2);
   const long long tick0 = wall_clock64();
@@ -1284,7 +1729,7 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
   pr.start(D.prof != nullptr && mode == kModeSolve, D.prof + (size_t)b * 12);
   __syncthreads();
 
-  ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
+  ref_eval<SUR>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
 
   if (mode == kModeEval) {
     for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
@@ -1300,7 +1745,7 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
     if (tid < 64) lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
     __syncthreads();
     if (sm.ist[iACTION] == kActDone) break;
-    ref_eval(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
+    ref_eval<SUR>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
   }
   for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
   if (tid == 0) {
@@ -1323,14 +1768,16 @@ __global__ void __launch_bounds__(256, CAP <= 32 ? 2 : 1) ref_kernel(const DevBa
 // ---- host side
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
-  if (S > 0 || L.M < 1 || L.n > 64 || L.H > 5 || L.Npts >= (1 << 26)) return false;
+  if (L.M < 1 || L.n > 64 || L.Npts >= (1 << 26)) return false;
+  if (S < 0 || 5 * L.H + S + 4 > 32) return false; // the mask of a point's active terms has 32 bits (H = 4: up to 8 moving obstacles)
+  if (S > 0 && L.M != 1) return false;              // moving obstacles: one gear segment
   for (int i = 0; i < L.M; i++)
     if (L.piece_nums[i] < 2) return false;
   const size_t lds = reford::lds_doubles(L, P.mem_size) * sizeof(double) + reford::lds_ints(L) * sizeof(int);
   return lds <= 160 * 1024 - 1024;
 }
 // doubles of term records a batch of B trajectories needs
-size_t reference_order_scratch_doubles(const DevLayout &L, int B) { return (size_t)B * L.Npts * (5 * L.H + 4) * reford::kRec; }
+size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S) { return (size_t)B * L.Npts * (5 * L.H + S + 4) * reford::kRec; }
 // doubles of the sweep tables of a segment of N pieces (the tables of a layout's segments follow one another)
 size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
@@ -1347,9 +1794,15 @@ static int ref_threads(int B) {
 template <int CAP>
 static hipError_t launch_ref_cap(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, size_t lds, hipStream_t stream) {
   const int threads = ref_threads(D.B);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (D.sur.S > 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((reford::ref_kernel<CAP, true>), dim3(D.B), dim3(threads), lds, stream, d_dev, mode, tabs, scratch);
+    return hipGetLastError();
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reford::ref_kernel<CAP>, dim3(D.B), dim3(threads), lds, stream, d_dev, mode, tabs, scratch);
+  hipLaunchKernelGGL((reford::ref_kernel<CAP, false>), dim3(D.B), dim3(threads), lds, stream, d_dev, mode, tabs, scratch);
   return hipGetLastError();
 }
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream) {

@@ -100,21 +100,64 @@ def test_whole_solves_are_bit_equal_to_the_reference(hiplib, oracle, name, B):
     h.close()
 
 
-def test_reference_order_is_refused_with_moving_obstacles(hiplib):
-    """moving obstacles (libm's exp / log per (point, obstacle) pair inside the loop) keep the device order; the batch stays usable"""
-    s5 = sc.baseline_config(5, B=2)
-    p5 = hiplib.default_params()
-    s5.apply_resolution(p5)
-    h5 = hiplib.Handle(p5)
-    h5.set_surround(s5.surround)
-    b5 = hiplib.Batch(h5, s5.layout, s5.B)
-    b5.upload(s5)
+def test_moving_obstacles_in_reference_order(hiplib, oracle):
+    """With moving obstacles the reference calls libm's exp (40 times) and log (9 times) per (constraint point, obstacle) pair and
+    pow(|v|, 3) in Piece::getRdot -- host-dependent bits, as with cos / sin.  The device runs the reference's program
+    (dynamicObsGradCostP, traj_optimizer.cpp:1311-1684, statement by statement) with the CORRECTLY ROUNDED exp / log / x^3
+    (cr_trig.h); oracle order 2 is that program on the CPU (through binary128).  Bar: bit-equal to order 2 -- evaluations
+    and whole solves -- on BASELINE configs[4] (32 pieces x 65 points, four moving cars) and a smaller layout with the
+    obstacles starting after t_now.  (Against libm's own bits no solve could agree: millions of exponentials per solve at
+    one misrounding in a thousand.)"""
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    for case in range(2):
+        p = hiplib.default_params()
+        if case == 0:
+            s = sc.baseline_config(5, B=4)
+        else:
+            s = sc.make_scenario([24], [1], 10, 16, 3, seed=80, with_moving=True, n_obs=20, start_centre=(-38.0, 5.0))
+            s.surround.start_time[:] = [2.0, 0.0, 5.5, 0.5]
+            s.t_now = 0.75
+        s.apply_resolution(p)
+        h = hiplib.Handle(p)
+        h.set_surround(s.surround)
+        bt = hiplib.Batch(h, s.layout, s.B)
+        bt.upload(s)
+        bt.set_order(hiplib.ORDER_REFERENCE)
+        x0 = bt.x0()
+        rng = np.random.default_rng(9)
+        active = 0
+        for x in (x0, x0 + rng.normal(0, 0.3, x0.shape)):
+            f, g = bt.eval(x)
+            for b in range(s.B):
+                o2 = oracle.OracleProblem(p, s, b, order=2)
+                f2, g2 = o2.eval(x[b])
+                assert f[b] == f2 and np.array_equal(g[b], g2), (case, b, f[b], f2, np.abs(g[b] - g2).max())
+                active += o2.cost_terms()[3] > 0.0
+                f0, g0 = oracle.OracleProblem(p, s, b, order=0).eval(x[b])      # libm: the same to rounding
+                assert abs(f[b] - f0) <= 1e-12 * abs(f0)
+        assert active > 0, case  # the moving-obstacle term is active somewhere, or this test checks nothing
+        r = bt.solve()
+        want = oracle.solve_batch(p, s, nthreads=4, order=2)
+        for k in keys:
+            assert np.array_equal(r[k], want[k]), (case, k)
+        assert r["success"].all()
+        bt.close()
+        h.close()
+    # more obstacles than the 32-bit term mask holds (5 H + S + 4 <= 32), or a gear shift with obstacles: the device order
+    p = hiplib.default_params()
+    s = sc.baseline_config(2, B=1)
+    s.apply_resolution(p)
+    s5 = sc.baseline_config(5, B=1)
+    h = hiplib.Handle(p)
+    h.set_surround(s5.surround)
+    bt = hiplib.Batch(h, s.layout, 1)
+    bt.upload(s)
     with pytest.raises(hiplib.DftpavError) as e:
-        b5.set_order(hiplib.ORDER_REFERENCE)
+        bt.set_order(hiplib.ORDER_REFERENCE)
     assert e.value.code == hiplib.E_UNSUPPORTED
-    assert b5.solve()["success"].all()
-    b5.close()
-    h5.close()
+    assert bt.solve()["success"].all()
+    bt.close()
+    h.close()
 
 
 def test_gear_shifts_in_reference_order(hiplib, oracle):
@@ -283,4 +326,6 @@ def test_class_mirror_in_reference_order_returns_the_reference_answer(hiplib, or
     opt5.setSurroundTrajs(s5.surround)
     ini, fin, inner, polys = containers(s5)
     assert opt5.OptimizeTrajectory(ini, fin, inner, s5.init_Ts[0], polys, list(s5.layout.singuls), 0.0, 0.0) is True
-    assert opt5.last["order"] == hiplib.ORDER_DEVICE      # moving obstacles: libm's exp / log inside the loop
+    assert opt5.last["order"] == hiplib.ORDER_REFERENCE   # moving obstacles: the reference's program with correctly rounded exp / log / pow
+    o5 = oracle.solve_batch(p5, s5, nthreads=1, order=2)
+    assert opt5.last["final_cost"][0] == o5["final_cost"][0] and np.array_equal(opt5.last["x"][0], o5["x"][0])
