@@ -449,6 +449,29 @@ def main():
                                             "instances": len(seeds)}}
             out["single"] = single(2, range(9))
             out["moving_obstacles_1024"] = side(5, 1024, 1, 4)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
+            # the same configuration in reference order: dynamicObsGradCostP statement by statement with the correctly rounded
+            # exp / log / x^3 (libm's own bits there belong to the host); checked against that program on the CPU (oracle order 2)
+            try:
+                p5 = capi.default_params()
+                s5 = sc.baseline_config(5, B=64, seed=args.seed)
+                s5.apply_resolution(p5)
+                h5 = capi.Handle(p5, device=local_rank)
+                h5.set_surround(s5.surround)
+                b5 = capi.Batch(h5, s5.layout, 64)
+                b5.upload(s5)
+                b5.set_order(capi.ORDER_REFERENCE)
+                b5.solve_async(); b5.sync()
+                b5.solve_async(); b5.sync()
+                r5 = b5.results()
+                pick5 = np.array([0, 21, 42, 63])
+                o5 = po.solve_batch(p5, s5.subset(pick5), nthreads=min(4, cpu["effective"]), order=2)
+                out["moving_obstacles_1024"]["reference_order"] = {
+                    "batch": 64, "kernel_ms": b5.last_solve_ms(), "us_per_iteration_of_the_longest": 1e3 * b5.last_solve_ms() / max(1, int(r5["iters"].max())),
+                    "bit_equal_to_the_reference_program_with_correctly_rounded_exp_log_pow_on_4_sampled":
+                        bool(all(np.array_equal(o5[k_], r5[k_][pick5]) for k_ in ("final_cost", "x", "iters", "evals", "status")))}
+                b5.close(); h5.close()
+            except capi.DftpavError as ex:
+                out["moving_obstacles_1024"]["reference_order"] = {"unsupported": str(ex)}
             # ---- the step before the solve: rectangle corridors of the shard's hypotheses on the device
             st = shard.meta["states"].reshape(-1, 3)
             cen = (0.5 * (st[:, 0].min() + st[:, 0].max()), 0.5 * (st[:, 1].min() + st[:, 1].max()))

@@ -19,13 +19,13 @@
 //   * no fused multiply-add anywhere except inside a division by a stored reciprocal (div_by_rcp: the correctly rounded
 //     quotient, i.e. the bits of a / b); contraction is off for the file.
 //
-// Scope: no moving obstacles, n <= 64 decision variables, H <= 5 half-planes per point.  With ONE gear segment the
-// reference's program has no libm call inside the loop and the device reproduces its bits.  With gear shifts the reference
-// calls libm's cos / sin of the junction angles in every evaluation -- bits that belong to the host (glibc's sin / cos are
-// not correctly rounded and IFUNC-dispatched by CPU model): the kernel uses the correctly rounded cos / sin (cr_trig.h), i.e.
-// runs the reference's program with those two calls defined instead of implemented (oracle order 2 is that program on the
-// CPU).  With moving obstacles the reference calls exp / log per (point, obstacle) pair: those layouts stay with solver.hip
-// (DESIGN.md section 2.3).  One workgroup per trajectory; a latency / verification mode, not the throughput path.
+// Scope: n <= 64 decision variables, at most 32 terms per constraint point (5 H + S + 4).  With ONE gear segment and no
+// moving obstacles the reference's program has no libm call inside the loop and the device reproduces its bits.  With gear
+// shifts the reference calls libm's cos / sin of the junction angles in every evaluation, with moving obstacles exp / log /
+// pow per (point, obstacle) pair -- bits that belong to the host (glibc's are not correctly rounded, IFUNC-dispatched by CPU
+// model, and gcc fuses cos + sin into sincos, which differs from both): the kernel uses the CORRECTLY ROUNDED functions
+// (cr_trig.h), i.e. runs the reference's program with those calls defined instead of implemented (oracle order 2 is that
+// program on the CPU).  One workgroup per trajectory; a latency / verification mode, not the throughput path.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

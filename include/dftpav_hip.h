@@ -294,7 +294,11 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *       IFUNC-dispatched by CPU model): this mode uses the CORRECTLY ROUNDED cos / sin instead (cr_trig.h) -- the
  *       reference's program with those two calls defined rather than implemented; it equals the reference's own result
  *       whenever the host's libm rounded every junction angle's cos / sin correctly (glibc: 999 arguments in 1 000);
- *     - moving obstacles (exp / log per point and obstacle), n > 64 or H > 5: DFTPAV_E_UNSUPPORTED, order unchanged. */
+ *     - with moving obstacles the reference calls libm's exp (40 times) and log (9 times) per (constraint point, obstacle)
+ *       pair and pow(|v|, 3) per pair (traj_optimizer.cpp:1686-1707, poly_traj_utils.hpp:109): likewise replaced by
+ *       the correctly rounded exp / log / x^3; one gear segment, 5 H + S + 4 <= 32 terms per point (H = 4: up to 8
+ *       obstacles).  Choose the order again after the number of obstacles on the handle changed;
+ *     - n > 64, or more terms per point than that: DFTPAV_E_UNSUPPORTED, order unchanged. */
 #define DFTPAV_ORDER_DEVICE 0
 #define DFTPAV_ORDER_REFERENCE 1
 int dftpav_batch_set_order(dftpav_batch *b, int order);
