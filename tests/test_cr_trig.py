@@ -53,3 +53,42 @@ def test_cr_sincos_equals_binary128_rounded(hiplib):
             libm_off += int((ls != sq[:50000]).sum() + (lc != cq[:50000]).sum())
             libm_n += 100000
     print("this host's libm differs from the correctly rounded sin / cos for %d of %d arguments" % (libm_off, libm_n))
+
+
+SRC2 = r"""
+#include <quadmath.h>
+void q_fn(int which, int n, const double *x, double *y) {
+  for (int i = 0; i < n; i++) { __float128 q = (__float128)x[i]; y[i] = which == 0 ? (double)expq(q) : (which == 1 ? (double)logq(q) : (double)(q * q * q)); }
+}
+"""
+
+
+def test_cr_exp_log_cube_equal_binary128_rounded(hiplib):
+    """exp, log and x^3 of cr_trig.h (the moving-obstacle term of the reference calls libm's exp / log / pow) against binary128"""
+    fn = hiplib.lib().dftpav_debug_cr_fn
+    fn.argtypes = [C.c_int, C.c_int, pods.c_double_p, pods.c_double_p]
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "q.c"), "w").write(SRC2)
+    so = os.path.join(d, "libq2.so")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", os.path.join(d, "q.c"), "-o", so, "-lquadmath"])
+    q = C.CDLL(so)
+    q.q_fn.argtypes = [C.c_int, C.c_int, pods.c_double_p, pods.c_double_p]
+    rng = np.random.default_rng(1)
+    n = 200000
+    sets = {0: [rng.uniform(-700, 1, n), rng.uniform(-30, 0, n), rng.uniform(-1e-3, 1e-3, n), np.array([0.0, -0.0, -745.0, -800.0] + [-1.0] * (n - 4))],
+            1: [rng.uniform(1, 8, n), rng.uniform(1e-3, 1e3, n), 1 + rng.uniform(-1e-6, 1e-6, n), np.exp(rng.uniform(-300, 300, n)),
+                np.array([1.0, 2.0, 8.0, 0.5] + [3.0] * (n - 4))],
+            2: [rng.uniform(0, 30, n), rng.normal(0, 1e3, n), rng.uniform(0, 1e-3, n)]}
+    off = {0: 0, 1: 0, 2: 0}
+    for which, xs in sets.items():
+        for x in xs:
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            y, yq = np.zeros(n), np.zeros(n)
+            assert fn(which, n, pods.dptr(x), pods.dptr(y)) == 0
+            q.q_fn(which, n, pods.dptr(x), pods.dptr(yq))
+            keep = (yq >= 2.3e-308) | (yq == 0.0) if which == 0 else np.ones(n, bool)   # subnormal exp: rounded twice (absorbed by the sums)
+            assert np.array_equal(y[keep], yq[keep]), which
+            lib = [math.exp, math.log, lambda v: math.pow(v, 3)][which]
+            off[which] += int(sum(lib(v) != w for v, w in zip(x[:20000], yq[:20000])))
+    print("this host's libm differs from the correctly rounded value: exp %d, log %d, pow(x, 3) %d of 80000 / 100000 / 60000 arguments" %
+          (off[0], off[1], off[2]))
