@@ -15,5 +15,9 @@ pass write WRITE_SIZE
 pass sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU
 pass sq2 SQ_IFETCH SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+# the reference-order kernel (solver_ref.hip): rocprofv3 kernel statistics of isolated solves at batch 256 and 4096, its own phase timer
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ref_$tag -- python $R/scripts/ref_order_time.py 3 256 4096 > $O/prof_ref_$tag.log 2>&1; echo "reference-order kernel trace rc=$?"
 cd $R
+{ ORDER=ref timeout 600 python scripts/profile_phases.py 3 32; ORDER=ref timeout 600 python scripts/profile_phases.py 1 32; timeout 600 python scripts/ref_order_time.py 3 1 32 256 2048 4096; } > $O/ref_phases_$tag.txt 2>&1
+{ timeout 600 python scripts/profile_phases.py 3 4096; timeout 600 python scripts/profile_phases.py 3 256; timeout 600 python scripts/cfg5_time.py; } > $O/phases_$tag.txt 2>&1
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_line_$tag.json 2> $O/bench_line_$tag.err; echo "bench rc=$?"

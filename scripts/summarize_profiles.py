@@ -106,6 +106,13 @@ if sq:
         rec["valu_instructions_per_solve"] = d["valu_instructions_per_solve"]   # bench.py: roofline.valu
     json.dump(d, open(os.path.join(out, "%s_sq.json" % tag), "w"), indent=1)
     print(json.dumps(d.get("fractions_of_wave_cycles")), d.get("icache_miss_rate"))
+for src, dst in (("ref_phases_%s.txt", "%s_phases_reference_order.txt"), ("phases_%s.txt", "%s_phases.txt")):
+    f_ = os.path.join(root, "gpurun_out", src % tag)
+    if os.path.exists(f_):
+        shutil.copy(f_, os.path.join(out, dst % tag))
+kr = glob.glob(os.path.join(root, "gpurun_out", "prof_ref_%s" % tag, "*", "*_kernel_stats.csv"))
+if kr:
+    shutil.copy(kr[0], os.path.join(out, "%s_reference_order_kernel_stats.csv" % tag))
 bl = os.path.join(root, "gpurun_out", "bench_line_%s.json" % tag)
 if os.path.exists(bl):
     shutil.copy(bl, os.path.join(out, "%s_bench_line.json" % tag))
