@@ -2,7 +2,8 @@
 Run on a GPU box: python scripts/ref_order_diag.py [cfg ...]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dftpav_amd import capi, scenarios as sc
 from oracle import pyoracle as po
 

@@ -1,6 +1,7 @@
 """Reference-order kernel: kernel time of isolated solves at a few batch sizes (developer script)."""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dftpav_amd import capi, scenarios as sc
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
