@@ -8,9 +8,9 @@
 // implemented: the correctly rounded one.  Any correctly rounded libm (CORE-MATH, LLVM libc) gives these bits; glibc
 // gives them for 999 arguments in 1 000.
 //
-// Method: x - k pi/2 with pi/2 in three 33-bit chunks and a tail (152 bits; k p_i exact for |k| < 2^20, i.e. |x| < 1.6e6),
-// carried in double-double; Taylor series of sin / cos on |r| <= pi/4 in double-double arithmetic (error-free sums and
-// FMA products) with the coefficients 1 / n! as double-double constants, to ~2^-100; the high word of the normalised
+// Method: x - k pi/2 with pi/2 in three 33-bit chunks and a tail (152 bits; k p_i exact for |k| < 2^20, used for |x| < 2^20;
+// from there on the reduction of Payne and Hanek over 1312 bits of 2/pi, reduce_large below), carried in double-double;
+// Taylor series of sin / cos on |r| <= pi/4 in double-double arithmetic (error-free sums and FMA products) with the coefficients 1 / n! as double-double constants, to ~2^-100; the high word of the normalised
 // result is the correctly rounded value unless the true value lies within ~2^-100 relative of a rounding boundary
 // (probability ~2^-47 per call; the known hardest cases of sin / cos in double need 2^-126).
 // tests/test_cr_trig.py checks it against binary128 (libquadmath) on millions of arguments.
@@ -86,6 +86,81 @@ DFTPAV_HD inline int reduce(double x, dd &r) {
   r = dd_add(a, dd_neg(t));
   return k;
 }
+// The same for every finite |x| >= 2^20 (Payne & Hanek): an L-BFGS line search may try a point 1e10 away, where the junction
+// angle is 1e10 too (found by scripts/fuzz_reference_order.py: the literal program returns a finite cost there and backs off).
+// |x| = m 2^E with m a 53-bit integer; of x 2/pi = m 2^E sum_j W[j] 2^(-32 (j+1)) the words j with E - 32 (j+1) >= 2 add
+// multiples of 4 and are dropped, the next nine words (288 bits) are multiplied by m exactly in 32-bit limbs, the words after
+// them add less than 2^-202.  The two bits above the binary point are k mod 4, the 320 bits below it the fraction f (made
+// |f| <= 1/2 by rounding k), and r = f pi/2 in double-double keeps >= 107 significant bits after a cancellation of up to 62.
+DFTPAV_HD __attribute__((noinline)) inline int reduce_large(double x, dd &r) {
+  const unsigned W[41] = { // 2/pi = 0.W[0] W[1] ... in base 2^32
+      0xa2f9836eu, 0x4e441529u, 0xfc2757d1u, 0xf534ddc0u, 0xdb629599u, 0x3c439041u, 0xfe5163abu, 0xdebbc561u, 0xb7246e3au, 0x424dd2e0u, 0x06492eeau,
+      0x09d1921cu, 0xfe1deb1cu, 0xb129a73eu, 0xe88235f5u, 0x2ebb4484u, 0xe99c7026u, 0xb45f7e41u, 0x3991d639u, 0x835339f4u, 0x9c845f8bu, 0xbdf9283bu,
+      0x1ff897ffu, 0xde05980fu, 0xef2f118bu, 0x5a0a6d1fu, 0x6d367ecfu, 0x27cb09b7u, 0x4f463f66u, 0x9e5fea2du, 0x7527bac7u, 0xebe5f17bu, 0x3d0739f7u,
+      0x8a5292eau, 0x6bfb5fb1u, 0x1f8d5d08u, 0x56033046u, 0xfc7b6babu, 0xf0cfbc20u, 0x9af4361du, 0xa9e39161u};
+  union {
+    double d;
+    unsigned long long u;
+  } v;
+  v.d = x < 0.0 ? -x : x;
+  const int E = (int)(v.u >> 52) - 1075;
+  const unsigned long long m = (v.u & ((1ull << 52) - 1ull)) | (1ull << 52);
+  const unsigned ml = (unsigned)m, mh = (unsigned)(m >> 32);
+  const int j0 = E >= 2 ? (E - 2) >> 5 : 0;
+  // P = m x (W[j0] .. W[j0+8]), little-endian limbs p[0..10]; p[0]'s unit is 2^(E - 32 (j0 + 9))
+  unsigned p[11];
+  for (int i = 0; i < 11; i++) p[i] = 0u;
+  unsigned long long carry = 0ull;
+  for (int i = 0; i < 9; i++) {
+    const unsigned long long t = (unsigned long long)ml * W[j0 + 8 - i] + carry;
+    p[i] = (unsigned)t;
+    carry = t >> 32;
+  }
+  p[9] = (unsigned)carry;
+  carry = 0ull;
+  for (int i = 0; i < 9; i++) {
+    const unsigned long long t = (unsigned long long)mh * W[j0 + 8 - i] + p[i + 1] + carry;
+    p[i + 1] = (unsigned)t;
+    carry = t >> 32;
+  }
+  p[10] = (unsigned)carry; // mh < 2^21: no further carry
+  // the binary point is at bit 32 (j0 + 9) - E in [255, 320]: move it to bit 320, the bottom of p[10]
+  const int sh = 320 - (32 * (j0 + 9) - E);
+  const int a = sh >> 5, b = sh & 31;
+  unsigned q[11];
+  for (int i = 10; i >= 0; i--) { // static indices: the limbs stay in registers on the device
+    const unsigned s0 = i >= 0 ? p[i] : 0u, s1 = i >= 1 ? p[i - 1] : 0u, s2 = i >= 2 ? p[i - 2] : 0u, s3 = i >= 3 ? p[i - 3] : 0u;
+    const unsigned hi = a == 0 ? s0 : (a == 1 ? s1 : s2), lo = a == 0 ? s1 : (a == 1 ? s2 : s3);
+    q[i] = b ? (hi << b) | (lo >> (32 - b)) : hi;
+  }
+  int k = (int)(q[10] & 3u);
+  const bool up = (q[9] & 0x80000000u) != 0u; // f >= 1/2: k + 1 and f - 1 = -(2^320 - fraction)
+  if (up) {
+    k += 1;
+    unsigned c = 1u;
+    for (int i = 0; i < 10; i++) {
+      const unsigned t = ~q[i] + c;
+      c = (c && t == 0u) ? 1u : 0u;
+      q[i] = t;
+    }
+  }
+  // |f| as a double-double: the limbs from the top down (non-overlapping, each product exact; what a double-double cannot hold
+  // is below 2^-106 of the leading limb)
+  dd f{0.0, 0.0};
+  double w = 0x1.0p-32;
+  for (int i = 9; i >= 0; i--) {
+    f = dd_add_d(f, (double)q[i] * w);
+    w *= 0x1.0p-32;
+  }
+  const dd pio2{0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54};
+  r = dd_mul(f, pio2);
+  if (up) r = dd_neg(r);
+  if (x < 0.0) { // x = -(k pi/2 + r)
+    r = dd_neg(r);
+    k = -k;
+  }
+  return k;
+}
 // sin and cos of a double-double |r| <= ~pi/4 by their Taylor series in double-double (Horner in r^2)
 DFTPAV_HD inline dd sin_dd(dd r) {
   const dd r2 = dd_mul(r, r);
@@ -110,8 +185,12 @@ DFTPAV_HD inline void sincos(double x, double &s, double &c) {
     c = 1.0;
     return;
   }
+  if (!(x - x == 0.0)) { // infinity or NaN: NaN, as libm
+    s = c = x - x;
+    return;
+  }
   dd r;
-  const int k = reduce(x, r);
+  const int k = (x < 0.0 ? -x : x) < 0x1.0p+20 ? reduce(x, r) : reduce_large(x, r);
   const dd sr = sin_dd(r), cr = cos_dd(r);
   switch (k & 3) {
     case 0: s = sr.hi; c = cr.hi; break;
@@ -171,7 +250,7 @@ DFTPAV_HD inline double exp_cr(double x) {
   for (int q = 0; q < 4; q++) e = dd_mul(e, e);
   return scale2(e.hi, k);
 }
-// log x (x > 0, normal): x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh((m - 1) / (m + 1)) by its series in double-double
+// log x: x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh((m - 1) / (m + 1)) by its series in double-double
 DFTPAV_HD inline double log_cr(double x) {
   const double t[21][2] = {
       {0x1.5555555555555p-2, 0x1.5555555555555p-56},  {0x1.999999999999ap-3, -0x1.999999999999ap-57}, {0x1.2492492492492p-3, 0x1.2492492492492p-57},
@@ -183,9 +262,16 @@ DFTPAV_HD inline double log_cr(double x) {
       {0x1.a41a41a41a41ap-6, 0x1.0690690690690p-60},  {0x1.8f9c18f9c18fap-6, -0x1.f3831f3831f38p-61}, {0x1.7d05f417d05f4p-6, 0x1.7d05f417d05f4p-62}};
   const double l1 = 0x1.62e42ff000000p-1, l2 = -0x1.718432a200000p-35, l3 = 0x1.3c76730000000p-69, l4 = 0x1.f97b57a079a19p-103;
   if (x == 1.0) return 0.0;
+  if (!(x > 0.0)) return x == 0.0 ? -1.0 / 0.0 : (x - x) / 0.0;   // log 0 = -inf; negative or NaN: NaN (an overflowed penalty of a far trial point)
+  if (x > 0x1.fffffffffffffp+1023) return x;                        // +inf
   union { double d; unsigned long long u; } v;
+  int e = -1023;
+  if (x < 0x1.0p-1022) { // subnormal: exact scaling into the normal range
+    x *= 0x1.0p+54;
+    e -= 54;
+  }
   v.d = x;
-  int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+  e += (int)((v.u >> 52) & 0x7ff);
   v.u = (v.u & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL; // mantissa in [1, 2)
   double m = v.d;
   if (m > 0x1.6a09e667f3bcdp+0) { // sqrt(2)
@@ -210,6 +296,8 @@ DFTPAV_HD inline double log_cr(double x) {
 }
 // x^3, correctly rounded (the reference: pow(x, 3))
 DFTPAV_HD inline double cube_cr(double x) {
+  const double plain = x * x * x;
+  if (!(plain - plain == 0.0) || plain == 0.0) return plain; // overflow, NaN, a zero or an underflow to zero: the error-free products below would give NaN
   const dd p = two_prod(x, x);
   return dd_mul_d(p, x).hi;
 }

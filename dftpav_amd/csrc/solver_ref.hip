@@ -1788,7 +1788,10 @@ int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kIn
 // the device -- most of a solve is its serial wave (two-loop recursion, sweeps), so more trajectories per CU is what pays:
 // 654 against 796 ms per 4096.  Same bits either way: no sum depends on the number of waves.
 static int ref_threads(int B) {
-  if (const char *e = std::getenv("DFTPAV_REF_THREADS")) return std::atoi(e);
+  if (const char *e = std::getenv("DFTPAV_REF_THREADS")) { // developer knob: whole waves, at most the launch bound
+    const int t = std::atoi(e);
+    if (t == 128 || t == 192 || t == 256) return t; // wave 1 has jobs of its own: at least two waves
+  }
   return B > 768 ? 128 : 256;
 }
 template <int CAP>

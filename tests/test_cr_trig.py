@@ -37,11 +37,17 @@ def test_cr_sincos_equals_binary128_rounded(hiplib):
     rng = np.random.default_rng(0)
     n = 200000
     libm_off = libm_n = 0
-    for scale in (3.2, 10.0, 100.0, 1.0e4, 1.0e-3, 1.0e-8):
-        x = rng.uniform(-scale, scale, n)
+    # 1e6 straddles the switch to the Payne-Hanek reduction at 2^20; a line search can try junction angles of 1e10 and beyond
+    for scale in (3.2, 10.0, 100.0, 1.0e4, 1.0e-3, 1.0e-8, 2.0e6, 1.0e10, 1.0e22, 1.0e150, 1.7e308):
+        x = rng.uniform(-1.0, 1.0, n) * scale
+        if scale >= 1.0e22:     # every binade up to the largest
+            x = x * 2.0 ** -rng.integers(0, int(np.log2(scale)) - 20, n)
         if scale == 3.2:        # close to the multiples of pi / 2, where the reduction loses the most
             x[: n // 2] = rng.integers(-50, 50, n // 2) * (np.pi / 2) + rng.normal(0, 1e-9, n // 2)
             x[n // 2: n // 2 + 4] = [0.0, -0.0, np.pi / 2, -np.pi]
+        if scale == 1.0e10:     # doubles next to large multiples of pi / 2: the reduction cancels up to 60 bits
+            kk = rng.integers(1, 2 ** 40, n // 2).astype(np.float64)
+            x[: n // 2] = kk * (np.pi / 2)
         s, c, sq, cq = (np.zeros(n) for _ in range(4))
         assert fn(n, pods.dptr(x), pods.dptr(s), pods.dptr(c)) == 0
         q.cr_sincos_q(n, pods.dptr(x), pods.dptr(sq), pods.dptr(cq))
@@ -52,6 +58,11 @@ def test_cr_sincos_equals_binary128_rounded(hiplib):
             lc = np.array([math.cos(v) for v in x[:50000]])
             libm_off += int((ls != sq[:50000]).sum() + (lc != cq[:50000]).sum())
             libm_n += 100000
+    x = np.array([np.inf, -np.inf, np.nan, 6381956970095103.0 * 2.0 ** 797, 1.7976931348623157e308, 5e-324, -2.85456754454990e10])
+    s, c, sq, cq = (np.zeros(len(x)) for _ in range(4))
+    fn(len(x), pods.dptr(x), pods.dptr(s), pods.dptr(c))
+    q.cr_sincos_q(len(x), pods.dptr(x), pods.dptr(sq), pods.dptr(cq))
+    assert np.array_equal(s, sq, equal_nan=True) and np.array_equal(c, cq, equal_nan=True)      # 6381956970095103 2^797: the double closest to a multiple of pi / 2
     print("this host's libm differs from the correctly rounded sin / cos for %d of %d arguments" % (libm_off, libm_n))
 
 
@@ -79,6 +90,16 @@ def test_cr_exp_log_cube_equal_binary128_rounded(hiplib):
             1: [rng.uniform(1, 8, n), rng.uniform(1e-3, 1e3, n), 1 + rng.uniform(-1e-6, 1e-6, n), np.exp(rng.uniform(-300, 300, n)),
                 np.array([1.0, 2.0, 8.0, 0.5] + [3.0] * (n - 4))],
             2: [rng.uniform(0, 30, n), rng.normal(0, 1e3, n), rng.uniform(0, 1e-3, n)]}
+    inf, nan = np.inf, np.nan
+    special = {0: [709.0, 709.78, 709.79, 710.0, 1e10, inf, -inf, nan, -708.5, -744.0, -745.1, -745.2, -1e10, 1e-300, 5e-324],
+               1: [inf, 0.0, -0.0, -1.0, nan, 5e-324, 1e-310, 2.2250738585072014e-308, 1e300, 1.7976931348623157e308],
+               2: [1e100, 5e102, 1e103, -1e103, inf, -inf, nan, 1e-110, 1e-105, -1e-108, 0.0, -0.0, 5e-324]}
+    for which, xs in special.items():   # overflowed penalties of a far trial point: what libm returns for them
+        x = np.array(xs)
+        y, yq = np.zeros(len(x)), np.zeros(len(x))
+        fn(which, len(x), pods.dptr(x), pods.dptr(y))
+        q.q_fn(which, len(x), pods.dptr(x), pods.dptr(yq))
+        assert np.array_equal(y, yq, equal_nan=True) and np.array_equal(np.signbit(y), np.signbit(yq)), (which, y, yq)
     off = {0: 0, 1: 0, 2: 0}
     for which, xs in sets.items():
         for x in xs:

@@ -220,6 +220,36 @@ def test_gear_shifts_in_reference_order(hiplib, oracle):
           "correctly): %d of %d" % (same_as_build, total_build))
 
 
+def test_far_trial_points_of_a_line_search(hiplib, oracle):
+    """A line search of lbfgs.hpp:276-390 starts an iteration at step 1 along the new direction; late in a hard solve that
+    point can lie 1e10 away (found by scripts/fuzz_reference_order.py: 8 + 10 + 5 pieces, iteration 1056 -- the literal program
+    returns a cost of 8e52 there and backs off 58 times).  The junction angle is 1e10 there too: cos / sin need the reduction of
+    Payne and Hanek (cr_trig.h reduce_large).  Evaluations at such points -- finite, and bit-equal to the literal program."""
+    p = hiplib.default_params()
+    s = sc.make_scenario([8, 10, 5], [1, -1, 1], 21, 8, 2, seed=23150, n_obs=30)
+    s.apply_resolution(p)
+    h, bt = _batch(hiplib, s, p)
+    x0 = bt.x0()
+    n = x0.shape[1]
+    rng = np.random.default_rng(5)
+    for scale in (1.0e3, 1.0e6, 3.0e10, 1.0e15):
+        x = x0.copy()
+        x[:, :40] += rng.normal(0, min(scale, 1.0e10), (2, 40))   # inner points
+        x[:, 40:43] = rng.uniform(-60, 60, (2, 3))                  # virtual times: durations of 1e-3 .. 1e3 s
+        x[:, 43:47] += rng.normal(0, min(scale, 1.0e10), (2, 4))   # junction positions
+        x[:, 47:] = rng.normal(0, scale, (2, 2))                    # junction angles
+        f, g = bt.eval(x)
+        for b in range(2):
+            f2, g2 = oracle.OracleProblem(p, s, b, order=2).eval(x[b])
+            assert np.isfinite(f2) and f[b] == f2 and np.array_equal(g[b], g2), (scale, b, f[b], f2)
+    r = bt.solve()
+    o2 = oracle.solve_batch(p, s, nthreads=2, order=2)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], o2[k]), k
+    bt.close()
+    h.close()
+
+
 def test_random_layouts_in_reference_order(hiplib, oracle):
     """Randomly shaped single-segment problems -- 2 to 32 pieces (n = 3 .. 63: the three widths of the sequential sums), sample
     resolutions 3-24, forward and reverse gears, 0-60 obstacles, L-BFGS memories from 3 pairs (the ring wraps after three
