@@ -19,6 +19,7 @@
 // rounding level.
 #pragma once
 #include "device_types.h"
+#include "cr_trig.h"
 
 // Keeps the instruction scheduler from interleaving the iterations of an unrolled loop (each iteration's temporaries then
 // die before the next one starts).  Only where the kernel is out of registers; no effect on results, nothing on the host.
@@ -50,10 +51,26 @@ DFTPAV_HD inline double div_rcp(double a, double b, double y) {
 DFTPAV_HD inline double p_abs(double x) { return x < 0.0 ? -x : x; }
 
 // sin/cos after fdlibm's k_sin.c / k_cos.c polynomial kernels with a
-// two-term Cody-Waite reduction by pi/2 (|x| < ~1e5 is plenty for a heading
-// angle).  Accuracy ~1 ulp; what matters is that host and device run the same
-// operations.
+// two-term Cody-Waite reduction by pi/2 for |x| < 2^20 (every heading angle of a
+// sane trajectory) and the Payne-Hanek reduction of cr_trig.h beyond: the first
+// trial point of a line search late in a hard solve can lie 1e10 away, junction
+// angle included, and the reference evaluates a finite cost there and backs off
+// (tests/test_gpu_parity.py::test_far_trial_points).  Accuracy ~1 ulp; what
+// matters is that host and device run the same operations.
 DFTPAV_HD inline void p_rem_pio2(double x, int &quad, double &y0, double &y1) {
+  if (!(p_abs(x) < 0x1.0p+20)) {
+    if (!(x - x == 0.0)) { // infinity, NaN: NaN, as libm
+      quad = 0;
+      y0 = x - x;
+      y1 = 0.0;
+      return;
+    }
+    crt::dd r;
+    quad = crt::reduce_large(x, r) & 3;
+    y0 = r.hi;
+    y1 = r.lo;
+    return;
+  }
   const double invpio2 = 6.36619772367581382433e-01;
   const double pio2_1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
   const double pio2_1t = 6.07710050650619224932e-11; // pi/2 - pio2_1

@@ -51,6 +51,34 @@ def test_eval_matches_oracle(hiplib, oracle, cfg, B):
     h.close()
 
 
+def test_far_trial_points(hiplib, oracle):
+    """The first trial point of a line search (step 1 along a fresh direction, lbfgs.hpp:276-390) can lie 1e10 away late in a hard
+    solve -- junction positions AND junction angles; the reference evaluates a finite cost there (8e52 in the case
+    scripts/fuzz_reference_order.py found) and backs off.  The portable cos / sin of traj_math.h reduce such angles with the
+    reduction of Payne and Hanek (up to 2^20: two-term Cody-Waite): evaluations stay finite, bit-equal to the device-order
+    oracle and at rounding distance from the literal program."""
+    p = hiplib.default_params()
+    s = sc.make_scenario([8, 10, 5], [1, -1, 1], 21, 8, 2, seed=23150, n_obs=30)
+    s.apply_resolution(p)
+    h, bt = _batch(hiplib, s, p)
+    x0 = bt.x0()
+    rng = np.random.default_rng(5)
+    for scale in (1.0e3, 1.0e6, 3.0e10, 1.0e15):
+        x = x0.copy()
+        x[:, :40] += rng.normal(0, min(scale, 1.0e10), (2, 40))   # inner points
+        x[:, 40:43] = rng.uniform(-60, 60, (2, 3))                  # virtual times: durations of 1e-3 .. 1e3 s
+        x[:, 43:47] += rng.normal(0, min(scale, 1.0e10), (2, 4))   # junction positions
+        x[:, 47:] = rng.normal(0, scale, (2, 2))                    # junction angles
+        f, g = bt.eval(x)
+        for b in range(2):
+            fd, gd = oracle.OracleProblem(p, s, b, order=1).eval(x[b])
+            assert np.isfinite(fd) and f[b] == fd and np.array_equal(g[b], gd), (scale, b, f[b], fd)
+            fl, gl = oracle.OracleProblem(p, s, b, order=0).eval(x[b])
+            assert abs(f[b] - fl) <= 1e-10 * abs(fl) and np.abs(g[b] - gl).max() <= 1e-9 * np.abs(gl).max(), (scale, b)
+    bt.close()
+    h.close()
+
+
 def test_moving_obstacles_that_start_after_t_now(hiplib, oracle):
     """An obstacle whose predicted trajectory starts later than the ego's clock (surround start_time > t_now, the normal
     swarm situation) is extrapolated BACKWARDS along its first piece (Trajectory::locatePieceIdx returns piece 0 with a
