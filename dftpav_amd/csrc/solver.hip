@@ -385,17 +385,6 @@ __device__ __forceinline__ double reduce16(const double (&v)[16], int lane) {
   return r;
 }
 
-// a / b from the correctly rounded reciprocal y = 1/b (Markstein): q0 = a*y,
-// r = a - b*q0 (exact in an FMA), q = q0 + r*y.  With y correctly rounded and
-// no over/underflow this is the correctly rounded quotient — the same bits as
-// a / b (2^31 random and edge-mantissa pairs checked on gfx950, 0 mismatches) —
-// in 3 dependent instructions instead of the ~12 of the division expansion.
-__device__ inline double div_by_rcp(double a, double b, double y) {
-  double q0 = a * y;
-  double r = __builtin_fma(-b, q0, a);
-  return __builtin_fma(r, y, q0);
-}
-
 // optional in-kernel phase timer (thread 0, shader clock); D.prof == nullptr turns it off
 struct Prof {
   // The twelve accumulators live in the trajectory's row of DevBatch::prof, not in registers: as a member array they
@@ -1207,9 +1196,10 @@ typedef double __attribute__((address_space(1))) *gwptr_t;
 // it stands at the start of the block (independent reductions, they overlap in the pipeline), and
 // what the block's earlier steps would have removed from d is restored from the stored products of
 // neighbouring pairs,   s_t.(d - sum_u alpha_u y_u) = s_t.d - sum_u alpha_u (s_t.y_u),
-// so only one multiply-add and the division of a step wait for the previous step.  histU / histV
-// hold s_j.y_k for the kLoopBlock-1 pairs on either side of a pair; they are written once, when the
-// newer pair of the two is stored (lbfgs_advance).  oracle/dftpav_oracle_dev.cpp replays the same
+// so only one multiply-add of a step waits for the previous step: the division by ys_t is a product
+// with the stored 1 / ys_t, applied to s_t.d once and folded into the stored products.  histU / histV
+// hold (s_j.y_k) / ys of the pair that owns the row, for the kLoopBlock-1 pairs on either side of a pair;
+// they are written once, when the newer pair of the two is stored (lbfgs_advance).  oracle/dftpav_oracle_dev.cpp replays the same
 // sequence.
 constexpr int kLoopBlock = 8;
 __device__ inline double readlane_f64(double v, int l) {
@@ -1338,29 +1328,28 @@ __device__ __forceinline__ void first_loop_block(const HistBlock &R, const LoopL
                                                  int &j, double &dreg) {
   int jown = j - step_of_lane(lane); // slot of the step this lane owns (the block starts at slot j and walks downwards)
   jown = jown < 0 ? jown + m : jown;
-  typedef double __attribute__((ext_vector_type(2))) d2r_t;
   typedef const char __attribute__((address_space(1))) *gbytes_t;
-  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)((gbytes_t)sm.ysr + (unsigned)jown * 16u); // first used after the reduction below
-  const double ys_ = yr_.x, ri_ = yr_.y;
+  const double ri_ = *(gptr_t)((gbytes_t)sm.ysr + ((unsigned)jown * 16u + 8u)); // 1 / lm_ys of my step; first used after the reduction below
   // Lanes at and past n hold zeros: their direction element enters as 0.0 and the rows of the history are zero
   // there (pad elements are never written), so no lane is masked in the products or in the updates below.
   double v[kLoopBlock];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) v[q] = R.s[q] * dreg; // lm_s.col(j).dot(d), steps past nb unused
-  double acc = wave_sum8_transposed<LV>(v, lane);
+  // ... / lm_ys(j) as a product with the stored reciprocal, taken once for the whole sum: the stored neighbour products
+  // coef[] carry the same factor (lbfgs_advance), so the chain of a step is one v_readlane pair and one multiply-add
+  double acc = wave_sum8_transposed<LV>(v, lane) * ri_;
   int st = step_of_lane(lane);
   asm volatile("" : "+v"(st));
 #pragma unroll
   for (int u = 0; u < kLoopBlock; u++) {
     if (FULL || i0 + u < nb) { // uniform
-      const double t = div_by_rcp(acc, ys_, ri_);               // ... / lm_ys(j): only the owner's quotient is used
-      const double au = readlane_f64(t, lane_of_step(u));       // alpha of step u for everybody
+      const double au = readlane_f64(acc, lane_of_step(u));     // alpha of step u for everybody (its owner's sum is complete)
       if (u < kLoopBlock - 1) acc = __builtin_fma(-au, R.coef[u], acc); // coef[u] == 0.0 for the lanes whose step is <= u
       dreg = __builtin_fma(-au, R.y[u], dreg);
     }
   }
-  // lanes 0..7 own one step each; their sum stopped changing at their own step, so its quotient is their alpha
-  const double mine = div_by_rcp(acc, ys_, ri_);
+  // lanes 0..7 own one step each; their sum stopped changing at their own step: it is their alpha
+  const double mine = acc;
   int js = j - st;
   js = js < 0 ? js + m : js;
   if (lane < kLoopBlock && (FULL || i0 + st < nb)) sm.alpha[js] = mine;
@@ -1373,29 +1362,24 @@ __device__ __forceinline__ void second_loop_block(const HistBlock &R, const Loop
                                                   double &dreg) {
   int jown = j2 + step_of_lane(lane); // the block starts at slot j2 and walks upwards
   jown = jown >= m ? jown - m : jown;
-  typedef double __attribute__((ext_vector_type(2))) d2r_t;
   typedef const char __attribute__((address_space(1))) *gbytes_t;
-  const d2r_t yr_ = *(const d2r_t __attribute__((address_space(1))) *)((gbytes_t)sm.ysr + (unsigned)jown * 16u);
-  const double ys_ = yr_.x, ri_ = yr_.y;
+  const double ri_ = *(gptr_t)((gbytes_t)sm.ysr + ((unsigned)jown * 16u + 8u));
   j2 += kLoopBlock;
   j2 = j2 >= m ? j2 - m : j2;
   double v[kLoopBlock];
 #pragma unroll
   for (int q = 0; q < kLoopBlock; q++) v[q] = R.y[q] * dreg; // lm_y.col(j).dot(d), steps past nb unused
-  double acc = wave_sum8_transposed<LV>(v, lane);
+  double acc = wave_sum8_transposed<LV>(v, lane) * ri_;
   int st = step_of_lane(lane);
   asm volatile("" : "+v"(st));
 #pragma unroll
   for (int u = 0; u < kLoopBlock; u++) {
     if (FULL || i0 + u < nb) { // uniform
-      const double t = div_by_rcp(acc, ys_, ri_);
-      const double bu = readlane_f64(t, lane_of_step(u));    // beta of step u
+      const double bu = readlane_f64(acc, lane_of_step(u));  // beta of step u
       const double au = readlane_f64(R.al, lane_of_step(u)); // alpha of step u (first loop), from the lane that owns the step
-      if (u < kLoopBlock - 1) {
-        acc = __builtin_fma(au, R.coef[u], acc); // coef[u] == 0.0 for the lanes whose step is <= u
-        acc = __builtin_fma(-bu, R.coef[u], acc);
-      }
-      dreg = __builtin_fma(au - bu, R.s[u], dreg);
+      const double df = au - bu;
+      if (u < kLoopBlock - 1) acc = __builtin_fma(df, R.coef[u], acc); // coef[u] == 0.0 for the lanes whose step is <= u
+      dreg = __builtin_fma(df, R.s[u], dreg);
     }
   }
 }
@@ -1746,22 +1730,24 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
           const bool act = lane < n;
           const int ln = act ? lane : 0;
           const int nold = bound - 1 < kLoopBlock - 1 ? bound - 1 : kLoopBlock - 1;
-          double sv[kLoopBlock - 1];
+          double sv[kLoopBlock - 1], rio[kLoopBlock - 1];
           int o = end;
 #pragma unroll
           for (int dd = 0; dd < kLoopBlock - 1; dd++) {
             o = o == 0 ? m - 1 : o - 1;
             sv[dd] = ((gptr_t)hS)[((size_t)o * npad + ln) * 2];
+            rio[dd] = ((gptr_t)hR_b)[2 * (size_t)o + 1]; // 1 / ys of the older pair (slots never stored: unused below)
           }
+          const double rin = 1.0 / ys; // what lane 0 stored above
           o = end;
 #pragma unroll
           for (int dd = 0; dd < kLoopBlock - 1; dd++) {
             o = o == 0 ? m - 1 : o - 1;
             if (dd < nold) {
               double v = wave_sum_raw<LV>((act ? sv[dd] : 0.0) * ylane);
-              if (lane == 0) {
-                hU[(size_t)o * 8 + dd] = v;
-                hV[(size_t)end * 8 + dd] = v;
+              if (lane == 0) { // each product is stored times 1 / ys of the pair whose step reads it (first / second loop)
+                hU[(size_t)o * 8 + dd] = v * rio[dd];
+                hV[(size_t)end * 8 + dd] = v * rin;
               }
             }
           }

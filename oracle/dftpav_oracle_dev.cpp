@@ -529,7 +529,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size;
   g_levels = levels_for(n);
-  std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), alpha_h(m, 0.0);
+  std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), ri_h(m, 0.0), alpha_h(m, 0.0);
   std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
   std::vector<double> hU((size_t)m * 8, 0.0), hV((size_t)m * 8, 0.0); // products with the kBand neighbouring pairs
   double pf[8];
@@ -665,6 +665,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
       double ss = wave_dot(sc, sc, n);
       double gpgp = wave_dot(gp.data(), gp.data(), n);
       ys_h[end] = ys;
+      ri_h[end] = 1.0 / ys;
       double cau = ss * std::sqrt(gpgp) * P.cautious_factor;
       if (ys > cau) {
         ++bound;
@@ -676,13 +677,14 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           // start of the block, and the effect of the block's earlier steps on a later dot product is
           // restored from the stored products s_j.y_k of neighbouring pairs,
           //     s_t.(d - sum_u alpha_u y_u) = s_t.d - sum_u alpha_u (s_t.y_u),
-          // so that only one multiply-add and the division of a step depend on the previous step.
+          // so that only one multiply-add of a step depends on the previous step: the division by ys_t is a product with
+          // the stored 1 / ys_t, applied to s_t.d once and folded into the stored neighbour products.
           const int cs = (end + m - 1) % m; // slot of the pair just stored
           for (int dd = 0; dd < kBand && dd < bound - 1; dd++) { // products of the new y with the kBand pairs before it
             const int o = (cs + m - 1 - dd) % m;
             const double v = lane_dot(&hS[(size_t)o * n], yc, n);
-            hU[(size_t)o * 8 + dd] = v;  // s_o . y_(dd+1 pairs after o)
-            hV[(size_t)cs * 8 + dd] = v; // y_cs . s_(dd+1 pairs before cs)
+            hU[(size_t)o * 8 + dd] = v * ri_h[o];   // s_o . y_(dd+1 pairs after o), over ys_o
+            hV[(size_t)cs * 8 + dd] = v * ri_h[cs]; // y_cs . s_(dd+1 pairs before cs), over ys_cs
           }
           auto nth_older = [&](int t) { return (cs - t % m + m) % m; }; // slot of the t-th pair before the newest
           double al[kLoopBlock], dt[kLoopBlock];
@@ -691,9 +693,9 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
             for (int q = 0; q < cnt; q++) dt[q] = lane_dot(&hS[(size_t)nth_older(t0 + q) * n], d.data(), n);
             for (int q = 0; q < cnt; q++) {
               const int j = nth_older(t0 + q);
-              double acc = dt[q];
+              double acc = dt[q] * ri_h[j];
               for (int u = 0; u < q; u++) acc = __builtin_fma(-al[u], hU[(size_t)j * 8 + (q - u - 1)], acc);
-              al[q] = acc / ys_h[j];
+              al[q] = acc;
               alpha_h[j] = al[q];
             }
             for (int q = 0; q < cnt; q++) {
@@ -709,13 +711,9 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
             for (int q = 0; q < cnt; q++) dt[q] = lane_dot(&hY[(size_t)nth_older(bound - 1 - (v0 + q)) * n], d.data(), n);
             for (int q = 0; q < cnt; q++) {
               const int j = nth_older(bound - 1 - (v0 + q));
-              double acc = dt[q];
-              for (int u = 0; u < q; u++) {
-                const double vv = hV[(size_t)j * 8 + (q - u - 1)];
-                acc = __builtin_fma(al[u], vv, acc);
-                acc = __builtin_fma(-be[u], vv, acc);
-              }
-              be[q] = acc / ys_h[j];
+              double acc = dt[q] * ri_h[j];
+              for (int u = 0; u < q; u++) acc = __builtin_fma(al[u] - be[u], hV[(size_t)j * 8 + (q - u - 1)], acc);
+              be[q] = acc;
               al[q] = alpha_h[j];
             }
             for (int q = 0; q < cnt; q++) {
