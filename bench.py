@@ -23,6 +23,11 @@ import time
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# The HIP runtime multiplexes a process's streams onto 4 hardware queues by default: the fifth batch in flight waits for one of
+# the first four to END, however empty the device is.  The side runs that keep 8..16 small batches in flight (a 512-trajectory
+# shard of a strong-scaled 4096, 8 planner threads of 256) want as many queues as streams: 19 k -> 33 k solves/s on 512-
+# trajectory steps.  Read once, when the runtime initialises; no effect on the value line (two streams).  INTEGRATION.md §5.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -113,29 +118,34 @@ def main():
             (dftpav_batch_solve_chained), the last batch is flushed in the latency shape.
           plain: isolated solves, a step waits for its own batch."""
 
-        def __init__(self, B_total, config, seed):
+        def __init__(self, B_total, config, seed, depth=2, residency=None):
             # every rank generates its own shard from (seed, rank) — trajectories are independent, nothing is scattered
             # (SURVEY §8e); rank r owns global trajectories [r*B/G, (r+1)*B/G)
+            # depth: resident batches = steps in flight (overlap schedule only; 2 for the value line).  A shard too small to
+            # fill the device alone (512 of a strong-scaled 4096) is run deeper, in the throughput residency, so that a GPU
+            # holds as many trajectories as it does at 4096 per step.
+            self.D = D = depth if schedule == "overlap" else 2
             self.B_total = B_total
             self.lo, self.hi = dd.shard_range(B_total, rank, world)
-            self.shards = [sc.baseline_config(config, B=self.hi - self.lo, seed=seed + 7919 * rank + 104729 * i) for i in range(2)]
+            self.shards = [sc.baseline_config(config, B=self.hi - self.lo, seed=seed + 7919 * rank + 104729 * i) for i in range(D)]
             for sh in self.shards:
                 sh.apply_resolution(params)
             self.shard = self.shards[0]
             h = capi.Handle(params, device=local_rank)
             h.set_surround(self.shard.surround)
-            self.hs = [h, h]
+            self.hs = [h] * D
             if schedule == "overlap":
-                self.hs = [h, capi.Handle(params, device=local_rank)]
-                self.hs[1].set_surround(self.shard.surround)
+                self.hs = [h] + [capi.Handle(params, device=local_rank) for _ in range(D - 1)]
+                for hh in self.hs[1:]:
+                    hh.set_surround(self.shard.surround)
             self.bts = []
             for hh, sh in zip(self.hs, self.shards):
-                b_ = capi.Batch(hh, sh.layout, sh.B)
+                b_ = capi.Batch(hh, sh.layout, sh.B) if residency is None else capi.Batch(hh, sh.layout, sh.B, residency=residency)
                 b_.upload(sh)  # resident in HBM from here on
                 if schedule == "overlap":
                     b_.set_hand_over(0)
                 self.bts.append(b_)
-            self.rec_dev = [torch.zeros((self.shard.B, dd.RECORD_BYTES), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.rec_dev = [torch.zeros((self.shard.B, dd.RECORD_BYTES), dtype=torch.uint8, device="cuda") for _ in range(D)]
             # the collective: RCCL behind the C-ABI (dftpav_comm_create / dftpav_batch_allgather_results, one communicator per
             # handle = per HIP stream), torch.distributed only carries the 128-byte id; DFTPAV_BENCH_COMM=torch (or a failure to
             # set the communicators up) takes torch.distributed's all_gather_into_tensor instead
@@ -153,8 +163,8 @@ def main():
                     except Exception as ex:  # noqa: BLE001
                         self.via += "; C-ABI communicator not set up: %s" % ex
                         self.comms = None
-            self.k, self.prev, self.rec = 0, None, None
-            self.t_launch = [0.0, 0.0]
+            self.k, self.out, self.rec = 0, [], None   # out: the batches in flight, oldest first
+            self.t_launch = [0.0] * D
             self.to_result, self.in_deliver = [], []
 
         def deliver(self, i):
@@ -174,8 +184,8 @@ def main():
             self.to_result.append(t2 - self.t_launch[i])
 
         def step(self, last=False):
-            i = self.k % 2
-            cur, prev = self.bts[i], self.prev
+            i = self.k % self.D
+            cur, prev = self.bts[i], (self.out[-1] if self.out else None)
             self.k += 1
             self.t_launch[i] = time.perf_counter()
             if schedule == "plain":
@@ -185,21 +195,21 @@ def main():
             if schedule == "chain":
                 cur.solve_chained(self.bts[prev] if prev is not None else None)  # prev is complete when this call's launches are
             else:
-                # prev keeps running on the other stream.  Nothing follows the last launch of a run, so it ends with the
-                # default end game (its stragglers in the latency shape) instead of thinning out alone.
+                # the earlier batches keep running on the other streams.  Nothing follows the last launch of a run, so it ends
+                # with the default end game (its stragglers in the latency shape) instead of thinning out alone.
                 cur.set_hand_over(-1 if last else 0)
                 cur.solve_async()
-            if prev is not None:
-                self.deliver(prev)
-            self.prev = i
+            self.out.append(i)
+            if len(self.out) >= self.D:
+                self.deliver(self.out.pop(0))
 
         def flush(self):
-            """the outstanding batch: its stragglers in the latency shape (chain) / the rest of its launch (overlap)"""
-            if self.prev is not None:
-                if schedule == "chain":
-                    self.bts[self.prev].finish()
-                self.deliver(self.prev)
-                self.prev = None
+            """the outstanding batches, oldest first: the stragglers in the latency shape (chain) / the rest of their launches
+            (overlap)"""
+            while self.out:
+                if schedule == "chain" and len(self.out) == 1:
+                    self.bts[self.out[0]].finish()
+                self.deliver(self.out.pop(0))
 
         def run(self, steps, warmup):
             for j in range(warmup):
@@ -209,7 +219,7 @@ def main():
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
-            first = self.k % 2
+            first = self.k % self.D
             self.hs[first].mark(0)  # HIP events on the library's own streams around the timed region
             t0 = time.perf_counter()
             for j in range(steps):
@@ -243,27 +253,48 @@ def main():
                 hh.close()
 
     # the value line: weak = --batch-per-gpu on every GPU, strong = --batch-per-gpu in all (BASELINE configs[3] as written)
+    def shard_schedule(per_gpu):
+        """steps in flight and residency for a per-GPU shard: a shard that is a fraction of --batch-per-gpu runs as many steps
+        deep as it takes to hold 2 x --batch-per-gpu trajectories per GPU (what the value line holds), at most 16, in the
+        throughput residency (several workgroups per CU)"""
+        if os.environ.get("DFTPAV_BENCH_DEPTH"):   # developer knob: "depth[,residency]"
+            v = os.environ["DFTPAV_BENCH_DEPTH"].split(",")
+            return int(v[0]), (int(v[1]) if len(v) > 1 else None)
+        if per_gpu >= args.batch_per_gpu or schedule != "overlap":
+            return 2, None
+        return max(2, min(16, 2 * args.batch_per_gpu // max(1, per_gpu))), 2
+
     B_main = args.batch_per_gpu * world if args.scaling == "weak" else args.batch_per_gpu
-    main_stream = Stream(B_main, args.config, args.seed)
+    d_main, r_main = shard_schedule(B_main // world)
+    main_stream = Stream(B_main, args.config, args.seed, depth=d_main, residency=r_main)
     res = main_stream.run(args.steps, args.warmup)
     other = None
     if world > 1:  # the other scaling mode beside it
         B_other = args.batch_per_gpu if args.scaling == "weak" else args.batch_per_gpu * world
-        o_stream = Stream(B_other, args.config, args.seed + 1)
-        o = o_stream.run(args.steps, args.warmup)
+        d_o, r_o = shard_schedule(B_other // world)
+        o_stream = Stream(B_other, args.config, args.seed + 1, depth=d_o, residency=r_o)
+        o = o_stream.run(max(args.steps, 2 * d_o), max(args.warmup, d_o))
         other = {"scaling": "strong" if args.scaling == "weak" else "weak", "global_batch": B_other, "per_gpu": B_other // world,
-                 "value": o["value"], "ms_per_step": o["ms_per_step"], "unit": "solves/s"}
+                 "value": o["value"], "ms_per_step": o["ms_per_step"], "unit": "solves/s", "steps_in_flight": d_o, "steps": o["steps"]}
         o_stream.close()
     strong_shard = None
     if world == 1 and not args.no_extras and args.scaling == "weak":
-        # BASELINE configs[3] as written is 4096 trajectories over 8 GPUs = 512 per GPU: that shard on this GPU, same two-stream
-        # schedule, so that the strong-scaling expectation is on record before the driver measures it
+        # BASELINE configs[3] as written is 4096 trajectories over 8 GPUs = 512 per GPU: that shard on this GPU, so that the
+        # strong-scaling expectation is on record before the driver measures it -- two steps in flight (the value line's
+        # schedule: the device is a quarter full) and as many as hold the value line's 8192 trajectories (16 steps of 512)
         per = max(1, args.batch_per_gpu // 8)
         s_stream = Stream(per, args.config, args.seed + 2)
         sr = s_stream.run(max(args.steps, 8), max(args.warmup, 2))
-        strong_shard = {"per_gpu": per, "solves_per_s": sr["value"], "ms_per_step": sr["ms_per_step"], "steps": sr["steps"],
-                        "of": "configs[3]: %d trajectories over 8 GPUs" % args.batch_per_gpu}
         s_stream.close()
+        d_s, r_s = shard_schedule(per)
+        s_stream = Stream(per, args.config, args.seed + 2, depth=d_s, residency=r_s)
+        sd = s_stream.run(max(args.steps, 4 * d_s), max(args.warmup, d_s))
+        s_stream.close()
+        strong_shard = {"per_gpu": per, "solves_per_s": sd["value"], "ms_per_step": sd["ms_per_step"], "steps": sd["steps"],
+                        "steps_in_flight": d_s, "time_to_result_ms": sd["to_result_ms"],
+                        "two_steps_in_flight": {"solves_per_s": sr["value"], "ms_per_step": sr["ms_per_step"], "steps": sr["steps"],
+                                                "time_to_result_ms": sr["to_result_ms"]},
+                        "of": "configs[3]: %d trajectories over 8 GPUs" % args.batch_per_gpu}
     B_total = B_main
     shard = scen = main_stream.shard
     bts, hs, bt, h = main_stream.bts, main_stream.hs, main_stream.bts[0], main_stream.hs[0]
@@ -277,7 +308,7 @@ def main():
         value = res["value"]
         lay = shard.layout
         eb = [float(algorithmic_bytes(lay, shard.n_points, lay.H, lay.M, q["iters"], q["evals"], q["hist_sum"]).sum()) for q in rs]
-        ebytes_steps = sum(eb[(state["k"] - args.steps + j) % 2] for j in range(args.steps))  # the batches the timed steps solved
+        ebytes_steps = sum(eb[(state["k"] - args.steps + j) % main_stream.D] for j in range(args.steps))  # the batches the timed steps solved
         kms = gpu_ms / args.steps  # device time of the timed region (marker events on the library's streams) per step
         achieved = ebytes_steps / args.steps / (kms * 1e-3) / 1e9
         traffic, traffic_source, valu_per_solve = None, None, None
@@ -337,8 +368,8 @@ def main():
             strong_shard["eight_gpu_expectation_solves_per_s"] = 8 * strong_shard["solves_per_s"]
             strong_shard["ratio_to_one_gpu_value"] = 8 * strong_shard["solves_per_s"] / value
             strong_shard["note"] = ("8 x the 512-trajectory shard rate over this line's 4096-per-GPU rate: what strong scaling of configs[3] "
-                                    "can reach at best (a 512-trajectory batch fills half of the device's one-wave slots; the weak curve, "
-                                    "4096 per GPU, is the one that scales with the GPU count)")
+                                    "can reach at best.  Two 512-trajectory steps in flight fill a quarter of the device's one-wave slots; "
+                                    "steps_in_flight of them hold what the value line holds, at a longer time to result")
             out["strong_shard"] = strong_shard
         cpu = effective_cores()
         if world == 1 and not args.no_extras:

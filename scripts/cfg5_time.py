@@ -15,7 +15,12 @@ ms = []
 for _ in range(2):
     bt.solve_async(); bt.sync(); ms.append(bt.last_solve_ms())
 r = bt.results()
-print("cfg5 B", B, "kernel ms", np.round(ms, 2), "solves/s", B / (np.mean(ms) * 1e-3), "mean iters", r["iters"].mean(), "evals", r["evals"].mean())
+print("cfg5 B", B, "kernel ms", np.round(ms, 2), "solves/s", B / (np.mean(ms) * 1e-3), "mean iters", r["iters"].mean(), "evals", r["evals"].mean(),
+      "longest", int(r["iters"].max()), "iterations /", int(r["evals"].max()), "evaluations; the five longest:", np.sort(r["evals"])[-5:])
+lat = r["latency_us"].astype(np.float64)
+order = np.argsort(r["evals"])
+print("time in service: sum %.1f s, max %.1f ms, mean us per evaluation %.1f; of the five longest: us per evaluation %s, in service ms %s, ids %s" %
+      (lat.sum() * 1e-6, lat.max() * 1e-3, lat.sum() / r["evals"].sum(), np.round(lat[order[-5:]] / r["evals"][order[-5:]], 1), np.round(lat[order[-5:]] * 1e-3, 1), order[-5:]))
 pick = np.array([0, B // 3, B - 1])
 ro = po.solve_batch(p, s.subset(pick), nthreads=2, order=1)
 print("bit-exact on 3 sampled:", all(np.array_equal(ro[k], r[k][pick]) for k in ("final_cost", "x", "iters", "evals")))

@@ -5,10 +5,15 @@ import numpy as np
 from dftpav_amd import capi, scenarios as sc
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 3          # 5: BASELINE configs[4] (its default: slice 32, hand-over 256)
 p = capi.default_params()
-s = sc.baseline_config(3, B=B); s.apply_resolution(p)
+s = sc.baseline_config(cfg, B=B); s.apply_resolution(p)
 ref = None
-for tag, env in [("plain", {"DFTPAV_SCHED": "0"}),
+CFG5 = [("default (s32 h256)", {}), ("s16", {"DFTPAV_SLICE": "16"}), ("s64", {"DFTPAV_SLICE": "64"}), ("s128", {"DFTPAV_SLICE": "128"}),
+        ("s100000 (run to completion)", {"DFTPAV_SLICE": "100000"}), ("h128", {"DFTPAV_HANDOVER": "128"}), ("h512", {"DFTPAV_HANDOVER": "512"}),
+        ("h768", {"DFTPAV_HANDOVER": "768"}), ("h0", {"DFTPAV_HANDOVER": "0"}), ("s64 h512", {"DFTPAV_SLICE": "64", "DFTPAV_HANDOVER": "512"}),
+        ("s16 h512", {"DFTPAV_SLICE": "16", "DFTPAV_HANDOVER": "512"}), ("plain", {"DFTPAV_SCHED": "0"})]
+for tag, env in CFG5 if cfg == 5 else [("plain", {"DFTPAV_SCHED": "0"}),
                  ("queue s48 h256", {"DFTPAV_SCHED": "1"}),
                  ("queue s24 h256", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "24"}),
                  ("queue s96 h256", {"DFTPAV_SCHED": "1", "DFTPAV_SLICE": "96"}),
@@ -21,7 +26,7 @@ for tag, env in [("plain", {"DFTPAV_SCHED": "0"}),
     for k in ("DFTPAV_SCHED", "DFTPAV_SLICE", "DFTPAV_HANDOVER", "DFTPAV_SLOTS"):
         os.environ.pop(k, None)
     os.environ.update(env)
-    h = capi.Handle(p); bt = capi.Batch(h, s.layout, B); bt.upload(s)
+    h = capi.Handle(p); h.set_surround(s.surround); bt = capi.Batch(h, s.layout, B); bt.upload(s)
     bt.solve_async(); bt.sync()
     ms = []
     for _ in range(3):
