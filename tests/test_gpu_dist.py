@@ -112,6 +112,27 @@ def test_bench_takes_the_rccl_path_when_forced(hiplib):
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 1024
 
 
+def test_bench_side_run_of_the_other_scaling_mode(hiplib):
+    """At N > 1 the bench times the other scaling mode after the value line, several steps deep (one RCCL communicator per
+    handle) and under a watchdog.  Forced here on one GPU: four steps in flight in the one-wave shape, and a time limit too
+    short for the side run, which must cost its own entry and not the line."""
+    base = dict(os.environ, DFTPAV_BENCH_FORCE_DIST="1", DFTPAV_BENCH_FORCE_OTHER="1", MASTER_ADDR="127.0.0.1", RANK="0",
+                WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--batch-per-gpu", "512",
+           "--no-extras", "--cpu-sample", "0"]
+    out = subprocess.run(cmd, env=dict(base, MASTER_PORT=str(_free_port()), DFTPAV_BENCH_DEPTH="4,2"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    o = d["other_scaling"]
+    assert "error" not in o and o["value"] > 0 and o["steps_in_flight"] == 4 and o["steps"] >= 8
+    assert "ncclAllGather behind the C-ABI" in json.dumps(d)
+    out = subprocess.run(cmd, env=dict(base, MASTER_PORT=str(_free_port()), DFTPAV_BENCH_SIDE_LIMIT_S="0.05"), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] > 0 and "time limit" in d["other_scaling"]["error"]
+
+
 def test_c_abi_communicator_gathers_the_records(hiplib):
     """dftpav_comm_create / dftpav_batch_allgather_results: RCCL behind the C-ABI, no torch.distributed in the data path
     (world size 1 on this box: init, pack, ncclAllGather on the handle's stream, layout with its zero pad)."""
