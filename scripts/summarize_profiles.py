@@ -6,7 +6,14 @@ reads  gpurun_out/prof_<tag>/*/*_kernel_stats.csv          (rocprofv3 --kernel-t
        gpurun_out/pmc_write_<tag>/*/*_counter_collection.csv (rocprofv3 --pmc WRITE_SIZE)
 writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, profiles/pmc_latest.json
 """
-import csv, glob, json, os, shutil, sys
+import csv, glob as _glob, json, os, shutil, sys
+
+
+class glob:   # gpurun merges into existing directories: a directory may hold the files of earlier collections -- the newest only
+    @staticmethod
+    def glob(pattern):
+        fs = sorted(_glob.glob(pattern), key=os.path.getmtime)
+        return fs[-1:]
 import numpy as np
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
