@@ -69,6 +69,46 @@ def effective_cores():
     return dict(logical=os.cpu_count() or 1, affinity=n_aff, cgroup_quota=quota, effective=eff)
 
 
+def live_pmc(args, schedule):
+    """HBM traffic and VALU instruction count of the dominant kernel, collected NOW: separate `rocprofv3 --pmc <one counter>`
+    passes (nothing else enabled: no trace domain, no --stats) of a short run of this same bench -- same batch, same seed, same
+    schedule, 1 warm-up + 2 timed steps -- each its own process, as MI355X_MICROARCH.md's HBM section prescribes.  Returns
+    (dict or None, note).  Per batch = summed over the kernel's dispatches (queue launch + straggler launch) / queue launches."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-sample", "0",
+             "--batch-per-gpu", str(args.batch_per_gpu), "--config", str(args.config), "--seed", str(args.seed), "--schedule", schedule]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got, t0 = {}, time.perf_counter()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        if time.perf_counter() - t0 > 150.0:
+            return (got or None), "time limit reached after %s" % ", ".join(got)
+        d = tempfile.mkdtemp(prefix="dftpav_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "solver_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                        rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+            if not rows:
+                return (got or None), "no %s rows for solver_kernel" % ctr
+            gmax = max(g for g, _ in rows)
+            got[ctr] = sum(v for _, v in rows) / sum(1 for g, _ in rows if g == gmax)
+        except Exception as ex:  # noqa: BLE001
+            return (got or None), "%s pass failed: %s" % (ctr, type(ex).__name__)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return got, "`rocprofv3 --pmc <counter> -- python bench.py %s`, one pass per counter, %.0f s" % (" ".join(child[2:]), time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +353,22 @@ def main():
                     pj.get("command", "bench.py --steps 3 --no-extras"), pj.get("collected", "round 1"))
             except Exception:
                 traffic = None
+        traffic_raw = None
+        if world == 1 and not args.no_extras and os.environ.get("DFTPAV_BENCH_PMC", "1") != "0":
+            # the counters of THIS tree on THIS box (the file above is the fallback: the last collection committed)
+            try:
+                lp, note = live_pmc(args, schedule)
+            except Exception as ex:  # noqa: BLE001
+                lp, note = None, "failed: %s" % type(ex).__name__
+            if lp and "FETCH_SIZE" in lp and "WRITE_SIZE" in lp:
+                # KB units; gfx950 counts a 128-byte read request as 64 bytes (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x 2
+                traffic = (2.0 * lp["FETCH_SIZE"] + lp["WRITE_SIZE"]) * 1024.0
+                traffic_raw = (lp["FETCH_SIZE"] + lp["WRITE_SIZE"]) * 1024.0
+                traffic_source = "live: " + note
+            else:
+                traffic_source = "%s [live collection: %s]" % (traffic_source, note)
+            if lp and "SQ_INSTS_VALU" in lp:
+                valu_per_solve = lp["SQ_INSTS_VALU"] / float(shard.B)
         out = {
             "metric": "trajectory solves/sec (batched), 16-piece MINCO",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -325,7 +381,8 @@ def main():
                        "n_vars": lay.n_vars, "parallelism": "batch-sharded x%d, 1 all-gather of 16B records" % world,
                        "allgather_via": main_stream.via},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_uncorrected": traffic_raw,
+                         "traffic_source": traffic_source,
                          "kernel": "solver_kernel", "kernel_ms": kms,
                          "launches_per_step": 1 if (schedule == "overlap" or shard.B < 4 * n_cu) else 2,
                          "algorithmic_bytes_per_launch": ebytes_steps / args.steps},
