@@ -46,6 +46,7 @@ def diagnose(p, s, bt, r, w):
             print("    evaluation %d: device f %r literal %r, %d gradient entries differ, |x| max %.3e, device g nan %s" %
                   (e, f[b], fo, nb, np.abs(xs[e]).max(), np.isnan(g[b]).any()))
             if f[b] != fo or nb:
+                os.makedirs("gpurun_out/fz", exist_ok=True)
                 np.save("gpurun_out/fz/x_case.npy", xs[e])
                 print("      x =", repr(xs[e].tolist()))
                 print("      literal terms", o.cost_terms())
