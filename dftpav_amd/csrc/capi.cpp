@@ -55,7 +55,9 @@ bool reference_order_supported(const DevLayout &L, const DevParams &P, int S);
 size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S);
 size_t reference_order_table_doubles(int N);
 int reference_order_interior_mask(int sweep, int row_mod_6);
-hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream);
+RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu);
+hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
+                             hipStream_t stream);
 }
 using namespace dftpav;
 
@@ -138,6 +140,7 @@ struct dftpav_batch {
   int order = DFTPAV_ORDER_DEVICE;
   int ref_S = 0; // moving obstacles on the handle when the reference order was chosen (the term records are sized for them)
   double *d_ref_tab = nullptr, *d_ref_scratch = nullptr;
+  RefPlan ref_plan{}; // its launch shape (chosen with the order)
   // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
   struct PlanCycle {
     double *d_poses = nullptr, *d_t = nullptr, *d_v = nullptr, *d_rd = nullptr;
@@ -1347,10 +1350,8 @@ static int sync_dev(dftpav_batch *b, DevBatch &D) {
   D = make_dev(b);
   int version = h->sur_version * 4 + (b->prof_on ? 1 : 0) + (b->uploaded ? 2 : 0);
   if (version != b->dev_version) {
-    if (!b->h_stage) {
-      HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), 2 * sizeof(DevBatch), hipHostMallocDefault));
-      HIPCHK(h, hipEventCreateWithFlags(&b->stage_ev, hipEventDisableTiming));
-    }
+    if (!b->h_stage) HIPCHK(h, hipHostMalloc(reinterpret_cast<void **>(&b->h_stage), 2 * sizeof(DevBatch), hipHostMallocDefault));
+    if (!b->stage_ev) HIPCHK(h, hipEventCreateWithFlags(&b->stage_ev, hipEventDisableTiming));
     if (b->stage_busy) HIPCHK(h, hipEventSynchronize(b->stage_ev)); // the previous copies out of the staging area (long done)
     b->h_stage[0] = D;
     DevBatch &D2 = b->h_stage[1];
@@ -1394,6 +1395,10 @@ extern "C" int dftpav_debug_profile(dftpav_batch *b, int enable, long long *out)
 extern "C" int dftpav_batch_trace_range(dftpav_batch *b, int first, int count, int max_evals) {
   if (!b || max_evals < 0 || (max_evals > 0 && (first < 0 || count < 1 || first + count > b->B))) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
+  if (max_evals > 0 && b->order == DFTPAV_ORDER_REFERENCE) { // solver_ref.hip records nothing: say so instead of returning empty traces
+    h->err = "dftpav_batch_trace: not available in the reference order (the lockstep replay is a check of the device order)";
+    return DFTPAV_E_UNSUPPORTED;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1449,7 +1454,7 @@ extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals
 
 // every launch of the solve kernel for a batch goes through here: the reference-order kernel when the batch asks for it
 static hipError_t launch_for(dftpav_batch *b, const DevBatch &D, int mode) {
-  if (b->order == DFTPAV_ORDER_REFERENCE) return launch_solver_ref(D, b->d_dev, mode, b->d_ref_tab, b->d_ref_scratch, b->h->stream);
+  if (b->order == DFTPAV_ORDER_REFERENCE) return launch_solver_ref(D, b->d_dev, mode, b->d_ref_tab, b->d_ref_scratch, b->ref_plan, 0, b->h->stream);
   return launch_solver(D, b->d_dev, mode, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, b->h->stream);
 }
 
@@ -1515,17 +1520,74 @@ extern "C" int dftpav_debug_reference_tables(int N, double *out) {
   return ok ? 1 : 0;
 }
 
+// the ring, the flags and the state records of a scheduled solve, for a batch whose device-order plan did not need them
+static hipError_t ensure_ring_buffers(dftpav_batch *b) {
+  if (b->d_queue && b->d_sflag && b->d_iota && b->d_qctl && b->d_state) return hipSuccess;
+  const int B = b->B;
+  const size_t stride = (size_t)solver_state_doubles(b->L, b->P);
+  int *q = nullptr, *fl = nullptr, *io = nullptr;
+  unsigned *ctl = nullptr;
+  double *st = nullptr;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) {
+    if (e == hipSuccess && r != hipSuccess) e = r;
+  };
+  const int qcap = 2 * B;
+  chk(hipMalloc(&q, sizeof(int) * (size_t)qcap));
+  chk(hipMalloc(&fl, sizeof(int) * (size_t)B));
+  chk(hipMalloc(&io, sizeof(int) * (size_t)B));
+  chk(hipMalloc(&ctl, sizeof(unsigned) * 16));
+  chk(hipMalloc(&st, sizeof(double) * stride * (size_t)B));
+  if (e == hipSuccess) {
+    const unsigned ctl0[8] = {0u, (unsigned)B, (unsigned)B, (unsigned)B, 0u, 0u, 0u, 0u};
+    chk(hipMemcpy(ctl + 8, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+    std::vector<int> iota(B);
+    for (int i = 0; i < B; i++) iota[i] = i;
+    chk(hipMemcpy(io, iota.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice));
+  }
+  if (e != hipSuccess) {
+    for (void *p : {(void *)q, (void *)fl, (void *)io, (void *)ctl, (void *)st})
+      if (p) (void)hipFree(p);
+    (void)hipGetLastError();
+    return e;
+  }
+  // (a batch either has all of them -- its device-order plan is scheduled -- or none)
+  b->d_queue = q;
+  b->d_sflag = fl;
+  b->d_iota = io;
+  b->d_qctl = ctl;
+  b->d_state = st;
+  b->qcap = qcap;
+  b->dev_version = -1; // the device descriptor carries these pointers
+  return hipSuccess;
+}
+
 extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
   if (!b || (order != DFTPAV_ORDER_DEVICE && order != DFTPAV_ORDER_REFERENCE)) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   if (order == b->order && (order == DFTPAV_ORDER_DEVICE || b->ref_S == h->S)) return DFTPAV_OK;
+  if (order == DFTPAV_ORDER_REFERENCE && b->d_trace) { // the reference-order kernel does not record evaluations
+    h->err = "reference order: dftpav_batch_trace is a device-order facility -- switch the trace off first";
+    return DFTPAV_E_UNSUPPORTED;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (order == DFTPAV_ORDER_REFERENCE) {
     if (!reference_order_supported(b->L, b->P, h->S)) {
-      h->err = "reference order: n <= 64 variables, 5 H + S + 4 <= 32 terms per point, one gear segment with moving obstacles";
+      h->err = "reference order: n <= 64 variables, 5 H + S + 4 <= 64 terms per point, every gear segment >= 2 pieces";
       return DFTPAV_E_UNSUPPORTED;
+    }
+    {
+      int n_cu = 256;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+      const RefPlan pl = reference_order_plan(b->L, b->P, h->S, b->B, n_cu);
+      if (pl.wave && ensure_ring_buffers(b) != hipSuccess) {
+        h->err = "reference order: no device memory for the ring of this batch";
+        return DFTPAV_E_HIP;
+      }
+      b->ref_plan = pl;
     }
     if (!b->d_ref_tab || !b->d_ref_scratch || b->ref_S != h->S) {
       std::vector<double> tab; // the tables of the segments, one after the other
@@ -1628,7 +1690,16 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
   if (b->order == DFTPAV_ORDER_REFERENCE) {
-    HIPCHK(h, launch_for(b, D, kModeSolve)); // one workgroup per trajectory, no scheduling: the verification / latency mode
+    if (b->ref_plan.wave && b->ref_plan.slots > 0 && b->ref_plan.slots * (b->ref_plan.threads / 64) < b->B && b->ref_plan.slice > 0) {
+      // more trajectories than resident waves: persistent workgroups whose waves pop trajectories from the ring and run them a
+      // slice of iterations at a time (solver_ref.hip); queue = all trajectories, flags cleared, counters reset on the stream
+      HIPCHK(h, hipMemcpyAsync(b->d_queue, b->d_iota, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, hipMemsetAsync(b->d_sflag, 0, sizeof(int) * (size_t)b->B, h->stream));
+      HIPCHK(h, hipMemcpyAsync(b->d_qctl, b->d_qctl + 8, sizeof(unsigned) * 8, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, launch_solver_ref(D, b->d_dev, kModeSolve, b->d_ref_tab, b->d_ref_scratch, b->ref_plan, 1, h->stream));
+    } else {
+      HIPCHK(h, launch_for(b, D, kModeSolve)); // every trajectory has its team from the start
+    }
   } else if (!b->sched) {
     HIPCHK(h, launch_solver(D, b->d_dev, kModeSolve, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, h->stream));
   } else {

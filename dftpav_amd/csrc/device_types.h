@@ -173,6 +173,16 @@ struct SchedArgs {
 // doubles of solver state per suspended trajectory
 inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { (void)P; return 5 * L.npad + 24 + 8; }
 
+// launch shape of a reference-order batch (solver_ref.hip: reference_order_plan)
+struct RefPlan {
+  int wave;      // 1: one wave per trajectory, several per workgroup (throughput); 0: one workgroup per trajectory (latency)
+  int threads;   // workgroup size
+  int wg_per_cu; // WAVE shape: resident workgroups per CU
+  int slots;     // WAVE shape: persistent workgroups of a scheduled solve
+  int slice;     // WAVE shape: iterations after which an unfinished trajectory goes back to the ring
+  size_t lds;    // dynamic LDS per workgroup
+};
+
 // host-side E4 lane plan of a layout for a workgroup size (tables of DevBatch::e4_*)
 struct E4Sizes {
   int rounds, groups, left, lcap;

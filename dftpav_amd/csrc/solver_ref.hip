@@ -19,16 +19,29 @@
 //   * no fused multiply-add anywhere except inside a division by a stored reciprocal (div_by_rcp: the correctly rounded
 //     quotient, i.e. the bits of a / b); contraction is off for the file.
 //
-// Scope: n <= 64 decision variables, at most 32 terms per constraint point (5 H + S + 4).  With ONE gear segment and no
+// Scope: n <= 64 decision variables, at most 64 terms per constraint point (5 H + S + 4), any number of gear segments with or
+// without moving obstacles (the reference's live call, traj_manager.cpp:604-610, installs both).  With ONE gear segment and no
 // moving obstacles the reference's program has no libm call inside the loop and the device reproduces its bits.  With gear
 // shifts the reference calls libm's cos / sin of the junction angles in every evaluation, with moving obstacles exp / log /
 // pow per (point, obstacle) pair -- bits that belong to the host (glibc's are not correctly rounded, IFUNC-dispatched by CPU
 // model, and gcc fuses cos + sin into sincos, which differs from both): the kernel uses the CORRECTLY ROUNDED functions
 // (cr_trig.h), i.e. runs the reference's program with those calls defined instead of implemented (oracle order 2 is that
-// program on the CPU).  One workgroup per trajectory; a latency / verification mode, not the throughput path.
+// program on the CPU).
+//
+// Two launch shapes, same bits (no sum depends on the shape):
+//   * TEAM: one workgroup of 2-4 waves per trajectory -- the parallel stages spread over the waves, the serial ones (row sweeps,
+//     L-BFGS) on wave 0.  The latency shape: few trajectories, each as fast as possible.
+//   * WAVE: one WAVE per trajectory, eight of them in a workgroup that shares the sweep tables in LDS (the only big LDS item
+//     that does not depend on the trajectory); every wave keeps its own < 17 KB of state, so a CU holds 8 trajectories that
+//     all advance, against 3 in the TEAM shape.  A solve is a chain of dependent fp64 operations whichever way it is cut --
+//     throughput is residency / latency -- so this is the throughput shape.  The waves of a workgroup never meet after the
+//     tables are staged: each pops trajectories from the batch's ring (DevBatch::queue, as solver.hip's scheduled launch
+//     does), runs one for a slice of iterations and puts it back unfinished, so that all trajectories advance together
+//     and the launch ends without a tail of long solves on an empty device.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 
 #include "device_types.h"
 #include "cr_trig.h"
@@ -95,10 +108,10 @@ struct Prof {
   long long *acc;
   long long last;
   bool on;
-  __device__ inline void start(bool enable, long long *row) {
-    on = enable && threadIdx.x == 0;
+  __device__ inline void start(bool leader, long long *row, bool resume) { // leader: the team's timing lane, profiling on
+    on = leader;
     acc = row;
-    if (on)
+    if (on && !resume)
       for (int i = 0; i < 12; i++) acc[i] = 0;
     last = on ? clock64() : 0;
   }
@@ -111,11 +124,37 @@ struct Prof {
   }
 };
 
-constexpr int kRec = 16;        // doubles per term record: 12 entries of gdC, gdT, cost, 2 unused
-constexpr int kListCap = 1024;  // active terms chained per window
+constexpr int kRec = 16;            // doubles per term record: 12 entries of gdC, gdT, cost, 2 more gdT addends of a moving-obstacle term
+constexpr int kListCapTeam = 1024;  // active terms chained per window (TEAM shape)
+constexpr int kListCapWave = 256;   // ... (WAVE shape: LDS is what limits the trajectories per CU)
+
+typedef unsigned long long mask_t;  // active terms of a constraint point, bit t = term t (5 H + S + 4 <= 64 terms)
+typedef unsigned short __attribute__((address_space(3))) *ldsh_t;
+
+// How a launch lays out its LDS.  Shared by the waves of a workgroup: the sweep tables and the piece table (they depend on
+// the layout only).  Per team (TEAM: the workgroup; WAVE: each wave): everything else.
+struct Shape {
+  int wave;     // 1: one wave per trajectory
+  int cap;      // 16 / 32 / 64 >= n: width of the sequential sums (the kernel's CAP)
+  int nl;       // doubles per solver vector in LDS
+  int mw;       // 32-bit words of a point's term mask (1: up to 32 terms, 2: up to 64)
+  int pf16;     // the running numbers of the active terms fit 16 bits
+  int list_cap; // window of the chain pass
+};
+__host__ __device__ inline Shape make_shape(const DevLayout &L, int S, bool wave) {
+  Shape sh;
+  sh.wave = wave ? 1 : 0;
+  sh.cap = L.n <= 16 ? 16 : (L.n <= 32 ? 32 : 64);
+  sh.nl = (L.n + 15) & ~15;
+  const int nterm = 5 * L.H + S + 4;
+  sh.mw = nterm > 32 ? 2 : 1;
+  sh.pf16 = (long long)L.Npts * nterm <= 65535 ? 1 : 0;
+  sh.list_cap = wave ? kListCapWave : kListCapTeam;
+  return sh;
+}
 
 struct Sm {
-  ldsd_t x, xp, g, gp, d;   // [npad]
+  ldsd_t x, xp, g, gp, d;   // [nl]
   ldsd_t bnd;               // [M][12] iniS [6], finS [6] of each gear segment as uploaded (clamped)
   ldsd_t pva;               // [M][12] head / tail position, velocity, acceleration in force for this x (junction overrides, traj_optimizer.cpp:273-282)
   ldsd_t trig;              // [M][2] cos, sin of the junction angles (M - 1 of them)
@@ -123,33 +162,63 @@ struct Sm {
   ldsd_t spow;              // [M][2][Kmax+1] the running sample offsets (s1 += step) for K and Kd
   ldsd_t b, c, gdC, adj;    // [6 Ntot][2]
   ldsd_t pE, pG, pA;        // [Ntot] per-piece energy, d(energy)/dT, chain-rule term of calGrads_PT
-  ldsd_t tab;               // per segment [4][6N][8]: rows of the four substitution sweeps (six coefficients, diagonal, 1 / diagonal)
+  ldscd_t tab;              // (shared) per segment [4][6N][8]: rows of the four substitution sweeps (six coefficients, diagonal, 1 / diagonal)
   ldsd_t segsum;            // [M][gNUM] per segment: gdT, corridor cost, feasibility cost, jerk energy, moving-obstacle cost
-  ldsd_t dot;               // [4][64] products of up to four sequential dot products
+  ldsd_t dot;               // [4][cap] products of up to four sequential dot products
   ldsd_t alpha;             // [mem]
   ldsd_t st;                // [sNUM]
   ldsi_t ist;               // [iNUM]
-  ldsi_t pinfo;             // [Ntot][4] segment, piece index inside it, first constraint point, intervals K
-  ldsi_t pmask;             // [Npts] active terms of a constraint point (bit t = term t)
-  ldsi_t pfirst;            // [Npts + 1] index of a point's first active term in (point, term) order
-  ldsi_t list;              // [kListCap] (point << 5 | term) of the active terms of the current window
+  ldsi_t pinfo;             // (shared) [Ntot][4] segment, piece index inside it, first constraint point, intervals K
+  ldsi_t pmask;             // [Npts][mw] active terms of a constraint point (bit t = term t)
+  ldsi_t pfirst;            // [Npts + 1] index of a point's first active term in (point, term) order (16-bit entries if pf16)
+  ldsi_t list;              // [list_cap] (point << 6 | term) of the active terms of the current window
+  int mw, pf16, list_cap;
+  __device__ __forceinline__ mask_t mask(int pt) const {
+    return mw == 2 ? ((mask_t)(unsigned)pmask[2 * pt] | ((mask_t)(unsigned)pmask[2 * pt + 1] << 32)) : (mask_t)(unsigned)pmask[pt];
+  }
+  __device__ __forceinline__ void set_mask(int pt, mask_t m) const {
+    if (mw == 2) {
+      pmask[2 * pt] = (int)(unsigned)(m & 0xffffffffull);
+      pmask[2 * pt + 1] = (int)(unsigned)(m >> 32);
+    } else {
+      pmask[pt] = (int)(unsigned)m;
+    }
+  }
+  __device__ __forceinline__ int first(int i) const { return pf16 ? (int)((ldsh_t)pfirst)[i] : pfirst[i]; }
+  __device__ __forceinline__ void set_first(int i, int v) const {
+    if (pf16) ((ldsh_t)pfirst)[i] = (unsigned short)v;
+    else pfirst[i] = v;
+  }
 };
 enum { gGDT = 0, gCOST0, gCOST2, gENERGY, gCOST1, gNUM = 6 };
 
-__host__ __device__ inline size_t lds_doubles(const DevLayout &L, int mem) {
-  return 5 * (size_t)L.npad + (size_t)L.M * (12 + 12 + 2 + 16 + gNUM) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3 + 4 * 48) * (size_t)L.Ntot + 4 * 64 +
+// bytes of the part of the LDS the waves of a workgroup share / of one team's part (both multiples of 16)
+__host__ __device__ inline size_t lds_shared_bytes(const DevLayout &L) {
+  return ((size_t)(4 * 48) * L.Ntot * sizeof(double) + 4 * (size_t)L.Ntot * sizeof(int) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t lds_team_doubles(const DevLayout &L, int mem, const Shape &sh) {
+  return 5 * (size_t)sh.nl + (size_t)L.M * (12 + 12 + 2 + 16 + gNUM) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3) * (size_t)L.Ntot + 4 * (size_t)sh.cap +
          (size_t)mem + sNUM;
 }
-__host__ __device__ inline size_t lds_ints(const DevLayout &L) { return iNUM + 4 * (size_t)L.Ntot + 2 * (size_t)L.Npts + 1 + kListCap; }
+__host__ __device__ inline size_t lds_team_ints(const DevLayout &L, const Shape &sh) {
+  const size_t pf = sh.pf16 ? ((size_t)L.Npts + 2) / 2 : (size_t)L.Npts + 1;
+  return iNUM + (size_t)sh.mw * L.Npts + pf + (size_t)sh.list_cap;
+}
+__host__ __device__ inline size_t lds_team_bytes(const DevLayout &L, int mem, const Shape &sh) {
+  return (lds_team_doubles(L, mem, sh) * sizeof(double) + lds_team_ints(L, sh) * sizeof(int) + 15) & ~(size_t)15;
+}
 
-__device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
+// shared: start of the workgroup's LDS; team: start of this team's part
+__device__ inline void carve(Sm &s, double *shared, double *team, const DevLayout &L, int mem, const Shape &sh) {
   const int M = L.M, Ntot = L.Ntot;
-  ldsd_t p = (ldsd_t)base;
-  s.x = p; p += L.npad;
-  s.xp = p; p += L.npad;
-  s.g = p; p += L.npad;
-  s.gp = p; p += L.npad;
-  s.d = p; p += L.npad;
+  s.tab = (ldscd_t)shared;
+  s.pinfo = (ldsi_t)((ldsd_t)shared + (4 * 48) * Ntot);
+  ldsd_t p = (ldsd_t)team;
+  s.x = p; p += sh.nl;
+  s.xp = p; p += sh.nl;
+  s.g = p; p += sh.nl;
+  s.gp = p; p += sh.nl;
+  s.d = p; p += sh.nl;
   s.bnd = p; p += 12 * M;
   s.pva = p; p += 12 * M;
   s.trig = p; p += 2 * M;
@@ -162,17 +231,25 @@ __device__ inline void carve(Sm &s, double *base, const DevLayout &L, int mem) {
   s.pE = p; p += Ntot;
   s.pG = p; p += Ntot;
   s.pA = p; p += Ntot;
-  s.tab = p; p += (4 * 48) * Ntot;
   s.segsum = p; p += gNUM * M;
-  s.dot = p; p += 4 * 64;
+  s.dot = p; p += 4 * sh.cap;
   s.alpha = p; p += mem;
   s.st = p; p += sNUM;
   ldsi_t q = (ldsi_t)p;
   s.ist = q; q += iNUM;
-  s.pinfo = q; q += 4 * Ntot;
-  s.pmask = q; q += L.Npts;
-  s.pfirst = q; q += L.Npts + 1;
+  s.pmask = q; q += sh.mw * L.Npts;
+  s.pfirst = q; q += sh.pf16 ? (L.Npts + 2) / 2 : L.Npts + 1;
   s.list = q;
+  s.mw = sh.mw;
+  s.pf16 = sh.pf16;
+  s.list_cap = sh.list_cap;
+}
+
+// A team's barrier: the workgroup's in the TEAM shape; in the WAVE shape the team is one wave, whose LDS operations execute
+// in program order -- all that is needed is that the compiler keeps them in that order.
+template <bool WAVE> __device__ __forceinline__ void team_sync() {
+  if (WAVE) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  else __syncthreads();
 }
 
 // One lane, one dimension: a substitution sweep over the 6N rows of the band system, row by row.  Row i (ascending
@@ -397,12 +474,14 @@ __device__ inline double lse_cr(double alpha, double *all_dists, int n, double *
 // The obstacle loop of dynamicObsGradCostP for one constraint point, statement by statement.  Every obstacle with a positive
 // penalty writes a record (term t_first + sur_id) and sets its bit in `mask`; the point's penalty -- the inner sum over the
 // obstacles, which the reference adds to costs(1) once per point -- goes into slot [13] of the first such record.
-__device__ __noinline__ unsigned surround_terms(const DevParams &P, const DevSurround &S, double t_now, double omg, double step, double t,
+// trajtime: what the reference passes for gear segment trajid, trajtimes[trajid] = 0 for the first segment and the DURATION OF
+// THE PREVIOUS SEGMENT (not the time since the start) for the others (traj_optimizer.cpp:230-234, 291, 1367-1369).
+__device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurround &S, double t_now, double omg, double step, double t,
                                                 const double beta0[6], const double beta1[6], double gama, int pieceid, int trajres,
                                                 const double sigma[2], const double dsigma[2], const double ddsigma[2], const double ego_R[4],
                                                 int singul_, int trajid, double trajtime, int Nseg, int t_first, gd_t rec) {
   const double B_h[4] = {0.0, -1.0, 1.0, 0.0}, B_hT[4] = {0.0, 1.0, -1.0, 0.0}; // traj_optimizer.cpp:1741-1742
-  unsigned mask = 0u;
+  mask_t mask = 0ull;
   int first_active = -1;
   const double alpha = 100.0, d_min = P.surround_clearance + crt::log_cr(8.0) / alpha; // traj_optimizer.cpp:1336 (the reference: std::log(8.0))
   double temp0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
@@ -651,13 +730,16 @@ __device__ __noinline__ unsigned surround_terms(const DevParams &P, const DevSur
       r_[2 * k + 0] = scale * (beta0[k] * pGs[0] + beta1[k] * pGds[0]);
       r_[2 * k + 1] = scale * (beta0[k] * pGs[1] + beta1[k] * pGds[1]);
     }
-    // the three `gdT +=` of traj_optimizer.cpp:1663-1676, kept apart: the chain adds them one after the other
+    // the `gdT +=` of traj_optimizer.cpp:1663-1676, kept apart: the chain adds them one after the other -- [12], then
+    // [14] * pieceid (the reference's product  omg * step * wei * grad_prev_t * penaD * pieceid  evaluates left to right, so its
+    // last factor can be applied by the chain lane), then [15], then `trajid` times [14] * piece_num_container[trajid]
+    // (:1674-1676: the loop over the previous segments adds to THIS segment's gdT)
     r_[12] = omg * P.wei_surround * (pena / trajres + penaD * gradViolaPt * step);
-    r_[14] = omg * step * P.wei_surround * pGthat * penaD * pieceid;
+    r_[14] = omg * step * P.wei_surround * pGthat * penaD;
     r_[15] = omg * step * P.wei_surround * gama * pGthat * penaD;
     r_[13] = 0.0;
     if (first_active < 0) first_active = sur_id;
-    mask |= 1u << (t_first + sur_id);
+    mask |= (mask_t)1 << (t_first + sur_id);
   }
   if (first_active >= 0) rec[(size_t)(t_first + first_active) * kRec + 13] = totalPenalty;
   return mask;
@@ -668,9 +750,9 @@ __device__ __noinline__ unsigned surround_terms(const DevParams &P, const DevSur
 // record for every active term and returns the mask of active terms.  cor: &corridor[b][0][pt] (component-major, pitch
 // NptsPad); rec: &scratch[pt][0][0].
 template <bool SUR>
-__device__ __forceinline__ unsigned point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
-                                             int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec, const DevSurround &S,
-                                             double t_now, double t_piece) {
+__device__ __forceinline__ mask_t point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
+                                            int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec, const DevSurround &S,
+                                            double t_now, double t_piece, int trajid, double trajtime) {
   double cc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) cc[k] = cc_[k];
@@ -696,7 +778,7 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
   const double z_h2 = dddsigma[0] * dsigma[0] + dddsigma[1] * dsigma[1];
   const double z_h3 = ddsigma[1] * dsigma[0] + (-ddsigma[0]) * dsigma[1];  // ddsigma^T B_h dsigma, :529
   const double z1 = dddsigma[1] * dsigma[0] + (-dddsigma[0]) * dsigma[1];  // :538
-  if (z_h0 < 1e-4 || (j == 0 && i == 0) || (i == N - 1 && j == K)) return 0u; // :550-553
+  if (z_h0 < 1e-4 || (j == 0 && i == 0) || (i == N - 1 && j == K)) return 0ull; // :550-553
 
   const double max_vel = singul_ > 0 ? P.max_vel[0] : P.max_vel[1];
   const double max_acc = singul_ > 0 ? P.max_acc[0] : P.max_acc[1];
@@ -722,7 +804,7 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
 #pragma unroll
   for (int k = 0; k < 4; k++) R_dot[k] = sg * (temp_a[k] * z_h0 - temp_v[k] * vel2_reci * z_h0 * z_h1);
 
-  unsigned mask = 0u;
+  mask_t mask = 0ull;
   // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634.  The 5 H tests first (term v H + k:
   // the order of the reference's nested loops), collected in the mask; then one pass over the set bits, so that a lane spends
   // time on its own violated half-planes only (as nested loops every body ran for the whole wave if a single lane needed it).
@@ -744,11 +826,11 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       const double violaPos = pn0[k] * (bpt0 - pq0[k]) + pn1[k] * (bpt1 - pq1[k]);
-      if (k < H && violaPos > 0) mask |= 1u << (v * H + k);
+      if (k < H && violaPos > 0) mask |= (mask_t)1 << (v * H + k);
     }
   }
-  for (unsigned m = mask; m;) {
-    const int t = __builtin_ctz(m);
+  for (mask_t m = mask; m;) {
+    const int t = __builtin_ctzll(m);
     m &= m - 1;
     int v = 0;
 #pragma unroll
@@ -793,10 +875,10 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
     r_[12] = omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
     r_[13] = omg * step * P.wei_obs * pena;
   }
-  // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1; one gear segment: trajid 0, trajtime 0)
+  // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1)
   if (SUR && S.S > 0)
-    mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, 0, 0.0, N,
-                           5 * H, rec);
+    mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, trajid, trajtime,
+                           N, 5 * H, rec);
   const int t0 = 5 * H + (SUR ? S.S : 0);
   if (violaVel > 0.0) { // :642-653
     double pena, penaD;
@@ -811,7 +893,7 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
     }
     r_[12] = omg * P.wei_feas * (penaD * gradViolaVt * step + pena / K);
     r_[13] = omg * step * P.wei_feas * pena;
-    mask |= 1u << t0;
+    mask |= (mask_t)1 << t0;
   }
   if (violaAcc > 0.0) { // :655-665
     double pena, penaD;
@@ -828,7 +910,7 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
     }
     r_[12] = omg * P.wei_feas * (penaD * gradViolaAt * step + pena / K);
     r_[13] = omg * step * P.wei_feas * pena;
-    mask |= 1u << (t0 + 1);
+    mask |= (mask_t)1 << (t0 + 1);
   }
   // ---- curvature, :684-705
   const double ku0 = vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0];
@@ -847,7 +929,7 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
     }
     r_[12] = omg * P.wei_feas * 10.0 * (penaD * kt * step + pena / K);
     r_[13] = omg * step * P.wei_feas * 10.0 * pena;
-    mask |= 1u << (t0 + 2);
+    mask |= (mask_t)1 << (t0 + 2);
   }
   if (violaCurR > 0.0) {
     double pena, penaD;
@@ -862,7 +944,7 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
     }
     r_[12] = omg * P.wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
     r_[13] = omg * step * P.wei_feas * 10.0 * pena;
-    mask |= 1u << (t0 + 3);
+    mask |= (mask_t)1 << (t0 + 3);
   }
   return mask;
 }
@@ -870,11 +952,14 @@ __device__ __forceinline__ unsigned point_terms(const DevParams &P, const double
 // ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350)
 // x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].  The gear segments are independent
 // up to the sums of :292-297 and the junction variables' gradients (:307-320), so every stage runs them side by side.
-template <bool SUR>
+template <bool SUR, bool WAVE>
 __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
-  const int tid = threadIdx.x, T = blockDim.x;
+  // the team: the workgroup, or (WAVE) this wave alone.  Stages with two independent jobs give the second one to the lanes of
+  // wave 1 in a workgroup and to the same lanes, afterwards, in a lone wave (u2: the index inside the second job).
+  const int tid = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x, T = WAVE ? 64 : (int)blockDim.x;
+  const int u2 = WAVE ? tid : tid - 64;
   const int M = L.M, Ntot = L.Ntot, Npts = L.Npts, H = L.H, nS = SUR ? D.sur.S : 0, nterm = 5 * H + nS + 4, Kmax1 = L.Kmax + 1;
 
   // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966); cos / sin of the junction angles
@@ -890,14 +975,15 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     se[1] = t1;
     se[2] = 1.0; se[3] = t1; se[4] = t2; se[5] = t3; se[6] = t4; se[7] = t5;
     se[8] = 1.0 / 1.0; se[9] = 1.0 / t1; se[10] = 1.0 / t2; se[11] = 1.0 / t3; se[12] = 1.0 / t4; se[13] = 1.0 / t5;
-  } else if (tid >= 64 && tid < 64 + M - 1) {
-    const int i = tid - 64;
+  }
+  if (u2 >= 0 && u2 < M - 1) {
+    const int i = u2;
     double sn, cs;
     crt::sincos(x[L.x_ang0 + i], sn, cs); // the reference: libm's cos / sin (host-dependent bits); here the correctly rounded ones
     sm.trig[2 * i] = cs;
     sm.trig[2 * i + 1] = sn;
   }
-  __syncthreads();
+  team_sync<WAVE>();
   // ---- boundary states in force (IniS / FinS of :270-282): junction position from x, junction velocity from the angle
   if (tid < M) {
     const int sg = tid;
@@ -920,7 +1006,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       tv[3] = P.non_sinv * sm.trig[2 * sg + 1];
     }
   }
-  __syncthreads();
+  team_sync<WAVE>();
   // ---- right-hand sides (poly_traj_utils.hpp:968-977)
   for (int w = tid; w < 12 * Ntot; w += T) {
     const int p = w / 12, q = w - 12 * p, k = q >> 1, d = q & 1;
@@ -938,8 +1024,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     else if (k == 5) v = x[x0 + 2 * lp + d];
     sm.b[w] = v;
   }
-  __syncthreads();
-  // ---- wave 0: BandedSystem::solve (poly_traj_utils.hpp:805-826), one lane per (segment, dimension); wave 1: the running sample
+  team_sync<WAVE>();
+  // ---- BandedSystem::solve (poly_traj_utils.hpp:805-826), one lane per (segment, dimension); second job: the running sample
   // offsets s1 += step (traj_optimizer.cpp:513), one lane per table
   if (tid < 2 * M) {
     const int sg = tid >> 1, d = tid & 1;
@@ -951,8 +1037,9 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     ldscd_t tb = sm.tab + 192 * p0;
     sweep<0>(tb, sm.b + 12 * p0, 6 * N, d);
     sweep<1>(tb + 48 * N, sm.b + 12 * p0, 6 * N, d);
-  } else if (tid >= 64 && tid < 64 + 2 * M) {
-    const int sg = (tid - 64) >> 1, which = (tid - 64) & 1;
+  }
+  if (u2 >= 0 && u2 < 2 * M) {
+    const int sg = u2 >> 1, which = u2 & 1;
     const int K = which ? L.Kd : L.K;
     const double step = sm.seg[16 * sg + 1] / K;
     ldsd_t tab = sm.spow + (2 * sg + which) * Kmax1;
@@ -974,14 +1061,14 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       }
     }
   }
-  __syncthreads();
+  team_sync<WAVE>();
   pr.tick(0);
   // ---- c = b * tInv (:979-984)
   for (int w = tid; w < 12 * Ntot; w += T) {
     const int p = w / 12, k = (w - 12 * p) >> 1;
     sm.c[w] = sm.b[w] * sm.seg[16 * sm.pinfo[4 * p] + 8 + k];
   }
-  __syncthreads();
+  team_sync<WAVE>();
   // ---- initSmGradCost / getTrajJerkCost per piece (poly_traj_utils.hpp:998-1035); the sums over the pieces are chained below
   for (int i = tid; i < Ntot; i += T) {
     ldscd_t c = sm.c + 12 * i;
@@ -1017,18 +1104,20 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * p + k];
     const double step = sm.seg[16 * sg + 1] / K;
     const double s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
-    sm.pmask[pt] = (int)point_terms<SUR>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
-                                    rec_b + (size_t)pt * nterm * kRec, D.sur, D.t_now, sm.pA[p]);
+    // trajtimes[sg] of traj_optimizer.cpp:230-234: 0, then the real duration of the PREVIOUS segment
+    const double trajtime = (SUR && sg > 0) ? sm.seg[16 * (sg - 1)] : 0.0;
+    sm.set_mask(pt, point_terms<SUR>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
+                                     rec_b + (size_t)pt * nterm * kRec, D.sur, D.t_now, SUR ? sm.pA[p] : 0.0, sg, trajtime));
   }
-  __threadfence_block(); // the records are read back by other threads of this workgroup
-  __syncthreads();
+  __threadfence_block(); // the records are read back by other lanes of this team
+  team_sync<WAVE>();
   pr.tick(2);
-  // ---- number the active terms in (point, term) order: exclusive prefix sum of the counts (wave 0); wave 1: the start values
-  // of the per-segment chains (`gdT +=`, `energy +=` over the pieces in order, from 0.0)
+  // ---- number the active terms in (point, term) order: exclusive prefix sum of the counts (wave 0); second job: the start
+  // values of the per-segment chains (`gdT +=`, `energy +=` over the pieces in order, from 0.0)
   if (tid < 64) {
     const int per = (Npts + 63) >> 6, start = tid * per;
     int sum = 0;
-    for (int i = start; i < start + per && i < Npts; i++) sum += __builtin_popcount((unsigned)sm.pmask[i]);
+    for (int i = start; i < start + per && i < Npts; i++) sum += __builtin_popcountll(sm.mask(i));
     int incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1037,12 +1126,13 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     }
     int run = incl - sum;
     for (int i = start; i < start + per && i < Npts; i++) {
-      sm.pfirst[i] = run;
-      run += __builtin_popcount((unsigned)sm.pmask[i]);
+      sm.set_first(i, run);
+      run += __builtin_popcountll(sm.mask(i));
     }
-    if (tid == 63) sm.pfirst[Npts] = incl;
-  } else if (tid < 64 + M) {
-    const int sg = tid - 64;
+    if (tid == 63) sm.set_first(Npts, incl);
+  }
+  if (u2 >= 0 && u2 < M) {
+    const int sg = u2;
     int p0 = 0, p1 = 0;
     for (int q = 0; q < M; q++) {
       p0 = q == sg ? L.seg_piece0[q] : p0;
@@ -1059,33 +1149,34 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     sm.segsum[gNUM * sg + gCOST2] = 0.0;
     sm.segsum[gNUM * sg + gCOST1] = 0.0;
   }
-  __syncthreads();
-  // ---- chains: the active terms in windows of kListCap; lane (piece, entry) adds its piece's records in order, three more
-  // lanes per segment walk all of the segment's for gdT, the corridor cost and the feasibility cost
-  const int n_act = sm.pfirst[Npts];
+  team_sync<WAVE>();
+  // ---- chains: the active terms in windows of list_cap; lane (piece, entry) adds its piece's records in order, four more
+  // lanes per segment walk all of the segment's for gdT, the corridor cost, the feasibility cost and the moving-obstacle cost
+  const int n_act = sm.first(Npts);
   const int n_chain = 12 * Ntot + 4 * M;
-  for (int c0 = 0; c0 < n_act; c0 += kListCap) {
-    const int c1 = c0 + kListCap < n_act ? c0 + kListCap : n_act;
+  const int cap = sm.list_cap;
+  for (int c0 = 0; c0 < n_act; c0 += cap) {
+    const int c1 = c0 + cap < n_act ? c0 + cap : n_act;
     for (int pt = tid; pt < Npts; pt += T) {
-      unsigned m = (unsigned)sm.pmask[pt];
-      int e = sm.pfirst[pt];
+      mask_t m = sm.mask(pt);
+      int e = sm.first(pt);
       while (m) {
-        const int t = __builtin_ctz(m);
+        const int t = __builtin_ctzll(m);
         m &= m - 1;
-        if (e >= c0 && e < c1) sm.list[e - c0] = (pt << 5) | t;
+        if (e >= c0 && e < c1) sm.list[e - c0] = (pt << 6) | t;
         e++;
       }
     }
-    __syncthreads();
+    team_sync<WAVE>();
     for (int w = tid; w < n_chain; w += T) {
-      int e0, e1, q, kind = -1;
+      int e0, e1, q, kind = -1, csg = 0;
       ldsd_t dst;
       if (w < 12 * Ntot) {
         const int p = w / 12;
         q = w - 12 * p;
         const int pt0 = sm.pinfo[4 * p + 2], pt1 = pt0 + sm.pinfo[4 * p + 3] + 1;
-        e0 = sm.pfirst[pt0];
-        e1 = sm.pfirst[pt1];
+        e0 = sm.first(pt0);
+        e1 = sm.first(pt1);
         dst = sm.gdC + w;
       } else {
         const int v = w - 12 * Ntot, sg = v >> 2, kd = v & 3; // per segment: 0 gdT, 1 corridor cost, 2 feasibility cost, 3 moving-obstacle cost
@@ -1094,11 +1185,12 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
           a0 = q2 == sg ? L.seg_pt0[q2] : a0;
           a1 = q2 == sg ? L.seg_pt0[q2 + 1] : a1;
         }
-        e0 = sm.pfirst[a0];
-        e1 = sm.pfirst[a1];
+        e0 = sm.first(a0);
+        e1 = sm.first(a1);
         q = kd == 0 ? 12 : 13;
         dst = sm.segsum + gNUM * sg + (kd == 0 ? gGDT : (kd == 1 ? gCOST0 : (kd == 2 ? gCOST2 : gCOST1)));
         kind = kd;
+        csg = sg;
       }
       e0 = e0 > c0 ? e0 : c0;
       e1 = e1 < c1 ? e1 : c1;
@@ -1113,57 +1205,62 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
 #pragma unroll
           for (int u = 0; u < 8; u++) id[u] = sm.list[e + u - c0];
 #pragma unroll
-          for (int u = 0; u < 8; u++) v[u] = rec_b[((size_t)(id[u] >> 5) * nterm + (id[u] & 31)) * kRec + q];
+          for (int u = 0; u < 8; u++) v[u] = rec_b[((size_t)(id[u] >> 6) * nterm + (id[u] & 63)) * kRec + q];
 #pragma unroll
           for (int u = 0; u < 8; u++) acc += v[u];
         }
         for (; e < e1; e++) {
           const int id = sm.list[e - c0];
-          acc += rec_b[((size_t)(id >> 5) * nterm + (id & 31)) * kRec + q];
+          acc += rec_b[((size_t)(id >> 6) * nterm + (id & 63)) * kRec + q];
         }
       } else {
         // the per-segment chains: what an entry adds depends on its kind of term; its values are requested eight entries at
         // a time in front of the additions (slots 14 / 15 only mean something for a moving-obstacle term and are only used there)
-        const unsigned smask = nS > 0 ? (1u << nS) - 1u : 0u;
+        const mask_t smask = nS > 0 ? (((mask_t)1 << nS) - 1ull) : 0ull;
+        int Nseg = 0;
+        for (int q2 = 0; q2 < M; q2++) Nseg = q2 == csg ? L.piece_nums[q2] : Nseg;
         for (int e = e0; e < e1; e += 8) {
           int id[8];
           double va[8], vb[8], vc[8];
-          unsigned pm[8];
+          mask_t pm[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) id[u] = sm.list[(e + u < e1 ? e + u : e1 - 1) - c0];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            gcd_t r_ = (gcd_t)(rec_b + ((size_t)(id[u] >> 5) * nterm + (id[u] & 31)) * kRec);
+            gcd_t r_ = (gcd_t)(rec_b + ((size_t)(id[u] >> 6) * nterm + (id[u] & 63)) * kRec);
             va[u] = r_[kind == 0 ? 12 : 13];
             vb[u] = r_[14];
             vc[u] = r_[15];
-            pm[u] = (unsigned)sm.pmask[id[u] >> 5];
+            pm[u] = sm.mask(id[u] >> 6);
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             if (e + u >= e1) break;
-            const int t = id[u] & 31;
+            const int t = id[u] & 63;
             const bool sur_term = t >= tS0 && t < tS1;
-            if (kind == 0) { // gdT: one `+=` per term, three for a moving-obstacle term (traj_optimizer.cpp:1663-1676)
+            if (kind == 0) { // gdT: one `+=` per term; a moving-obstacle term: three, and one more per previous segment (traj_optimizer.cpp:1663-1676)
               acc += va[u];
               if (sur_term) {
-                acc += vb[u];
+                const int lp = sm.pinfo[4 * (int)D.pt_piece[id[u] >> 6] + 1]; // pieceid
+                acc += vb[u] * lp;
                 acc += vc[u];
+                const double prev = vb[u] * Nseg; // ... * piece_num_container[trajid]
+                for (int idx = 0; idx < csg; idx++) acc += prev;
               }
             } else if (kind == 1) {
               if (t < tS0) acc += va[u];
             } else if (kind == 2) {
               if (t >= tS1) acc += va[u];
             } else if (sur_term) { // costs(1) += the point's penalty, once per point: carried by its first active obstacle term
-              const unsigned sb = (pm[u] >> tS0) & smask;
-              if ((int)__builtin_ctz(sb) == t - tS0) acc += va[u];
+              const mask_t sb = (pm[u] >> tS0) & smask;
+              if ((int)__builtin_ctzll(sb) == t - tS0) acc += va[u];
             }
           }
         }
       }
       *dst = acc;
     }
-    __syncthreads();
+    team_sync<WAVE>();
   }
   pr.tick(3);
   // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
@@ -1171,7 +1268,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     const int p = w / 12, k = (w - 12 * p) >> 1;
     sm.adj[w] = sm.gdC[w] * sm.seg[16 * sm.pinfo[4 * p] + 8 + k];
   }
-  __syncthreads();
+  team_sync<WAVE>();
   if (tid < 2 * M) {
     const int sg = tid >> 1, d = tid & 1;
     int N = 0, p0 = 0;
@@ -1182,8 +1279,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     ldscd_t tb = sm.tab + 192 * p0;
     sweep<2>(tb + 96 * N, sm.adj + 12 * p0, 6 * N, d);
     sweep<3>(tb + 144 * N, sm.adj + 12 * p0, 6 * N, d);
-  } else if (tid >= 64 && tid < 64 + Ntot) { // the per-piece chain-rule terms (they only need gdC and b)
-    const int i = tid - 64;
+  }
+  for (int i = u2; i >= 0 && i < Ntot; i += (WAVE ? 64 : T - 64)) { // the per-piece chain-rule terms (they only need gdC and b)
     ldscd_t tInv = sm.seg + 16 * sm.pinfo[4 * i] + 8;
     const double gdtInv[6] = {0.0, -1.0 * tInv[2], -2.0 * tInv[3], -3.0 * tInv[4], -4.0 * tInv[5], -5.0 * tInv[5] * tInv[1]};
     double acc = 0.0;
@@ -1194,14 +1291,13 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     }
     sm.pA[i] = acc;
   }
-  __syncthreads();
+  team_sync<WAVE>();
   pr.tick(4);
   // ---- gradient and cost (traj_optimizer.cpp:299-344)
   for (int e = tid; e < L.x_tau0; e += T) { // gdP of every segment: rows 6 i + 5 of its adjoint
-    int sg = 0, x0 = 0, p0 = 0;
+    int x0 = 0, p0 = 0;
     for (int q = 0; q < M; q++) {
       const bool in = e >= L.seg_x0[q];
-      sg = in ? q : sg;
       x0 = in ? L.seg_x0[q] : x0;
       p0 = in ? L.seg_piece0[q] : p0;
     }
@@ -1234,8 +1330,9 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       gdVT2Rt = (1.0 - VT) / (denSqrt * denSqrt);
     }
     g[L.x_tau0 + sg] = (gdT / N + P.wei_time) * gdVT2Rt;
-  } else if (tid >= 64 && tid < 64 + M - 1 && P.gear_opt) { // junction i: position and angle (traj_optimizer.cpp:307-320)
-    const int i = tid - 64;
+  }
+  if (u2 >= 0 && u2 < M - 1 && P.gear_opt) { // junction i: position and angle (traj_optimizer.cpp:307-320)
+    const int i = u2;
     int Ni = 0, p0i = 0, p0n = 0;
     for (int q = 0; q < M; q++) {
       Ni = q == i ? L.piece_nums[q] : Ni;
@@ -1260,13 +1357,13 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     va += fin1[0] * (-P.non_sinv * sn) + fin1[1] * (P.non_sinv * cs);
     va += ini1[0] * (P.non_sinv * sn) + ini1[1] * (-P.non_sinv * cs);
     g[L.x_ang0 + i] = va;
-  } else if (tid >= 64 && tid < 64 + M - 1) { // gear_opt off: the junction variables keep a zero gradient
-    const int i = tid - 64;
+  } else if (u2 >= 0 && u2 < M - 1) { // gear_opt off: the junction variables keep a zero gradient
+    const int i = u2;
     g[L.x_gear0 + 2 * i] = 0.0;
     g[L.x_gear0 + 2 * i + 1] = 0.0;
     g[L.x_ang0 + i] = 0.0;
   }
-  if (tid == 128 || (T <= 128 && tid == 0)) { // the cost: sums over the segments in order (:292-297, :328-330)
+  if (tid == (T > 128 ? 128 : 0)) { // the cost: sums over the segments in order (:292-297, :328-330)
     double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
     for (int sg = 0; sg < M; sg++) {
       total_smcost += sm.segsum[gNUM * sg + gENERGY];
@@ -1275,7 +1372,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
     for (int sg = 0; sg < M; sg++) total_timecost += sm.seg[16 * sg] * P.wei_time;
     sm.st[sF] = total_smcost + total_timecost + penalty_cost;
   }
-  __syncthreads();
+  team_sync<WAVE>();
   pr.tick(5);
 }
 
@@ -1290,7 +1387,7 @@ __device__ __forceinline__ void wave_lds_order() { __builtin_amdgcn_fence(__ATOM
 // simply run to CAP.
 template <int CAP>
 __device__ __forceinline__ double seq_sum(double p, int n, ldsd_t buf, int lane) {
-  buf[lane] = lane < n ? p : -0.0;
+  if (lane < CAP) buf[lane] = lane < n ? p : -0.0;
   wave_lds_order();
   double s = 0.0;
 #if DFTPAV_REF_SUM_ALL_LANES
@@ -1602,18 +1699,20 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
   // the four dot products of lbfgs.hpp:683-694, their chains side by side
   double ys, yy, ss, gpgp;
   {
-    sm.dot[lane] = yv * sv;
-    sm.dot[64 + lane] = yv * yv;
-    sm.dot[128 + lane] = sv * sv;
-    sm.dot[192 + lane] = gpv * gpv;
+    if (lane < CAP) {
+      sm.dot[lane] = yv * sv;
+      sm.dot[CAP + lane] = yv * yv;
+      sm.dot[2 * CAP + lane] = sv * sv;
+      sm.dot[3 * CAP + lane] = gpv * gpv;
+    }
     wave_lds_order();
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 4
     for (int e = 0; e < n; e++) {
       a0 += sm.dot[e];
-      a1 += sm.dot[64 + e];
-      a2 += sm.dot[128 + e];
-      a3 += sm.dot[192 + e];
+      a1 += sm.dot[CAP + e];
+      a2 += sm.dot[2 * CAP + e];
+      a3 += sm.dot[3 * CAP + e];
     }
     wave_lds_order();
     ys = a0; yy = a1; ss = a2; gpgp = a3;
@@ -1680,19 +1779,81 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
 }
 
 // ------------------------------------------------ the kernel
-// (two workgroups per CU = two waves per SIMD where the registers allow it: a second trajectory fills the issue slots the
-// dependent chains of the first leave empty)
-template <int CAP, bool SUR>
-__global__ void __launch_bounds__(256, (CAP <= 32 && !SUR) ? 2 : 1) ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch) {
+// Work ring of a scheduled launch (source 1): DevBatch::queue / qctl, the protocol of solver.hip's queue_pop / queue_push --
+// CAS on the head, release / acquire on the published tail, device-scope fences, because the next slice of a trajectory may
+// run behind another XCD's L2.  Popped and pushed by lane 0 of a wave.
+__device__ inline int ring_pop(unsigned *ctl, const int *ring, int cap) {
+  while (true) {
+    const unsigned h = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (h >= t) return -1;
+    if (atomicCAS(&ctl[0], h, h + 1) == h) {
+      const int id = __hip_atomic_load(&ring[h % (unsigned)cap], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      return id;
+    }
+  }
+}
+__device__ inline void ring_push(unsigned *ctl, int *ring, int cap, int id) {
+  __threadfence();
+  const unsigned t = atomicAdd(&ctl[2], 1u);
+  __hip_atomic_store(&ring[t % (unsigned)cap], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) { // publish in reservation order
+    unsigned expect = t;
+    if (__hip_atomic_compare_exchange_strong(&ctl[1], &expect, t + 1, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+  }
+}
+// solver state of a suspended trajectory <-> its record in DevBatch::state (layout as solver.hip's: five vectors at pitch
+// npad, the scalars, the integers); the history and (ys, 1 / ys) of the stored pairs live in HBM anyway
+__device__ inline void state_io(const DevBatch &D, const Sm &sm, int b, int lane, int nl, bool save) {
+  const int n = D.L.n, npad = D.L.npad;
+  double *rec = D.state + (size_t)b * D.state_stride;
+  ldsd_t vecs[5] = {sm.x, sm.xp, sm.g, sm.gp, sm.d};
+#pragma unroll
+  for (int a = 0; a < 5; a++)
+    for (int e = lane; e < nl; e += 64) {
+      if (save) {
+        if (e < n) rec[a * npad + e] = vecs[a][e];
+      } else {
+        vecs[a][e] = e < n ? rec[a * npad + e] : 0.0;
+      }
+    }
+  double *r2 = rec + 5 * npad;
+  for (int w = lane; w < sNUM; w += 64) {
+    if (save) r2[w] = sm.st[w];
+    else sm.st[w] = r2[w];
+  }
+  int *ri = reinterpret_cast<int *>(r2 + 24);
+  for (int w = lane; w < iNUM; w += 64) {
+    if (save) ri[w] = sm.ist[w];
+    else sm.ist[w] = ri[w];
+  }
+}
+
+// TEAM: one workgroup per trajectory (blockIdx.x).  WAVE: every wave of the workgroup is a team of its own; source 0: wave w of
+// workgroup i takes trajectory i * W + w; source 1 (solves only): it pops trajectories from the ring until the ring is empty,
+// runs each for `slice` iterations and pushes it back unfinished.
+// Registers: 256 per lane (two waves per SIMD) for the kernels that fit them -- a second trajectory fills the issue slots the
+// dependent chains of the first leave empty; the wide (n > 32) and the moving-obstacle kernels take 512.
+template <int CAP, bool SUR, bool WAVE>
+__global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAVE && CAP <= 32 && !SUR) ? 2 : 1)
+    ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch, int source, int slice) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
   const DevLayout &L = D.L;
-  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63;
-  const int n = L.n, b = blockIdx.x;
+  const int tidb = threadIdx.x, Tb = blockDim.x, lane = tidb & 63, wv = tidb >> 6, W = Tb >> 6;
+  const int tid = WAVE ? lane : tidb, T = WAVE ? 64 : Tb; // inside the team
+  const int n = L.n;
+  const Shape sh = make_shape(L, SUR ? D.sur.S : 0, WAVE);
   Sm sm;
-  carve(sm, lds_raw, L, D.P.mem_size);
-  for (int i = tid; i < 4 * 48 * L.Ntot; i += T) sm.tab[i] = tabs[i];
-  for (int p = tid; p < L.Ntot; p += T) { // piece -> segment, index inside it, first constraint point, intervals
+  {
+    char *base = reinterpret_cast<char *>(lds_raw);
+    char *team = base + lds_shared_bytes(L) + (WAVE ? (size_t)wv * lds_team_bytes(L, D.P.mem_size, sh) : 0);
+    carve(sm, lds_raw, reinterpret_cast<double *>(team), L, D.P.mem_size, sh);
+  }
+  // ---- shared by the workgroup: the sweep tables and the piece table
+  for (int i = tidb; i < 4 * 48 * L.Ntot; i += Tb) ((ldsd_t)sm.tab)[i] = tabs[i];
+  for (int p = tidb; p < L.Ntot; p += Tb) { // piece -> segment, index inside it, first constraint point, intervals
     int sg = 0, p0 = 0, N = 0, pt0s = 0;
     for (int q = 0; q < L.M; q++) {
       const bool in = p >= L.seg_piece0[q];
@@ -1707,59 +1868,103 @@ __global__ void __launch_bounds__(256, (CAP <= 32 && !SUR) ? 2 : 1) ref_kernel(c
     sm.pinfo[4 * p + 2] = pt0s + (lp == 0 ? 0 : (L.Kd + 1) + (lp - 1) * (L.K + 1)); // pieces of a segment are [Kd+1, K+1, ..., K+1, Kd+1] points long
     sm.pinfo[4 * p + 3] = (lp == 0 || lp == N - 1) ? L.Kd : L.K;
   }
-  for (int e = tid; e < L.npad; e += T) {
-    const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
-    sm.x[e] = e < n ? xsrc[(size_t)b * n + e] : 0.0;
-    sm.xp[e] = 0.0;
-    sm.g[e] = 0.0;
-    sm.gp[e] = 0.0;
-    sm.d[e] = 0.0;
-  }
-  if (tid < iNUM) sm.ist[tid] = 0;
-  for (int w = tid; w < 12 * L.M; w += T) {
-    const int sg = w / 12, q = w - 12 * sg;
-    sm.bnd[w] = q < 6 ? D.iniS[((size_t)b * L.M + sg) * 6 + q] : D.finS[((size_t)b * L.M + sg) * 6 + (q - 6)];
-  }
-  const gcd_t cor_b = (gcd_t)(D.corridor + (size_t)b * L.H * 4 * D.NptsPad);
-  const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * (5 * L.H + (SUR ? D.sur.S : 0) + 4) * kRec);
-  const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
-  const gd_t hR = (gd_t)(D.histR + (size_t)b * D.P.mem_size * 2);
-  const long long tick0 = wall_clock64();
+  __syncthreads(); // the only time the waves of a WAVE-shaped workgroup meet
+  const bool ring = WAVE && mode == kModeSolve && source == 1;
+  const int nterm = 5 * L.H + (SUR ? D.sur.S : 0) + 4;
   Prof pr;
-  pr.start(D.prof != nullptr && mode == kModeSolve, D.prof + (size_t)b * 12);
-  __syncthreads();
 
-  ref_eval<SUR>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
+  for (int pass = 0;; pass++) {
+    int b;
+    if (ring) {
+      int id = -1;
+      if (lane == 0) id = ring_pop(D.qctl, D.queue, D.qcap);
+      b = __builtin_amdgcn_readfirstlane(id);
+    } else {
+      b = pass == 0 ? (WAVE ? (int)blockIdx.x * W + wv : (int)blockIdx.x) : -1;
+      if (b >= D.B) b = -1;
+    }
+    if (b < 0) break;
+    const bool resume = ring && D.sflag[b] == 1;
+    if (resume) {
+      state_io(D, sm, b, tid, sh.nl, false);
+    } else {
+      const double *xsrc = (mode == kModeSolve) ? D.x0 : (mode == kModeEval ? D.x_in : D.x_out);
+      for (int e = tid; e < sh.nl; e += T) {
+        sm.x[e] = e < n ? xsrc[(size_t)b * n + e] : 0.0;
+        sm.xp[e] = 0.0;
+        sm.g[e] = 0.0;
+        sm.gp[e] = 0.0;
+        sm.d[e] = 0.0;
+      }
+      if (tid < iNUM) sm.ist[tid] = 0;
+    }
+    for (int w = tid; w < 12 * L.M; w += T) {
+      const int sg = w / 12, q = w - 12 * sg;
+      sm.bnd[w] = q < 6 ? D.iniS[((size_t)b * L.M + sg) * 6 + q] : D.finS[((size_t)b * L.M + sg) * 6 + (q - 6)];
+    }
+    const gcd_t cor_b = (gcd_t)(D.corridor + (size_t)b * L.H * 4 * D.NptsPad);
+    const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * nterm * kRec);
+    const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
+    const gd_t hR = (gd_t)(D.histR + (size_t)b * D.P.mem_size * 2);
+    const long long tick0 = wall_clock64();
+    pr.start(D.prof != nullptr && mode == kModeSolve && tid == 0, D.prof + (size_t)b * 12, resume);
+    team_sync<WAVE>();
+    const int k_start = sm.ist[iK];
 
-  if (mode == kModeEval) {
-    for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
-    if (tid == 0) D.f_eval[b] = sm.st[sF];
-    return;
-  }
-  if (mode == kModeCoeffs) {
-    for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
-    for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[16 * sg + 1];
-    return;
-  }
-  while (true) {
-    if (tid < 64) lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
-    __syncthreads();
-    if (sm.ist[iACTION] == kActDone) break;
-    ref_eval<SUR>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
-  }
-  for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
-  if (tid == 0) {
-    const double fx = sm.st[sFX];
-    const int ret = sm.ist[iRET];
-    D.f_out[b] = fx;
-    D.status[b] = ret;
-    D.iters[b] = sm.ist[iK];
-    D.evals[b] = sm.ist[iEVALS];
-    D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
-    D.ticks[b] = wall_clock64() - tick0;
-    int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
-    if (fx >= D.P.fail_cost) ok = 0;
-    D.success[b] = ok;
+    ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
+
+    if (mode == kModeEval) {
+      for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
+      if (tid == 0) D.f_eval[b] = sm.st[sF];
+      return;
+    }
+    if (mode == kModeCoeffs) {
+      for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
+      for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[16 * sg + 1];
+      return;
+    }
+    bool finished = true;
+    while (true) {
+      if (tid < 64) lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
+      team_sync<WAVE>();
+      if (sm.ist[iACTION] == kActDone) break;
+      if (ring && slice > 0 && sm.ist[iK] - k_start >= slice) { // uniform
+        finished = false;
+        break;
+      }
+      ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
+    }
+    const long long spent = wall_clock64() - tick0;
+    if (finished) {
+      for (int e = tid; e < n; e += T) D.x_out[(size_t)b * n + e] = sm.x[e];
+      if (tid == 0) {
+        const double fx = sm.st[sFX];
+        const int ret = sm.ist[iRET];
+        D.f_out[b] = fx;
+        D.status[b] = ret;
+        D.iters[b] = sm.ist[iK];
+        D.evals[b] = sm.ist[iEVALS];
+        D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+        D.ticks[b] = (resume ? D.ticks[b] : 0) + spent; // time in service
+        int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
+        if (fx >= D.P.fail_cost) ok = 0;
+        D.success[b] = ok;
+        if (ring) {
+          D.sflag[b] = 2;
+          atomicSub(&D.qctl[3], 1u);
+        }
+      }
+    } else {
+      state_io(D, sm, b, tid, sh.nl, true);
+      __threadfence(); // the record and the history rows of this slice are out before the id is handed on
+      if (tid == 0) {
+        D.ticks[b] = (resume ? D.ticks[b] : 0) + spent;
+        D.sflag[b] = 1;
+        ring_push(D.qctl, D.queue, D.qcap, b);
+      }
+    }
+    if (!ring) break;
+    team_sync<WAVE>(); // this pass is done with the team's LDS
   }
 }
 
@@ -1768,12 +1973,12 @@ __global__ void __launch_bounds__(256, (CAP <= 32 && !SUR) ? 2 : 1) ref_kernel(c
 // ---- host side
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
-  if (L.M < 1 || L.n > 64 || L.Npts >= (1 << 26)) return false;
-  if (S < 0 || 5 * L.H + S + 4 > 32) return false; // the mask of a point's active terms has 32 bits (H = 4: up to 8 moving obstacles)
-  if (S > 0 && L.M != 1) return false;              // moving obstacles: one gear segment
+  if (L.M < 1 || L.n > 64 || L.Npts >= (1 << 25)) return false;
+  if (S < 0 || 5 * L.H + S + 4 > 64) return false; // the mask of a point's active terms has 64 bits
   for (int i = 0; i < L.M; i++)
     if (L.piece_nums[i] < 2) return false;
-  const size_t lds = reford::lds_doubles(L, P.mem_size) * sizeof(double) + reford::lds_ints(L) * sizeof(int);
+  const reford::Shape sh = reford::make_shape(L, S, false);
+  const size_t lds = reford::lds_shared_bytes(L) + reford::lds_team_bytes(L, P.mem_size, sh);
   return lds <= 160 * 1024 - 1024;
 }
 // doubles of term records a batch of B trajectories needs
@@ -1783,36 +1988,100 @@ size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
 int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior[sweep][row_mod_6]; }
 
-// Workgroup size: four waves per trajectory while the batch leaves CUs to spare (the parallel stages finish sooner: 70 against
-// 73 ms at batch 32, 133 against 140 at 256); two waves, i.e. four trajectories per CU instead of two, for batches that fill
-// the device -- most of a solve is its serial wave (two-loop recursion, sweeps), so more trajectories per CU is what pays:
-// 654 against 796 ms per 4096.  Same bits either way: no sum depends on the number of waves.
-static int ref_threads(int B) {
-  if (const char *e = std::getenv("DFTPAV_REF_THREADS")) { // developer knob: whole waves, at most the launch bound
-    const int t = std::atoi(e);
-    if (t == 128 || t == 192 || t == 256) return t; // wave 1 has jobs of its own: at least two waves
+// The launch shape of a batch (see the header).  TEAM: four waves per trajectory while the batch leaves CUs to spare (the
+// parallel stages finish sooner: 70 against 73 ms at batch 32, 133 against 140 at 256), two for more.  WAVE: as many waves per
+// workgroup as keep the most trajectories resident on a CU -- 8 waves of 256 registers (4 for the kernels that take 512), the
+// LDS of the shared tables plus a team's part per wave.
+RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu) {
+  RefPlan pl{};
+  const bool narrow = L.n <= 32 && S == 0; // the kernels that fit 256 registers
+  const int max_waves_cu = narrow ? 8 : 4;
+  const reford::Shape sw = reford::make_shape(L, S, true);
+  const size_t shared = reford::lds_shared_bytes(L), team_w = reford::lds_team_bytes(L, P.mem_size, sw);
+  const size_t budget = 160 * 1024;
+  int best_w = 0, best_res = 0, best_wg = 0;
+  for (int w = max_waves_cu; w >= 1; w--) {
+    const size_t lds = shared + (size_t)w * team_w;
+    if (lds > budget) continue;
+    const int wg = (int)std::min<size_t>((size_t)(max_waves_cu / w), budget / lds);
+    if (wg * w >= best_res) { // ties: the smaller workgroup (its waves leave sooner at the end of a launch)
+      best_res = wg * w;
+      best_w = w;
+      best_wg = wg;
+    }
   }
-  return B > 768 ? 128 : 256;
+  bool wave = best_w > 0 && B > 3 * n_cu; // up to three per CU the TEAM shape holds them all at once, each one faster
+  if (const char *e = std::getenv("DFTPAV_REF_SHAPE")) { // developer knob: "team" / "wave"
+    if (e[0] == 't') wave = false;
+    if (e[0] == 'w' && best_w > 0) wave = true;
+  }
+  if (const char *e = std::getenv("DFTPAV_REF_WAVES")) { // developer knob: waves per workgroup in the WAVE shape
+    const int w = std::atoi(e);
+    if (w >= 1 && w <= max_waves_cu && shared + (size_t)w * team_w <= budget) {
+      best_w = w;
+      best_wg = (int)std::min<size_t>((size_t)(max_waves_cu / w), budget / (shared + (size_t)w * team_w));
+    }
+  }
+  pl.wave = wave ? 1 : 0;
+  if (wave) {
+    pl.threads = 64 * best_w;
+    pl.lds = shared + (size_t)best_w * team_w;
+    pl.wg_per_cu = best_wg;
+    pl.slots = n_cu * best_wg; // persistent workgroups of a scheduled solve
+    pl.slice = 128;
+    if (const char *e = std::getenv("DFTPAV_REF_SLICE")) pl.slice = std::atoi(e);
+    if (const char *e = std::getenv("DFTPAV_REF_SLOTS")) pl.slots = std::max(1, std::atoi(e)); // developer knob: persistent workgroups
+  } else {
+    int threads = B > 768 ? 128 : 256;
+    if (const char *e = std::getenv("DFTPAV_REF_THREADS")) { // developer knob: whole waves, at most the launch bound
+      const int t = std::atoi(e);
+      if (t == 128 || t == 192 || t == 256) threads = t; // wave 1 has jobs of its own: at least two waves
+    }
+    const reford::Shape st = reford::make_shape(L, S, false);
+    pl.threads = threads;
+    pl.lds = shared + reford::lds_team_bytes(L, P.mem_size, st);
+    pl.wg_per_cu = 0;
+    pl.slots = 0;
+    pl.slice = 0;
+  }
+  return pl;
 }
-template <int CAP>
-static hipError_t launch_ref_cap(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, size_t lds, hipStream_t stream) {
-  const int threads = ref_threads(D.B);
-  if (D.sur.S > 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((reford::ref_kernel<CAP, true>), dim3(D.B), dim3(threads), lds, stream, d_dev, mode, tabs, scratch);
-    return hipGetLastError();
-  }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+
+template <int CAP, bool SUR, bool WAVE>
+static hipError_t launch_ref_variant(const DevBatch *d_dev, int grid, int threads, size_t lds, int mode, const double *tabs, double *scratch, int source, int slice,
+                                     hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<CAP, SUR, WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((reford::ref_kernel<CAP, false>), dim3(D.B), dim3(threads), lds, stream, d_dev, mode, tabs, scratch);
+  hipLaunchKernelGGL((reford::ref_kernel<CAP, SUR, WAVE>), dim3(grid), dim3(threads), lds, stream, d_dev, mode, tabs, scratch, source, slice);
   return hipGetLastError();
 }
-hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, hipStream_t stream) {
-  const size_t lds = reford::lds_doubles(D.L, D.P.mem_size) * sizeof(double) + reford::lds_ints(D.L) * sizeof(int);
-  if (D.L.n <= 16) return launch_ref_cap<16>(D, d_dev, mode, tabs, scratch, lds, stream);
-  if (D.L.n <= 32) return launch_ref_cap<32>(D, d_dev, mode, tabs, scratch, lds, stream);
-  return launch_ref_cap<64>(D, d_dev, mode, tabs, scratch, lds, stream);
+template <int CAP>
+static hipError_t launch_ref_cap(bool sur, bool wave, const DevBatch *d_dev, int grid, int threads, size_t lds, int mode, const double *tabs, double *scratch,
+                                 int source, int slice, hipStream_t stream) {
+  if (sur) {
+    if (wave) return launch_ref_variant<CAP, true, true>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
+    return launch_ref_variant<CAP, true, false>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
+  }
+  if (wave) return launch_ref_variant<CAP, false, true>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
+  return launch_ref_variant<CAP, false, false>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
+}
+// scheduled != 0: a solve in the WAVE shape whose waves pop from the batch's ring (the caller has reset it)
+hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
+                             hipStream_t stream) {
+  const bool wave = pl.wave != 0, sur = D.sur.S > 0;
+  const int W = pl.threads / 64;
+  int grid = wave ? (D.B + W - 1) / W : D.B, source = 0, slice = 0;
+  if (wave && scheduled && mode == kModeSolve) {
+    grid = pl.slots < grid ? pl.slots : grid;
+    source = 1;
+    slice = pl.slice;
+  }
+  if (std::getenv("DFTPAV_VERBOSE"))
+    std::fprintf(stderr, "[dftpav] reference order, %s shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", wave ? "WAVE" : "TEAM", grid, pl.threads,
+                 pl.lds, source, slice);
+  if (D.L.n <= 16) return launch_ref_cap<16>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  if (D.L.n <= 32) return launch_ref_cap<32>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  return launch_ref_cap<64>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
 }
 
 } // namespace dftpav

@@ -143,21 +143,161 @@ def test_moving_obstacles_in_reference_order(hiplib, oracle):
         assert r["success"].all()
         bt.close()
         h.close()
-    # more obstacles than the 32-bit term mask holds (5 H + S + 4 <= 32), or a gear shift with obstacles: the device order
+
+
+def _live_case(layout, B, seed):
+    """gear shifts AND moving obstacles in one call -- what the reference's only live caller passes (traj_manager.cpp:604-610):
+    the four cars of dynamicObs.yaml around a multi-segment layout"""
+    pieces, sing = layout
+    s = sc.make_scenario(pieces, sing, 12, 16, B, seed=seed, with_moving=True, n_obs=25, start_centre=(-38.0, 5.0))
+    s.surround.start_time[:] = [0.5, 0.0, 1.5, 0.25]     # obstacle clocks that differ from the ego's (OPT:1367-1369)
+    s.t_now = 0.6
+    return s
+
+
+@pytest.mark.parametrize("layout,seed", [(([7, 6], [1, -1]), 81), (([5, 4, 6], [1, -1, 1]), 82)])
+def test_gear_shifts_with_moving_obstacles_in_reference_order(hiplib, oracle, layout, seed):
+    """The reference's live case: dynamicObsGradCostP inside a multi-segment solve.  This is where two quirks of the
+    reference matter: trajtimes[i] is the duration of segment i - 1, not the time since the start (traj_optimizer.cpp:230-234,
+    291, 1367-1369), and a moving-obstacle term of segment `trajid` adds `trajid` more addends to that segment's gdT
+    (:1674-1676).  Bar: 64 trajectories, every evaluation and every whole solve bit-equal to oracle order 2 (the reference's
+    program with correctly rounded cos / sin / exp / log / pow); every evaluation within 1e-12 of the reference BUILD
+    (oracle/_ref, libm's bits) where it travelled; the moving-obstacle term active."""
+    B = 64
     p = hiplib.default_params()
-    s = sc.baseline_config(2, B=1)
+    s = _live_case(layout, B, seed)
     s.apply_resolution(p)
-    s5 = sc.baseline_config(5, B=1)
     h = hiplib.Handle(p)
-    h.set_surround(s5.surround)
-    bt = hiplib.Batch(h, s.layout, 1)
+    h.set_surround(s.surround)
+    bt = hiplib.Batch(h, s.layout, s.B)
     bt.upload(s)
-    with pytest.raises(hiplib.DftpavError) as e:
-        bt.set_order(hiplib.ORDER_REFERENCE)
-    assert e.value.code == hiplib.E_UNSUPPORTED
-    assert bt.solve()["success"].all()
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    pyref = _ref()
+    x0 = bt.x0()
+    rng = np.random.default_rng(seed)
+    active = later_segment_active = 0
+    for x in (x0, x0 + rng.normal(0, 0.25, x0.shape)):
+        f, g = bt.eval(x)
+        for b in range(B):
+            o2 = oracle.OracleProblem(p, s, b, order=2)
+            f2, g2 = o2.eval(x[b])
+            assert f[b] == f2 and np.array_equal(g[b], g2), (layout, b, f[b], f2, np.abs(g[b] - g2).max())
+            active += o2.cost_terms()[3] > 0.0
+            if pyref and b < 16:
+                fr, gr = pyref.RefProblem(p, s, b).eval(x[b])
+                assert abs(f[b] - fr) <= 1e-12 * abs(fr), (layout, b, f[b], fr)
+                assert np.abs(g[b] - gr).max() <= 1e-12 * max(1.0, np.abs(gr).max())
+    assert active > B // 4, active   # the moving-obstacle term is active on a good part of the batch
+    r = bt.solve()
+    want = oracle.solve_batch(p, s, nthreads=8, order=2)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], want[k]), (layout, k)
     bt.close()
     h.close()
+
+
+def test_configs4_in_reference_order_at_batch_64(hiplib, oracle):
+    """BASELINE configs[4] (32 pieces x 65 points, four moving cars), 64 trajectories: whole solves bit-equal to order 2"""
+    p = hiplib.default_params()
+    s = sc.baseline_config(5, B=64)
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    h.set_surround(s.surround)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    r = bt.solve()
+    want = oracle.solve_batch(p, s, nthreads=8, order=2)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], want[k]), k
+    assert r["success"].all()
+    bt.close()
+    h.close()
+
+
+def test_more_than_eight_moving_obstacles(hiplib, oracle):
+    """5 H + S + 4 > 32 terms per constraint point: the 64-bit term mask (12 obstacles: the four cars three times, shifted)"""
+    from dftpav_amd.pods import SurroundSet
+    p = hiplib.default_params()
+    s = sc.make_scenario([10], [1], 8, 8, 8, seed=90, with_moving=True, n_obs=10, start_centre=(-38.0, 5.0))
+    sur, reps = s.surround, 3
+    npieces = int(sur.piece_offsets[-1])
+    offs = np.concatenate([[0]] + [sur.piece_offsets[1:] + k * npieces for k in range(reps)])
+    coeffs = np.concatenate([sur.coeffs] * reps).copy()
+    for k in range(1, reps):    # shift the copies sideways: the constant terms of x / y (Piece::coeffMat column 5: entries 10, 11)
+        coeffs[k * npieces:(k + 1) * npieces, 10] += 0.7 * k
+        coeffs[k * npieces:(k + 1) * npieces, 11] -= 0.4 * k
+    s.surround = SurroundSet(offs, np.concatenate([sur.durations] * reps), coeffs, np.concatenate([sur.total_duration] * reps),
+                             np.concatenate([sur.start_time + 0.3 * k for k in range(reps)]))
+    assert s.surround.S == 12
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    h.set_surround(s.surround)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    x = bt.x0() + np.random.default_rng(1).normal(0, 0.2, bt.x0().shape)
+    f, g = bt.eval(x)
+    for b in range(s.B):
+        f2, g2 = oracle.OracleProblem(p, s, b, order=2).eval(x[b])
+        assert f[b] == f2 and np.array_equal(g[b], g2), b
+    r = bt.solve()
+    want = oracle.solve_batch(p, s, nthreads=8, order=2)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], want[k]), k
+    bt.close()
+    h.close()
+
+
+@pytest.mark.parametrize("case", ["cfg3", "cfg2", "cfg5", "live"])
+def test_wave_shape_and_ring_are_bit_identical(hiplib, oracle, monkeypatch, case):
+    """The throughput shape of the reference order -- one WAVE per trajectory, the waves of a workgroup sharing the sweep tables,
+    trajectories popped from the batch's ring and suspended after a slice of iterations (solver_ref.hip) -- forced on small
+    batches with 2 persistent workgroups and slices of 3 and 17 iterations: every field of every solve equal to the latency
+    shape's and to the oracle's (no sum depends on the shape; suspending and resuming moves no bit)."""
+    p = hiplib.default_params()
+    if case == "cfg3":
+        s, order = sc.baseline_config(3, B=40), 0
+    elif case == "cfg2":
+        s, order = sc.baseline_config(2, B=24), 2
+    elif case == "cfg5":
+        s, order = sc.baseline_config(5, B=10), 2
+    else:
+        s, order = _live_case(([5, 4, 6], [1, -1, 1]), 20, 83), 2
+    s.apply_resolution(p)
+    want = oracle.solve_batch(p, s, nthreads=8, order=order)
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    x = None
+    for slice_ in (3, 17):
+        monkeypatch.setenv("DFTPAV_REF_SHAPE", "wave")
+        monkeypatch.setenv("DFTPAV_REF_SLOTS", "2")
+        monkeypatch.setenv("DFTPAV_REF_SLICE", str(slice_))
+        h = hiplib.Handle(p)
+        if s.surround is not None:
+            h.set_surround(s.surround)
+        bt = hiplib.Batch(h, s.layout, s.B)
+        bt.upload(s)
+        bt.set_order(hiplib.ORDER_REFERENCE)
+        if x is None:
+            x = bt.x0() + np.random.default_rng(4).normal(0, 0.2, bt.x0().shape)
+        f, g = bt.eval(x)                      # evaluations in the WAVE shape (static assignment of waves)
+        for b in range(0, s.B, 5):
+            fo, go = oracle.OracleProblem(p, s, b, order=order).eval(x[b])
+            assert f[b] == fo and np.array_equal(g[b], go), (case, b)
+        for rep in range(2):                   # twice: the ring is reset by every solve
+            r = bt.solve()
+            for k in keys:
+                assert np.array_equal(r[k], want[k]), (case, slice_, rep, k)
+        c, dt = bt.coeffs()
+        lp = oracle.OracleProblem(p, s, s.B - 1, order=order)
+        lp.eval(r["x"][s.B - 1])
+        co, dto = lp.coeffs()
+        assert np.array_equal(c[s.B - 1], co) and np.array_equal(dt[s.B - 1], dto)
+        bt.close()
+        h.close()
+    monkeypatch.delenv("DFTPAV_REF_SHAPE")
+    monkeypatch.delenv("DFTPAV_REF_SLOTS")
+    monkeypatch.delenv("DFTPAV_REF_SLICE")
 
 
 def test_gear_shifts_in_reference_order(hiplib, oracle):
