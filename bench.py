@@ -160,7 +160,7 @@ def main():
             (dftpav_batch_solve_chained), the last batch is flushed in the latency shape.
           plain: isolated solves, a step waits for its own batch."""
 
-        def __init__(self, B_total, config, seed, depth=2, residency=None):
+        def __init__(self, B_total, config, seed, depth=2, residency=None, order=None):
             # every rank generates its own shard from (seed, rank) — trajectories are independent, nothing is scattered
             # (SURVEY §8e); rank r owns global trajectories [r*B/G, (r+1)*B/G)
             # depth: resident batches = steps in flight (overlap schedule only; 2 for the value line).  A shard too small to
@@ -184,6 +184,8 @@ def main():
             for hh, sh in zip(self.hs, self.shards):
                 b_ = capi.Batch(hh, sh.layout, sh.B) if residency is None else capi.Batch(hh, sh.layout, sh.B, residency=residency)
                 b_.upload(sh)  # resident in HBM from here on
+                if order is not None:   # capi.ORDER_REFERENCE: the same stream of cycles in the reference's floating-point order
+                    b_.set_order(order)
                 if schedule == "overlap":
                     b_.set_hand_over(0)
                 self.bts.append(b_)
@@ -715,7 +717,33 @@ def main():
                         ro["against_reference_build"] = {"trajectories": int(n_ref), "bit_equal": int(sum(eq_ref))}
                     if "isolated" in out:
                         ro["slowdown_vs_device_order_isolated"] = ref_ms / out["isolated"]["kernel_ms"]
+                    ro["isolated_solves_per_s"] = ro["solves_per_s"]
                     out["parity"]["reference_order"] = ro
+                    # the same stream of planning cycles as the value line -- two resident batches on two HIP streams, one launched
+                    # while the other thins out -- in the REFERENCE'S order: the throughput of the bit-equal mode
+                    try:
+                        bR.close(); hR.close()
+                        bR = hR = None
+                        stR = Stream(B_total, args.config, args.seed, depth=2, order=capi.ORDER_REFERENCE)
+                        k_ref = max(4, min(args.steps, 8))
+                        rR = stR.run(k_ref, 2)
+                        same = all(np.array_equal(rR["rs"][i_]["final_cost"], po_) for i_, po_ in [(0, ref_gpu["final_cost"])]) if stR.shards[0].B == shard.B else None
+                        ro["overlapped"] = {"solves_per_s": rR["value"], "ms_per_step": rR["ms_per_step"], "steps": k_ref, "warmup": 2,
+                                            "schedule": schedule, "first_batch_equals_the_isolated_solve": same}
+                        ro["solves_per_s"] = rR["value"]
+                        ro["solves_per_s_is"] = "the overlapped stream of %d steps (as the value line); isolated_solves_per_s: one batch alone" % k_ref
+                        stR.close()
+                        hR = capi.Handle(params, device=local_rank)
+                        bR = capi.Batch(hR, shard.layout, shard.B)
+                        bR.upload(shard)
+                        bR.set_order(capi.ORDER_REFERENCE)
+                    except capi.DftpavError as ex:
+                        ro["overlapped"] = {"failed": str(ex)}
+                        if bR is None:
+                            hR = capi.Handle(params, device=local_rank)
+                            bR = capi.Batch(hR, shard.layout, shard.B)
+                            bR.upload(shard)
+                            bR.set_order(capi.ORDER_REFERENCE)
                     # (3) device order against the reference over the WHOLE batch, with the reference-order solves standing for the
                     # reference (they are it, bit for bit): the solver is chaotic, so the two follow different iterate
                     # sequences after the first rounding difference; the question is whether the device order is BIASED.  Control: the

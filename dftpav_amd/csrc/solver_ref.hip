@@ -46,6 +46,12 @@
 #include "device_types.h"
 #include "cr_trig.h"
 
+#ifndef DFTPAV_REF_TL_ATTR
+#define DFTPAV_REF_TL_ATTR __noinline__   // the two-loop recursion as a function of its own (see two_loop)
+#endif
+#ifndef DFTPAV_REF_EVAL_ATTR
+#define DFTPAV_REF_EVAL_ATTR __forceinline__
+#endif
 #ifndef DFTPAV_REF_SUM_ALL_LANES
 #define DFTPAV_REF_SUM_ALL_LANES 1 // measured: the chain on one lane + broadcast costs 637 cycles per history step against 546
 #endif
@@ -114,6 +120,9 @@ struct Prof {
     if (on && !resume)
       for (int i = 0; i < 12; i++) acc[i] = 0;
     last = on ? clock64() : 0;
+  }
+  __device__ inline void count(int i, long long v) {
+    if (on) acc[i] += v;
   }
   __device__ inline void tick(int i) {
     if (on) {
@@ -953,7 +962,7 @@ __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double c
 // x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].  The gear segments are independent
 // up to the sums of :292-297 and the junction variables' gradients (:307-320), so every stage runs them side by side.
 template <bool SUR, bool WAVE>
-__device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
+__device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
   // the team: the workgroup, or (WAVE) this wave alone.  Stages with two independent jobs give the second one to the lanes of
@@ -1155,6 +1164,8 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
   const int n_act = sm.first(Npts);
   const int n_chain = 12 * Ntot + 4 * M;
   const int cap = sm.list_cap;
+  pr.tick(10);     // numbering
+  pr.count(9, n_act); // active terms of this evaluation (a count, not cycles)
   for (int c0 = 0; c0 < n_act; c0 += cap) {
     const int c1 = c0 + cap < n_act ? c0 + cap : n_act;
     for (int pt = tid; pt < Npts; pt += T) {
@@ -1168,6 +1179,7 @@ __device__ __forceinline__ void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t re
       }
     }
     team_sync<WAVE>();
+    pr.tick(11);   // the window's list
     for (int w = tid; w < n_chain; w += T) {
       int e0, e1, q, kind = -1, csg = 0;
       ldsd_t dst;
@@ -1441,14 +1453,14 @@ __device__ __forceinline__ void pin_blk(HistBlk &R) {
 }
 // kPB steps of the first loop (lbfgs.hpp:722-726): alpha_j = s_j . d / ys_j ; d -= alpha_j y_j
 template <int CAP>
-__device__ __forceinline__ void first_steps(const HistBlk &R, const Sm &sm, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
+__device__ __forceinline__ void first_steps(const HistBlk &R, ldsd_t dot_buf, ldsd_t alpha_buf, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
 #pragma unroll
   for (int u = 0; u < kPB; u++) {
     if (i0 + u < bound) { // uniform
       j = j == 0 ? m - 1 : j - 1;
-      const double dot = seq_sum<CAP>(R.sy[u].x * dreg, n, sm.dot, lane);
+      const double dot = seq_sum<CAP>(R.sy[u].x * dreg, n, dot_buf, lane);
       const double a = div_by_rcp(dot, R.yr[u].x, R.yr[u].y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
-      if (lane == 0) sm.alpha[j] = a;
+      if (lane == 0) alpha_buf[j] = a;
       const double na = -a;
       dreg = dreg + na * R.sy[u].y; // d += (-alpha) * lm_y.col(j)
     }
@@ -1456,26 +1468,74 @@ __device__ __forceinline__ void first_steps(const HistBlk &R, const Sm &sm, int 
 }
 // kPB steps of the second loop (lbfgs.hpp:732-738): beta = y_j . d / ys_j ; d += (alpha_j - beta) s_j
 template <int CAP>
-__device__ __forceinline__ void second_steps(const HistBlk &R, const Sm &sm, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
+__device__ __forceinline__ void second_steps(const HistBlk &R, ldsd_t dot_buf, ldsd_t alpha_buf, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
   double al[kPB];
   {
     int jj = j;
 #pragma unroll
     for (int u = 0; u < kPB; u++) {
-      al[u] = sm.alpha[jj];
+      al[u] = alpha_buf[jj];
       jj = jj == m - 1 ? 0 : jj + 1;
     }
   }
 #pragma unroll
   for (int u = 0; u < kPB; u++) {
     if (i0 + u < bound) { // uniform
-      const double dot = seq_sum<CAP>(R.sy[u].y * dreg, n, sm.dot, lane);
+      const double dot = seq_sum<CAP>(R.sy[u].y * dreg, n, dot_buf, lane);
       const double beta = div_by_rcp(dot, R.yr[u].x, R.yr[u].y);
       const double cf = al[u] - beta;
       dreg = dreg + cf * R.sy[u].x; // d += (alpha - beta) * lm_s.col(j)
       j = j == m - 1 ? 0 : j + 1;
     }
   }
+}
+
+// The two-loop recursion (lbfgs.hpp:716-739) over `bound` stored pairs, the newest in slot ne - 1: d = -g on entry (lanes >= n:
+// 0.0), H0 = ys / yy between the loops.  A function of its own: its registers -- two history blocks in flight, the 32 values of
+// a sequential sum -- are then allocated for it alone, not squeezed between whatever the rest of the kernel keeps live (inlined,
+// the cost of a history step moved between 850 and 1850 cycles with unrelated edits elsewhere in the kernel).
+template <int CAP>
+__device__ DFTPAV_REF_TL_ATTR double two_loop(ldsd_t dot_buf_, ldsd_t alpha_buf_, gcd2_t cS_, gcd2_t cR_, int npad_, int m_, int n_, int lane, int bound_, int ne_,
+                                             double dreg, double sc0) {
+  // arguments of an out-of-line function arrive in vector registers: everything but the lane's own values is the same in every
+  // lane -- say so, and the loop control, the addresses and the branches below are scalar again
+  const int npad = __builtin_amdgcn_readfirstlane(npad_), m = __builtin_amdgcn_readfirstlane(m_), n = __builtin_amdgcn_readfirstlane(n_);
+  const int bound = __builtin_amdgcn_readfirstlane(bound_), ne = __builtin_amdgcn_readfirstlane(ne_);
+  const ldsd_t dot_buf = (ldsd_t)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)dot_buf_);
+  const ldsd_t alpha_buf = (ldsd_t)(size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)alpha_buf_);
+  const unsigned long long cS_u = (unsigned long long)cS_, cR_u = (unsigned long long)cR_;
+  const gcd2_t cS = (gcd2_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cS_u >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(cS_u & 0xffffffffull)));
+  const gcd2_t cR = (gcd2_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cR_u >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(cR_u & 0xffffffffull)));
+  const int ln = lane < n ? lane : 0;
+  HistBlk A, B;
+  // first loop: newest -> oldest (slots ne-1, ne-2, ...)
+  int j = ne;
+  int jl = ne == 0 ? m - 1 : ne - 1;
+  load_blk<-1>(A, cS, cR, npad, m, ln, jl);
+  for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
+    pin_blk(A);
+    load_blk<-1>(B, cS, cR, npad, m, ln, jl);
+    first_steps<CAP>(A, dot_buf, alpha_buf, i0, bound, m, n, lane, j, dreg);
+    pin_blk(B);
+    load_blk<-1>(A, cS, cR, npad, m, ln, jl);
+    first_steps<CAP>(B, dot_buf, alpha_buf, i0 + kPB, bound, m, n, lane, j, dreg);
+  }
+  dreg = dreg * sc0;
+  wave_lds_order(); // alpha written by lane 0, read by all below
+  // second loop: oldest -> newest, from the slot the first loop ended on
+  jl = j;
+  load_blk<+1>(A, cS, cR, npad, m, ln, jl);
+  for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
+    pin_blk(A);
+    load_blk<+1>(B, cS, cR, npad, m, ln, jl);
+    second_steps<CAP>(A, dot_buf, alpha_buf, i0, bound, m, n, lane, j, dreg);
+    pin_blk(B);
+    load_blk<+1>(A, cS, cR, npad, m, ln, jl);
+    second_steps<CAP>(B, dot_buf, alpha_buf, i0 + kPB, bound, m, n, lane, j, dreg);
+  }
+  return dreg;
 }
 
 // Start of an outer iteration (lbfgs.hpp:559-574, 290-315): xp = x, gp = g, dginit = gp . d, first trial point
@@ -1731,35 +1791,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     const int ne = end + 1 == m ? 0 : end + 1;
     __threadfence_block(); // lane 0's (ys, 1 / ys) of the newest pair is read by every lane below
     double dreg = lane < n ? -sm.g[lane] : 0.0;
-    const int ln = lane < n ? lane : 0;
-    const gcd2_t cS = (gcd2_t)hS, cR = (gcd2_t)hR;
-    HistBlk A, B;
-    // first loop: newest -> oldest (slots ne-1, ne-2, ...)
-    int j = ne;
-    int jl = ne == 0 ? m - 1 : ne - 1;
-    load_blk<-1>(A, cS, cR, npad, m, ln, jl);
-    for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
-      pin_blk(A);
-      load_blk<-1>(B, cS, cR, npad, m, ln, jl);
-      first_steps<CAP>(A, sm, i0, bound, m, n, lane, j, dreg);
-      pin_blk(B);
-      load_blk<-1>(A, cS, cR, npad, m, ln, jl);
-      first_steps<CAP>(B, sm, i0 + kPB, bound, m, n, lane, j, dreg);
-    }
-    const double sc0 = ys / yy;
-    dreg = dreg * sc0;
-    wave_lds_order(); // alpha written by lane 0, read by all below
-    // second loop: oldest -> newest, from the slot the first loop ended on
-    jl = j;
-    load_blk<+1>(A, cS, cR, npad, m, ln, jl);
-    for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
-      pin_blk(A);
-      load_blk<+1>(B, cS, cR, npad, m, ln, jl);
-      second_steps<CAP>(A, sm, i0, bound, m, n, lane, j, dreg);
-      pin_blk(B);
-      load_blk<+1>(A, cS, cR, npad, m, ln, jl);
-      second_steps<CAP>(B, sm, i0 + kPB, bound, m, n, lane, j, dreg);
-    }
+    dreg = two_loop<CAP>(sm.dot, sm.alpha, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, lane, bound, ne, dreg, ys / yy);
     if (lane < n) sm.d[lane] = dreg;
     if (lane == 0) {
       sm.ist[iEND] = ne;
@@ -1911,20 +1943,25 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
     team_sync<WAVE>();
     const int k_start = sm.ist[iK];
 
-    ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr); // x0, or the trial point the trajectory was suspended on
-
-    if (mode == kModeEval) {
-      for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
-      if (tid == 0) D.f_eval[b] = sm.st[sF];
-      return;
-    }
-    if (mode == kModeCoeffs) {
-      for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
-      for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[16 * sg + 1];
-      return;
-    }
     bool finished = true;
-    while (true) {
+#ifdef DFTPAV_REF_TWO_CALLS
+    ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
+    for (bool first = true;; first = false) {
+      if (!first) ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
+#else
+    while (true) { // (one call site of the evaluation: the kernel is instruction-cache-sized as it is)
+      ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr); // x0 / the trial point the trajectory was suspended on / the next trial point
+#endif
+      if (mode == kModeEval) {
+        for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
+        if (tid == 0) D.f_eval[b] = sm.st[sF];
+        return;
+      }
+      if (mode == kModeCoeffs) {
+        for (int w = tid; w < 12 * L.Ntot; w += T) D.coef_out[(size_t)b * 12 * L.Ntot + w] = sm.c[w];
+        for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[16 * sg + 1];
+        return;
+      }
       if (tid < 64) lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
       team_sync<WAVE>();
       if (sm.ist[iACTION] == kActDone) break;
@@ -1932,7 +1969,6 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
         finished = false;
         break;
       }
-      ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr);
     }
     const long long spent = wall_clock64() - tick0;
     if (finished) {

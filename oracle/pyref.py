@@ -17,6 +17,10 @@ from oracle.pyoracle import EVAL_FN, Problem
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_ref", "libdftpav_ref.so")
 _LIB = None
+# the same driver linked against the DROP-IN's implementation of the reference's class (oracle/Makefile.dropin:
+# dftpav_amd/csrc/host/dropin/traj_optimizer_hip.cpp over libdftpav_hip.so) -- needs a GPU at run time
+_SO_DROPIN = os.path.join(_HERE, "_ref", "libdftpav_dropin.so")
+_LIB_DROPIN = None
 
 
 def build():
@@ -27,6 +31,44 @@ def build():
 
 def available():
     return os.path.exists(_SO)
+
+
+def dropin_available():
+    return os.path.exists(_SO_DROPIN)
+
+
+def build_dropin():
+    subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.dropin", "-s"])
+    return _SO_DROPIN
+
+
+def dropin_lib():
+    """The reference's PolyTrajOptimizer class with the drop-in's implementation behind it (GPU)."""
+    global _LIB_DROPIN
+    if _LIB_DROPIN is None:
+        if not dropin_available():
+            build_dropin()
+        L = C.CDLL(_SO_DROPIN)
+        _bind_common(L)
+        assert L.ref_is_dropin() == 1
+        _LIB_DROPIN = L
+    return _LIB_DROPIN
+
+
+def _bind_common(L):
+    L.ref_prepare.restype = C.c_void_p
+    L.ref_prepare.argtypes = [C.POINTER(Params), C.POINTER(Problem)]
+    L.ref_free.argtypes = [C.c_void_p]
+    L.ref_optimize.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p]
+    L.ref_num_vars.argtypes = [C.c_void_p]
+    L.ref_trace_num_evals.argtypes = [C.c_void_p]
+    L.ref_trace_num_iters.argtypes = [C.c_void_p]
+    L.ref_trace_evals.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
+    L.ref_trace_iters.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_int_p, c_int_p]
+    L.ref_eval.restype = C.c_double
+    L.ref_eval.argtypes = [C.c_void_p, c_double_p, c_double_p]
+    L.ref_last_coeffs.argtypes = [C.c_void_p, c_double_p, c_double_p]
+    L.ref_surround_state.argtypes = [C.c_void_p, C.c_int, C.c_double, c_double_p]
 
 
 def lib():
@@ -62,10 +104,12 @@ def lib():
 
 
 class RefProblem:
-    """PolyTrajOptimizer of the reference on element b of a Scenario (same inputs as oracle.pyoracle.OracleProblem)."""
+    """PolyTrajOptimizer of the reference on element b of a Scenario (same inputs as oracle.pyoracle.OracleProblem).
+    dropin=True: the same class object with the drop-in's implementation behind it (libdftpav_dropin.so, GPU)."""
 
-    def __init__(self, params, scen, b=0):
+    def __init__(self, params, scen, b=0, dropin=False):
         from oracle.pyoracle import OracleProblem
+        self._L = dropin_lib() if dropin else lib()
         # reuse the flattening of the oracle's wrapper (plain arrays; nothing of the oracle's arithmetic is involved)
         self._flat = OracleProblem.__new__(OracleProblem)
         lay = scen.layout
@@ -88,27 +132,27 @@ class RefProblem:
         pb.surround = C.pointer(self._sur) if self._sur is not None else None
         self._keep, self.pb, self.scen = keep, pb, scen
         self.n = lay.n_vars
-        self.ctx = lib().ref_prepare(C.byref(params), C.byref(pb))
+        self.ctx = self._L.ref_prepare(C.byref(params), C.byref(pb))
         self.result = None
 
     def __del__(self):
-        if getattr(self, "ctx", None):
-            lib().ref_free(self.ctx)
+        if getattr(self, "ctx", None) and getattr(self, "_L", None) is not None:
+            self._L.ref_free(self.ctx)
             self.ctx = None
 
     def optimize(self, trace=False):
         """OptimizeTrajectory.  Returns dict(ok, x, final_cost, status, iters, evals) (+ trace arrays)."""
         x = np.zeros(self.n)
         f, st, it, ev = C.c_double(0), C.c_int(0), C.c_int(0), C.c_int(0)
-        ok = lib().ref_optimize(self.ctx, int(trace), dptr(x), C.byref(f), C.byref(st), C.byref(it), C.byref(ev))
+        ok = self._L.ref_optimize(self.ctx, int(trace), dptr(x), C.byref(f), C.byref(st), C.byref(it), C.byref(ev))
         r = dict(ok=bool(ok), x=x, final_cost=f.value, status=st.value, iters=it.value, evals=ev.value)
         if trace:
-            ne, ni = lib().ref_trace_num_evals(self.ctx), lib().ref_trace_num_iters(self.ctx)
+            ne, ni = self._L.ref_trace_num_evals(self.ctx), self._L.ref_trace_num_iters(self.ctx)
             ex, eg, ef = np.zeros((ne, self.n)), np.zeros((ne, self.n)), np.zeros(ne)
-            lib().ref_trace_evals(self.ctx, dptr(ex), dptr(eg), dptr(ef))
+            self._L.ref_trace_evals(self.ctx, dptr(ex), dptr(eg), dptr(ef))
             ix, ig, ifx, istp = np.zeros((ni, self.n)), np.zeros((ni, self.n)), np.zeros(ni), np.zeros(ni)
             ik, ils = np.zeros(ni, dtype=np.int32), np.zeros(ni, dtype=np.int32)
-            lib().ref_trace_iters(self.ctx, dptr(ix), dptr(ig), dptr(ifx), dptr(istp), iptr(ik), iptr(ils))
+            self._L.ref_trace_iters(self.ctx, dptr(ix), dptr(ig), dptr(ifx), dptr(istp), iptr(ik), iptr(ils))
             r.update(eval_x=ex, eval_g=eg, eval_f=ef, iter_x=ix, iter_g=ig, iter_fx=ifx, iter_step=istp, iter_k=ik, iter_ls=ils)
         self.result = r
         return r
@@ -119,18 +163,18 @@ class RefProblem:
             self.optimize()
         x = np.ascontiguousarray(x, dtype=np.float64)
         g = np.zeros(self.n)
-        f = lib().ref_eval(self.ctx, dptr(x), dptr(g))
+        f = self._L.ref_eval(self.ctx, dptr(x), dptr(g))
         return f, g
 
     def coeffs(self):
         c = np.zeros((self.scen.layout.n_pieces, 6, 2))
         dt = np.zeros(self.scen.layout.M)
-        lib().ref_last_coeffs(self.ctx, dptr(c), dptr(dt))
+        self._L.ref_last_coeffs(self.ctx, dptr(c), dptr(dt))
         return c, dt
 
     def surround_state(self, o, t):
         out = np.zeros(14)
-        lib().ref_surround_state(self.ctx, int(o), float(t), dptr(out))
+        self._L.ref_surround_state(self.ctx, int(o), float(t), dptr(out))
         return out
 
 

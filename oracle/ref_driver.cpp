@@ -8,6 +8,12 @@
 // against the interface stand-ins under oracle/ref_shim/ (Eigen, ROS, protobuf config: none is installed here).
 // It computes nothing itself.  `#define private public` gives the tests access to costFunctionCallback and the time maps
 // (private in traj_optimizer.h:125-148); it changes no layout and no code.
+//
+// With -DDFTPAV_DROPIN (oracle/Makefile.dropin) the same driver is linked against the DROP-IN's implementation of the class
+// (dftpav_amd/csrc/host/dropin/traj_optimizer_hip.cpp over libdftpav_hip.so) instead of the reference's traj_optimizer.cpp:
+// the same calls on the same object -- setParam, setSurroundTrajs, OptimizeTrajectory, costFunctionCallback,
+// getMinJerkOptPtr -- then run on the GPU.  What OptimizeTrajectory keeps in locals comes from the drop-in's accessor there
+// (no lbfgs_optimize call site to observe); the hooks on private helpers the drop-in does not have are left out.
 #include <sstream>
 #define private public
 #include "plan_manage/traj_optimizer.h"
@@ -16,6 +22,9 @@
 #include "dftpav_oracle.h"
 
 using plan_manage::PolyTrajOptimizer;
+#ifdef DFTPAV_DROPIN
+extern "C" int dftpav_dropin_last_solve(const void *optimizer, int *n, const double **x, double *final_cost, int *status, int *iters, int *evals, int *order);
+#endif
 
 namespace {
 struct Quiet {  // the reference prints its progress on std::cout (traj_optimizer.cpp:34,144,154,168)
@@ -104,6 +113,11 @@ double bridge_eval(void *b, const Eigen::VectorXd &x, Eigen::VectorXd &g) {
 extern "C" {
 
 int ref_abi_version(void) { return 1; }
+#ifdef DFTPAV_DROPIN
+int ref_is_dropin(void) { return 1; }
+#else
+int ref_is_dropin(void) { return 0; }
+#endif
 
 /* Builds the argument objects of OptimizeTrajectory (traj_optimizer.h:118-120) from the flat problem. */
 void *ref_prepare(const dftpav_params *p, const oracle_problem *pb) {
@@ -179,6 +193,23 @@ int ref_optimize(void *h, int trace, double *x_out, double *final_cost, int *sta
   std::vector<std::vector<Eigen::MatrixXd>> hp = c->hpolys;
   bool ok = c->opt.OptimizeTrajectory(c->ini, c->fin, inner, c->Ts, hp, c->singuls, c->t_now, c->help_eps);
   dftpav_ref::current_record() = nullptr;
+#ifdef DFTPAV_DROPIN
+  {  // the drop-in has no lbfgs_optimize call site to observe: its accessor returns what the device solve left
+    int n = 0, st = 0, it = 0, ev = 0, order = 0;
+    const double *xs = nullptr;
+    double fc = 0.0;
+    c->solved = dftpav_dropin_last_solve(&c->opt, &n, &xs, &fc, &st, &it, &ev, &order) != 0;
+    c->success = ok;
+    c->n = c->opt.variable_num_;
+    if (!c->solved) return ok ? 1 : 0;
+    if (x_out) std::memcpy(x_out, xs, sizeof(double) * n);
+    if (final_cost) *final_cost = fc;
+    if (status) *status = st;
+    if (iters) *iters = it;
+    if (evals) *evals = ev;
+    return ok ? 1 : 0;
+  }
+#endif
   c->solved = c->rec.have;
   c->success = ok;
   c->n = c->opt.variable_num_;
@@ -308,6 +339,7 @@ void ref_surround_state(void *h, int o, double t, double *out) {
   std::memcpy(out + 10, Rd.data(), 4 * sizeof(double));
 }
 
+#ifndef DFTPAV_DROPIN
 /* positiveSmoothedL1, traj_optimizer.cpp:783-806 */
 void ref_smoothed_l1(const dftpav_params *p, double x, double *f, double *df) {
   PolyTrajOptimizer o;
@@ -331,4 +363,5 @@ double ref_log_sum_exp(double alpha, int n, double *dists, double *exp_sum) {
   std::memcpy(dists, d.data(), sizeof(double) * n);
   return r;
 }
+#endif  // !DFTPAV_DROPIN
 }  // extern "C"
