@@ -135,7 +135,7 @@ struct Prof {
 
 constexpr int kRec = 16;            // doubles per term record: 12 entries of gdC, gdT, cost, 2 more gdT addends of a moving-obstacle term
 constexpr int kListCapTeam = 1024;  // active terms chained per window (TEAM shape)
-constexpr int kListCapWave = 256;   // ... (WAVE shape: LDS is what limits the trajectories per CU)
+constexpr int kRecWave = 32;        // WAVE shape: records kept in LDS per evaluation (LDS is what limits the trajectories per CU)
 
 typedef unsigned long long mask_t;  // active terms of a constraint point, bit t = term t (5 H + S + 4 <= 64 terms)
 typedef unsigned short __attribute__((address_space(3))) *ldsh_t;
@@ -148,7 +148,8 @@ struct Shape {
   int nl;       // doubles per solver vector in LDS
   int mw;       // 32-bit words of a point's term mask (1: up to 32 terms, 2: up to 64)
   int pf16;     // the running numbers of the active terms fit 16 bits
-  int list_cap; // window of the chain pass
+  int list_cap; // window of the chain pass (TEAM)
+  int nrec;     // WAVE: term records (and their list entries) of an evaluation kept in LDS
 };
 __host__ __device__ inline Shape make_shape(const DevLayout &L, int S, bool wave) {
   Shape sh;
@@ -158,7 +159,8 @@ __host__ __device__ inline Shape make_shape(const DevLayout &L, int S, bool wave
   const int nterm = 5 * L.H + S + 4;
   sh.mw = nterm > 32 ? 2 : 1;
   sh.pf16 = (long long)L.Npts * nterm <= 65535 ? 1 : 0;
-  sh.list_cap = wave ? kListCapWave : kListCapTeam;
+  sh.list_cap = wave ? 0 : kListCapTeam;
+  sh.nrec = wave ? kRecWave : 0;
   return sh;
 }
 
@@ -178,10 +180,13 @@ struct Sm {
   ldsd_t st;                // [sNUM]
   ldsi_t ist;               // [iNUM]
   ldsi_t pinfo;             // (shared) [Ntot][4] segment, piece index inside it, first constraint point, intervals K
-  ldsi_t pmask;             // [Npts][mw] active terms of a constraint point (bit t = term t)
-  ldsi_t pfirst;            // [Npts + 1] index of a point's first active term in (point, term) order (16-bit entries if pf16)
-  ldsi_t list;              // [list_cap] (point << 6 | term) of the active terms of the current window
-  int mw, pf16, list_cap;
+  ldsi_t pmask;             // TEAM: [Npts][mw] active terms of a constraint point (bit t = term t)
+  ldsi_t pfirst;            // TEAM: [Npts + 1] index of a point's first active term in (point, term) order (16-bit entries if pf16)
+  ldsi_t list;              // TEAM: [list_cap] (point << 6 | term) of the active terms of the current window; WAVE: [2][nrec]: that
+                            //   (bit 31 = the first moving-obstacle term of its point), then the term's piece
+  ldsi_t pstart;            // WAVE: [Ntot + 1] number of active terms in front of a piece
+  ldsd_t lrec;              // WAVE: [nrec][kRec] the first records of the evaluation, in (point, term) order
+  int mw, pf16, list_cap, nrec;
   __device__ __forceinline__ mask_t mask(int pt) const {
     return mw == 2 ? ((mask_t)(unsigned)pmask[2 * pt] | ((mask_t)(unsigned)pmask[2 * pt + 1] << 32)) : (mask_t)(unsigned)pmask[pt];
   }
@@ -207,9 +212,10 @@ __host__ __device__ inline size_t lds_shared_bytes(const DevLayout &L) {
 }
 __host__ __device__ inline size_t lds_team_doubles(const DevLayout &L, int mem, const Shape &sh) {
   return 5 * (size_t)sh.nl + (size_t)L.M * (12 + 12 + 2 + 16 + gNUM) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3) * (size_t)L.Ntot + 4 * (size_t)sh.cap +
-         (size_t)mem + sNUM;
+         (size_t)mem + sNUM + (size_t)sh.nrec * kRec;
 }
 __host__ __device__ inline size_t lds_team_ints(const DevLayout &L, const Shape &sh) {
+  if (sh.wave) return iNUM + (size_t)L.Ntot + 1 + 2 * (size_t)sh.nrec;
   const size_t pf = sh.pf16 ? ((size_t)L.Npts + 2) / 2 : (size_t)L.Npts + 1;
   return iNUM + (size_t)sh.mw * L.Npts + pf + (size_t)sh.list_cap;
 }
@@ -244,14 +250,24 @@ __device__ inline void carve(Sm &s, double *shared, double *team, const DevLayou
   s.dot = p; p += 4 * sh.cap;
   s.alpha = p; p += mem;
   s.st = p; p += sNUM;
+  s.lrec = p; p += (size_t)sh.nrec * kRec;
   ldsi_t q = (ldsi_t)p;
   s.ist = q; q += iNUM;
-  s.pmask = q; q += sh.mw * L.Npts;
-  s.pfirst = q; q += sh.pf16 ? (L.Npts + 2) / 2 : L.Npts + 1;
-  s.list = q;
+  if (sh.wave) {
+    s.pstart = q; q += L.Ntot + 1;
+    s.list = q;
+    s.pmask = q; // (unused in this shape)
+    s.pfirst = q;
+  } else {
+    s.pmask = q; q += sh.mw * L.Npts;
+    s.pfirst = q; q += sh.pf16 ? (L.Npts + 2) / 2 : L.Npts + 1;
+    s.list = q;
+    s.pstart = q; // (unused in this shape)
+  }
   s.mw = sh.mw;
   s.pf16 = sh.pf16;
   s.list_cap = sh.list_cap;
+  s.nrec = sh.nrec;
 }
 
 // A team's barrier: the workgroup's in the TEAM shape; in the WAVE shape the team is one wave, whose LDS operations execute
@@ -754,14 +770,49 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
   return mask;
 }
 
+// inclusive prefix sum over the 64 lanes (row_shr 1, 2, 4, 8 inside the rows of 16, then the rows' totals by row_bcast 15 / 31)
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // last lane of rows 0 / 2 onto rows 1 / 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // lane 31 onto rows 2 and 3
+  return v;
+}
+
 // ------------------------------------------------ one constraint point (traj_optimizer.cpp:499-705)
-// Point j of piece i (K intervals, offset s1 = the running sum of traj_optimizer.cpp:513, taken from the table).  Writes a
-// record for every active term and returns the mask of active terms.  cor: &corridor[b][0][pt] (component-major, pitch
-// NptsPad); rec: &scratch[pt][0][0].
+// What a constraint point keeps between its tests (point_masks: which terms are active) and its records (point_emit: what an
+// active term adds).  Most points have no active term at all (24 of 14 784 terms per evaluation on BASELINE configs[2]), so
+// everything only a record needs is formed in point_emit.
+// (kept small: it is live in every lane across the numbering of a round; what can be formed again from it with the same
+// expressions -- the powers of s1, R * vertex, the half-planes themselves -- is)
+struct PtState {
+  double s1, alpha, omg, step, sg;
+  double dsigma[2], ddsigma[2];
+  double z_h0 /* 1 / |dsigma| */, z_h1, z_h2, z_h3, z1, z_h4;
+  double vel2_reci, vel2_reci_e, vel3_2_reci_e;
+  double violaVel, violaAcc, violaCurL, violaCurR;
+  double bp0, bp1; // sigma
+  int K;
+};
+
+// Point j of piece i (K intervals, offset s1 = the running sum of traj_optimizer.cpp:513, taken from the table): the state and
+// the mask of active terms -- term v H + k: vertex v against half-plane k (:592-634); 5 H + s: moving obstacle s (:636-638,
+// whose records surround_terms writes to `sur_rec` [S][kRec] at once: its test IS its cost); then velocity, acceleration,
+// curvature left / right (:642-705).  pl: the point's half-planes (load_planes), (n_x, n_y, p_x, p_y) of plane k at 4 k.
+// cor: &corridor[b][0][pt] (component-major, pitch NptsPad); planes past H are never used.
+__device__ __forceinline__ void load_planes(gcd_t cor, size_t pitch, int H, double pl[20]) {
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) pl[4 * k + q] = k < H ? cor[(size_t)(4 * k + q) * pitch] : 0.0; // (uniform: planes past H are not fetched)
+  }
+}
 template <bool SUR>
-__device__ __forceinline__ mask_t point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
-                                            int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec, const DevSurround &S,
-                                            double t_now, double t_piece, int trajid, double trajtime) {
+__device__ __forceinline__ mask_t point_masks(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1, int singul_,
+                                            double epis, int H, const double pl[20], gd_t sur_rec, const DevSurround &S, double t_now, double t_piece,
+                                            int trajid, double trajtime, PtState &st) {
   double cc[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) cc[k] = cc_[k];
@@ -807,58 +858,87 @@ __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double c
   const double violaCurR = -cur - max_cur;
 
   const double ego_R[4] = {sg * dsigma[0] * z_h0, sg * -dsigma[1] * z_h0, sg * dsigma[1] * z_h0, sg * dsigma[0] * z_h0}; // :581-583
-  const double temp_a[4] = {ddsigma[0], -ddsigma[1], ddsigma[1], ddsigma[0]};
-  const double temp_v[4] = {dsigma[0], -dsigma[1], dsigma[1], dsigma[0]};
-  double R_dot[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) R_dot[k] = sg * (temp_a[k] * z_h0 - temp_v[k] * vel2_reci * z_h0 * z_h1);
 
   mask_t mask = 0ull;
-  // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634.  The 5 H tests first (term v H + k:
-  // the order of the reference's nested loops), collected in the mask; then one pass over the set bits, so that a lane spends
-  // time on its own violated half-planes only (as nested loops every body ran for the whole wave if a single lane needed it).
-  double pn0[5], pn1[5], pq0[5], pq1[5], rl0[5], rl1[5];
+  // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634: the 5 H tests (term v H + k: the order
+  // of the reference's nested loops)
+  double pn0[5], pn1[5], pq0[5], pq1[5];
 #pragma unroll
   for (int k = 0; k < 5; k++) {
-    const int kk = k < H ? k : 0; // rows past H re-read plane 0 and are never used
-    pn0[k] = cor[(size_t)(4 * kk + 0) * pitch];
-    pn1[k] = cor[(size_t)(4 * kk + 1) * pitch];
-    pq0[k] = cor[(size_t)(4 * kk + 2) * pitch];
-    pq1[k] = cor[(size_t)(4 * kk + 3) * pitch];
+    pn0[k] = pl[4 * k + 0];
+    pn1[k] = pl[4 * k + 1];
+    pq0[k] = pl[4 * k + 2];
+    pq1[k] = pl[4 * k + 3];
   }
 #pragma unroll
   for (int v = 0; v < 5; v++) {
     const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
-    rl0[v] = ego_R[0] * le0 + ego_R[1] * le1;
-    rl1[v] = ego_R[2] * le0 + ego_R[3] * le1;
-    const double bpt0 = sigma[0] + rl0[v], bpt1 = sigma[1] + rl1[v];
+    const double rl0 = ego_R[0] * le0 + ego_R[1] * le1;
+    const double rl1 = ego_R[2] * le0 + ego_R[3] * le1;
+    const double bpt0 = sigma[0] + rl0, bpt1 = sigma[1] + rl1;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       const double violaPos = pn0[k] * (bpt0 - pq0[k]) + pn1[k] * (bpt1 - pq1[k]);
       if (k < H && violaPos > 0) mask |= (mask_t)1 << (v * H + k);
     }
   }
-  for (mask_t m = mask; m;) {
-    const int t = __builtin_ctzll(m);
-    m &= m - 1;
+  // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1)
+  if (SUR && S.S > 0)
+    mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, trajid, trajtime,
+                           N, 5 * H, sur_rec - (size_t)(5 * H) * kRec);
+  const int t0 = 5 * H + (SUR ? S.S : 0);
+  if (violaVel > 0.0) mask |= (mask_t)1 << t0;        // :642
+  if (violaAcc > 0.0) mask |= (mask_t)1 << (t0 + 1);  // :655
+  if (violaCurL > 0.0) mask |= (mask_t)1 << (t0 + 2); // :684
+  if (violaCurR > 0.0) mask |= (mask_t)1 << (t0 + 3); // :695
+  st.s1 = s1; st.alpha = alpha; st.omg = omg; st.step = step; st.sg = sg;
+  st.dsigma[0] = dsigma[0]; st.dsigma[1] = dsigma[1]; st.ddsigma[0] = ddsigma[0]; st.ddsigma[1] = ddsigma[1];
+  st.z_h0 = z_h0; st.z_h1 = z_h1; st.z_h2 = z_h2; st.z_h3 = z_h3; st.z1 = z1; st.z_h4 = z_h4;
+  st.vel2_reci = vel2_reci; st.vel2_reci_e = vel2_reci_e; st.vel3_2_reci_e = vel3_2_reci_e;
+  st.violaVel = violaVel; st.violaAcc = violaAcc; st.violaCurL = violaCurL; st.violaCurR = violaCurR;
+  st.bp0 = sigma[0]; st.bp1 = sigma[1];
+  st.K = K;
+  return mask;
+}
+
+// The record of an active static term t (not a moving-obstacle term) of a point: what the term adds to gdC (12), gdT [12] and the
+// cost [13], exactly the expressions of traj_optimizer.cpp:600-705.  t0 = 5 H + S: the first feasibility term.  R: any pointer
+// type (global records of the TEAM shape, LDS / flat records of the WAVE shape).
+template <typename R>
+__device__ __forceinline__ void point_emit(const DevParams &P, const PtState &st, int t, int H, int t0, gcd_t cor, size_t pitch, R r_) {
+  const double s1 = st.s1;
+  const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1; // the expressions of point_masks: the same bits
+  const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+  const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  const double beta2[6] = {0.0, 0.0, 2.0, 6.0 * s1, 12.0 * s2, 20.0 * s3};
+  const double alpha = st.alpha, omg = st.omg, step = st.step, sg = st.sg;
+  const double *dsigma = st.dsigma, *ddsigma = st.ddsigma;
+  const double z_h0 = st.z_h0, z_h1 = st.z_h1, z_h2 = st.z_h2, z_h3 = st.z_h3, z1 = st.z1, z_h4 = st.z_h4;
+  const double vel2_reci = st.vel2_reci, vel2_reci_e = st.vel2_reci_e, vel3_2_reci_e = st.vel3_2_reci_e;
+  const int K = st.K;
+  if (t < 5 * H) { // ---- corridor: vertex v against half-plane k (:600-634)
     int v = 0;
 #pragma unroll
     for (int q = 1; q < 5; q++) v += t >= q * H ? 1 : 0;
     const int k = t - v * H;
-    double on0 = pn0[0], on1 = pn1[0], q0 = pq0[0], q1 = pq1[0];
-    double Rle0 = rl0[0], Rle1 = rl1[0], le0 = P.vec_le[0][0], le1 = P.vec_le[0][1];
+    // the half-plane and the vertex of this term, fetched again (they are what point_masks tested)
+    const double on0 = cor[(size_t)(4 * k + 0) * pitch], on1 = cor[(size_t)(4 * k + 1) * pitch];
+    const double q0 = cor[(size_t)(4 * k + 2) * pitch], q1 = cor[(size_t)(4 * k + 3) * pitch];
+    double le0 = P.vec_le[0][0], le1 = P.vec_le[0][1];
 #pragma unroll
     for (int q = 1; q < 5; q++) {
-      on0 = k == q ? pn0[q] : on0;
-      on1 = k == q ? pn1[q] : on1;
-      q0 = k == q ? pq0[q] : q0;
-      q1 = k == q ? pq1[q] : q1;
-      Rle0 = v == q ? rl0[q] : Rle0;
-      Rle1 = v == q ? rl1[q] : Rle1;
       le0 = v == q ? P.vec_le[q][0] : le0;
       le1 = v == q ? P.vec_le[q][1] : le1;
     }
-    const double bpt0 = sigma[0] + Rle0, bpt1 = sigma[1] + Rle1;
+    const double ego_R[4] = {sg * dsigma[0] * z_h0, sg * -dsigma[1] * z_h0, sg * dsigma[1] * z_h0, sg * dsigma[0] * z_h0}; // :581-583
+    const double Rle0 = ego_R[0] * le0 + ego_R[1] * le1;
+    const double Rle1 = ego_R[2] * le0 + ego_R[3] * le1;
+    const double temp_a[4] = {ddsigma[0], -ddsigma[1], ddsigma[1], ddsigma[0]};
+    const double temp_v[4] = {dsigma[0], -dsigma[1], dsigma[1], dsigma[0]};
+    double R_dot[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) R_dot[q] = sg * (temp_a[q] * z_h0 - temp_v[q] * vel2_reci * z_h0 * z_h1);
+    const double bpt0 = st.bp0 + Rle0, bpt1 = st.bp1 + Rle1;
     const double violaPos = on0 * (bpt0 - q0) + on1 * (bpt1 - q1); // the expression of the test: > 0 here
     const double tl[4] = {le0, -le1, le1, le0};
     double pena, penaD;
@@ -872,7 +952,6 @@ __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double c
     const double w1 = dsigma[1] + (R_dot[2] * le0 + R_dot[3] * le1);
     const double gradViolaPt = (alpha * on0) * w0 + (alpha * on1) * w1;
     const double sc = omg * step * P.wei_obs * penaD;
-    gd_t r_ = rec + (size_t)t * kRec;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       const double b1n0 = beta1[r] * on0, b1n1 = beta1[r] * on1;
@@ -883,18 +962,14 @@ __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double c
     }
     r_[12] = omg * P.wei_obs * (penaD * gradViolaPt * step + pena / K);
     r_[13] = omg * step * P.wei_obs * pena;
+    return;
   }
-  // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1)
-  if (SUR && S.S > 0)
-    mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, trajid, trajtime,
-                           N, 5 * H, rec);
-  const int t0 = 5 * H + (SUR ? S.S : 0);
-  if (violaVel > 0.0) { // :642-653
+  const int f = t - t0;
+  if (f == 0) { // :642-653
     double pena, penaD;
-    smoothed_l1(violaVel, pena, penaD);
+    smoothed_l1(st.violaVel, pena, penaD);
     const double gradViolaVt = 2.0 * alpha * z_h1;
     const double sc = omg * step * P.wei_feas * penaD;
-    gd_t r_ = rec + (size_t)t0 * kRec;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       r_[2 * r + 0] = sc * (2.0 * beta1[r] * dsigma[0]);
@@ -902,16 +977,13 @@ __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double c
     }
     r_[12] = omg * P.wei_feas * (penaD * gradViolaVt * step + pena / K);
     r_[13] = omg * step * P.wei_feas * pena;
-    mask |= (mask_t)1 << t0;
-  }
-  if (violaAcc > 0.0) { // :655-665
+  } else if (f == 1) { // :655-665
     double pena, penaD;
-    smoothed_l1(violaAcc, pena, penaD);
+    smoothed_l1(st.violaAcc, pena, penaD);
     const double u0 = z_h4 * ddsigma[0] - z_h4 * z_h4 * dsigma[0], u1 = z_h4 * ddsigma[1] - z_h4 * z_h4 * dsigma[1];
     const double sqn = ddsigma[0] * ddsigma[0] + ddsigma[1] * ddsigma[1];
     const double gradViolaAt = 2.0 * alpha * (z_h4 * (sqn + z_h2) - z_h4 * z_h4 * z_h1);
     const double sc = omg * step * P.wei_feas * penaD;
-    gd_t r_ = rec + (size_t)(t0 + 1) * kRec;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       r_[2 * r + 0] = sc * (2.0 * beta1[r] * u0 + 2.0 * beta2[r] * z_h4 * dsigma[0]);
@@ -919,41 +991,49 @@ __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double c
     }
     r_[12] = omg * P.wei_feas * (penaD * gradViolaAt * step + pena / K);
     r_[13] = omg * step * P.wei_feas * pena;
-    mask |= (mask_t)1 << (t0 + 1);
-  }
-  // ---- curvature, :684-705
-  const double ku0 = vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0];
-  const double ku1 = vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1];
-  const double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
-  if (violaCurL > 0.0) {
+  } else { // ---- curvature, :684-705 (f == 2: left, f == 3: right)
+    const double ku0 = vel3_2_reci_e * ddsigma[1] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[0];
+    const double ku1 = vel3_2_reci_e * -ddsigma[0] - 3 * vel3_2_reci_e * vel2_reci_e * z_h3 * dsigma[1];
+    const double kt = alpha * vel3_2_reci_e * (z1 - 3 * vel2_reci_e * z_h3 * z_h1);
     double pena, penaD;
-    smoothed_l1(violaCurL, pena, penaD);
+    smoothed_l1(f == 2 ? st.violaCurL : st.violaCurR, pena, penaD);
     const double sc = omg * step * P.wei_feas * 10.0 * penaD;
-    gd_t r_ = rec + (size_t)(t0 + 2) * kRec;
+    if (f == 2) {
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const double kw0 = -((beta2[r] * vel3_2_reci_e) * dsigma[1]), kw1 = (beta2[r] * vel3_2_reci_e) * dsigma[0];
-      r_[2 * r + 0] = sc * (beta1[r] * ku0 + kw0);
-      r_[2 * r + 1] = sc * (beta1[r] * ku1 + kw1);
+      for (int r = 0; r < 6; r++) {
+        const double kw0 = -((beta2[r] * vel3_2_reci_e) * dsigma[1]), kw1 = (beta2[r] * vel3_2_reci_e) * dsigma[0];
+        r_[2 * r + 0] = sc * (beta1[r] * ku0 + kw0);
+        r_[2 * r + 1] = sc * (beta1[r] * ku1 + kw1);
+      }
+      r_[12] = omg * P.wei_feas * 10.0 * (penaD * kt * step + pena / K);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const double kw0 = -((beta2[r] * vel3_2_reci_e) * dsigma[1]), kw1 = (beta2[r] * vel3_2_reci_e) * dsigma[0];
+        r_[2 * r + 0] = sc * -(beta1[r] * ku0 + kw0);
+        r_[2 * r + 1] = sc * -(beta1[r] * ku1 + kw1);
+      }
+      r_[12] = omg * P.wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
     }
-    r_[12] = omg * P.wei_feas * 10.0 * (penaD * kt * step + pena / K);
     r_[13] = omg * step * P.wei_feas * 10.0 * pena;
-    mask |= (mask_t)1 << (t0 + 2);
   }
-  if (violaCurR > 0.0) {
-    double pena, penaD;
-    smoothed_l1(violaCurR, pena, penaD);
-    const double sc = omg * step * P.wei_feas * 10.0 * penaD;
-    gd_t r_ = rec + (size_t)(t0 + 3) * kRec;
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const double kw0 = -((beta2[r] * vel3_2_reci_e) * dsigma[1]), kw1 = (beta2[r] * vel3_2_reci_e) * dsigma[0];
-      r_[2 * r + 0] = sc * -(beta1[r] * ku0 + kw0);
-      r_[2 * r + 1] = sc * -(beta1[r] * ku1 + kw1);
-    }
-    r_[12] = omg * P.wei_feas * 10.0 * (penaD * (-kt) * step + pena / K);
-    r_[13] = omg * step * P.wei_feas * 10.0 * pena;
-    mask |= (mask_t)1 << (t0 + 3);
+}
+
+// TEAM shape: the point's tests, then a record per active term in the point's own slots rec[t][kRec] (global scratch)
+template <bool SUR>
+__device__ __forceinline__ mask_t point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
+                                            int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec, const DevSurround &S,
+                                            double t_now, double t_piece, int trajid, double trajtime) {
+  PtState st;
+  const int nS = SUR ? S.S : 0, tS0 = 5 * H, t0 = tS0 + nS;
+  double pl[20];
+  load_planes(cor, pitch, H, pl);
+  const mask_t mask = point_masks<SUR>(P, cc_, i, N, j, K, step, s1, singul_, epis, H, pl, rec + (size_t)tS0 * kRec, S, t_now, t_piece, trajid, trajtime, st);
+  for (mask_t m = mask; m;) {
+    const int t = __builtin_ctzll(m);
+    m &= m - 1;
+    if (t >= tS0 && t < t0) continue; // a moving-obstacle term: surround_terms has written its record
+    point_emit(P, st, t, H, t0, cor, pitch, rec + (size_t)t * kRec);
   }
   return mask;
 }
@@ -1098,6 +1178,277 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
     }
   }
   pr.tick(1);
+  if (WAVE) {
+  // ================= WAVE shape: tests, numbering and records in one pass over the points; chains from LDS
+  // The points are taken 64 at a time IN ORDER, so the running number of active terms is known at the end of every round: a
+  // lane numbers its point's active terms (exclusive prefix over the wave + the running base) and writes each record straight
+  // to its place in (point, term) order -- the first `nrec` of an evaluation in LDS (an evaluation of BASELINE configs[2] has
+  // 24 active terms on average), the rest in global scratch.  No mask table, no second pass.
+  const int nrec = sm.nrec, tS0 = 5 * H, t0 = tS0 + nS;
+  const gd_t stage_b = rec_b + (size_t)Npts * nterm * kRec;                         // moving obstacles: a point's records as surround_terms leaves them
+  int *glist = reinterpret_cast<int *>((double *)(stage_b + (size_t)Npts * nS * kRec)); // entries beyond the LDS window
+  int base = 0;
+  // (requesting the half-planes one round ahead was tried: 40 more live registers, 100 -> 116 k cycles per evaluation)
+  for (int r0 = 0; r0 < Npts; r0 += 64) {
+    const int pt = r0 + tid;
+    const bool in = pt < Npts;
+    mask_t m = 0ull;
+    PtState st;
+    int p = 0, j = 1;
+    if (in) {
+      double pl[20];
+      load_planes(cor_b + pt, (size_t)D.NptsPad, H, pl);
+      p = D.pt_piece[pt];
+      j = D.pt_j[pt];
+      const int sg = sm.pinfo[4 * p], lp = sm.pinfo[4 * p + 1], K = sm.pinfo[4 * p + 3];
+      int N = 0, singul_ = 1;
+      for (int q = 0; q < M; q++) {
+        N = q == sg ? L.piece_nums[q] : N;
+        singul_ = q == sg ? L.singuls[q] : singul_;
+      }
+      const bool edge = lp == 0 || lp == N - 1;
+      double cc[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * p + k];
+      const double step = sm.seg[16 * sg + 1] / K;
+      const double s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
+      const double trajtime = (SUR && sg > 0) ? sm.seg[16 * (sg - 1)] : 0.0;
+      m = point_masks<SUR>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, pl, stage_b + (size_t)pt * nS * kRec, D.sur, D.t_now, SUR ? sm.pA[p] : 0.0, sg,
+                           trajtime, st);
+    }
+    const int c = __builtin_popcountll(m);
+    if (__builtin_amdgcn_ballot_w64(c != 0) == 0ull) { // (uniform) nothing active in this round
+      if (in && j == 0) sm.pstart[p] = base;
+      continue;
+    }
+    const int incl = wave_incl_scan_i32(c);
+    int e = base + incl - c;
+    if (in && j == 0) sm.pstart[p] = e; // a piece's terms start where its first point's do
+    if (SUR && c != 0) __threadfence_block(); // this lane reads its moving-obstacle records back below
+    bool sur_seen = false;
+    for (mask_t mm = m; mm;) {
+      const int t = __builtin_ctzll(mm);
+      mm &= mm - 1;
+      const bool sur_term = t >= tS0 && t < t0;
+      int entry = (pt << 6) | t;
+      if (sur_term && !sur_seen) entry |= (int)0x80000000u; // carries the point's moving-obstacle penalty (costs(1) += once per point)
+      sur_seen = sur_seen || sur_term;
+      double *r_ = e < nrec ? (double *)(sm.lrec + (size_t)e * kRec) : (double *)(rec_b + (size_t)e * kRec);
+      if (e < nrec) {
+        sm.list[e] = entry;
+        sm.list[nrec + e] = p; // its piece
+      } else {
+        glist[e] = entry;
+      }
+      if (sur_term) {
+        const gcd_t src = (gcd_t)(stage_b + ((size_t)pt * nS + (t - tS0)) * kRec);
+#pragma unroll
+        for (int q = 0; q < kRec; q++) r_[q] = src[q];
+      } else {
+        point_emit(P, st, t, H, t0, cor_b + pt, (size_t)D.NptsPad, r_);
+      }
+      e++;
+    }
+    base += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (tid == 0) sm.pstart[Ntot] = base;
+  // the start values of the per-segment chains (`gdT +=`, `energy +=` over the pieces in order, from 0.0)
+  if (tid < M) {
+    const int sg = tid;
+    int p0 = 0, p1 = 0;
+    for (int q = 0; q < M; q++) {
+      p0 = q == sg ? L.seg_piece0[q] : p0;
+      p1 = q == sg ? L.seg_piece0[q + 1] : p1;
+    }
+    double gdT = 0.0, en = 0.0;
+    for (int i = p0; i < p1; i++) {
+      gdT += sm.pG[i];
+      en += sm.pE[i];
+    }
+    sm.segsum[gNUM * sg + gGDT] = gdT;
+    sm.segsum[gNUM * sg + gENERGY] = en;
+    sm.segsum[gNUM * sg + gCOST0] = 0.0;
+    sm.segsum[gNUM * sg + gCOST2] = 0.0;
+    sm.segsum[gNUM * sg + gCOST1] = 0.0;
+  }
+  __threadfence_block(); // records beyond the LDS window went to global memory
+  team_sync<WAVE>();
+  pr.tick(2);
+  pr.count(9, base); // active terms of this evaluation (a count, not cycles)
+  pr.count(10, base > nrec ? 1 : 0);   // evaluations whose records do not all fit the LDS window ...
+  pr.count(11, base > nrec ? base : 0); // ... and their active terms
+  // ---- chains: lane (piece, entry) adds its piece's records in order; four more lanes per segment walk all of the segment's
+  // for gdT, the corridor cost, the feasibility cost and the moving-obstacle cost (they go first: theirs are the long walks)
+  if (base > 0 && base <= nrec) {
+    // Every record of the evaluation is in LDS (the usual case): ONE pass over the terms in order on 16 lanes -- lane q < 12
+    // carries entry q of gdC of the piece the terms belong to, lane 12 that segment's gdT, lane 13 its three costs -- each term
+    // one LDS read and one addition per lane, the reads of eight terms in flight; a change of piece (segment) stores the
+    // sums and fetches the next piece's (segment's).  Same chains as the lanes per (piece, entry) below, term after term.
+    if (tid < 16) {
+      int curp = -1, cursg = -1, Nseg = 0;
+      double acc = 0.0, c2 = 0.0, c1 = 0.0; // lane < 12: gdC entry; 12: gdT; 13: corridor cost (acc), feasibility (c2), moving obstacles (c1)
+      for (int e0 = 0; e0 < base; e0 += 8) {
+        int ent[8], pc[8];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int e = e0 + u < base ? e0 + u : base - 1;
+          ent[u] = sm.list[e];
+          pc[u] = sm.list[nrec + e];
+          v[u] = sm.lrec[(size_t)e * kRec + tid];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (e0 + u >= base) break; // uniform
+          const int p = pc[u];
+          if (p != curp) { // uniform: the terms come piece after piece, segment after segment
+            const int sg = sm.pinfo[4 * p];
+            if (tid < 12) {
+              if (curp >= 0) sm.gdC[12 * curp + tid] = acc;
+              acc = sm.gdC[12 * p + tid];
+            } else if (sg != cursg) {
+              if (cursg >= 0) {
+                if (tid == 12) sm.segsum[gNUM * cursg + gGDT] = acc;
+                if (tid == 13) {
+                  sm.segsum[gNUM * cursg + gCOST0] = acc;
+                  sm.segsum[gNUM * cursg + gCOST2] = c2;
+                  sm.segsum[gNUM * cursg + gCOST1] = c1;
+                }
+              }
+              if (tid == 12) acc = sm.segsum[gNUM * sg + gGDT];
+              if (tid == 13) {
+                acc = sm.segsum[gNUM * sg + gCOST0];
+                c2 = sm.segsum[gNUM * sg + gCOST2];
+                c1 = sm.segsum[gNUM * sg + gCOST1];
+              }
+            }
+            if (sg != cursg) {
+              Nseg = 0;
+              for (int q2 = 0; q2 < M; q2++) Nseg = q2 == sg ? L.piece_nums[q2] : Nseg;
+            }
+            curp = p;
+            cursg = sg;
+          }
+          const int t = ent[u] & 63;
+          const bool sur_term = t >= tS0 && t < t0;
+          if (tid < 12) {
+            acc += v[u];
+          } else if (tid == 12) { // gdT: one `+=` per term; a moving-obstacle term: three, and one more per previous segment (traj_optimizer.cpp:1663-1676)
+            acc += v[u];
+            if (sur_term) {
+              ldscd_t r_ = sm.lrec + (size_t)(e0 + u) * kRec;
+              const double vb = r_[14], vc = r_[15];
+              acc += vb * sm.pinfo[4 * p + 1]; // * pieceid
+              acc += vc;
+              const double prev = vb * Nseg; // * piece_num_container[trajid]
+              for (int idx = 0; idx < cursg; idx++) acc += prev;
+            }
+          } else if (tid == 13) {
+            if (t < tS0) acc += v[u];
+            else if (t >= t0) c2 += v[u];
+            else if (ent[u] < 0) c1 += v[u]; // costs(1) += the point's penalty, once per point: carried by its first active obstacle term
+          }
+        }
+      }
+      if (tid < 12) sm.gdC[12 * curp + tid] = acc;
+      if (tid == 12) sm.segsum[gNUM * cursg + gGDT] = acc;
+      if (tid == 13) {
+        sm.segsum[gNUM * cursg + gCOST0] = acc;
+        sm.segsum[gNUM * cursg + gCOST2] = c2;
+        sm.segsum[gNUM * cursg + gCOST1] = c1;
+      }
+    }
+    team_sync<WAVE>();
+  } else if (base > 0) {
+    const int n_chain = 4 * M + 12 * Ntot;
+    for (int w = tid; w < n_chain; w += 64) {
+      int e0, e1, q, kind = -1, csg = 0;
+      ldsd_t dst;
+      if (w >= 4 * M) {
+        const int p = (w - 4 * M) / 12;
+        q = (w - 4 * M) - 12 * p;
+        e0 = sm.pstart[p];
+        e1 = sm.pstart[p + 1];
+        dst = sm.gdC + (w - 4 * M);
+      } else {
+        const int sg = w >> 2, kd = w & 3; // per segment: 0 gdT, 1 corridor cost, 2 feasibility cost, 3 moving-obstacle cost
+        int a0 = 0, a1 = 0;
+        for (int q2 = 0; q2 < M; q2++) {
+          a0 = q2 == sg ? L.seg_piece0[q2] : a0;
+          a1 = q2 == sg ? L.seg_piece0[q2 + 1] : a1;
+        }
+        e0 = sm.pstart[a0];
+        e1 = sm.pstart[a1];
+        q = kd == 0 ? 12 : 13;
+        dst = sm.segsum + gNUM * sg + (kd == 0 ? gGDT : (kd == 1 ? gCOST0 : (kd == 2 ? gCOST2 : gCOST1)));
+        kind = kd;
+        csg = sg;
+      }
+      if (e1 <= e0) continue;
+      double acc = *dst;
+      if (kind < 0) { // an entry of gdC: every term of the piece, in order
+        int e = e0;
+        const int eL = e1 < nrec ? e1 : nrec; // the part in LDS
+        for (; e < eL; e++) acc += sm.lrec[(size_t)e * kRec + q];
+        for (; e + 8 <= e1; e += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) v[u] = rec_b[(size_t)(e + u) * kRec + q];
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; e < e1; e++) acc += rec_b[(size_t)e * kRec + q];
+      } else {
+        int Nseg = 0;
+        for (int q2 = 0; q2 < M; q2++) Nseg = q2 == csg ? L.piece_nums[q2] : Nseg;
+        for (int eb = e0; eb < e1; eb += 8) { // what the next eight terms add is requested in front of the additions
+          int ent[8];
+          double va8[8], vb8[8], vc8[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int e = eb + u < e1 ? eb + u : e1 - 1;
+            if (e < nrec) {
+              ent[u] = sm.list[e];
+              ldscd_t r_ = sm.lrec + (size_t)e * kRec;
+              va8[u] = r_[q]; vb8[u] = r_[14]; vc8[u] = r_[15];
+            } else {
+              ent[u] = glist[e];
+              gcd_t r_ = (gcd_t)(rec_b + (size_t)e * kRec);
+              va8[u] = r_[q]; vb8[u] = r_[14]; vc8[u] = r_[15];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+          if (eb + u >= e1) break;
+          const int entry = ent[u];
+          const double va = va8[u], vb = vb8[u], vc = vc8[u];
+          const int t = entry & 63;
+          const bool sur_term = t >= tS0 && t < t0;
+          if (kind == 0) { // gdT: one `+=` per term; a moving-obstacle term: three, and one more per previous segment (traj_optimizer.cpp:1663-1676)
+            acc += va;
+            if (sur_term) {
+              const int lp = sm.pinfo[4 * (int)D.pt_piece[(entry >> 6) & 0x1ffffff] + 1]; // pieceid
+              acc += vb * lp;
+              acc += vc;
+              const double prev = vb * Nseg; // ... * piece_num_container[trajid]
+              for (int idx = 0; idx < csg; idx++) acc += prev;
+            }
+          } else if (kind == 1) {
+            if (t < tS0) acc += va;
+          } else if (kind == 2) {
+            if (t >= t0) acc += va;
+          } else if (sur_term && entry < 0) { // costs(1) += the point's penalty, once per point: carried by its first active obstacle term
+            acc += va;
+          }
+          }
+        }
+      }
+      *dst = acc;
+    }
+    team_sync<WAVE>();
+  }
+  } else {
+  // ================= TEAM shape
   // ---- the constraint points, each on a lane of its own
   for (int pt = tid; pt < Npts; pt += T) {
     const int p = D.pt_piece[pt], j = D.pt_j[pt];
@@ -1274,6 +1625,7 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
     }
     team_sync<WAVE>();
   }
+  } // TEAM shape
   pr.tick(3);
   // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
   for (int w = tid; w < 12 * Ntot; w += T) {
@@ -1902,7 +2254,8 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
   }
   __syncthreads(); // the only time the waves of a WAVE-shaped workgroup meet
   const bool ring = WAVE && mode == kModeSolve && source == 1;
-  const int nterm = 5 * L.H + (SUR ? D.sur.S : 0) + 4;
+  const int nterm = 5 * L.H + (SUR ? D.sur.S : 0) + 4, nS_ = SUR ? D.sur.S : 0;
+  const size_t scratch_per_traj = (size_t)L.Npts * nterm * kRec + (size_t)L.Npts * nS_ * kRec + ((size_t)L.Npts * nterm + 1) / 2;
   Prof pr;
 
   for (int pass = 0;; pass++) {
@@ -1935,7 +2288,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
       sm.bnd[w] = q < 6 ? D.iniS[((size_t)b * L.M + sg) * 6 + q] : D.finS[((size_t)b * L.M + sg) * 6 + (q - 6)];
     }
     const gcd_t cor_b = (gcd_t)(D.corridor + (size_t)b * L.H * 4 * D.NptsPad);
-    const gd_t rec_b = (gd_t)(scratch + (size_t)b * L.Npts * nterm * kRec);
+    const gd_t rec_b = (gd_t)(scratch + (size_t)b * scratch_per_traj);
     const gd_t hS = (gd_t)(D.histS + (size_t)b * D.P.mem_size * L.npad * 2);
     const gd_t hR = (gd_t)(D.histR + (size_t)b * D.P.mem_size * 2);
     const long long tick0 = wall_clock64();
@@ -2018,7 +2371,13 @@ bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
   return lds <= 160 * 1024 - 1024;
 }
 // doubles of term records a batch of B trajectories needs
-size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S) { return (size_t)B * L.Npts * (5 * L.H + S + 4) * reford::kRec; }
+// (per trajectory: the records [Npts][nterm][kRec] -- TEAM: a point's own slots; WAVE: in (point, term) order -- then, WAVE
+// with moving obstacles, the staging of surround_terms [Npts][S][kRec], then the list entries beyond the LDS window)
+size_t reference_order_scratch_per_traj(const DevLayout &L, int S) {
+  const size_t nterm = (size_t)(5 * L.H + S + 4);
+  return (size_t)L.Npts * nterm * reford::kRec + (size_t)L.Npts * S * reford::kRec + ((size_t)L.Npts * nterm + 1) / 2;
+}
+size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S) { return (size_t)B * reference_order_scratch_per_traj(L, S); }
 // doubles of the sweep tables of a segment of N pieces (the tables of a layout's segments follow one another)
 size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check

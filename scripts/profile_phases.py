@@ -35,8 +35,10 @@ for i, nm in enumerate(NAMES):
     print("%-18s %6.1f%%   %9.0f cycles per %s" % (nm, 100 * pr[:, i].sum() / tot.sum(), np.median(per), "eval" if i < 6 or i in (9, 11) else "iter"))
 hs = r["hist_sum"].astype(float)
 if os.environ.get("ORDER") == "ref":
-    print("reference order: active terms per evaluation, mean", round(float((pr[:, 9] / ev).mean()), 1), " numbering", round(float(np.median(pr[:, 10] / ev))),
-          " list", round(float(np.median(pr[:, 11] / ev))), "cycles per eval (slots 9-11 above are these, not what their names say)")
+    big = pr[:, 10].sum()
+    print("reference order: active terms per evaluation, mean", round(float(pr[:, 9].sum() / ev.sum()), 1), "; evaluations with more than the LDS window holds:",
+          round(float(100 * big / ev.sum()), 1), "% of all, with", round(float(pr[:, 11].sum() / max(1.0, big)), 1), "active terms on average",
+          "(slots 9-11 above are these counts, not what their names say)")
 print("two-loop cycles per history step (2 per entry per iteration):", round(float(np.median(pr[:, 8] / (2 * hs))), 1),
       " mean depth", round(float((hs / it).mean()), 1))
 print("solves/s (kernel)", B / (np.mean(ms0) * 1e-3))
