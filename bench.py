@@ -198,33 +198,53 @@ def main():
                 self.via = "torch.distributed all_gather_into_tensor (RCCL)"
                 if os.environ.get("DFTPAV_BENCH_COMM", "capi") == "capi":
                     try:
-                        cm = {}
+                        # ONE communicator per rank: the first handle owns it, the others borrow it (dftpav_comm_share) -- 16 steps in
+                        # flight would otherwise mean 16 ncclCommInitRank rendezvous and 16 sets of RCCL buffers per rank
+                        # (DFTPAV_BENCH_COMM_PER_HANDLE=1: a communicator per handle, as in round 3)
+                        cm, owner = {}, None
                         for hh in self.hs:
                             if id(hh) not in cm:
-                                cm[id(hh)] = dd.RcclComm(hh)
+                                if owner is None or os.environ.get("DFTPAV_BENCH_COMM_PER_HANDLE") == "1":
+                                    cm[id(hh)] = dd.RcclComm(hh)
+                                    owner = owner or cm[id(hh)]
+                                else:
+                                    cm[id(hh)] = dd.RcclComm(hh, share=owner)
                         self.comms = [cm[id(hh)] for hh in self.hs]
                         self.via = "dftpav_batch_allgather_results (ncclAllGather behind the C-ABI, on the solve's stream)"
-                    except Exception as ex:  # noqa: BLE001
+                    except Exception as ex:  # noqa: BLE001  (RcclComm decides collectively: it raises on every rank or on none)
                         self.via += "; C-ABI communicator not set up: %s" % ex
                         self.comms = None
+                    # belt and braces: the path is the same on every rank or the job would hang in the first collective
+                    flag = torch.tensor([1 if self.comms is not None else 0], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) == 0 and self.comms is not None:
+                        for c_ in set(self.comms):
+                            c_.close()
+                        self.comms = None
+                        self.via += "; C-ABI communicator not set up on another rank"
             self.k, self.out, self.rec = 0, [], None   # out: the batches in flight, oldest first
             self.t_launch = [0.0] * D
-            self.to_result, self.in_deliver = [], []
+            self.to_result, self.in_deliver, self.wait_solve = [], [], []
 
         def deliver(self, i):
             t1 = time.perf_counter()
             if self.comms is not None:
-                try:
-                    self.rec = (self.comms[i].allgather(self.bts[i], self.B_total), i)
-                except capi.DftpavError as ex:  # the collective behind the C-ABI failed: torch.distributed's from here on
-                    self.via = "torch.distributed all_gather_into_tensor (RCCL); the C-ABI collective failed: %s" % ex
-                    self.comms = None
+                # (a failure here is fatal, not a reason to change path: the other ranks are inside the same ncclAllGather)
+                self.rec = (self.comms[i].allgather(self.bts[i], self.B_total), i)
+            t_mid = t1
             if self.comms is None:
-                self.bts[i].pack_results(self.rec_dev[i].data_ptr())
+                # the records are written by the solve kernels' epilogues: nothing of ours runs between the solve and their delivery
                 self.bts[i].sync()
-                self.rec = (dd.allgather_records(self.rec_dev[i], self.B_total) if distributed else self.rec_dev[i], i)
+                t_mid = time.perf_counter()          # the batch's solve is complete here
+                if distributed:
+                    self.bts[i].pack_results(self.rec_dev[i].data_ptr())
+                    self.bts[i].sync()
+                    self.rec = (dd.allgather_records(self.rec_dev[i], self.B_total), i)
+                else:
+                    self.rec = (self.bts[i].records(), i)   # one DMA copy to the host
             t2 = time.perf_counter()
-            self.in_deliver.append(t2 - t1)
+            self.in_deliver.append(t2 - t_mid)       # delivery proper (with the C-ABI collective: the wait for the solve included)
+            self.wait_solve.append(t_mid - t1)
             self.to_result.append(t2 - self.t_launch[i])
 
         def step(self, last=False):
@@ -259,7 +279,7 @@ def main():
             for j in range(warmup):
                 self.step(last=(j == warmup - 1))
             self.flush()  # the warm-up leaves nothing in flight: the timed region starts on an idle device
-            self.to_result, self.in_deliver = [], []
+            self.to_result, self.in_deliver, self.wait_solve = [], [], []
             if distributed:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -282,14 +302,15 @@ def main():
                 elapsed = float(tmax.item())
             allrec, last = self.rec
             rs = [b_.results() for b_ in self.bts]
-            cost_all, status_all, iters_all = dd.unpack_records(allrec.cpu().numpy())
+            cost_all, status_all, iters_all = dd.unpack_records(allrec if isinstance(allrec, np.ndarray) else allrec.cpu().numpy())
             assert len(cost_all) == self.B_total and np.array_equal(cost_all[self.lo:self.hi], rs[last]["final_cost"])
             return dict(elapsed=elapsed, gpu_ms=gpu_ms, rs=rs, steps=steps, value=self.B_total * steps / elapsed,
                         ms_per_step=1e3 * elapsed / steps, to_result_ms=1e3 * float(np.mean(self.to_result)),
-                        deliver_ms=1e3 * float(np.mean(self.in_deliver)))
+                        deliver_ms=1e3 * float(np.mean(self.in_deliver)), wait_for_solve_ms=1e3 * float(np.mean(self.wait_solve)))
 
         def close(self):
-            for c_ in set(self.comms or []):
+            cs = list(dict.fromkeys(self.comms or []))
+            for c_ in reversed(cs):   # borrowers before the owner of the communicator
                 c_.close()
             for b_ in self.bts:
                 b_.close()
@@ -399,7 +420,10 @@ def main():
             "p95_ms_per_solve": float(np.percentile(r["latency_us"], 95)) * 1e-3,
             # host clock, per batch of the timed steps: launch -> its records delivered (the pack kernel of a batch waits for
             # workgroup slots behind the other stream's persistent workgroups), and the part of it spent inside deliver()
-            "time_to_result_ms": res["to_result_ms"], "deliver_ms": res["deliver_ms"],
+            # deliver_ms: from the completion of a batch's solve to its records in the caller's hands (the records are written by the
+            # solve kernels' epilogues; one DMA copy at N = 1, the all-gather at N > 1 -- with the C-ABI collective the figure includes
+            # the wait for the solve, which is enqueued behind it on the same stream); wait_for_solve_ms: the host blocked on the solve
+            "time_to_result_ms": res["to_result_ms"], "deliver_ms": res["deliver_ms"], "wait_for_solve_ms": res["wait_for_solve_ms"],
             "mean_iters": float(r["iters"].mean()), "mean_evals": float(r["evals"].mean()),
             "mean_hist_depth": float(r["hist_sum"].sum() / max(1, r["iters"].sum())),
             "success_rate": float(r["success"].mean()),

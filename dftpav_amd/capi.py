@@ -26,7 +26,7 @@ EXPORTS = [
     "dftpav_default_params", "dftpav_num_vars", "dftpav_num_points", "dftpav_create", "dftpav_destroy",
     "dftpav_last_error", "dftpav_set_surround", "dftpav_batch_create", "dftpav_batch_destroy",
     "dftpav_batch_upload", "dftpav_batch_get_x0", "dftpav_batch_eval", "dftpav_batch_solve_async",
-    "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
+    "dftpav_batch_sync", "dftpav_batch_results", "dftpav_batch_pack_results", "dftpav_batch_records", "dftpav_batch_coeffs", "dftpav_batch_last_solve_ms",
     "dftpav_solve_batch", "dftpav_stream", "dftpav_set_grid_map", "dftpav_corridor_rectangles",
     "dftpav_corridor_last_ms", "dftpav_batch_corridor_from_states", "dftpav_batch_validate",
     "dftpav_fit_surround", "dftpav_get_surround", "dftpav_frontend_resample",
@@ -116,6 +116,7 @@ def lib():
         L.dftpav_batch_results.argtypes = [vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_ll_p,
                                            c_double_p]
         L.dftpav_batch_pack_results.argtypes = [vp, vp]
+        L.dftpav_batch_records.argtypes = [vp, vp]
         L.dftpav_batch_coeffs.argtypes = [vp, c_double_p, c_double_p]
         L.dftpav_batch_last_solve_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.dftpav_solve_batch.argtypes = [vp, C.POINTER(Layout), C.c_int, C.POINTER(BatchData), c_double_p,
@@ -185,6 +186,12 @@ class Handle:
         buf = np.ascontiguousarray(unique_id, dtype=np.uint8)
         assert buf.size == 128
         self._check(fn(self._h, int(nranks), int(rank), buf.ctypes.data_as(C.c_void_p)), "comm_create")
+
+    def comm_share(self, owner):
+        """this handle uses `owner`'s communicator (dftpav_comm_share): one communicator per rank for several streams"""
+        fn = lib().dftpav_comm_share
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(fn(self._h, owner._h), "comm_share")
 
     def comm_destroy(self):
         fn = lib().dftpav_comm_destroy
@@ -514,6 +521,12 @@ class Batch:
         fn = lib().dftpav_batch_allgather_results
         fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         self.handle._check(fn(self._b, int(global_B), C.c_void_p(device_ptr)), "batch_allgather_results")
+
+    def records(self):
+        """the 16-byte result records of the last solve, uint8 [B][16] on the host (waits for the solve; one DMA copy)"""
+        out = np.zeros((self.B, 16), dtype=np.uint8)
+        self.handle._check(lib().dftpav_batch_records(self._b, out.ctypes.data_as(C.c_void_p)), "records")
+        return out
 
     def pack_results(self, device_ptr):
         """16-byte {f64 cost, i32 status, i32 iters} records into device memory (async on the handle's stream)."""

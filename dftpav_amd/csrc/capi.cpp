@@ -47,7 +47,6 @@ hipError_t launch_shots(const double *from, const double *to, int n, double rho,
                         const unsigned char *cells, int size_x, int size_y, double resolution, double origin_x, double origin_y,
                         double veh_width, double veh_length, double veh_dcr, const double *v_tab, int n_v, double *length, int *type,
                         double *seg, double *samples, int *n_samples, int *collides, hipStream_t stream);
-hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream);
 hipError_t launch_corridor_layout(const double *raw, double *out, int B, int Npts, int H, int NptsPad, hipStream_t stream);
 hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream);
 // solver_ref.hip: the same path in the reference's own floating-point order
@@ -84,6 +83,7 @@ struct dftpav_handle {
   std::vector<struct dftpav_batch *> batches; // every live batch of this handle (obstacle changes finish their chained stragglers)
   // RCCL communicator of dftpav_comm_create (one rank per handle = per GPU), and the staging block of this rank's records
   void *comm = nullptr;
+  bool comm_borrowed = false; // the communicator belongs to another handle of this process (dftpav_comm_share)
   int comm_ranks = 0, comm_rank = 0;
   unsigned char *d_comm_send = nullptr;
   size_t comm_send_bytes = 0;
@@ -124,6 +124,7 @@ struct dftpav_batch {
   double *d_x_in = nullptr, *d_x_out = nullptr, *d_f = nullptr, *d_g = nullptr;
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
+  unsigned char *d_records = nullptr; // [B + 1][16] result records written by the solver's epilogue (+ one zero record of padding)
   DevBatch *d_dev = nullptr; // device copy of the launch descriptor
   int dev_version = -1;
   // pinned host staging of the two descriptors and the event behind their last copy: refreshing the device copies then
@@ -869,7 +870,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   (void)hipStreamSynchronize(b->h->stream);
   void *ptrs[] = {b->d_x0, b->d_iniS, b->d_finS, b->d_corridor, b->d_pt_piece, b->d_pt_j, b->d_histS, b->d_histU, b->d_histV, b->d_histR,
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
-                  b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt,
+                  b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt, b->d_records,
                   b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
                   b->d_f_eval, b->d_trace, b->d_cor_raw, b->d_ref_tab, b->d_ref_scratch, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
                   b->pc.d_valid};
@@ -1079,6 +1080,8 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
   BCHK(hipMalloc(&b->d_hist, sizeof(long long) * (size_t)B));
   BCHK(hipMalloc(&b->d_ticks, sizeof(long long) * (size_t)B));
   BCHK(hipMalloc(&b->d_prof, sizeof(long long) * (size_t)B * 12));
+  BCHK(hipMalloc(&b->d_records, (size_t)16 * (B + 1)));
+  BCHK(hipMemset(b->d_records, 0, (size_t)16 * (B + 1)));
   BCHK(hipMalloc(&b->d_dev, sizeof(DevBatch)));
   BCHK(hipMalloc(&b->d_dev2, sizeof(DevBatch)));
   if (b->sched) {
@@ -1325,6 +1328,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.evals = b->d_evals;
   D.hist_sum = b->d_hist;
   D.ticks = b->d_ticks;
+  D.records = b->d_records;
   D.prof = b->prof_on ? b->d_prof : nullptr;
   D.coef_out = b->d_coef;
   D.dt_out = b->d_dt;
@@ -1874,9 +1878,10 @@ extern "C" int dftpav_comm_destroy(dftpav_handle *h) {
   if (h->comm) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    (void)rccl().CommDestroy(h->comm);
+    if (!h->comm_borrowed) (void)rccl().CommDestroy(h->comm);
     h->comm = nullptr;
   }
+  h->comm_borrowed = false;
   if (h->d_comm_send) (void)hipFree(h->d_comm_send);
   h->d_comm_send = nullptr;
   h->comm_send_bytes = 0;
@@ -1896,6 +1901,23 @@ extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const 
   RCCLCHK(h, rccl().CommInitRank(&h->comm, nranks, u, rank));
   h->comm_ranks = nranks;
   h->comm_rank = rank;
+  return DFTPAV_OK;
+}
+// Several handles (= HIP streams) of one process on one communicator: a host that keeps k batches in flight on k handles sets
+// ONE communicator up per rank instead of k (k ncclCommInitRank rendezvous and k sets of RCCL buffers per rank otherwise).
+// RCCL orders successive operations of a communicator among the streams they are enqueued on; what the host owes it is the
+// same order of collectives on every rank -- which a round-robin over the handles is.
+extern "C" int dftpav_comm_share(dftpav_handle *h, dftpav_handle *owner) {
+  if (!h || !owner || h == owner) return DFTPAV_E_INVALID;
+  if (!owner->comm || owner->comm_borrowed || owner->device != h->device) {
+    h->err = "dftpav_comm_share: the owner needs a communicator of its own (dftpav_comm_create) on the same device";
+    return DFTPAV_E_INVALID;
+  }
+  if (int rc = dftpav_comm_destroy(h)) return rc;
+  h->comm = owner->comm;
+  h->comm_borrowed = true;
+  h->comm_ranks = owner->comm_ranks;
+  h->comm_rank = owner->comm_rank;
   return DFTPAV_OK;
 }
 extern "C" int dftpav_comm_layout(int global_B, int nranks, int rank, int *first, int *count, int *block) {
@@ -1922,15 +1944,20 @@ extern "C" int dftpav_batch_allgather_results(dftpav_batch *b, int global_B, voi
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = finish_pending(b)) return rc;
   const size_t bytes = (size_t)block * 16;
+  if (block <= b->B + 1) {
+    // the send buffer IS the batch's record array (its epilogue-written records, one zero record of padding behind them for
+    // the ranks whose shard is one short of the block): nothing of ours runs between the solve and the collective
+    RCCLCHK(h, rccl().AllGather(b->d_records, all_records, bytes, kNcclUint8, h->comm, h->stream));
+    return DFTPAV_OK;
+  }
   if (h->comm_send_bytes < bytes) {
     if (h->d_comm_send) (void)hipFree(h->d_comm_send);
     h->d_comm_send = nullptr;
     HIPCHK(h, hipMalloc(&h->d_comm_send, bytes));
     h->comm_send_bytes = bytes;
   }
-  if ((size_t)count * 16 < bytes) HIPCHK(h, hipMemsetAsync(h->d_comm_send + (size_t)count * 16, 0, bytes - (size_t)count * 16, h->stream));
-  DevBatch D = make_dev(b);
-  HIPCHK(h, launch_pack(D, h->d_comm_send, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_comm_send, 0, bytes, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_comm_send, b->d_records, (size_t)16 * count, hipMemcpyDeviceToDevice, h->stream));
   RCCLCHK(h, rccl().AllGather(h->d_comm_send, all_records, bytes, kNcclUint8, h->comm, h->stream));
   return DFTPAV_OK;
 }
@@ -1940,8 +1967,20 @@ extern "C" int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst) {
   dftpav_handle *h = b->h;
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
-  DevBatch D = make_dev(b);
-  HIPCHK(h, launch_pack(D, device_dst, h->stream));
+  // the records are written by the solver's epilogue as trajectories finish: a copy on the stream, no kernel of ours
+  HIPCHK(h, hipMemcpyAsync(device_dst, b->d_records, (size_t)16 * b->B, hipMemcpyDeviceToDevice, h->stream));
+  return DFTPAV_OK;
+}
+
+// The 16-byte records of the last solve on the host: waits for the solve, then one device-to-host copy (a DMA engine: no
+// workgroup slot is needed, so delivery does not queue behind another stream's persistent workgroups)
+extern "C" int dftpav_batch_records(dftpav_batch *b, void *host_dst) {
+  if (!b || !host_dst || !b->solved) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  if (int rc = finish_pending(b)) return rc;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(host_dst, b->d_records, (size_t)16 * b->B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFTPAV_OK;
 }
 

@@ -147,6 +147,9 @@ struct DevBatch {
   double *f_eval;     // eval mode: [B] (apart from f_out, which holds the final costs of the last solve)
   int *status, *success, *iters, *evals;
   long long *hist_sum;
+  // [B + 1] 16-byte result records {f64 final cost, i32 status, i32 iterations} (what the all-gather carries),
+  // written by the solver's epilogue when a trajectory finishes -- no packing kernel between the solve and the collective
+  unsigned char *records;
   long long *ticks; // per-trajectory solve time in wall_clock64 ticks (100 MHz)
   long long *prof;  // optional [B][12] shader-clock phase profile (nullptr = off)
   double *coef_out; // [B][Ntot][6][2]

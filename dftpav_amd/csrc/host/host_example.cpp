@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <thread>
 
 #include <hip/hip_runtime_api.h>
@@ -17,6 +18,64 @@ using namespace plan_manage;
 // thread and one dftpav_handle per GPU here; one process per GPU works the same way, the 128-byte id then travels over the
 // host's own channel), a batch of restarts sharded contiguously, every rank solves its shard, ONE RCCL all-gather of the
 // 16-byte records, every rank ends with every result.  Needs N GPUs (RCCL ranks cannot share a device).
+// The gathered buffer of dftpav_batch_allgather_results -> the records of the global batch in order: rank r's shard sits at the
+// start of block r (dftpav_comm_layout), the pad behind a short shard is zero.  Used after the real collective below and by
+// `--placement` (no GPU), which stands in for the collective with a plain copy.
+static bool unpack_gathered(const std::vector<unsigned char> &all, int nranks, int B, std::vector<unsigned char> &out) {
+  out.assign((size_t)B * 16, 0);
+  int expect_first = 0;
+  for (int r = 0; r < nranks; r++) {
+    int first = 0, count = 0, block = 0;
+    if (dftpav_comm_layout(B, nranks, r, &first, &count, &block) != DFTPAV_OK) return false;
+    if (first != expect_first || count < 0 || count > block || all.size() != (size_t)nranks * block * 16) return false; // contiguous, in rank order
+    std::memcpy(&out[(size_t)first * 16], &all[(size_t)r * block * 16], (size_t)count * 16);
+    for (size_t q = ((size_t)r * block + count) * 16; q < (size_t)(r + 1) * block * 16; q++)
+      if (all[q] != 0) return false; // the pad of a short shard
+    expect_first = first + count;
+  }
+  return expect_first == B;
+}
+
+// `host_example --placement N B`: the sharding and the placement of the records for N ranks and B trajectories WITHOUT a device:
+// every rank's send buffer is built as dftpav_batch_allgather_results builds it (its `count` records, zero up to `block`),
+// the collective is a plain concatenation, and the unpacked result must be records 0 .. B-1 in order.  Run by the CPU tests
+// for uneven shards (B % N != 0, B < N ...), so that the first real N > 1 run cannot fail on bookkeeping.
+static int run_placement(int nranks, int B) {
+  int block0 = 0;
+  if (dftpav_comm_layout(B, nranks, 0, nullptr, nullptr, &block0) != DFTPAV_OK) {
+    std::printf("--placement %d %d: invalid\n", nranks, B);
+    return 1;
+  }
+  std::vector<unsigned char> all((size_t)nranks * block0 * 16, 0xff); // what the collective overwrites entirely
+  for (int r = 0; r < nranks; r++) {
+    int first = 0, count = 0, block = 0;
+    dftpav_comm_layout(B, nranks, r, &first, &count, &block);
+    if (block != block0) return 1;
+    std::vector<unsigned char> send((size_t)block * 16, 0);
+    for (int i = 0; i < count; i++) { // record of global trajectory g: cost = g + 0.5, status = -g, iterations = 7 g
+      const int g = first + i;
+      const double c = g + 0.5;
+      const int st = -g, it = 7 * g;
+      std::memcpy(&send[(size_t)i * 16], &c, 8);
+      std::memcpy(&send[(size_t)i * 16 + 8], &st, 4);
+      std::memcpy(&send[(size_t)i * 16 + 12], &it, 4);
+    }
+    std::memcpy(&all[(size_t)r * block * 16], send.data(), send.size()); // the all-gather, stubbed
+  }
+  std::vector<unsigned char> out;
+  bool ok = unpack_gathered(all, nranks, B, out);
+  for (int g = 0; ok && g < B; g++) {
+    double c;
+    int st, it;
+    std::memcpy(&c, &out[(size_t)g * 16], 8);
+    std::memcpy(&st, &out[(size_t)g * 16 + 8], 4);
+    std::memcpy(&it, &out[(size_t)g * 16 + 12], 4);
+    ok = c == g + 0.5 && st == -g && it == 7 * g;
+  }
+  std::printf("--placement %d ranks, %d trajectories, blocks of %d: %s\n", nranks, B, block0, ok ? "every record in its place" : "FAILED");
+  return ok ? 0 : 1;
+}
+
 static int run_ranks(int nranks) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < nranks) {
@@ -37,6 +96,7 @@ static int run_ranks(int nranks) {
     return 0;
   }
   std::vector<int> ok(nranks, 0);
+  std::vector<double> wait_ms(nranks, 0.0), solve_ms(nranks, 0.0);
   std::vector<std::vector<unsigned char>> gathered(nranks);
   std::vector<std::thread> th;
   for (int r = 0; r < nranks; r++)
@@ -64,7 +124,15 @@ static int run_ranks(int nranks) {
       void *all = nullptr;
       good = good && dftpav_batch_upload(b, &d) == DFTPAV_OK && dftpav_batch_solve_async(b) == DFTPAV_OK;
       good = good && hipSetDevice(r) == hipSuccess && hipMalloc(&all, (size_t)nranks * block * 16) == hipSuccess;
+      // how long a rank waits for the COLLECTIVE after its own solve is done: the all-gather completes at the pace of the slowest
+      // rank, so this is the coupling between the ranks (the first N > 1 run shows it directly)
+      const auto t0 = std::chrono::steady_clock::now();
+      good = good && dftpav_batch_sync(b) == DFTPAV_OK; // this rank's solve is complete
+      const auto t1 = std::chrono::steady_clock::now();
       good = good && dftpav_batch_allgather_results(b, B, all) == DFTPAV_OK && dftpav_batch_sync(b) == DFTPAV_OK;
+      const auto t2 = std::chrono::steady_clock::now();
+      solve_ms[r] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+      wait_ms[r] = std::chrono::duration<double, std::milli>(t2 - t1).count();
       gathered[r].resize((size_t)nranks * block * 16);
       good = good && hipMemcpy(gathered[r].data(), all, gathered[r].size(), hipMemcpyDeviceToHost) == hipSuccess;
       std::vector<double> cost(count);
@@ -83,12 +151,16 @@ static int run_ranks(int nranks) {
   for (auto &t : th) t.join();
   bool all_ok = true;
   for (int r = 0; r < nranks; r++) all_ok = all_ok && ok[r] && gathered[r] == gathered[0]; // every rank sees every result
+  std::vector<unsigned char> in_order;
+  all_ok = all_ok && unpack_gathered(gathered[0], nranks, B, in_order);
+  for (int r = 0; r < nranks; r++) std::printf("rank %d: solve %.2f ms, then %.2f ms in the collective\n", r, solve_ms[r], wait_ms[r]);
   std::printf("--ranks %d: %d trajectories sharded, solved, one all-gather of 16-byte records -> %s\n", nranks, B, all_ok ? "identical on every rank" : "FAILED");
   return all_ok ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
   if (argc >= 3 && std::strcmp(argv[1], "--ranks") == 0) return run_ranks(std::atoi(argv[2]));
+  if (argc >= 4 && std::strcmp(argv[1], "--placement") == 0) return run_placement(std::atoi(argv[2]), std::atoi(argv[3]));
   PolyTrajOptimizer opt;
   dftpav_params p;
   dftpav_default_params(&p);

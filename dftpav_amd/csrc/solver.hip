@@ -2082,6 +2082,13 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
         Db.iters[b] = sm.ist[iK];
         Db.evals[b] = sm.ist[iEVALS];
         Db.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+        {
+          double *rec = reinterpret_cast<double *>(Db.records + (size_t)16 * b); // the all-gather record, ready when the trajectory is
+          rec[0] = fx;
+          int *ri = reinterpret_cast<int *>(rec + 1);
+          ri[0] = ret;
+          ri[1] = sm.ist[iK];
+        }
         Db.ticks[b] = (resume ? Db.ticks[b] : 0) + spent; // time in service
         // flag_success, traj_optimizer.cpp:176-201
         int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;
@@ -2136,23 +2143,6 @@ __global__ void adopt_kernel(unsigned *ctl, int *queue, int qcap, unsigned *prev
 }
 hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t stream) {
   hipLaunchKernelGGL(adopt_kernel, dim3(1), dim3(256), 0, stream, D.qctl, D.queue, D.qcap, prev.qctl, prev.stragglers);
-  return hipGetLastError();
-}
-
-// {f64 cost, i32 status, i32 iters} records for the all-gather of SURVEY §8(e)
-__global__ void pack_results_kernel(const double *f, const int *status, const int *iters, int B, unsigned char *dst) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) {
-    double *rec = reinterpret_cast<double *>(dst + (size_t)16 * i);
-    rec[0] = f[i];
-    int *ri = reinterpret_cast<int *>(rec + 1);
-    ri[0] = status[i];
-    ri[1] = iters[i];
-  }
-}
-hipError_t launch_pack(const DevBatch &D, void *dst, hipStream_t stream) {
-  hipLaunchKernelGGL(pack_results_kernel, dim3((D.B + 255) / 256), dim3(256), 0, stream, D.f_out, D.status, D.iters, D.B,
-                     static_cast<unsigned char *>(dst));
   return hipGetLastError();
 }
 

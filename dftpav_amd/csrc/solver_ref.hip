@@ -2334,6 +2334,13 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
         D.iters[b] = sm.ist[iK];
         D.evals[b] = sm.ist[iEVALS];
         D.hist_sum[b] = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+        {
+          double *rec = reinterpret_cast<double *>(D.records + (size_t)16 * b); // the all-gather record (as solver.hip's epilogue)
+          rec[0] = fx;
+          int *ri = reinterpret_cast<int *>(rec + 1);
+          ri[0] = ret;
+          ri[1] = sm.ist[iK];
+        }
         D.ticks[b] = (resume ? D.ticks[b] : 0) + spent; // time in service
         int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
         if (fx >= D.P.fail_cost) ok = 0;

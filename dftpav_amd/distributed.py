@@ -64,18 +64,54 @@ class RcclComm:
     is the library's (ncclAllGather on the handle's stream), so a C++ host without PyTorch runs the identical path
     (dftpav_amd/csrc/host/host_example.cpp --ranks N)."""
 
-    def __init__(self, handle, group=None):
+    def __init__(self, handle, group=None, share=None):
+        """share: an RcclComm of this process whose communicator this handle borrows (dftpav_comm_share) -- a host with k batches
+        in flight on k handles sets up ONE communicator per rank; no collective call is made here then."""
         from . import capi
         self.handle = handle
+        if share is not None:
+            self.world, self.rank = share.world, share.rank
+            handle.comm_share(share.handle)
+            self._recv = None
+            return
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        uid = capi.comm_unique_id() if self.rank == 0 else np.zeros(128, dtype=np.uint8)
+        # Every decision on the way is taken by ALL ranks together: a rank that raised on its own would leave the others inside a
+        # broadcast or inside ncclCommInitRank.  (1) can every rank reach RCCL through the library at all?  (2) the id, with a
+        # status byte behind it;  (3) did every rank's dftpav_comm_create succeed?
+        dev = "cpu"
         if self.world > 1:
             dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-            t = torch.from_numpy(uid).to(dev)
+        uid, ok = np.zeros(128, dtype=np.uint8), 1
+        try:
+            probe = capi.comm_unique_id()      # loads RCCL behind the C-ABI; every rank probes, rank 0's id is the one used
+            if self.rank == 0:
+                uid = probe
+        except Exception as ex:  # noqa: BLE001
+            ok, self._err = 0, str(ex)
+        if self.world > 1:
+            t = torch.from_numpy(np.concatenate([uid, np.array([ok], dtype=np.uint8)])).to(dev)
             dist.broadcast(t, src=0, group=group)
-            uid = t.cpu().numpy()
-        handle.comm_create(self.world, self.rank, uid)
+            got = t.cpu().numpy()
+            uid, ok0 = got[:128].copy(), int(got[128])
+            flag = torch.tensor([min(ok, ok0)], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = int(flag.item())
+        if not ok:
+            raise RuntimeError("RCCL behind the C-ABI is not available on every rank: %s" % getattr(self, "_err", "another rank failed"))
+        created = 1
+        try:
+            handle.comm_create(self.world, self.rank, uid)
+        except Exception as ex:  # noqa: BLE001
+            created, self._err = 0, str(ex)
+        if self.world > 1:
+            flag = torch.tensor([created], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0 and created:
+                handle.comm_destroy()
+                created, self._err = 0, "dftpav_comm_create failed on another rank"
+        if not created:
+            raise RuntimeError("dftpav_comm_create: %s" % self._err)
         self._recv = None
 
     def allgather(self, batch, B):

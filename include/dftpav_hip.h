@@ -393,10 +393,14 @@ int dftpav_marks_elapsed_ms(dftpav_handle *from, int from_slot, dftpav_handle *t
  * it thins out, which keeps the device full without any hand-over (bench.py's default). */
 int dftpav_batch_set_hand_over(dftpav_batch *b, int hand_over);
 
-/* Multi-GPU hand-off: packs one 16-byte record {f64 final_cost, i32 status, i32 iters}
- * per trajectory into caller-owned DEVICE memory (asynchronously, on the handle's
- * stream) — the send buffer of the single all-gather of SURVEY §8(e). */
+/* Multi-GPU hand-off: one 16-byte record {f64 final_cost, i32 status, i32 iters} per trajectory — what the single
+ * all-gather of SURVEY §8(e) carries.  The solve kernels write a trajectory's record in their epilogue, the moment it
+ * finishes; there is no packing kernel between the solve and the collective (it used to wait up to 110 ms for a workgroup
+ * slot behind the other stream's persistent workgroups).
+ *   dftpav_batch_pack_results: copies the records into caller-owned DEVICE memory, asynchronously on the handle's stream.
+ *   dftpav_batch_records:      waits for the solve and copies them to HOST memory [B][16] (a DMA copy, no kernel). */
 int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst);
+int dftpav_batch_records(dftpav_batch *b, void *host_dst);
 
 /* The collective itself behind the C-ABI, for a C++ host (the reference's caller is one: TrajPlanner::RunMINCOParking,
  * traj_manager.cpp:608-610) that shards its restarts / hypotheses over the GPUs of a node, one process (or thread) and one
@@ -404,16 +408,27 @@ int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst);
  *   dftpav_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands the bytes to the other ranks by whatever
  *                           channel the host has (MPI, a socket, torch.distributed ...)
  *   dftpav_comm_create      every rank, collectively: ncclCommInitRank on the handle's device
+ *   dftpav_comm_share       another handle (= HIP stream) of the same process and device uses the owner's communicator: a host
+ *                           with k batches in flight on k handles sets up one communicator per rank, not k.  The owner must
+ *                           outlive the borrowers' use; every rank issues its collectives in the same order (round-robin over
+ *                           the handles does)
  *   dftpav_comm_layout      the contiguous shard [first, first + count) of a rank out of global_B trajectories, and `block` =
  *                           the largest shard: the gathered buffer holds nranks blocks of `block` records, rank r's shard at
  *                           the start of block r (the pad, at most one record, is zero)
- *   dftpav_batch_allgather_results   packs this rank's records and all-gathers them into all_records (DEVICE memory,
- *                           nranks * block * 16 bytes); asynchronous: the caller synchronises the handle's stream (dftpav_batch_sync)
- * RCCL is loaded on first use (librccl.so.1); DFTPAV_E_COMM where it is absent or a call fails. */
+ *   dftpav_batch_allgather_results   all-gathers this rank's records (written by the solve kernels' epilogues: the send
+ *                           buffer is the batch's own record array) into all_records (DEVICE memory, nranks * block * 16 bytes);
+ *                           asynchronous: the caller synchronises the handle's stream (dftpav_batch_sync)
+ * RCCL is loaded on first use (librccl.so.1); DFTPAV_E_COMM where it is absent or a call fails.
+ *
+ * HARD REQUIREMENT for more than four handles with work in flight in one process (strong scaling keeps up to 16 steps in
+ * flight per GPU): the environment variable GPU_MAX_HW_QUEUES must be set to at least that number BEFORE the HIP runtime
+ * starts (the default is 4 hardware queues per process: the fifth stream's launch waits for one of the first four to drain,
+ * which halves the throughput of 8 batches in flight and lets a collective queue behind an unrelated batch). */
 #define DFTPAV_UNIQUE_ID_BYTES 128
 int dftpav_comm_unique_id(void *id128);
 int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const void *id128);
 int dftpav_comm_destroy(dftpav_handle *h);
+int dftpav_comm_share(dftpav_handle *h, dftpav_handle *owner);
 int dftpav_comm_layout(int global_B, int nranks, int rank, int *first, int *count, int *block);
 int dftpav_batch_allgather_results(dftpav_batch *b, int global_B, void *all_records);
 

@@ -75,3 +75,17 @@ def test_two_rank_allgather_equals_single_process():
     ref = po.solve_batch(p, s, nthreads=1, order=1)
     c, st, it = dd.unpack_records(got[0])
     assert np.array_equal(c, ref["final_cost"]) and np.array_equal(st, ref["status"]) and np.array_equal(it, ref["iters"])
+
+
+def test_cpp_host_shard_layout_and_record_placement_without_a_device():
+    """dftpav_comm_layout + the placement of the 16-byte records in the gathered buffer, through the C++ host
+    (dftpav_amd/csrc/host/host_example --placement N B: every rank's send block built as dftpav_batch_allgather_results builds
+    it, the collective replaced by a plain copy) for even and uneven shards: the pre-flight of the first real N > 1 run."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "dftpav_amd", "csrc", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    for nranks, B in [(2, 7), (2, 8), (8, 4096), (8, 4099), (8, 4103), (4, 3), (3, 1), (16, 512), (7, 1000)]:
+        out = subprocess.run([os.path.join(host, "host_example"), "--placement", str(nranks), str(B)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and "every record in its place" in out.stdout, (nranks, B, out.stdout, out.stderr)

@@ -167,3 +167,76 @@ def test_cpp_host_runs_the_collective_through_the_c_abi(hiplib):
     out = subprocess.run([exe, "--ranks", "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "identical on every rank" in out.stdout
+
+
+@pytest.mark.parametrize("mode", ["device", "device_sliced", "reference", "reference_wave"])
+def test_records_are_written_by_the_solve_kernels(hiplib, monkeypatch, mode):
+    """The 16-byte records of the all-gather are written by the solver's epilogue when a trajectory finishes (no packing kernel):
+    dftpav_batch_records / dftpav_batch_pack_results return {final cost, status, iterations} of dftpav_batch_results for every
+    launch shape -- plain and time-sliced device order (the straggler launch writes its own), both shapes of the reference order --
+    and a second solve of the same batch overwrites them."""
+    from dftpav_amd import capi, scenarios as sc
+    if mode == "device_sliced":
+        monkeypatch.setenv("DFTPAV_SCHED", "1")
+        monkeypatch.setenv("DFTPAV_SLOTS", "3")
+        monkeypatch.setenv("DFTPAV_SLICE", "7")
+        monkeypatch.setenv("DFTPAV_HANDOVER", "2")
+    if mode == "reference_wave":
+        monkeypatch.setenv("DFTPAV_REF_SHAPE", "wave")
+        monkeypatch.setenv("DFTPAV_REF_SLOTS", "1")
+        monkeypatch.setenv("DFTPAV_REF_SLICE", "9")
+    p = capi.default_params()
+    s = sc.baseline_config(1, B=20)
+    s.apply_resolution(p)
+    h = capi.Handle(p, device=0)
+    bt = capi.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    if mode.startswith("reference"):
+        bt.set_order(capi.ORDER_REFERENCE)
+    for rep in range(2):
+        bt.solve_async()
+        rec_dev = torch.zeros((s.B, dd.RECORD_BYTES), dtype=torch.uint8, device="cuda:0")
+        bt.pack_results(rec_dev.data_ptr())
+        rec_host = bt.records()
+        r = bt.results()
+        for rec in (rec_host, rec_dev.cpu().numpy()):
+            cost, status, iters = dd.unpack_records(rec)
+            assert np.array_equal(cost, r["final_cost"]) and np.array_equal(status, r["status"]) and np.array_equal(iters, r["iters"]), (mode, rep)
+    bt.close()
+    h.close()
+
+
+def test_one_communicator_shared_by_several_handles(hiplib):
+    """dftpav_comm_share at world size 1: three handles (= HIP streams) of one process, ONE communicator -- the owner's -- and an
+    all-gather of the epilogue-written records on each of the three streams, round-robin, twice; the borrowers are destroyed
+    before the owner.  (What bench.py does at N > 1 instead of a communicator per handle.)"""
+    from dftpav_amd import capi, scenarios as sc
+    p = capi.default_params()
+    B = 9
+    s = sc.baseline_config(1, B=B)
+    s.apply_resolution(p)
+    hs = [capi.Handle(p, device=0) for _ in range(3)]
+    owner = dd.RcclComm(hs[0])
+    comms = [owner] + [dd.RcclComm(h_, share=owner) for h_ in hs[1:]]
+    bts = []
+    for k, h_ in enumerate(hs):
+        sub = s.subset(np.arange(B))
+        sub.inner_pts = np.ascontiguousarray(sub.inner_pts).copy()
+        sub.inner_pts[:, 1] += 0.01 * k          # three different batches
+        bt = capi.Batch(h_, sub.layout, B)
+        bt.upload(sub)
+        bts.append(bt)
+    for rep in range(2):
+        for bt in bts:
+            bt.solve_async()
+        for c_, bt in zip(comms, bts):
+            allrec = c_.allgather(bt, B)
+            cost, status, iters = dd.unpack_records(allrec.cpu().numpy())
+            r = bt.results()
+            assert np.array_equal(cost, r["final_cost"]) and np.array_equal(status, r["status"]) and np.array_equal(iters, r["iters"])
+    for bt in bts:
+        bt.close()
+    for c_ in reversed(comms):
+        c_.close()
+    for h_ in hs:
+        h_.close()
