@@ -1497,7 +1497,10 @@ static bool reference_order_tables(int N, std::vector<double> &out) {
         if (t[q][8 * i + k] != 0.0) m |= 1 << k;
       if (i >= 6 && i < n6 - 6 && m != reference_order_interior_mask(q, i % 6)) ok = false;
       t[q][8 * i + 6] = A.at(i, i);
-      t[q][8 * i + 7] = 1.0 / A.at(i, i);
+      { // (solver_ref.hip: rcp_or_nan -- a diagonal outside [2^-500, 2^500] makes the kernel divide instead)
+        const double dg = std::fabs(A.at(i, i));
+        t[q][8 * i + 7] = (dg >= 0x1p-500 && dg <= 0x1p500) ? 1.0 / A.at(i, i) : std::nan("");
+      }
     }
   }
   return ok;

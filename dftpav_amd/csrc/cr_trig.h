@@ -229,6 +229,7 @@ DFTPAV_HD inline double scale2(double v, int k) { // v 2^k, in two steps so that
 // Results below the normal range (x < -708.4) go through a second rounding in scale2 (the reference's sums absorb them:
 // they are weights relative to a term that is exactly 1).
 DFTPAV_HD inline double exp_cr(double x) {
+  if (x != x) return x; // NaN in, NaN out (before the conversion to int below, which is undefined for a NaN on the host)
   if (x < -745.2) return 0.0;
   if (x > 709.8) return 1.0e308 * 1.0e308;
   if (x == 0.0) return 1.0;

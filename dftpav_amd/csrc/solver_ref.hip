@@ -67,11 +67,22 @@ typedef const double __attribute__((address_space(1))) *gcd_t;
 typedef double __attribute__((address_space(1))) *gd_t;
 
 // a / b from y = 1 / b (Markstein): the correctly rounded quotient, i.e. the bits of a / b (solver.hip: checked on 2^31
-// pairs on gfx950 against the division)
+// pairs on gfx950 against the division) -- as long as nothing under- or overflows on the way.  Guarded: a dividend outside
+// [2^-500, 2^500] (zero included: the sign of a zero quotient) or a reciprocal marked unusable by rcp_or_nan (divisor outside
+// that range) takes the division itself, as the reference does.  Both are a few cycles on a branch that is never taken in a
+// real solve (stored y . s products and LU diagonals are O(1e-8 .. 1e8)).
 __device__ __forceinline__ double div_by_rcp(double a, double b, double y) {
   const double q0 = a * y;
   const double r = __builtin_fma(-b, q0, a);
-  return __builtin_fma(r, y, q0);
+  const double q = __builtin_fma(r, y, q0);
+  const double aa = __builtin_fabs(a);
+  if (__builtin_expect(!(aa >= 0x1p-500 && aa <= 0x1p500) || y != y, 0)) return a / b;
+  return q;
+}
+// 1 / b for div_by_rcp, or NaN where the reciprocal route would not give the bits of the division
+__host__ __device__ __forceinline__ double rcp_or_nan(double b) {
+  const double ab = __builtin_fabs(b);
+  return (ab >= 0x1p-500 && ab <= 0x1p500) ? 1.0 / b : __builtin_nan("");
 }
 template <int CTRL> __device__ __forceinline__ double mov_dpp(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -2132,7 +2143,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
   if (lane == 0) {
     d2_t yr;
     yr.x = ys;
-    yr.y = 1.0 / ys;
+    yr.y = rcp_or_nan(ys);
     ((gd2_t)hR)[end] = yr;
   }
   const double cau = ss * sqrt(gpgp) * P.cautious_factor;
