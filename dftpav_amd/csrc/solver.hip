@@ -587,6 +587,21 @@ __device__ inline void prep_durations(const DevBatch &D, const Smem &sm, const d
   }
 }
 
+// One (constraint point, obstacle) pair that passed the gate: dynamicObsGradCostP's body (traj_math.h: dynamic_pair, 9.2 k
+// instructions) and the pair's 14 contributions to its piece, stored at dst[k * stride].  A function of its own: inlined into
+// the evaluation its ~250 live values were allocated together with everything the kernel keeps across the stage -- 151 spilled
+// vector and 927 spilled scalar registers, 416 B of scratch per lane, the spill code inside the pair loop.
+#ifndef DFTPAV_PAIR_OUT_OF_LINE
+#define DFTPAV_PAIR_OUT_OF_LINE 1
+#endif
+__device__ __attribute__((noinline)) void pair_eval(const DevParams &P, const SurLds &surL, const SampleIn &in, int u, double *dst, int stride) {
+  double o[8], v[14];
+  dynamic_pair_math(P, surL, in, u, o);
+  point_contributions(in.s1, o, v);
+#pragma unroll
+  for (int k = 0; k < 14; k++) dst[k * stride] = v[k];
+}
+
 template <bool SUR>
 __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_b, const Smem &sm, const double *x, double *g,
                                            Prof &pr) {
@@ -947,11 +962,20 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
         in.trajtime = sg == 0 ? 0.0 : sm.seg[(sg > 0 ? sg - 1 : 0) * 16];
         in.t_piece = sm.tpc[p];
         in.t_now = D.t_now;
+#if DFTPAV_PAIR_OUT_OF_LINE
+        {
+          // copies, so that only they escape to the call (the kernel's own surL / in stay in registers)
+          const SurLds sl = surL;
+          const SampleIn in2 = in;
+          pair_eval(P, sl, in2, u, sm.dpart + tid, dstride);
+        }
+#else
         double o[8], v[14];
         dynamic_pair_math(P, surL, in, u, o);
         point_contributions(in.s1, o, v);
 #pragma unroll
         for (int k = 0; k < 14; k++) sm.dpart[k * dstride + tid] = v[k];
+#endif
       }
       pr.tick(kPMISC);
       __syncthreads();

@@ -554,7 +554,7 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     double surround_R[4];
     traj_getR(st, pt_time, surround_R); // OPT:1410
 
-    double surround2ego_sum_exp_vec[4], d_U[4];
+    double surround2ego_sum_exp_vec[4], d_U[4], d_U_tilde[4], d_E_tilde[4];
     double ego_normal[4][2], vec_d_Uo_e[4][4], F_delta_le_v[4][4], F_le_v[4][4];
     for (int e = 0; e < nE; e++) { // OPT:1417-1461
       const double *le = P.vec_le[e];
@@ -596,9 +596,7 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
         const double *lo = P.vec_le[o];
         vec_d_Uo_e[e][o] = HtR[0] * lo[0] + HtR[1] * lo[1];
       }
-      double exp_sum;
-      d_U[e] = lse_cr(-alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_e_tilde;
-      surround2ego_sum_exp_vec[e] = exp_sum;
+      d_U_tilde[e] = d_U_e_tilde; // (its log_sum_exp follows the bound below: the same values in another instruction order)
     }
 
     double ego2surround_sum_exp_vec[4], d_E[4];
@@ -623,8 +621,34 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
         const double *le = P.vec_le[e];
         vec_d_Ee_o[o][e] = HtR[0] * le[0] + HtR[1] * le[1];
       }
+      d_E_tilde[o] = d_E_o_tilde;
+    }
+    {
+      // A bound before any exponential (the correctly rounded ones are double-double series).  With m_k = min_j v_kj:
+      // log_sum_exp(-alpha, v_k) lies in [m_k - ln 4 / alpha, m_k] and log_sum_exp(alpha, d) >= max_k d_k, hence
+      //     d_value_test = d_min - log_sum_exp(alpha, d_test)  <=  d_min + ln 4 / alpha - max_k (m_k + t_k);
+      // below -1e-9 (the roundings of the full evaluation are 1e-14) the reference's `if (costp <= 0) continue` is taken.
+      double best = -1.0e300;
+      for (int k = 0; k < 4; k++) {
+        double mU = vec_d_Uo_e[k][0], mE = vec_d_Ee_o[k][0];
+        for (int j = 1; j < 4; j++) {
+          mU = vec_d_Uo_e[k][j] < mU ? vec_d_Uo_e[k][j] : mU;
+          mE = vec_d_Ee_o[k][j] < mE ? vec_d_Ee_o[k][j] : mE;
+        }
+        const double a = mU + d_U_tilde[k], b = mE + d_E_tilde[k];
+        best = a > best ? a : best;
+        best = b > best ? b : best;
+      }
+      if (d_min + 1.38629436111989061883e+00 / alpha - best < -1.0e-9) continue;
+    }
+    for (int e = 0; e < nE; e++) {
       double exp_sum;
-      d_E[o] = lse_cr(-alpha, vec_d_Ee_o[o], nE, &exp_sum) + d_E_o_tilde;
+      d_U[e] = lse_cr(-alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_tilde[e];
+      surround2ego_sum_exp_vec[e] = exp_sum;
+    }
+    for (int o = 0; o < nO; o++) {
+      double exp_sum;
+      d_E[o] = lse_cr(-alpha, vec_d_Ee_o[o], nE, &exp_sum) + d_E_tilde[o];
       ego2surround_sum_exp_vec[o] = exp_sum;
     }
 

@@ -625,6 +625,10 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const SV &S, int u, con
     bh_times(Rud, BRud);
     double s2e_sum[4], d_test[8];
     double egoN[4][2], dUo[4][4];
+    double dUt4[4], dEt4[4];
+    // The geometry of the eight separating directions first (traj_optimizer.cpp:1417-1461, 1464-1496 without their
+    // log_sum_exp), the 40 exponentials and 9 logarithms of the three-level soft min / max afterwards: the same values in
+    // another instruction order.
     for (int e = 0; e < 4; e++) { // traj_optimizer.cpp:1417-1461
       const double *le = vle[e];
       const double dl[2] = {edl[e][0], edl[e][1]};
@@ -637,13 +641,9 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const SV &S, int u, con
       egoN[e][0] = Ht[0];
       egoN[e][1] = Ht[1];
       double w[2] = {sp[0] - sigma[0] - Rle[0], sp[1] - sigma[1] - Rle[1]};
-      double dUt = Ht[0] * w[0] + Ht[1] * w[1];
+      dUt4[e] = Ht[0] * w[0] + Ht[1] * w[1];
       double HtR[2] = {Ht[0] * sR[0] + Ht[1] * sR[2], Ht[0] * sR[1] + Ht[1] * sR[3]};
       for (int o = 0; o < 4; o++) dUo[e][o] = HtR[0] * vle[o][0] + HtR[1] * vle[o][1];
-      double es;
-      d_test[e] = log_sum_exp<4>(-alpha, dUo[e], es) + dUt;
-      s2e_sum[e] = es;
-      DFTPAV_SCHED_FENCE();
     }
     double e2s_sum[4];
     double surN[4][2], dEe[4][4];
@@ -658,11 +658,41 @@ DFTPAV_HD inline double dynamic_pair(const DevParams &P, const SV &S, int u, con
       surN[o][1] = Ht[1];
       mat_vec(sR, lo, Rlo);
       double w[2] = {sigma[0] - sp[0] - Rlo[0], sigma[1] - sp[1] - Rlo[1]};
-      double dEt = Ht[0] * w[0] + Ht[1] * w[1];
+      dEt4[o] = Ht[0] * w[0] + Ht[1] * w[1];
       double HtR[2] = {Ht[0] * ego_R[0] + Ht[1] * ego_R[2], Ht[0] * ego_R[1] + Ht[1] * ego_R[3]};
       for (int e = 0; e < 4; e++) dEe[o][e] = HtR[0] * vle[e][0] + HtR[1] * vle[e][1];
+    }
+    DFTPAV_SCHED_FENCE();
+    {
+      // A bound before any exponential.  With m_k = min_j v_kj: log_sum_exp(-alpha, v_k) lies in [m_k - ln 4 / alpha, m_k] (its sum
+      // of four exponentials lies in [1, 4]) and log_sum_exp(alpha, d) >= max_k d_k, hence
+      //     costp = d_min - log_sum_exp(alpha, d_test)  <=  d_min + ln 4 / alpha - max_k (m_k + t_k).
+      // When that is below -1e-9 (the roundings of the full evaluation are 1e-14) the full evaluation returns 0.0 at
+      // `costp <= 0` below -- and so does this, 40 exponentials and 9 logarithms earlier.  Two footprints whose centres pass the
+      // distance gate of :1393 (7 m) are rarely within the 0.42 m at which the penalty starts.
+      double best = -1.0e300;
+      for (int k = 0; k < 4; k++) {
+        double mU = dUo[k][0], mE = dEe[k][0];
+        for (int j = 1; j < 4; j++) {
+          mU = dUo[k][j] < mU ? dUo[k][j] : mU;
+          mE = dEe[k][j] < mE ? dEe[k][j] : mE;
+        }
+        const double a = mU + dUt4[k], b = mE + dEt4[k];
+        best = a > best ? a : best;
+        best = b > best ? b : best;
+      }
+      const double ln4 = 1.38629436111989061883e+00;
+      if (d_min + ln4 / alpha - best < -1.0e-9) return 0.0;
+    }
+    for (int e = 0; e < 4; e++) {
       double es;
-      d_test[4 + o] = log_sum_exp<4>(-alpha, dEe[o], es) + dEt;
+      d_test[e] = log_sum_exp<4>(-alpha, dUo[e], es) + dUt4[e];
+      s2e_sum[e] = es;
+      DFTPAV_SCHED_FENCE();
+    }
+    for (int o = 0; o < 4; o++) {
+      double es;
+      d_test[4 + o] = log_sum_exp<4>(-alpha, dEe[o], es) + dEt4[o];
       e2s_sum[o] = es;
       DFTPAV_SCHED_FENCE();
     }

@@ -57,7 +57,9 @@ def test_solve_is_in_lockstep_with_the_reference_lbfgs(hiplib, oracle, cfg, B, b
     # (poly_traj_utils.hpp:831-852): two roundings of the same sum.  1e-11 / 1e-10 hold at x0 (test_eval_matches_oracle); along
     # a whole solve the bounds are those of test_lockstep_over_64_trajectories below (which points a solve visits changes with
     # any change of a rounding anywhere; the largest differences seen on single trajectories are 3.4e-12 and 1.9e-6).
-    assert rep["rel_f"] <= 1e-8 and rep["rel_g"] <= 1e-4
+    # Bounds 3-8 x above the largest values seen on these five trajectories (profiles/r04_lockstep.txt: f 6.4e-12, g 1.9e-6, the
+    # gear-shift case cfg 2; the others stay below 5e-8 on g)
+    assert rep["rel_f"] <= 5e-11 and rep["rel_g"] <= (5e-6 if cfg == 2 else 5e-7)
     assert rep["rel_x"] <= 1e-15
     assert rep["rel_d"] <= 1e-9
     # the replay covers the whole solve unless a branch sat within rounding of its threshold
@@ -119,7 +121,11 @@ def test_lockstep_over_64_trajectories(hiplib, oracle, monkeypatch, cfg, B):
         # are two solutions of it (forward errors cond x 1e-16 apart); absolute errors of 1e-5 on a gradient whose penalty terms
         # have curvature 6e8 x weight (traj_optimizer.cpp:783-806) are position roundings of 1e-14 m.  What decides is below:
         # every BRANCH taken from the literal values is the branch the kernel took.
-        assert rep["rel_f"] <= 1e-8 and rep["rel_g"] <= 1e-4 and rep["rel_x"] <= 1e-15 and rep["rel_d"] <= 1e-9
+        # Bounds: 1e-9 on f and 1e-5 on g -- 3 x above the largest values seen over the 64 trajectories of cfg 0, 1, 3, 5
+        # (profiles/r04_lockstep.txt: f 5.8e-11, g 3.1e-6); the gear-shift configuration cfg 2 (short pieces at the junction, the
+        # worst-conditioned MINCO systems) reaches f 1.9e-9 and g 1.8e-5 and gets 5e-9 / 5e-5
+        f_tol, g_tol = (5e-9, 5e-5) if cfg == 2 else (1e-9, 1e-5)
+        assert rep["rel_f"] <= f_tol and rep["rel_g"] <= g_tol and rep["rel_x"] <= 1e-15 and rep["rel_d"] <= 1e-9
         if rep["flip"] is None:
             assert abs(rep["iterations"] - r["iters"][b]) <= 1
         reps.append(rep)
