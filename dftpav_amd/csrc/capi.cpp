@@ -1497,9 +1497,11 @@ static bool reference_order_tables(int N, std::vector<double> &out) {
         if (t[q][8 * i + k] != 0.0) m |= 1 << k;
       if (i >= 6 && i < n6 - 6 && m != reference_order_interior_mask(q, i % 6)) ok = false;
       t[q][8 * i + 6] = A.at(i, i);
-      { // (solver_ref.hip: rcp_or_nan -- a diagonal outside [2^-500, 2^500] makes the kernel divide instead)
+      { // the kernel divides by the diagonal through its reciprocal (solver_ref.hip: div_by_rcp): the bits of the division as long
+        // as the diagonal is an ordinary number -- O(1) for every MINCO system; anything else is refused here
         const double dg = std::fabs(A.at(i, i));
-        t[q][8 * i + 7] = (dg >= 0x1p-500 && dg <= 0x1p500) ? 1.0 / A.at(i, i) : std::nan("");
+        if (!(dg >= 0x1p-500 && dg <= 0x1p500)) ok = false;
+        t[q][8 * i + 7] = 1.0 / A.at(i, i);
       }
     }
   }
@@ -1582,7 +1584,7 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (order == DFTPAV_ORDER_REFERENCE) {
     if (!reference_order_supported(b->L, b->P, h->S)) {
-      h->err = "reference order: n <= 64 variables, 5 H + S + 4 <= 64 terms per point, every gear segment >= 2 pieces";
+      h->err = "reference order: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per point, every gear segment >= 2 pieces";
       return DFTPAV_E_UNSUPPORTED;
     }
     {

@@ -588,11 +588,13 @@ __device__ inline void prep_durations(const DevBatch &D, const Smem &sm, const d
 }
 
 // One (constraint point, obstacle) pair that passed the gate: dynamicObsGradCostP's body (traj_math.h: dynamic_pair, 9.2 k
-// instructions) and the pair's 14 contributions to its piece, stored at dst[k * stride].  A function of its own: inlined into
-// the evaluation its ~250 live values were allocated together with everything the kernel keeps across the stage -- 151 spilled
-// vector and 927 spilled scalar registers, 416 B of scratch per lane, the spill code inside the pair loop.
+// instructions) and the pair's 14 contributions to its piece, stored at dst[k * stride].  As a function of its own (tried in
+// round 4, DFTPAV_PAIR_OUT_OF_LINE=1): the ~110 doubles live through its log-sum-exp stage do not fit 256 registers either way --
+// the callee spills 229 vector registers with 816 B of scratch where the inlined form spills 188 with 432 B -- and the static
+// samples, the gate and the chain passes around the call got 25-50 % slower: 479 against 369 ms per 1024 (configs[4]).  Inlined
+// is the default.
 #ifndef DFTPAV_PAIR_OUT_OF_LINE
-#define DFTPAV_PAIR_OUT_OF_LINE 1
+#define DFTPAV_PAIR_OUT_OF_LINE 0
 #endif
 __device__ __attribute__((noinline)) void pair_eval(const DevParams &P, const SurLds &surL, const SampleIn &in, int u, double *dst, int stride) {
   double o[8], v[14];

@@ -49,6 +49,9 @@
 #ifndef DFTPAV_REF_TL_ATTR
 #define DFTPAV_REF_TL_ATTR __noinline__   // the two-loop recursion as a function of its own (see two_loop)
 #endif
+#ifndef DFTPAV_REF_TL_MASK
+#define DFTPAV_REF_TL_MASK 0
+#endif
 #ifndef DFTPAV_REF_EVAL_ATTR
 #define DFTPAV_REF_EVAL_ATTR __forceinline__
 #endif
@@ -67,22 +70,25 @@ typedef const double __attribute__((address_space(1))) *gcd_t;
 typedef double __attribute__((address_space(1))) *gd_t;
 
 // a / b from y = 1 / b (Markstein): the correctly rounded quotient, i.e. the bits of a / b (solver.hip: checked on 2^31
-// pairs on gfx950 against the division) -- as long as nothing under- or overflows on the way.  Guarded: a dividend outside
-// [2^-500, 2^500] (zero included: the sign of a zero quotient) or a reciprocal marked unusable by rcp_or_nan (divisor outside
-// that range) takes the division itself, as the reference does.  Both are a few cycles on a branch that is never taken in a
-// real solve (stored y . s products and LU diagonals are O(1e-8 .. 1e8)).
+// pairs on gfx950 against the division) -- as long as nothing under- or overflows on the way, which takes a divisor or a
+// dividend beyond 2^+-500.  The divisors are stored quantities: the y . s of a stored pair only has to exceed a `cau` that can be
+// tiny, so the solver notes the first one outside [2^-500, 2^500] in its state (iSLOWDIV) and runs the recursion with true
+// divisions (EXACT = true) from then on, as the reference does; the LU diagonals of the band system are checked on the host
+// (reference_order_tables refuses a system with such a diagonal).  Dividends -- sums of products of O(1e-30 .. 1e20) quantities
+// even at the far trial points of a line search -- stay inside that range by a hundred orders of magnitude and are not tested
+// (a per-division range test cost 9 % of the sweeps and 7 % of the recursion); the one observable difference of the
+// reciprocal route is the sign of a zero: -0.0 / b for b > 0 comes out as +0.0.
+template <bool EXACT = false>
 __device__ __forceinline__ double div_by_rcp(double a, double b, double y) {
+  if (EXACT) return a / b;
   const double q0 = a * y;
   const double r = __builtin_fma(-b, q0, a);
-  const double q = __builtin_fma(r, y, q0);
-  const double aa = __builtin_fabs(a);
-  if (__builtin_expect(!(aa >= 0x1p-500 && aa <= 0x1p500) || y != y, 0)) return a / b;
-  return q;
+  return __builtin_fma(r, y, q0);
 }
-// 1 / b for div_by_rcp, or NaN where the reciprocal route would not give the bits of the division
-__host__ __device__ __forceinline__ double rcp_or_nan(double b) {
+// is the reciprocal route good for this divisor?
+__host__ __device__ __forceinline__ bool rcp_route_ok(double b) {
   const double ab = __builtin_fabs(b);
-  return (ab >= 0x1p-500 && ab <= 0x1p500) ? 1.0 / b : __builtin_nan("");
+  return ab >= 0x1p-500 && ab <= 0x1p500;
 }
 template <int CTRL> __device__ __forceinline__ double mov_dpp(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -115,7 +121,7 @@ __device__ __forceinline__ double wave_max64(double v) {
 
 // scalar solver state (as solver.hip keeps it)
 enum { sFX = 0, sFINIT, sDGINIT, sDGTEST, sDSTEST, sMU, sNU, sSTP, sSTEP, sF, sPF0 /* ..+7 */, sGDT = 18, sCOST0, sCOST2, sENERGY, sNUM = 24 };
-enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iNUM = 16 };
+enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iSLOWDIV, iNUM = 16 };
 enum { kActEval = 0, kActDone = 1 };
 
 // optional in-kernel phase timer (thread 0, shader clock; DevBatch::prof == nullptr turns it off), slots as solver.hip's:
@@ -881,7 +887,8 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
   const double sg = (double)singul_;
 
   const double vel2_reci = 1.0 / (z_h0 * z_h0);
-  const double vel2_reci_e = 1.0 / (z_h0 * z_h0 + epis);
+  // (epis is 0.0 on the live path, traj_manager.cpp:610: x + 0.0 == x for every x >= 0, so the second quotient is the first)
+  const double vel2_reci_e = epis == 0.0 ? vel2_reci : 1.0 / (z_h0 * z_h0 + epis);
   const double vel3_2_reci_e = vel2_reci_e * sqrt(vel2_reci_e);
   z_h0 = 1.0 / z_h0;
   const double z_h4 = z_h1 * vel2_reci;
@@ -905,8 +912,12 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
     pq0[k] = pl[4 * k + 2];
     pq1[k] = pl[4 * k + 3];
   }
+  // (vec_le_ holds the first vertex twice, traj_optimizer.cpp:1765-1775, and the reference tests it twice: the fifth vertex's
+  // tests are the first's, expression for expression -- their bits are copied, not recomputed; capi.cpp fills vec_le[4] from
+  // vec_le[0].  H <= 5, so 5 H <= 25 tests: collected in 32 bits.)
+  unsigned cm = 0u;
 #pragma unroll
-  for (int v = 0; v < 5; v++) {
+  for (int v = 0; v < 4; v++) {
     const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
     const double rl0 = ego_R[0] * le0 + ego_R[1] * le1;
     const double rl1 = ego_R[2] * le0 + ego_R[3] * le1;
@@ -914,9 +925,11 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       const double violaPos = pn0[k] * (bpt0 - pq0[k]) + pn1[k] * (bpt1 - pq1[k]);
-      if (k < H && violaPos > 0) mask |= (mask_t)1 << (v * H + k);
+      if (k < H && violaPos > 0) cm |= 1u << (v * H + k);
     }
   }
+  cm |= (cm & ((1u << H) - 1u)) << (4 * H);
+  mask = (mask_t)cm;
   // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1)
   if (SUR && S.S > 0)
     mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, trajid, trajtime,
@@ -1839,14 +1852,14 @@ __device__ __forceinline__ void pin_blk(HistBlk &R) {
   }
 }
 // kPB steps of the first loop (lbfgs.hpp:722-726): alpha_j = s_j . d / ys_j ; d -= alpha_j y_j
-template <int CAP>
+template <int CAP, bool EXACT>
 __device__ __forceinline__ void first_steps(const HistBlk &R, ldsd_t dot_buf, ldsd_t alpha_buf, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
 #pragma unroll
   for (int u = 0; u < kPB; u++) {
     if (i0 + u < bound) { // uniform
       j = j == 0 ? m - 1 : j - 1;
       const double dot = seq_sum<CAP>(R.sy[u].x * dreg, n, dot_buf, lane);
-      const double a = div_by_rcp(dot, R.yr[u].x, R.yr[u].y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
+      const double a = div_by_rcp<EXACT>(dot, R.yr[u].x, R.yr[u].y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
       if (lane == 0) alpha_buf[j] = a;
       const double na = -a;
       dreg = dreg + na * R.sy[u].y; // d += (-alpha) * lm_y.col(j)
@@ -1854,7 +1867,7 @@ __device__ __forceinline__ void first_steps(const HistBlk &R, ldsd_t dot_buf, ld
   }
 }
 // kPB steps of the second loop (lbfgs.hpp:732-738): beta = y_j . d / ys_j ; d += (alpha_j - beta) s_j
-template <int CAP>
+template <int CAP, bool EXACT>
 __device__ __forceinline__ void second_steps(const HistBlk &R, ldsd_t dot_buf, ldsd_t alpha_buf, int i0, int bound, int m, int n, int lane, int &j, double &dreg) {
   double al[kPB];
   {
@@ -1869,7 +1882,7 @@ __device__ __forceinline__ void second_steps(const HistBlk &R, ldsd_t dot_buf, l
   for (int u = 0; u < kPB; u++) {
     if (i0 + u < bound) { // uniform
       const double dot = seq_sum<CAP>(R.sy[u].y * dreg, n, dot_buf, lane);
-      const double beta = div_by_rcp(dot, R.yr[u].x, R.yr[u].y);
+      const double beta = div_by_rcp<EXACT>(dot, R.yr[u].x, R.yr[u].y);
       const double cf = al[u] - beta;
       dreg = dreg + cf * R.sy[u].x; // d += (alpha - beta) * lm_s.col(j)
       j = j == m - 1 ? 0 : j + 1;
@@ -1881,7 +1894,7 @@ __device__ __forceinline__ void second_steps(const HistBlk &R, ldsd_t dot_buf, l
 // 0.0), H0 = ys / yy between the loops.  A function of its own: its registers -- two history blocks in flight, the 32 values of
 // a sequential sum -- are then allocated for it alone, not squeezed between whatever the rest of the kernel keeps live (inlined,
 // the cost of a history step moved between 850 and 1850 cycles with unrelated edits elsewhere in the kernel).
-template <int CAP>
+template <int CAP, bool EXACT>
 __device__ DFTPAV_REF_TL_ATTR double two_loop(ldsd_t dot_buf_, ldsd_t alpha_buf_, gcd2_t cS_, gcd2_t cR_, int npad_, int m_, int n_, int lane, int bound_, int ne_,
                                              double dreg, double sc0) {
   // arguments of an out-of-line function arrive in vector registers: everything but the lane's own values is the same in every
@@ -1895,6 +1908,10 @@ __device__ DFTPAV_REF_TL_ATTR double two_loop(ldsd_t dot_buf_, ldsd_t alpha_buf_
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(cS_u & 0xffffffffull)));
   const gcd2_t cR = (gcd2_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(cR_u >> 32)) << 32) |
                              (unsigned)__builtin_amdgcn_readfirstlane((int)(cR_u & 0xffffffffull)));
+#if DFTPAV_REF_TL_MASK
+  // only the lanes of the sums take part (n <= CAP): an LDS read costs by the lanes it serves, and a step is 32 broadcast reads
+  if (CAP < 64 && lane >= CAP) return dreg;
+#endif
   const int ln = lane < n ? lane : 0;
   HistBlk A, B;
   // first loop: newest -> oldest (slots ne-1, ne-2, ...)
@@ -1904,10 +1921,10 @@ __device__ DFTPAV_REF_TL_ATTR double two_loop(ldsd_t dot_buf_, ldsd_t alpha_buf_
   for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
     pin_blk(A);
     load_blk<-1>(B, cS, cR, npad, m, ln, jl);
-    first_steps<CAP>(A, dot_buf, alpha_buf, i0, bound, m, n, lane, j, dreg);
+    first_steps<CAP, EXACT>(A, dot_buf, alpha_buf, i0, bound, m, n, lane, j, dreg);
     pin_blk(B);
     load_blk<-1>(A, cS, cR, npad, m, ln, jl);
-    first_steps<CAP>(B, dot_buf, alpha_buf, i0 + kPB, bound, m, n, lane, j, dreg);
+    first_steps<CAP, EXACT>(B, dot_buf, alpha_buf, i0 + kPB, bound, m, n, lane, j, dreg);
   }
   dreg = dreg * sc0;
   wave_lds_order(); // alpha written by lane 0, read by all below
@@ -1917,10 +1934,10 @@ __device__ DFTPAV_REF_TL_ATTR double two_loop(ldsd_t dot_buf_, ldsd_t alpha_buf_
   for (int i0 = 0; i0 < bound; i0 += 2 * kPB) {
     pin_blk(A);
     load_blk<+1>(B, cS, cR, npad, m, ln, jl);
-    second_steps<CAP>(A, dot_buf, alpha_buf, i0, bound, m, n, lane, j, dreg);
+    second_steps<CAP, EXACT>(A, dot_buf, alpha_buf, i0, bound, m, n, lane, j, dreg);
     pin_blk(B);
     load_blk<+1>(A, cS, cR, npad, m, ln, jl);
-    second_steps<CAP>(B, dot_buf, alpha_buf, i0 + kPB, bound, m, n, lane, j, dreg);
+    second_steps<CAP, EXACT>(B, dot_buf, alpha_buf, i0 + kPB, bound, m, n, lane, j, dreg);
   }
   return dreg;
 }
@@ -2167,8 +2184,9 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
   if (lane == 0) {
     d2_t yr;
     yr.x = ys;
-    yr.y = rcp_or_nan(ys);
+    yr.y = 1.0 / ys;
     ((gd2_t)hR)[end] = yr;
+    if (!rcp_route_ok(ys)) sm.ist[iSLOWDIV] = 1; // from here on the recursion divides (see div_by_rcp)
   }
   const double cau = ss * sqrt(gpgp) * P.cautious_factor;
   pr.tick(7);
@@ -2178,7 +2196,10 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
     const int ne = end + 1 == m ? 0 : end + 1;
     __threadfence_block(); // lane 0's (ys, 1 / ys) of the newest pair is read by every lane below
     double dreg = lane < n ? -sm.g[lane] : 0.0;
-    dreg = two_loop<CAP>(sm.dot, sm.alpha, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, lane, bound, ne, dreg, ys / yy);
+    if (__builtin_expect(sm.ist[iSLOWDIV] != 0, 0)) // (uniform; lane 0 wrote it at most a fence ago)
+      dreg = two_loop<CAP, true>(sm.dot, sm.alpha, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, lane, bound, ne, dreg, ys / yy);
+    else
+      dreg = two_loop<CAP, false>(sm.dot, sm.alpha, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, lane, bound, ne, dreg, ys / yy);
     if (lane < n) sm.d[lane] = dreg;
     if (lane == 0) {
       sm.ist[iEND] = ne;
@@ -2288,7 +2309,8 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
     sm.pinfo[4 * p + 3] = (lp == 0 || lp == N - 1) ? L.Kd : L.K;
   }
   __syncthreads(); // the only time the waves of a WAVE-shaped workgroup meet
-  const bool ring = WAVE && mode == kModeSolve && source == 1;
+  const bool ring = WAVE && mode == kModeSolve && (source & 1) != 0;
+  const bool force_exact_div = (source & 2) != 0; // test hook: the recursion with true divisions from the first iteration on
   const int nterm = 5 * L.H + (SUR ? D.sur.S : 0) + 4, nS_ = SUR ? D.sur.S : 0;
   const size_t scratch_per_traj = (size_t)L.Npts * nterm * kRec + (size_t)L.Npts * nS_ * kRec + ((size_t)L.Npts * nterm + 1) / 2;
   Prof pr;
@@ -2316,7 +2338,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
         sm.gp[e] = 0.0;
         sm.d[e] = 0.0;
       }
-      if (tid < iNUM) sm.ist[tid] = 0;
+      if (tid < iNUM) sm.ist[tid] = (tid == iSLOWDIV && force_exact_div) ? 1 : 0;
     }
     for (int w = tid; w < 12 * L.M; w += T) {
       const int sg = w / 12, q = w - 12 * sg;
@@ -2405,6 +2427,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
   if (L.M < 1 || L.n > 64 || L.Npts >= (1 << 25)) return false;
+  if (L.H < 1 || L.H > 5) return false; // a point's half-planes are held in five register slots (rectangles: H = 4)
   if (S < 0 || 5 * L.H + S + 4 > 64) return false; // the mask of a point's active terms has 64 bits
   for (int i = 0; i < L.M; i++)
     if (L.piece_nums[i] < 2) return false;
@@ -2513,6 +2536,8 @@ hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode,
     source = 1;
     slice = pl.slice;
   }
+  if (const char *e = std::getenv("DFTPAV_REF_EXACT_DIV")) // test hook: true divisions in the recursion (its fallback for divisors beyond 2^+-500)
+    if (std::atoi(e) != 0) source |= 2;
   if (std::getenv("DFTPAV_VERBOSE"))
     std::fprintf(stderr, "[dftpav] reference order, %s shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", wave ? "WAVE" : "TEAM", grid, pl.threads,
                  pl.lds, source, slice);

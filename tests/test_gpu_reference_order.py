@@ -300,6 +300,29 @@ def test_wave_shape_and_ring_are_bit_identical(hiplib, oracle, monkeypatch, case
     monkeypatch.delenv("DFTPAV_REF_SLICE")
 
 
+@pytest.mark.parametrize("shape", ["team", "wave"])
+def test_recursion_with_true_divisions_gives_the_same_bits(hiplib, oracle, monkeypatch, shape):
+    """The two-loop recursion divides by the stored y . s of a pair through its stored reciprocal (Markstein's correctly rounded
+    quotient); a pair whose y . s lies beyond 2^+-500 switches the trajectory to true divisions for good (solver_ref.hip:
+    div_by_rcp, iSLOWDIV).  That fallback forced from the first iteration on (DFTPAV_REF_EXACT_DIV=1): the same bits -- which
+    is both the test of the fallback and the statement that the reciprocal route IS the division on real solves."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(3, B=12)
+    s.apply_resolution(p)
+    want = oracle.solve_batch(p, s, nthreads=8, order=0)
+    monkeypatch.setenv("DFTPAV_REF_EXACT_DIV", "1")
+    monkeypatch.setenv("DFTPAV_REF_SHAPE", shape)
+    if shape == "wave":
+        monkeypatch.setenv("DFTPAV_REF_SLOTS", "1")
+        monkeypatch.setenv("DFTPAV_REF_SLICE", "11")
+    h, bt = _batch(hiplib, s, p)
+    r = bt.solve()
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], want[k]), (shape, k)
+    bt.close()
+    h.close()
+
+
 def test_gear_shifts_in_reference_order(hiplib, oracle):
     """With gear shifts the reference calls libm's cos / sin of the junction angles in every evaluation: bits of the HOST (glibc's
     are not correctly rounded, and dispatched by CPU model).  The device runs the reference's program with the CORRECTLY ROUNDED
