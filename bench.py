@@ -514,7 +514,15 @@ def main():
                     b2.close(); h2.close()
                     for hh in hx:
                         hh.close()
-                    return {"batch": B, "solves_per_s": B * len(draws) / (sum(draws) * 1e-3), "kernel_ms": float(np.mean(draws)),
+                    # the HBM roofline of this side run: algorithmic bytes of the first draw's solves (E_eval with this layout's n and
+                    # Npts) over the mean isolated kernel time
+                    lay2 = s2.layout
+                    npts2 = int(s2.corridor.shape[1])
+                    ab2 = float(algorithmic_bytes(lay2, npts2, lay2.H, lay2.M, r2["iters"], r2["evals"], r2["hist_sum"]).sum())
+                    roof2 = {"bound": "hbm", "algorithmic_bytes_per_batch": ab2, "achieved": ab2 / (float(np.mean(draws)) * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": ab2 / (float(np.mean(draws)) * 1e-3) / 1e9 / HBM_PEAK_GBS, "n": int(lay2.n_vars), "Npts": npts2,
+                             "note": "isolated batch: its duration is that of its longest solve; algorithmic bytes as for the value line"}
+                    return {"batch": B, "solves_per_s": B * len(draws) / (sum(draws) * 1e-3), "kernel_ms": float(np.mean(draws)), "roofline": roof2,
                             "draws": {"kernel_ms": draws, "longest_solve_iterations": longest,
                                       "note": "the batch as generated, then with x0 moved by one ulp in one coordinate, twice: an isolated "
                                               "batch lasts as long as its longest solve, which differs from draw to draw; solves_per_s is "
@@ -572,7 +580,7 @@ def main():
                                                 "bit_equal_to_the_reference_build_on_this_host": (int(sum(eqb)) if eqb else None),
                                                 "instances": len(seeds)}}
                 out["single"] = single(2, range(9))
-                out["moving_obstacles_1024"] = side(5, 1024, 1, 4)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
+                out["moving_obstacles_1024"] = side(5, 1024, 1, 8)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
                 # the same configuration in reference order: dynamicObsGradCostP statement by statement with the correctly rounded
                 # exp / log / x^3 (libm's own bits there belong to the host); checked against that program on the CPU (oracle order 2)
                 try:
@@ -596,6 +604,46 @@ def main():
                     b5.close(); h5.close()
                 except capi.DftpavError as ex:
                     out["moving_obstacles_1024"]["reference_order"] = {"unsupported": str(ex)}
+                # ---- reference order on the remaining configurations: configs[0]'s layout (one forward segment, 8 pieces: no libm call in
+                # the reference's loop, so the reference BUILD itself is the yardstick) and the reference's live case (gear shifts
+                # together with moving obstacles, traj_manager.cpp:604-610: the reference's program with correctly rounded libm calls
+                # is the yardstick; how many solves the build on this host happens to share is reported beside it)
+                try:
+                    from oracle import pyref as _pr2
+                    rows = {}
+                    for name_, mk in (("forward_8_pieces", lambda: sc.baseline_config(1, B=16, seed=args.seed)),
+                                      ("gear_shifts_with_moving_obstacles", lambda: sc.make_scenario([5, 4, 6], [1, -1, 1], 12, 16, 8, seed=args.seed + 82, with_moving=True,
+                                                                                                   n_obs=25, start_centre=(-38.0, 5.0)))):
+                        pz = capi.default_params()
+                        sz = mk()
+                        sz.apply_resolution(pz)
+                        hz = capi.Handle(pz, device=local_rank)
+                        hz.set_surround(sz.surround)
+                        bz = capi.Batch(hz, sz.layout, sz.B)
+                        bz.upload(sz)
+                        bz.set_order(capi.ORDER_REFERENCE)
+                        rz = bz.solve()
+                        libm = sz.layout.M > 1 or sz.surround is not None
+                        oz = po.solve_batch(pz, sz, nthreads=cpu["effective"], order=2 if libm else 0)
+                        eq_prog = int(sum(bool(oz["final_cost"][i_] == rz["final_cost"][i_] and np.array_equal(oz["x"][i_], rz["x"][i_]) and
+                                               oz["iters"][i_] == rz["iters"][i_] and oz["evals"][i_] == rz["evals"][i_] and oz["status"][i_] == rz["status"][i_])
+                                          for i_ in range(sz.B)))
+                        row = {"trajectories": int(sz.B), "bit_equal_to_the_reference_program" + ("_with_correctly_rounded_libm_calls" if libm else ""): eq_prog,
+                               "libm_calls_in_the_reference_loop": bool(libm)}
+                        if _pr2.available():
+                            eqb_ = 0
+                            for i_ in range(sz.B):
+                                rr_ = _pr2.RefProblem(pz, sz, i_).optimize()
+                                eqb_ += int(rr_["final_cost"] == rz["final_cost"][i_] and np.array_equal(rr_["x"], rz["x"][i_]) and rr_["iters"] == rz["iters"][i_])
+                            row["against_reference_build"] = {"trajectories": int(sz.B), "bit_equal": eqb_,
+                                                              "note": ("every solve must agree" if not libm else
+                                                                       "agrees where this host's libm rounded every call of the solve correctly")}
+                        rows[name_] = row
+                        bz.close(); hz.close()
+                    out["parity"] = out.get("parity", {})
+                    out["parity"]["reference_order_other_configs"] = rows
+                except capi.DftpavError as ex:
+                    out.setdefault("parity", {})["reference_order_other_configs"] = {"failed": str(ex)}
                 # ---- the step before the solve: rectangle corridors of the shard's hypotheses on the device
                 st = shard.meta["states"].reshape(-1, 3)
                 cen = (0.5 * (st[:, 0].min() + st[:, 0].max()), 0.5 * (st[:, 1].min() + st[:, 1].max()))
@@ -712,7 +760,7 @@ def main():
                 rd = po.solve_batch(params, shard.subset(pick), nthreads=cores, order=1)
                 match = bool(np.array_equal(rd["final_cost"], r["final_cost"][pick]) and np.array_equal(rd["x"], r["x"][pick]) and
                              np.array_equal(rd["iters"], r["iters"][pick]))
-                out["parity"] = {"device_order_oracle_bit_exact_on_%d_sampled" % nd: match}
+                out["parity"] = dict(out.get("parity", {}), **{"device_order_oracle_bit_exact_on_%d_sampled" % nd: match})
                 # (2) the REFERENCE-ORDER device mode (dftpav_batch_set_order, solver_ref.hip) on the whole batch: every sum in the
                 # reference's order, so its solves must equal OptimizeTrajectory's bit for bit -- checked against the reference build on
                 # the 64 trajectories timed above and against the restatement on all it solved

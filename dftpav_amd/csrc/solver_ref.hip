@@ -152,6 +152,7 @@ struct Prof {
 
 constexpr int kRec = 16;            // doubles per term record: 12 entries of gdC, gdT, cost, 2 more gdT addends of a moving-obstacle term
 constexpr int kListCapTeam = 1024;  // active terms chained per window (TEAM shape)
+constexpr int kSerialMax = 512;     // WAVE shape: evaluations with up to this many active terms chain them in one pass on 16 lanes
 constexpr int kRecWave = 32;        // WAVE shape: records kept in LDS per evaluation (LDS is what limits the trajectories per CU)
 
 typedef unsigned long long mask_t;  // active terms of a constraint point, bit t = term t (5 H + S + 4 <= 64 terms)
@@ -1286,7 +1287,8 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
         sm.list[e] = entry;
         sm.list[nrec + e] = p; // its piece
       } else {
-        glist[e] = entry;
+        glist[2 * e] = entry;
+        glist[2 * e + 1] = p;
       }
       if (sur_term) {
         const gcd_t src = (gcd_t)(stage_b + ((size_t)pt * nS + (t - tS0)) * kRec);
@@ -1327,26 +1329,35 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
   pr.count(11, base > nrec ? base : 0); // ... and their active terms
   // ---- chains: lane (piece, entry) adds its piece's records in order; four more lanes per segment walk all of the segment's
   // for gdT, the corridor cost, the feasibility cost and the moving-obstacle cost (they go first: theirs are the long walks)
-  if (base > 0 && base <= nrec) {
-    // Every record of the evaluation is in LDS (the usual case): ONE pass over the terms in order on 16 lanes -- lane q < 12
-    // carries entry q of gdC of the piece the terms belong to, lane 12 that segment's gdT, lane 13 its three costs -- each term
-    // one LDS read and one addition per lane, the reads of eight terms in flight; a change of piece (segment) stores the
-    // sums and fetches the next piece's (segment's).  Same chains as the lanes per (piece, entry) below, term after term.
+  if (base > 0 && base <= kSerialMax) {
+    // Up to a few hundred active terms (nearly every evaluation; most have all their records in LDS): ONE pass over the terms in
+    // order on 16 lanes -- lane q < 12 carries entry q of gdC of the piece the terms belong to, lane 12 that segment's gdT,
+    // lane 13 its three costs -- each term one read and one addition per lane, the reads of sixteen terms in flight (the ones
+    // beyond the LDS window come from L2: one round trip per sixteen terms for all the sums together); a change of piece
+    // (segment) stores the sums and fetches the next piece's (segment's).  Same chains as the lanes per (piece, entry) below,
+    // term after term.
     if (tid < 16) {
+      constexpr int kU = 16;
       int curp = -1, cursg = -1, Nseg = 0;
       double acc = 0.0, c2 = 0.0, c1 = 0.0; // lane < 12: gdC entry; 12: gdT; 13: corridor cost (acc), feasibility (c2), moving obstacles (c1)
-      for (int e0 = 0; e0 < base; e0 += 8) {
-        int ent[8], pc[8];
-        double v[8];
+      for (int e0 = 0; e0 < base; e0 += kU) {
+        int ent[kU], pc[kU];
+        double v[kU];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < kU; u++) {
           const int e = e0 + u < base ? e0 + u : base - 1;
-          ent[u] = sm.list[e];
-          pc[u] = sm.list[nrec + e];
-          v[u] = sm.lrec[(size_t)e * kRec + tid];
+          if (e < nrec) { // (uniform)
+            ent[u] = sm.list[e];
+            pc[u] = sm.list[nrec + e];
+            v[u] = sm.lrec[(size_t)e * kRec + tid];
+          } else {
+            ent[u] = glist[2 * e];
+            pc[u] = glist[2 * e + 1];
+            v[u] = rec_b[(size_t)e * kRec + tid];
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < kU; u++) {
           if (e0 + u >= base) break; // uniform
           const int p = pc[u];
           if (p != curp) { // uniform: the terms come piece after piece, segment after segment
@@ -1384,8 +1395,9 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
           } else if (tid == 12) { // gdT: one `+=` per term; a moving-obstacle term: three, and one more per previous segment (traj_optimizer.cpp:1663-1676)
             acc += v[u];
             if (sur_term) {
-              ldscd_t r_ = sm.lrec + (size_t)(e0 + u) * kRec;
-              const double vb = r_[14], vc = r_[15];
+              const int e = e0 + u;
+              const double vb = e < nrec ? sm.lrec[(size_t)e * kRec + 14] : rec_b[(size_t)e * kRec + 14];
+              const double vc = e < nrec ? sm.lrec[(size_t)e * kRec + 15] : rec_b[(size_t)e * kRec + 15];
               acc += vb * sm.pinfo[4 * p + 1]; // * pieceid
               acc += vc;
               const double prev = vb * Nseg; // * piece_num_container[trajid]
@@ -1460,7 +1472,7 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
               ldscd_t r_ = sm.lrec + (size_t)e * kRec;
               va8[u] = r_[q]; vb8[u] = r_[14]; vc8[u] = r_[15];
             } else {
-              ent[u] = glist[e];
+              ent[u] = glist[2 * e];
               gcd_t r_ = (gcd_t)(rec_b + (size_t)e * kRec);
               va8[u] = r_[q]; vb8[u] = r_[14]; vc8[u] = r_[15];
             }
@@ -2312,7 +2324,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
   const bool ring = WAVE && mode == kModeSolve && (source & 1) != 0;
   const bool force_exact_div = (source & 2) != 0; // test hook: the recursion with true divisions from the first iteration on
   const int nterm = 5 * L.H + (SUR ? D.sur.S : 0) + 4, nS_ = SUR ? D.sur.S : 0;
-  const size_t scratch_per_traj = (size_t)L.Npts * nterm * kRec + (size_t)L.Npts * nS_ * kRec + ((size_t)L.Npts * nterm + 1) / 2;
+  const size_t scratch_per_traj = (size_t)L.Npts * nterm * kRec + (size_t)L.Npts * nS_ * kRec + (size_t)L.Npts * nterm;
   Prof pr;
 
   for (int pass = 0;; pass++) {
@@ -2437,10 +2449,11 @@ bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
 }
 // doubles of term records a batch of B trajectories needs
 // (per trajectory: the records [Npts][nterm][kRec] -- TEAM: a point's own slots; WAVE: in (point, term) order -- then, WAVE
-// with moving obstacles, the staging of surround_terms [Npts][S][kRec], then the list entries beyond the LDS window)
+// with moving obstacles, the staging of surround_terms [Npts][S][kRec], then the (entry, piece) pairs of the terms beyond the
+// LDS window)
 size_t reference_order_scratch_per_traj(const DevLayout &L, int S) {
   const size_t nterm = (size_t)(5 * L.H + S + 4);
-  return (size_t)L.Npts * nterm * reford::kRec + (size_t)L.Npts * S * reford::kRec + ((size_t)L.Npts * nterm + 1) / 2;
+  return (size_t)L.Npts * nterm * reford::kRec + (size_t)L.Npts * S * reford::kRec + (size_t)L.Npts * nterm;
 }
 size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S) { return (size_t)B * reference_order_scratch_per_traj(L, S); }
 // doubles of the sweep tables of a segment of N pieces (the tables of a layout's segments follow one another)
