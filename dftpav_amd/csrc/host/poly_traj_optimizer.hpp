@@ -95,8 +95,9 @@ class PolyTrajOptimizer {
   int get_destraj_resolution_() const { return params_.des_traj_resolution; } // traj_optimizer.h:114
   const std::vector<MinJerkOptView> *getMinJerkOptPtr() const { return &mjo_; } // traj_optimizer.h:112
   // extras of the new build.  setReferenceOrder(true): solves run with every sum in the order the reference executes it and
-  // return OptimizeTrajectory's own bits (one gear segment, no moving obstacles; include/dftpav_hip.h:
-  // dftpav_batch_set_order); where the layout does not allow it the throughput order runs and last_order() says so
+  // return the bits of the reference's program with sequential reductions, no FMA and -- gear shifts, moving obstacles --
+  // correctly rounded libm calls (include/dftpav_hip.h: dftpav_batch_set_order states the contract); where the layout is
+  // outside its limits the throughput order runs and last_order() says so
   void setReferenceOrder(bool on) { want_reference_order_ = on; }
   int last_order() const { return order_; } // DFTPAV_ORDER_* of the last solve
   // status of the last solve

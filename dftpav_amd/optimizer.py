@@ -32,9 +32,10 @@ class MinJerkOptView:
 
 class PolyTrajOptimizer:
     def __init__(self, device=0, reference_order=False):
-        """reference_order: solve with every sum in the order the reference executes it -- OptimizeTrajectory's own bits
-        (one gear segment, no moving obstacles; dftpav_batch_set_order).  Where the layout does not allow it the
-        throughput order runs; `last["order"]` says which one did."""
+        """reference_order: solve with every sum in the order the reference executes it (dftpav_batch_set_order): the bits of
+        the reference's program with sequential reductions, no FMA and -- gear shifts, moving obstacles -- correctly rounded
+        libm calls (include/dftpav_hip.h states the contract).  Where the layout is outside its limits (n > 64, H > 5,
+        5 H + S + 4 > 64) the throughput order runs; `last["order"]` says which one did."""
         self._device = device
         self._reference_order = bool(reference_order)
         self._params = capi.default_params()

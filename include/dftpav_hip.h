@@ -285,20 +285,29 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *   equals it statistically.
  * DFTPAV_ORDER_REFERENCE: every sum in the order PolyTrajOptimizer executes it (traj_optimizer.cpp:486-705 sample ->
  *   vertex -> plane accumulation, poly_traj_utils.hpp:805-852 banded substitutions, lbfgs.hpp:716-739 two-loop with
- *   sequential dot products), no fused multiply-adds.  One workgroup per trajectory, slower per iteration: the mode of a
- *   drop-in that must reproduce the CPU planner's decision exactly, and the parity proof of the other one.
- *     - one gear segment: final x, cost, status, iterations and evaluations are BIT-EQUAL to OptimizeTrajectory's on the
- *       same inputs (the reference's program has no libm call inside the loop there);
- *     - with gear shifts the reference calls libm's cos / sin of every junction angle per evaluation
+ *   sequential dot products), no fused multiply-adds: the mode of a drop-in that must reproduce the CPU planner's
+ *   decision exactly, and the parity proof of the other one.  THE CONTRACT, precisely: final x, cost, status, iterations
+ *   and evaluations are bit-equal to those of the reference's PROGRAM evaluated with sequential reductions (dot products,
+ *   norms and matrix products as one chain from their first term), no FMA contraction and -- where the program calls libm --
+ *   correctly rounded calls.  That program is what oracle/_ref (the reference's sources compiled unmodified against an
+ *   Eigen stand-in with sequential reductions) executes; an upstream binary built against a real Eigen vectorises
+ *   reductions into 2- or 4-lane partial sums and may differ in last bits, as two such builds differ from each other.
+ *     - one gear segment, no moving obstacles: the reference's program has no libm call inside the loop; this mode
+ *       returns the bits of oracle/_ref;
+ *     - gear shifts: the reference calls libm's cos / sin of every junction angle per evaluation
  *       (traj_optimizer.cpp:273-282, 311-318), whose bits depend on the host (glibc's are not correctly rounded and are
- *       IFUNC-dispatched by CPU model): this mode uses the CORRECTLY ROUNDED cos / sin instead (cr_trig.h) -- the
- *       reference's program with those two calls defined rather than implemented; it equals the reference's own result
- *       whenever the host's libm rounded every junction angle's cos / sin correctly (glibc: 999 arguments in 1 000);
- *     - with moving obstacles the reference calls libm's exp (40 times) and log (9 times) per (constraint point, obstacle)
- *       pair and pow(|v|, 3) per pair (traj_optimizer.cpp:1686-1707, poly_traj_utils.hpp:109): likewise replaced by
- *       the correctly rounded exp / log / x^3; one gear segment, 5 H + S + 4 <= 32 terms per point (H = 4: up to 8
- *       obstacles).  Choose the order again after the number of obstacles on the handle changed;
- *     - n > 64, or more terms per point than that: DFTPAV_E_UNSUPPORTED, order unchanged. */
+ *       IFUNC-dispatched by CPU model): this mode uses the CORRECTLY ROUNDED cos / sin (cr_trig.h); it equals the
+ *       reference build's own result whenever the host's libm rounded every junction angle's cos / sin correctly;
+ *     - moving obstacles: libm's exp (40 times) and log (9 times) per (constraint point, obstacle) pair and pow(|v|, 3)
+ *       (traj_optimizer.cpp:1686-1707, poly_traj_utils.hpp:109) are likewise the correctly rounded exp / log / x^3;
+ *     - gear shifts TOGETHER WITH moving obstacles -- the reference's live call, traj_manager.cpp:604-610 -- are covered,
+ *       including trajtimes[i] = duration of segment i - 1 (traj_optimizer.cpp:230-234) and the extra gdT addends per
+ *       previous segment (:1674-1676);
+ *     - limits: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per constraint point, every gear segment
+ *       >= 2 pieces; otherwise DFTPAV_E_UNSUPPORTED, order unchanged.  Choose the order again after the number of
+ *       obstacles on the handle changed.  dftpav_batch_trace* is a device-order facility (DFTPAV_E_UNSUPPORTED here).
+ *   Launch shape by batch size: up to three trajectories per CU one workgroup each (lowest latency); beyond, one WAVE per
+ *   trajectory, eight per CU, popped from the batch's ring in slices of 128 iterations (14.9 k solves/s at 4096 on MI355X). */
 #define DFTPAV_ORDER_DEVICE 0
 #define DFTPAV_ORDER_REFERENCE 1
 int dftpav_batch_set_order(dftpav_batch *b, int order);
