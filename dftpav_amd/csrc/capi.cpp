@@ -53,6 +53,7 @@ hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t str
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S);
 size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S);
 size_t reference_order_table_doubles(int N);
+void reference_order_pack_tables(int N, const double *full, double *packed);
 int reference_order_interior_mask(int sweep, int row_mod_6);
 RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu);
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
@@ -1475,7 +1476,7 @@ static bool reference_order_tables(int N, std::vector<double> &out) {
   BandedLU A{n6, 6, 6, band.data()};
   minco_fill(A, N);
   banded_factorize(A);
-  out.assign(reference_order_table_doubles(N), 0.0);
+  out.assign((size_t)(4 * 48) * N, 0.0); // the full form [4][6N][8]; reference_order_pack_tables makes the kernel's
   double *t[4];
   for (int q = 0; q < 4; q++) t[q] = out.data() + (size_t)q * 8 * n6;
   bool ok = true;
@@ -1606,7 +1607,9 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
           h->err = "reference order: the LU factors of this band system do not have the pattern the kernel assumes";
           return DFTPAV_E_UNSUPPORTED;
         }
-        tab.insert(tab.end(), one.begin(), one.end());
+        std::vector<double> packed(reference_order_table_doubles(b->L.piece_nums[sg]));
+        reference_order_pack_tables(b->L.piece_nums[sg], one.data(), packed.data());
+        tab.insert(tab.end(), packed.begin(), packed.end());
       }
       double *d_tab = nullptr, *d_scr = nullptr;
       if (hipMalloc(&d_tab, sizeof(double) * tab.size()) != hipSuccess ||

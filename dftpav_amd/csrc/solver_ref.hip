@@ -153,7 +153,7 @@ struct Prof {
 constexpr int kRec = 16;            // doubles per term record: 12 entries of gdC, gdT, cost, 2 more gdT addends of a moving-obstacle term
 constexpr int kListCapTeam = 1024;  // active terms chained per window (TEAM shape)
 constexpr int kSerialMax = 512;     // WAVE shape: evaluations with up to this many active terms chain them in one pass on 16 lanes
-constexpr int kRecWave = 32;        // WAVE shape: records kept in LDS per evaluation (LDS is what limits the trajectories per CU)
+constexpr int kRecWave = 48;        // WAVE shape: records kept in LDS per evaluation (LDS is what limits the trajectories per CU)
 
 typedef unsigned long long mask_t;  // active terms of a constraint point, bit t = term t (5 H + S + 4 <= 64 terms)
 typedef unsigned short __attribute__((address_space(3))) *ldsh_t;
@@ -224,9 +224,15 @@ struct Sm {
 };
 enum { gGDT = 0, gCOST0, gCOST2, gENERGY, gCOST1, gNUM = 6 };
 
+// doubles of the sweep tables of all segments of a layout (pk_segment_doubles)
+__host__ __device__ inline size_t table_doubles(const DevLayout &L) {
+  size_t t = 0;
+  for (int sg = 0; sg < L.M; sg++) t += (size_t)(384 + 88 * (L.piece_nums[sg] - 2));
+  return t;
+}
 // bytes of the part of the LDS the waves of a workgroup share / of one team's part (both multiples of 16)
 __host__ __device__ inline size_t lds_shared_bytes(const DevLayout &L) {
-  return ((size_t)(4 * 48) * L.Ntot * sizeof(double) + 4 * (size_t)L.Ntot * sizeof(int) + 15) & ~(size_t)15;
+  return (table_doubles(L) * sizeof(double) + 4 * (size_t)L.Ntot * sizeof(int) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t lds_team_doubles(const DevLayout &L, int mem, const Shape &sh) {
   return 5 * (size_t)sh.nl + (size_t)L.M * (12 + 12 + 2 + 16 + gNUM) + 2 * (size_t)L.M * (L.Kmax + 1) + (4 * 12 + 3) * (size_t)L.Ntot + 4 * (size_t)sh.cap +
@@ -245,7 +251,7 @@ __host__ __device__ inline size_t lds_team_bytes(const DevLayout &L, int mem, co
 __device__ inline void carve(Sm &s, double *shared, double *team, const DevLayout &L, int mem, const Shape &sh) {
   const int M = L.M, Ntot = L.Ntot;
   s.tab = (ldscd_t)shared;
-  s.pinfo = (ldsi_t)((ldsd_t)shared + (4 * 48) * Ntot);
+  s.pinfo = (ldsi_t)((ldsd_t)shared + table_doubles(L));
   ldsd_t p = (ldsd_t)team;
   s.x = p; p += sh.nl;
   s.xp = p; p += sh.nl;
@@ -306,72 +312,141 @@ template <bool WAVE> __device__ __forceinline__ void team_sync() {
 // without a test; the first and the last block test every coefficient.
 // Table row of a sweep: the six coefficients, then (diagonal, 1 / diagonal).
 //   sweep 0: solve, forward (L)   1: solve, backward (U, / diagonal)   2: solveAdj, forward (U^T, / diagonal)   3: solveAdj, backward (L^T)
+__host__ __device__ constexpr int kInterior_(int q, int r) {
+  constexpr int t[4][6] = {{0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e}, {0x00, 0x18, 0x30, 0x31, 0x21, 0x06}, {0x00, 0x00, 0x00, 0x35, 0x3b, 0x30}, {0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38}};
+  return t[q][r];
+}
 __device__ constexpr int kInterior[4][6] = {{0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e},
                                             {0x00, 0x18, 0x30, 0x31, 0x21, 0x06},
                                             {0x00, 0x00, 0x00, 0x35, 0x3b, 0x30},
                                             {0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38}};
 typedef double __attribute__((ext_vector_type(2))) v2d_t;
 typedef const v2d_t __attribute__((address_space(3))) *ldscv2_t;
-struct SweepBlk {
-  v2d_t c[6][4]; // rows of the table: (c0,c1) (c2,c3) (c4,c5) (diagonal, 1 / diagonal)
+// The table of one sweep of a segment of N pieces, blocks of six rows in the order the sweep TRAVERSES them (descending
+// sweeps: row n6-1 first):
+//   block 0 and block N-1 (the ends of the system): six rows of 8 doubles -- the six coefficients, the diagonal, 1 / diagonal;
+//   blocks 1 .. N-2 (the interior): kPack[Q] doubles -- only the coefficients the pattern kInterior[Q] keeps, in (row, k)
+//   order, then (diagonal, 1 / diagonal) of the six rows for the sweeps that divide.
+// 384 + 88 (N - 2) doubles per segment instead of 192 N: 12.9 KB instead of 24.6 KB for 16 pieces, and 10-12 LDS reads per
+// interior block instead of 24.
+__host__ __device__ constexpr int pk_popc6(int m) { return (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1) + ((m >> 3) & 1) + ((m >> 4) & 1) + ((m >> 5) & 1); }
+__host__ __device__ constexpr int pk_mask(int Q, int r) { // traversal row r of an interior block
+  return kInterior_(Q, (Q == 1 || Q == 3) ? 5 - r : r);
+}
+__host__ __device__ constexpr int pk_off(int Q, int r, int k) { // position of coefficient k of traversal row r inside the block
+  int o = 0;
+  for (int rr = 0; rr < r; rr++) o += pk_popc6(pk_mask(Q, rr));
+  for (int kk = 0; kk < k; kk++) o += (pk_mask(Q, r) >> kk) & 1;
+  return o;
+}
+__host__ __device__ constexpr int pk_ncoef(int Q) { return pk_off(Q, 6, 0); }
+__host__ __device__ constexpr int pk_diag0(int Q) { return (pk_ncoef(Q) + 1) & ~1; } // (diagonal, 1 / diagonal) pairs start on an even slot
+__host__ __device__ constexpr int pk_size(int Q) { return (Q == 1 || Q == 2) ? pk_diag0(Q) + 12 : ((pk_ncoef(Q) + 1) & ~1); }
+__host__ __device__ constexpr int pk_sweep_doubles(int Q, int N) { return 96 + (N > 2 ? (N - 2) * pk_size(Q) : 0); }
+__host__ __device__ constexpr int pk_sweep_offset(int Q, int N) { // start of sweep Q inside a segment's tables
+  int o = 0;
+  for (int q = 0; q < Q; q++) o += pk_sweep_doubles(q, N);
+  return o;
+}
+__host__ __device__ constexpr int pk_segment_doubles(int N) { return pk_sweep_offset(4, N); }
+
+struct SweepBlk { // a block of the ends: whole rows
+  v2d_t c[6][4]; // (c0,c1) (c2,c3) (c4,c5) (diagonal, 1 / diagonal)
   double bi[6];
 };
+template <int Q> struct PackBlk { // an interior block
+  v2d_t c[pk_size(Q) / 2];
+  double bi[6];
+  __device__ __forceinline__ double at(int o) const { return (o & 1) ? c[o >> 1].y : c[o >> 1].x; }
+};
 template <int Q>
-__device__ __forceinline__ void sweep_load(SweepBlk &R, ldscd_t tab, ldscd_t b, int n6, int d, int i0) {
+__device__ __forceinline__ void load_end(SweepBlk &R, ldscd_t blk, ldscd_t b, int n6, int d, int i0) {
   constexpr bool DESC = Q == 1 || Q == 3;
-  i0 = i0 < n6 ? i0 : n6 - 6; // a block past the end re-reads the last one (never used)
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
-    const ldscv2_t a = (ldscv2_t)(tab + 8 * i);
+    const ldscv2_t a = (ldscv2_t)(blk + 8 * r);
 #pragma unroll
     for (int q = 0; q < 4; q++) R.c[r][q] = a[q];
     R.bi[r] = b[2 * i + d];
   }
 }
-template <int Q, bool GENERIC>
-__device__ __forceinline__ void sweep_rows(const SweepBlk &R, ldsd_t b, int n6, int d, int i0, double (&w)[6]) {
+template <int Q>
+__device__ __forceinline__ void load_pack(PackBlk<Q> &R, ldscd_t blk, ldscd_t b, int n6, int d, int i0) {
+  constexpr bool DESC = Q == 1 || Q == 3;
+  const ldscv2_t a = (ldscv2_t)blk;
+#pragma unroll
+  for (int q = 0; q < pk_size(Q) / 2; q++) R.c[q] = a[q];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
+    R.bi[r] = b[2 * i + d];
+  }
+}
+// six rows of an end block: every coefficient is tested, as the reference does (`if (a != 0.0)`)
+template <int Q>
+__device__ __forceinline__ void rows_end(const SweepBlk &R, ldsd_t b, int n6, int d, int i0, double (&w)[6]) {
   constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
 #pragma unroll
   for (int r = 0; r < 6; r++) {
     const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
-    const int mask = GENERIC ? 0x3f : kInterior[Q][DESC ? 5 - r : r];
     double acc = R.bi[r];
 #pragma unroll
-    for (int k = 0; k < 6; k++)
-      if (mask & (1 << k)) {
-        const double ck = (k & 1) ? R.c[r][k >> 1].y : R.c[r][k >> 1].x;
-        const double t = ck * w[(r + k) % 6];
-        if (GENERIC) acc = ck != 0.0 ? acc - t : acc;
-        else acc = acc - t;
-      }
+    for (int k = 0; k < 6; k++) {
+      const double ck = (k & 1) ? R.c[r][k >> 1].y : R.c[r][k >> 1].x;
+      const double t = ck * w[(r + k) % 6];
+      acc = ck != 0.0 ? acc - t : acc;
+    }
     if (DIV) acc = div_by_rcp(acc, R.c[r][3].x, R.c[r][3].y);
     w[r] = acc;
     b[2 * i + d] = acc;
   }
 }
+// six rows of an interior block: the non-zero terms only, no test
+template <int Q>
+__device__ __forceinline__ void rows_pack(const PackBlk<Q> &R, ldsd_t b, int n6, int d, int i0, double (&w)[6]) {
+  constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int i = DESC ? n6 - 1 - (i0 + r) : i0 + r;
+    constexpr int dummy = 0;
+    (void)dummy;
+    double acc = R.bi[r];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (pk_mask(Q, r) & (1 << k)) acc = acc - R.at(pk_off(Q, r, k)) * w[(r + k) % 6];
+    if (DIV) acc = div_by_rcp(acc, R.at(pk_diag0(Q) + 2 * r), R.at(pk_diag0(Q) + 2 * r + 1));
+    w[r] = acc;
+    b[2 * i + d] = acc;
+  }
+}
+// tab: this sweep's table (see above); b: the right-hand side / solution [n6][2]; d: the lane's dimension
 template <int Q>
 __device__ __forceinline__ void sweep(ldscd_t tab, ldsd_t b, int n6, int d) {
   double w[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  SweepBlk A, B;
-  sweep_load<Q>(A, tab, b, n6, d, 0);
-  sweep_load<Q>(B, tab, b, n6, d, 6);
-  sweep_rows<Q, true>(A, b, n6, d, 0, w); // the first block tests every coefficient
-  // middle blocks 6 .. n6-12, two per turn; the block after the next is requested before a block is worked on
-  int i0 = 6;
-  for (; i0 + 6 < n6 - 6; i0 += 12) {
-    sweep_load<Q>(A, tab, b, n6, d, i0 + 6);
-    sweep_rows<Q, false>(B, b, n6, d, i0, w);
-    sweep_load<Q>(B, tab, b, n6, d, i0 + 12);
-    sweep_rows<Q, false>(A, b, n6, d, i0 + 6, w);
+  const int N = n6 / 6;
+  SweepBlk E;
+  load_end<Q>(E, tab, b, n6, d, 0);
+  ldscd_t ip = tab + 48; // interior blocks
+  PackBlk<Q> A, B;
+  if (N > 2) load_pack<Q>(A, ip, b, n6, d, 6);
+  rows_end<Q>(E, b, n6, d, 0, w);
+  // interior blocks 1 .. N-2, two per turn; the next block is requested before a block is worked on
+  int k = 1;
+  for (; k + 1 <= N - 2; k += 2) {
+    load_pack<Q>(B, ip + (k) * pk_size(Q), b, n6, d, 6 * (k + 1));
+    rows_pack<Q>(A, b, n6, d, 6 * k, w);
+    if (k + 2 <= N - 2) load_pack<Q>(A, ip + (k + 1) * pk_size(Q), b, n6, d, 6 * (k + 2));
+    else load_end<Q>(E, ip + (N - 2) * pk_size(Q), b, n6, d, n6 - 6);
+    rows_pack<Q>(B, b, n6, d, 6 * (k + 1), w);
   }
-  if (i0 < n6 - 6) { // one middle block left (B holds it); then the last block
-    sweep_load<Q>(A, tab, b, n6, d, i0 + 6);
-    sweep_rows<Q, false>(B, b, n6, d, i0, w);
-    sweep_rows<Q, true>(A, b, n6, d, n6 - 6, w);
-  } else {
-    sweep_rows<Q, true>(B, b, n6, d, n6 - 6, w); // B holds the last block
+  if (k <= N - 2) { // one interior block left (A holds it)
+    load_end<Q>(E, ip + (N - 2) * pk_size(Q), b, n6, d, n6 - 6);
+    rows_pack<Q>(A, b, n6, d, 6 * k, w);
+  } else if (N <= 2) {
+    load_end<Q>(E, ip, b, n6, d, n6 - 6);
   }
+  rows_end<Q>(E, b, n6, d, n6 - 6, w);
 }
 
 // positiveSmoothedL1, traj_optimizer.cpp:783-806
@@ -1172,9 +1247,11 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
       N = q == sg ? L.piece_nums[q] : N;
       p0 = q == sg ? L.seg_piece0[q] : p0;
     }
-    ldscd_t tb = sm.tab + 192 * p0;
+    int toff = 0;
+    for (int q = 0; q < M; q++) toff += q < sg ? pk_segment_doubles(L.piece_nums[q]) : 0;
+    ldscd_t tb = sm.tab + toff;
     sweep<0>(tb, sm.b + 12 * p0, 6 * N, d);
-    sweep<1>(tb + 48 * N, sm.b + 12 * p0, 6 * N, d);
+    sweep<1>(tb + pk_sweep_offset(1, N), sm.b + 12 * p0, 6 * N, d);
   }
   if (u2 >= 0 && u2 < 2 * M) {
     const int sg = u2 >> 1, which = u2 & 1;
@@ -1700,9 +1777,11 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
       N = q == sg ? L.piece_nums[q] : N;
       p0 = q == sg ? L.seg_piece0[q] : p0;
     }
-    ldscd_t tb = sm.tab + 192 * p0;
-    sweep<2>(tb + 96 * N, sm.adj + 12 * p0, 6 * N, d);
-    sweep<3>(tb + 144 * N, sm.adj + 12 * p0, 6 * N, d);
+    int toff = 0;
+    for (int q = 0; q < M; q++) toff += q < sg ? pk_segment_doubles(L.piece_nums[q]) : 0;
+    ldscd_t tb = sm.tab + toff;
+    sweep<2>(tb + pk_sweep_offset(2, N), sm.adj + 12 * p0, 6 * N, d);
+    sweep<3>(tb + pk_sweep_offset(3, N), sm.adj + 12 * p0, 6 * N, d);
   }
   for (int i = u2; i >= 0 && i < Ntot; i += (WAVE ? 64 : T - 64)) { // the per-piece chain-rule terms (they only need gdC and b)
     ldscd_t tInv = sm.seg + 16 * sm.pinfo[4 * i] + 8;
@@ -2304,7 +2383,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
     carve(sm, lds_raw, reinterpret_cast<double *>(team), L, D.P.mem_size, sh);
   }
   // ---- shared by the workgroup: the sweep tables and the piece table
-  for (int i = tidb; i < 4 * 48 * L.Ntot; i += Tb) ((ldsd_t)sm.tab)[i] = tabs[i];
+  for (int i = tidb; i < (int)table_doubles(L); i += Tb) ((ldsd_t)sm.tab)[i] = tabs[i];
   for (int p = tidb; p < L.Ntot; p += Tb) { // piece -> segment, index inside it, first constraint point, intervals
     int sg = 0, p0 = 0, N = 0, pt0s = 0;
     for (int q = 0; q < L.M; q++) {
@@ -2456,8 +2535,44 @@ size_t reference_order_scratch_per_traj(const DevLayout &L, int S) {
   return (size_t)L.Npts * nterm * reford::kRec + (size_t)L.Npts * S * reford::kRec + (size_t)L.Npts * nterm;
 }
 size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S) { return (size_t)B * reference_order_scratch_per_traj(L, S); }
-// doubles of the sweep tables of a segment of N pieces (the tables of a layout's segments follow one another)
-size_t reference_order_table_doubles(int N) { return (size_t)(4 * 48) * N; }
+// doubles of the sweep tables of a segment of N pieces as the kernel reads them (the tables of a layout's segments follow one
+// another)
+size_t reference_order_table_doubles(int N) { return (size_t)reford::pk_segment_doubles(N); }
+// full: the four sweeps of a segment as [4][6N][8] (row i of a sweep: its six coefficients, the diagonal, 1 / diagonal) -> the
+// kernel's layout (solver_ref.hip: "The table of one sweep"): blocks in traversal order, whole rows at the two ends, only the
+// coefficients of the interior pattern in between
+void reference_order_pack_tables(int N, const double *full, double *packed) {
+  using namespace reford;
+  const int n6 = 6 * N;
+  size_t o = 0;
+  for (int q = 0; q < 4; q++) {
+    const bool desc = q == 1 || q == 3, div = q == 1 || q == 2;
+    const double *t = full + (size_t)q * 8 * n6;
+    auto row = [&](int blk, int r) { return desc ? n6 - 1 - (6 * blk + r) : 6 * blk + r; }; // natural row of traversal row r of block blk
+    for (int r = 0; r < 6; r++) // first end block
+      for (int k = 0; k < 8; k++) packed[o++] = t[8 * row(0, r) + k];
+    const int mask_of[4][6] = {{pk_mask(0, 0), pk_mask(0, 1), pk_mask(0, 2), pk_mask(0, 3), pk_mask(0, 4), pk_mask(0, 5)},
+                               {pk_mask(1, 0), pk_mask(1, 1), pk_mask(1, 2), pk_mask(1, 3), pk_mask(1, 4), pk_mask(1, 5)},
+                               {pk_mask(2, 0), pk_mask(2, 1), pk_mask(2, 2), pk_mask(2, 3), pk_mask(2, 4), pk_mask(2, 5)},
+                               {pk_mask(3, 0), pk_mask(3, 1), pk_mask(3, 2), pk_mask(3, 3), pk_mask(3, 4), pk_mask(3, 5)}};
+    const int size_of[4] = {pk_size(0), pk_size(1), pk_size(2), pk_size(3)}, diag_of[4] = {pk_diag0(0), pk_diag0(1), pk_diag0(2), pk_diag0(3)};
+    for (int blk = 1; blk <= N - 2; blk++) {
+      const size_t o0 = o;
+      for (int r = 0; r < 6; r++)
+        for (int k = 0; k < 6; k++)
+          if (mask_of[q][r] & (1 << k)) packed[o++] = t[8 * row(blk, r) + k];
+      while (o < o0 + (size_t)(div ? diag_of[q] : size_of[q])) packed[o++] = 0.0;
+      if (div)
+        for (int r = 0; r < 6; r++) {
+          packed[o++] = t[8 * row(blk, r) + 6];
+          packed[o++] = t[8 * row(blk, r) + 7];
+        }
+    }
+    if (N >= 2) // last end block
+      for (int r = 0; r < 6; r++)
+        for (int k = 0; k < 8; k++) packed[o++] = t[8 * row(N - 1, r) + k];
+  }
+}
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
 int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior[sweep][row_mod_6]; }
 
