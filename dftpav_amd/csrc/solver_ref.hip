@@ -160,6 +160,11 @@ typedef unsigned short __attribute__((address_space(3))) *ldsh_t;
 
 // How a launch lays out its LDS.  Shared by the waves of a workgroup: the sweep tables and the piece table (they depend on
 // the layout only).  Per team (TEAM: the workgroup; WAVE: each wave): everything else.
+// The width of the sequential sums: the smallest of the instantiated CAPs that holds the n decision variables.  A chain runs
+// to CAP (lanes from n on contribute -0.0), so a CAP just above n matters: BASELINE configs[1] (8 + 8 pieces with a gear shift)
+// has n = 33 -- 40 dependent additions per sum instead of 64.
+__host__ __device__ inline int ref_cap_of(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 40 ? 40 : (n <= 48 ? 48 : 64))); }
+
 struct Shape {
   int wave;     // 1: one wave per trajectory
   int cap;      // 16 / 32 / 64 >= n: width of the sequential sums (the kernel's CAP)
@@ -172,7 +177,7 @@ struct Shape {
 __host__ __device__ inline Shape make_shape(const DevLayout &L, int S, bool wave) {
   Shape sh;
   sh.wave = wave ? 1 : 0;
-  sh.cap = L.n <= 16 ? 16 : (L.n <= 32 ? 32 : 64);
+  sh.cap = ref_cap_of(L.n);
   sh.nl = (L.n + 15) & ~15;
   const int nterm = 5 * L.H + S + 4;
   sh.mw = nterm > 32 ? 2 : 1;
@@ -307,7 +312,7 @@ template <bool WAVE> __device__ __forceinline__ void team_sync() {
 // rows i+6 .. i+1), skipping exact zeros as the reference does (`if (a != 0.0)`), then -- sweeps 1 and 2 -- divides by the
 // diagonal.  The six previous results live in registers (rows are taken six at a time, so the window is indexed
 // statically).  The LU factors of the MINCO band are sparse (3.2 non-zeros per row of L, 1.75 of U) and away from the two
-// ends of the system the pattern repeats with the pieces: kInterior[sweep][i mod 6] below (the host checks it against the
+// ends of the system the pattern repeats with the pieces: kInterior_(sweep, i mod 6) below (the host checks it against the
 // factors it uploads, capi.cpp: reference_order_tables), so the rows of the middle blocks compute their non-zero terms only,
 // without a test; the first and the last block test every coefficient.
 // Table row of a sweep: the six coefficients, then (diagonal, 1 / diagonal).
@@ -316,16 +321,12 @@ __host__ __device__ constexpr int kInterior_(int q, int r) {
   constexpr int t[4][6] = {{0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e}, {0x00, 0x18, 0x30, 0x31, 0x21, 0x06}, {0x00, 0x00, 0x00, 0x35, 0x3b, 0x30}, {0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38}};
   return t[q][r];
 }
-__device__ constexpr int kInterior[4][6] = {{0x3f, 0x1f, 0x0f, 0x00, 0x00, 0x3e},
-                                            {0x00, 0x18, 0x30, 0x31, 0x21, 0x06},
-                                            {0x00, 0x00, 0x00, 0x35, 0x3b, 0x30},
-                                            {0x03, 0x07, 0x0f, 0x1e, 0x3c, 0x38}};
 typedef double __attribute__((ext_vector_type(2))) v2d_t;
 typedef const v2d_t __attribute__((address_space(3))) *ldscv2_t;
 // The table of one sweep of a segment of N pieces, blocks of six rows in the order the sweep TRAVERSES them (descending
 // sweeps: row n6-1 first):
 //   block 0 and block N-1 (the ends of the system): six rows of 8 doubles -- the six coefficients, the diagonal, 1 / diagonal;
-//   blocks 1 .. N-2 (the interior): kPack[Q] doubles -- only the coefficients the pattern kInterior[Q] keeps, in (row, k)
+//   blocks 1 .. N-2 (the interior): pk_size(Q) doubles -- only the coefficients the pattern kInterior_(Q, .) keeps, in (row, k)
 //   order, then (diagonal, 1 / diagonal) of the six rows for the sweeps that divide.
 // 384 + 88 (N - 2) doubles per segment instead of 192 N: 12.9 KB instead of 24.6 KB for 16 pieces, and 10-12 LDS reads per
 // interior block instead of 24.
@@ -2515,6 +2516,12 @@ __global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAV
 } // namespace reford
 
 // ---- host side
+// The file is compiled as two translation units, side by side (Makefile): DFTPAV_REF_PART=1 holds the kernels with CAP 16 / 32
+// and everything that is not a kernel, DFTPAV_REF_PART=2 the kernels with CAP 40 / 48 / 64; 0 (default) = one unit with all.
+#ifndef DFTPAV_REF_PART
+#define DFTPAV_REF_PART 0
+#endif
+#if DFTPAV_REF_PART != 2
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
   if (L.M < 1 || L.n > 64 || L.Npts >= (1 << 25)) return false;
@@ -2573,8 +2580,8 @@ void reference_order_pack_tables(int N, const double *full, double *packed) {
         for (int k = 0; k < 8; k++) packed[o++] = t[8 * row(N - 1, r) + k];
   }
 }
-// the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior), for the host's check
-int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior[sweep][row_mod_6]; }
+// the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior_), for the host's check
+int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior_(sweep, row_mod_6); }
 
 // The launch shape of a batch (see the header).  TEAM: four waves per trajectory while the batch leaves CUs to spare (the
 // parallel stages finish sooner: 70 against 73 ms at batch 32, 133 against 140 at 256), two for more.  WAVE: as many waves per
@@ -2635,6 +2642,7 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
   return pl;
 }
 
+#endif // DFTPAV_REF_PART != 2
 template <int CAP, bool SUR, bool WAVE>
 static hipError_t launch_ref_variant(const DevBatch *d_dev, int grid, int threads, size_t lds, int mode, const double *tabs, double *scratch, int source, int slice,
                                      hipStream_t stream) {
@@ -2644,7 +2652,7 @@ static hipError_t launch_ref_variant(const DevBatch *d_dev, int grid, int thread
   return hipGetLastError();
 }
 template <int CAP>
-static hipError_t launch_ref_cap(bool sur, bool wave, const DevBatch *d_dev, int grid, int threads, size_t lds, int mode, const double *tabs, double *scratch,
+hipError_t launch_ref_cap(bool sur, bool wave, const DevBatch *d_dev, int grid, int threads, size_t lds, int mode, const double *tabs, double *scratch,
                                  int source, int slice, hipStream_t stream) {
   if (sur) {
     if (wave) return launch_ref_variant<CAP, true, true>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
@@ -2653,6 +2661,17 @@ static hipError_t launch_ref_cap(bool sur, bool wave, const DevBatch *d_dev, int
   if (wave) return launch_ref_variant<CAP, false, true>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
   return launch_ref_variant<CAP, false, false>(d_dev, grid, threads, lds, mode, tabs, scratch, source, slice, stream);
 }
+#define DFTPAV_REF_CAP_ARGS bool, bool, const DevBatch *, int, int, size_t, int, const double *, double *, int, int, hipStream_t
+#if DFTPAV_REF_PART == 1 // the wide kernels live in the other unit
+extern template hipError_t launch_ref_cap<40>(DFTPAV_REF_CAP_ARGS);
+extern template hipError_t launch_ref_cap<48>(DFTPAV_REF_CAP_ARGS);
+extern template hipError_t launch_ref_cap<64>(DFTPAV_REF_CAP_ARGS);
+#elif DFTPAV_REF_PART == 2
+template hipError_t launch_ref_cap<40>(DFTPAV_REF_CAP_ARGS);
+template hipError_t launch_ref_cap<48>(DFTPAV_REF_CAP_ARGS);
+template hipError_t launch_ref_cap<64>(DFTPAV_REF_CAP_ARGS);
+#endif
+#if DFTPAV_REF_PART != 2
 // scheduled != 0: a solve in the WAVE shape whose waves pop from the batch's ring (the caller has reset it)
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
                              hipStream_t stream) {
@@ -2669,9 +2688,14 @@ hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode,
   if (std::getenv("DFTPAV_VERBOSE"))
     std::fprintf(stderr, "[dftpav] reference order, %s shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", wave ? "WAVE" : "TEAM", grid, pl.threads,
                  pl.lds, source, slice);
-  if (D.L.n <= 16) return launch_ref_cap<16>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
-  if (D.L.n <= 32) return launch_ref_cap<32>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
-  return launch_ref_cap<64>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  switch (reford::ref_cap_of(D.L.n)) {
+  case 16: return launch_ref_cap<16>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  case 32: return launch_ref_cap<32>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  case 40: return launch_ref_cap<40>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  case 48: return launch_ref_cap<48>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  default: return launch_ref_cap<64>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  }
 }
+#endif // DFTPAV_REF_PART != 2
 
 } // namespace dftpav

@@ -12,5 +12,5 @@ if [ -n "$VARIANT_TRAJ_MATH" ]; then cp "$VARIANT_TRAJ_MATH" /tmp/variant_$name/
 /opt/rocm/bin/hipcc -O2 -mllvm -amdgpu-sched-strategy=max-ilp -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed "$@" \
   -c /tmp/variant_$name/solver.hip -o /tmp/variant_$name/solver.o
 make -s
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libdftpav_hip_$name.so /tmp/variant_$name/solver.o solver_ref.o corridor.o validate.o states.o shot.o fit.o frontend.o restart.o capi.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libdftpav_hip_$name.so /tmp/variant_$name/solver.o solver_ref.o solver_ref_wide.o corridor.o validate.o states.o shot.o fit.o frontend.o restart.o capi.o
 echo built ../variants/libdftpav_hip_$name.so
