@@ -165,6 +165,11 @@ typedef unsigned short __attribute__((address_space(3))) *ldsh_t;
 // has n = 33 -- 40 dependent additions per sum instead of 64.
 __host__ __device__ inline int ref_cap_of(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 40 ? 40 : (n <= 48 ? 48 : 64))); }
 
+#ifndef DFTPAV_REF_NARROW_CAP
+#define DFTPAV_REF_NARROW_CAP 32
+#endif
+constexpr int kNarrowCap = DFTPAV_REF_NARROW_CAP; // WAVE shape: the kernels up to this width are built for 256 registers, eight waves per CU
+
 struct Shape {
   int wave;     // 1: one wave per trajectory
   int cap;      // 16 / 32 / 64 >= n: width of the sequential sums (the kernel's CAP)
@@ -2368,7 +2373,7 @@ __device__ inline void state_io(const DevBatch &D, const Sm &sm, int b, int lane
 // Registers: 256 per lane (two waves per SIMD) for the kernels that fit them -- a second trajectory fills the issue slots the
 // dependent chains of the first leave empty; the wide (n > 32) and the moving-obstacle kernels take 512.
 template <int CAP, bool SUR, bool WAVE>
-__global__ void __launch_bounds__((WAVE && CAP <= 32 && !SUR) ? 512 : 256, (!WAVE && CAP <= 32 && !SUR) ? 2 : 1)
+__global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 256, (!WAVE && CAP <= 32 && !SUR) ? 2 : 1)
     ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch, int source, int slice) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
@@ -2589,7 +2594,7 @@ int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kIn
 // LDS of the shared tables plus a team's part per wave.
 RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu) {
   RefPlan pl{};
-  const bool narrow = L.n <= 32 && S == 0; // the kernels that fit 256 registers
+  const bool narrow = reford::ref_cap_of(L.n) <= reford::kNarrowCap && S == 0; // the kernels built for 256 registers (two waves per SIMD)
   const int max_waves_cu = narrow ? 8 : 4;
   const reford::Shape sw = reford::make_shape(L, S, true);
   const size_t shared = reford::lds_shared_bytes(L), team_w = reford::lds_team_bytes(L, P.mem_size, sw);
