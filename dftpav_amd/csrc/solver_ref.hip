@@ -2610,7 +2610,9 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
       best_wg = wg;
     }
   }
-  bool wave = best_w > 0 && B > 3 * n_cu; // up to three per CU the TEAM shape holds them all at once, each one faster
+  // up to four per CU the TEAM shape (128 threads, 34 KB of LDS with the compact tables) holds them all at once, each one faster:
+  // 171 against 195 ms at 1024, 133 against 189 at 512; at 2048 the WAVE shape is ahead, 262 against 320 ms
+  bool wave = best_w > 0 && B > 5 * n_cu;
   if (const char *e = std::getenv("DFTPAV_REF_SHAPE")) { // developer knob: "team" / "wave"
     if (e[0] == 't') wave = false;
     if (e[0] == 'w' && best_w > 0) wave = true;

@@ -306,8 +306,8 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *     - limits: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per constraint point, every gear segment
  *       >= 2 pieces; otherwise DFTPAV_E_UNSUPPORTED, order unchanged.  Choose the order again after the number of
  *       obstacles on the handle changed.  dftpav_batch_trace* is a device-order facility (DFTPAV_E_UNSUPPORTED here).
- *   Launch shape by batch size: up to three trajectories per CU one workgroup each (lowest latency); beyond, one WAVE per
- *   trajectory, eight per CU, popped from the batch's ring in slices of 128 iterations (14.9 k solves/s at 4096 on MI355X). */
+ *   Launch shape by batch size: up to five trajectories per CU one workgroup each (lowest latency); beyond, one WAVE per
+ *   trajectory, eight per CU, popped from the batch's ring in slices of 128 iterations (15.5 k solves/s at 4096 on MI355X). */
 #define DFTPAV_ORDER_DEVICE 0
 #define DFTPAV_ORDER_REFERENCE 1
 int dftpav_batch_set_order(dftpav_batch *b, int order);
