@@ -1,7 +1,9 @@
 """Developer script: reference-order GPU solves against the literal oracle on randomly shaped problems (run through gpurun).
 
 Random layouts inside what the mode accepts (1-3 gear segments, n <= 64, sample resolutions 3-24, with and without moving
-obstacles on single-segment layouts), random limits / weights / L-BFGS memories, random launch widths; every field of every
+obstacles -- on multi-segment layouts too, the reference's live call -- and with up to 12 of them), random limits / weights /
+L-BFGS memories, random launch shapes (a workgroup per trajectory of 128-256 threads, or a wave per trajectory with 1-2
+persistent workgroups and slices of 2-40 iterations through the ring); every field of every
 solve must be bit-identical to the literal program with correctly rounded libm functions (oracle order 2), and on static
 single-segment layouts to the literal program with this host's libm (order 0, the one tests/test_ref_pin.py pins to the
 reference build) as well.
@@ -63,10 +65,31 @@ for c in range(n_cases):
         sing.append(-sing[-1])
     K = int(rng.integers(3, 25)); Kd = int(rng.integers(3, 25))
     B = int(rng.integers(1, 6))
-    moving = M == 1 and bool(rng.uniform() < 0.3) and pieces[0] <= 24
+    moving = bool(rng.uniform() < 0.35) and sum(pieces) <= 24
     os.environ["DFTPAV_REF_THREADS"] = str(int(rng.choice([128, 192, 256])))
+    shape = str(rng.choice(["team", "wave", "wave"]))
+    os.environ["DFTPAV_REF_SHAPE"] = shape
+    os.environ["DFTPAV_REF_SLOTS"] = str(int(rng.integers(1, 3)))
+    os.environ["DFTPAV_REF_SLICE"] = str(int(rng.integers(2, 41)))
     p = capi.default_params()
-    s = sc.make_scenario(pieces, sing, K, Kd, B, seed=23000 + seed0 + c, with_moving=moving, n_obs=int(rng.integers(0, 60)))
+    if shape == "wave":
+        B = int(rng.integers(1, 12 if moving else 40))  # more trajectories than the waves of the persistent workgroups: the ring is used
+        os.environ["DFTPAV_REF_WAVES"] = str(int(rng.choice([1, 2, 4])))
+    s = sc.make_scenario(pieces, sing, K, Kd, B, seed=23000 + seed0 + c, with_moving=moving, n_obs=int(rng.integers(0, 60)),
+                         **({"start_centre": (-38.0, 5.0)} if moving and rng.uniform() < 0.5 else {}))
+    if moving and rng.uniform() < 0.25:  # the four cars three times over, shifted: 12 obstacles, more than 32 terms per constraint point
+        from dftpav_amd.pods import SurroundSet
+        sur, reps = s.surround, 3
+        npc = int(sur.piece_offsets[-1])
+        offs = np.concatenate([[0]] + [sur.piece_offsets[1:] + k * npc for k in range(reps)])
+        cf = np.concatenate([sur.coeffs] * reps).copy()
+        for k in range(1, reps):
+            cf[k * npc:(k + 1) * npc, 10] += 0.7 * k
+            cf[k * npc:(k + 1) * npc, 11] -= 0.4 * k
+        s.surround = SurroundSet(offs, np.concatenate([sur.durations] * reps), cf, np.concatenate([sur.total_duration] * reps),
+                                 np.concatenate([sur.start_time + 0.3 * k for k in range(reps)]))
+    if moving and rng.uniform() < 0.5:
+        s.surround.start_time[:] = rng.uniform(0.0, 4.0, len(s.surround.start_time))
     s.apply_resolution(p)
     if rng.uniform() < 0.4:
         p.lbfgs_mem_size = int(rng.choice([3, 4, 8, 17, 64, 300]))
@@ -98,8 +121,9 @@ for c in range(n_cases):
         stat[int(st)] = stat.get(int(st), 0) + 1
     if not ok:
         bad += 1
-        print("MISMATCH case %d: pieces %s singuls %s K %d Kd %d B %d moving %s threads %s mem %d" %
-              (c, pieces, sing, K, Kd, B, moving, os.environ["DFTPAV_REF_THREADS"], p.lbfgs_mem_size), flush=True)
+        print("MISMATCH case %d: pieces %s singuls %s K %d Kd %d B %d moving %s (%d obstacles) shape %s threads %s slots %s slice %s mem %d" %
+              (c, pieces, sing, K, Kd, B, moving, s.surround.S if s.surround is not None else 0, shape, os.environ["DFTPAV_REF_THREADS"],
+               os.environ["DFTPAV_REF_SLOTS"], os.environ["DFTPAV_REF_SLICE"], p.lbfgs_mem_size), flush=True)
         if only is not None:
             diagnose(p, s, bt, r, want[0])
     bt.close(); h.close()

@@ -450,6 +450,31 @@ def test_random_layouts_in_reference_order(hiplib, oracle):
         h.close()
 
 
+def test_trace_is_a_device_order_facility(hiplib):
+    """dftpav_batch_trace records nothing in the reference order: asking for it there, or choosing the reference order while a
+    trace is on, is refused with DFTPAV_E_UNSUPPORTED (it used to return empty traces); the batch stays usable."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(1, B=2)
+    s.apply_resolution(p)
+    h, bt = _batch(hiplib, s, p)
+    with pytest.raises(hiplib.DftpavError) as e:
+        bt.trace(0, 64)
+    assert e.value.code == hiplib.E_UNSUPPORTED
+    assert bt.solve()["success"].all()
+    bt.set_order(hiplib.ORDER_DEVICE)
+    bt.trace(0, 4096)
+    with pytest.raises(hiplib.DftpavError) as e:
+        bt.set_order(hiplib.ORDER_REFERENCE)
+    assert e.value.code == hiplib.E_UNSUPPORTED
+    r = bt.solve()
+    assert len(bt.get_trace()["f"]) == r["evals"][0]
+    bt.trace(0, 0)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    assert bt.solve()["success"].all()
+    bt.close()
+    h.close()
+
+
 def test_six_half_planes_and_wide_layouts_are_refused_cleanly(hiplib):
     """H > 5 (the term mask has 32 bits) and n > 64 stay with the device order"""
     p = hiplib.default_params()
