@@ -79,6 +79,27 @@ def test_far_trial_points(hiplib, oracle):
     h.close()
 
 
+def test_configs4_sixty_four_solves_are_bit_exact(hiplib, oracle):
+    """BASELINE configs[4] (32 pieces x 65 points, four moving cars), 64 trajectories in the device order: every field of every
+    solve equal to the device-order oracle's -- with the round-4 bound that rejects a (point, obstacle) pair before any
+    exponential when its penalty is certainly zero (traj_math.h: dynamic_pair; the oracle shares that code) -- and the literal
+    cost at every final x within 1e-11 (the literal oracle evaluates every pair in full: the bound changes no value)."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(5, B=64)
+    s.apply_resolution(p)
+    h, bt = _batch(hiplib, s, p)
+    r = bt.solve()
+    ro = oracle.solve_batch(p, s, nthreads=8, order=1)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], ro[k]), k
+    f, _ = bt.eval(r["x"])
+    for b in range(0, s.B, 4):
+        fl, _ = oracle.OracleProblem(p, s, b, order=0).eval(r["x"][b])
+        assert abs(f[b] - fl) <= 1e-11 * abs(fl), (b, f[b], fl)
+    bt.close()
+    h.close()
+
+
 def test_moving_obstacles_that_start_after_t_now(hiplib, oracle):
     """An obstacle whose predicted trajectory starts later than the ego's clock (surround start_time > t_now, the normal
     swarm situation) is extrapolated BACKWARDS along its first piece (Trajectory::locatePieceIdx returns piece 0 with a
