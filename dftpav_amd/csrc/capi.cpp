@@ -1018,7 +1018,7 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
     // they are finished by a second launch in the latency shape (one wide workgroup per CU).
     b->slots = n_cu * per_cu;
     // iterations per slice: long slices cost fewer suspensions, short ones balance the end of a solve better; layouts with
-    // many constraint points (costly iterations, few trajectories per slot) take the short ones (measured, DESIGN.md §4.4)
+    // many constraint points (costly iterations, few trajectories per slot) take the short ones (measured, DESIGN.md §4.1)
     b->slice = L.Npts > 1024 ? (b->threads >= 4 * kWave ? 32 : 48) : 128;
     b->hand_over = n_cu;
     if (const char *e = std::getenv("DFTPAV_SLOTS")) b->slots = std::atoi(e);

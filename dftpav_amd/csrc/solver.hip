@@ -178,7 +178,7 @@ size_t solver_lds_bytes(const DevLayout &L, const DevParams &P, int threads, boo
 int solver_threads(const DevLayout &L, int shape) {
   // Every stage is a strided loop, so any multiple of 64 works; the choice trades the latency of one
   // solve against how many trajectories a CU holds (256 VGPRs per lane => 8 waves per CU).  Measured on
-  // 528-point problems (scripts/profile_phases.py, DESIGN.md §4.4):
+  // 528-point problems (scripts/profile_phases.py, DESIGN.md §4.1):
   //   shape 0, <= 1 trajectory per CU : about two constraint points per thread, up to 8 waves
   //   shape 1, <= 2 per CU            : 4 waves, two workgroups resident per CU
   //   shape 2, more                   : 1 wave, eight workgroups resident per CU (the 256-VGPR budget allows 8 waves)

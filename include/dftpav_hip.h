@@ -399,7 +399,7 @@ int dftpav_marks_elapsed_ms(dftpav_handle *from, int from_slot, dftpav_handle *t
  * leave the queue launch and finish in the latency shape (default: one per CU; negative restores it).  0 keeps every
  * trajectory in the queue launch to its end -- the setting for a stream of batches solved alternately on TWO handles
  * (two HIP streams): the queue launch of the next batch then fills the workgroup slots the previous one frees while
- * it thins out, which keeps the device full without any hand-over (DESIGN.md §4.4; bench.py's default). */
+ * it thins out, which keeps the device full without any hand-over (DESIGN.md §4.1; bench.py's default). */
 int dftpav_batch_set_hand_over(dftpav_batch *b, int hand_over);
 
 /* Multi-GPU hand-off: one 16-byte record {f64 final_cost, i32 status, i32 iters} per trajectory — what the single
