@@ -1530,6 +1530,18 @@ extern "C" int dftpav_debug_reference_tables(int N, double *out) {
   return ok ? 1 : 0;
 }
 
+// test hook (host only): the same tables in the layout the kernel reads (solver_ref.hip: "The table of one sweep"): blocks in
+// traversal order, whole rows at the two ends, only the coefficients of the interior pattern in between; *n_doubles = their size
+extern "C" int dftpav_debug_reference_tables_packed(int N, double *out, int *n_doubles) {
+  if (N < 2 || !n_doubles) return DFTPAV_E_INVALID;
+  *n_doubles = (int)reference_order_table_doubles(N);
+  if (!out) return DFTPAV_OK;
+  std::vector<double> full;
+  const bool ok = reference_order_tables(N, full);
+  reference_order_pack_tables(N, full.data(), out);
+  return ok ? 1 : 0;
+}
+
 // the ring, the flags and the state records of a scheduled solve, for a batch whose device-order plan did not need them
 static hipError_t ensure_ring_buffers(dftpav_batch *b) {
   if (b->d_queue && b->d_sflag && b->d_iota && b->d_qctl && b->d_state) return hipSuccess;

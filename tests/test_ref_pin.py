@@ -247,3 +247,72 @@ def test_row_sweeps_of_the_reference_order_kernel_equal_banded_solve(ref, hiplib
         want_adj = ref.banded_solve(A, 6, 6, b, adjoint=True)[:, 0]
         got_adj = _row_sweep(tab, 3, _row_sweep(tab, 2, b))
         assert np.array_equal(got_adj, want_adj)
+
+
+def _packed_sweep(pk, off, N, q, b):
+    """the kernel's sweep q over one right-hand side from the PACKED table (solver_ref.hip: "The table of one sweep"): blocks of six
+    rows in traversal order; the two end blocks hold whole rows (six coefficients, diagonal, 1 / diagonal) and test every
+    coefficient; an interior block holds only the coefficients of the pattern _INTERIOR, in (row, k) order, then -- for the sweeps
+    that divide -- (diagonal, 1 / diagonal) of its six rows from an even slot on."""
+    n6 = 6 * N
+    desc, div = q in (1, 3), q in (1, 2)
+    masks = [_INTERIOR[q][5 - r] if desc else _INTERIOR[q][r] for r in range(6)]
+    ncoef = sum(bin(m).count("1") for m in masks)
+    diag0 = (ncoef + 1) & ~1
+    size = diag0 + 12 if div else (ncoef + 1) & ~1
+    b = b.copy()
+    w = [0.0] * 6
+    o = off
+    for blk in range(N):
+        end = blk == 0 or blk == N - 1
+        for r in range(6):
+            i = n6 - 1 - (6 * blk + r) if desc else 6 * blk + r
+            acc = b[i]
+            if end:
+                row = pk[o + 8 * r: o + 8 * r + 8]
+                for k in range(6):
+                    if row[k] != 0.0:
+                        acc = acc - row[k] * w[(r + k) % 6]
+                if div:
+                    assert row[7] == 1.0 / row[6]
+                    acc = acc / row[6]
+            else:
+                pos = o + sum(bin(masks[rr]).count("1") for rr in range(r))
+                for k in range(6):
+                    if masks[r] >> k & 1:
+                        acc = acc - pk[pos] * w[(r + k) % 6]
+                        pos += 1
+                if div:
+                    assert pk[o + diag0 + 2 * r + 1] == 1.0 / pk[o + diag0 + 2 * r]
+                    acc = acc / pk[o + diag0 + 2 * r]
+            w[r] = acc
+            b[i] = acc
+        o += 48 if end else size
+    return b, o
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 9, 16, 32])
+def test_packed_sweep_tables_of_the_reference_order_kernel(ref, hiplib, N):
+    """What the kernel reads is the packed form of those tables (12.9 KB instead of 24.6 KB for 16 pieces): sweeping over it as
+    the kernel does -- the window of the six previous results indexed (r + k) mod 6 -- gives BandedSystem::solve / solveAdj of the
+    reference build bit for bit, and the four sweeps fill exactly the size the host allocates."""
+    import ctypes as C
+    from dftpav_amd import pods
+    fn = hiplib.lib().dftpav_debug_reference_tables_packed
+    fn.argtypes = [C.c_int, pods.c_double_p, C.POINTER(C.c_int)]
+    nd = C.c_int(0)
+    assert fn(N, None, C.byref(nd)) == 0 and nd.value == 384 + 88 * (N - 2)
+    pk = np.zeros(nd.value)
+    assert fn(N, pods.dptr(pk), C.byref(nd)) == 1
+    A = sc.minco_matrix(N)
+    rng = np.random.default_rng(100 + N)
+    for trial in range(2):
+        b = rng.normal(0, 10.0 ** rng.integers(-2, 3), 6 * N)
+        y, o = _packed_sweep(pk, 0, N, 0, b)
+        x, o = _packed_sweep(pk, o, N, 1, y)
+        assert np.array_equal(x, ref.banded_solve(A, 6, 6, b)[:, 0])
+        y, o = _packed_sweep(pk, o, N, 2, b)
+        x, o = _packed_sweep(pk, o, N, 3, y)
+        assert np.array_equal(x, ref.banded_solve(A, 6, 6, b, adjoint=True)[:, 0])
+        assert o == nd.value
+
