@@ -895,6 +895,62 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   delete b;
 }
 
+// the kernels' view of a layout: offsets of the segments' pieces, waypoints, right-hand-side rows and constraint points, and of
+// tau | gear xy | gear angle inside x (traj_optimizer.cpp:96-115)
+static void fill_dev_layout(const dftpav_layout &layout, int K, int Kd, DevLayout &L) {
+  L = DevLayout{};
+  L.M = layout.M;
+  L.H = layout.H;
+  L.K = K;
+  L.Kd = Kd;
+  L.Kmax = L.K > L.Kd ? L.K : L.Kd;
+  int xoff = 0, poff = 0, roff = 0, ptoff = 0;
+  for (int i = 0; i < L.M; i++) {
+    int N = layout.piece_nums[i];
+    L.piece_nums[i] = N;
+    L.singuls[i] = layout.singuls[i];
+    L.seg_piece0[i] = poff;
+    L.seg_x0[i] = xoff;
+    L.seg_rhs0[i] = roff;
+    L.seg_pt0[i] = ptoff;
+    poff += N;
+    xoff += 2 * (N - 1);
+    roff += N + 5;
+    ptoff += (N - 2) * (L.K + 1) + 2 * (L.Kd + 1);
+  }
+  L.seg_piece0[L.M] = poff;
+  L.seg_rhs0[L.M] = roff;
+  L.seg_pt0[L.M] = ptoff;
+  L.Ntot = poff;
+  L.rhs_tot = roff;
+  L.Npts = ptoff;
+  L.x_tau0 = xoff;
+  L.x_gear0 = xoff + L.M;
+  L.x_ang0 = L.x_gear0 + 2 * (L.M - 1);
+  L.n = L.x_ang0 + (L.M - 1);
+  L.npad = ((L.n + 63) / 64) * 64;
+}
+// test hook (host only): is the reference order available for this layout with S moving obstacles, and which launch shape would
+// a batch of B trajectories take on a device of n_cu CUs?  out = {supported, wave, threads, workgroups per CU, persistent
+// workgroups, slice, LDS bytes per workgroup, width of the sequential sums}
+extern "C" int dftpav_debug_reference_plan(const dftpav_layout *layout, const dftpav_params *p, int S, int B, int n_cu, long long *out) {
+  if (!layout || !p || !out || layout->M < 1 || layout->M > kMaxSeg || B < 1 || n_cu < 1) return DFTPAV_E_INVALID;
+  DevLayout L;
+  fill_dev_layout(*layout, p->traj_resolution, p->des_traj_resolution, L);
+  DevParams P;
+  fill_dev_params(*p, P);
+  out[0] = reference_order_supported(L, P, S) ? 1 : 0;
+  const RefPlan pl = reference_order_plan(L, P, S, B, n_cu);
+  out[1] = pl.wave;
+  out[2] = pl.threads;
+  out[3] = pl.wg_per_cu;
+  out[4] = pl.slots;
+  out[5] = pl.slice;
+  out[6] = (long long)pl.lds;
+  out[7] = L.n <= 16 ? 16 : (L.n <= 32 ? 32 : (L.n <= 40 ? 40 : (L.n <= 48 ? 48 : 64)));
+  return DFTPAV_OK;
+}
+
 static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int B, int residency, dftpav_batch **out);
 extern "C" int dftpav_batch_create(dftpav_handle *h, const dftpav_layout *layout, int B, dftpav_batch **out) {
   return batch_create_impl(h, layout, B, -1, out);
@@ -919,36 +975,7 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
   b->h = h;
   b->B = B;
   DevLayout &L = b->L;
-  L.M = layout->M;
-  L.H = layout->H;
-  L.K = p.traj_resolution;
-  L.Kd = p.des_traj_resolution;
-  L.Kmax = L.K > L.Kd ? L.K : L.Kd;
-  int xoff = 0, poff = 0, roff = 0, ptoff = 0;
-  for (int i = 0; i < L.M; i++) {
-    int N = layout->piece_nums[i];
-    L.piece_nums[i] = N;
-    L.singuls[i] = layout->singuls[i];
-    L.seg_piece0[i] = poff;
-    L.seg_x0[i] = xoff;
-    L.seg_rhs0[i] = roff;
-    L.seg_pt0[i] = ptoff;
-    poff += N;
-    xoff += 2 * (N - 1);
-    roff += N + 5;
-    ptoff += (N - 2) * (L.K + 1) + 2 * (L.Kd + 1);
-  }
-  L.seg_piece0[L.M] = poff;
-  L.seg_rhs0[L.M] = roff;
-  L.seg_pt0[L.M] = ptoff;
-  L.Ntot = poff;
-  L.rhs_tot = roff;
-  L.Npts = ptoff;
-  L.x_tau0 = xoff;
-  L.x_gear0 = xoff + L.M;
-  L.x_ang0 = L.x_gear0 + 2 * (L.M - 1);
-  L.n = L.x_ang0 + (L.M - 1);
-  L.npad = ((L.n + 63) / 64) * 64;
+  fill_dev_layout(*layout, p.traj_resolution, p.des_traj_resolution, L);
   if (L.n > 256 || L.Ntot > 1024 || L.Npts > 32767) {
     delete b;
     return DFTPAV_E_UNSUPPORTED;

@@ -157,3 +157,45 @@ def test_product_does_not_reference_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "pyoracle" not in txt and "dftpav_oracle.h" not in txt and "libdftpav_oracle" not in txt, fn
+
+
+def test_launch_shapes_of_the_reference_order(hiplib):
+    """Host logic of dftpav_batch_set_order(DFTPAV_ORDER_REFERENCE), without a device (solver_ref.hip: reference_order_supported /
+    reference_order_plan through a test hook): what is supported, and which launch shape a batch takes on a 256-CU device --
+    a workgroup per trajectory up to five trajectories per CU, beyond that one wave per trajectory, as many waves per workgroup
+    as keep the most trajectories resident, the shared tables plus the waves' own state inside one CU's 160 KB of LDS."""
+    import ctypes as C
+    from dftpav_amd import scenarios as sc
+    fn = hiplib.lib().dftpav_debug_reference_plan
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+
+    def plan(pieces, singuls, K, Kd, S, B, H=4):
+        from dftpav_amd.pods import LayoutSpec
+        p = hiplib.default_params()
+        p.traj_resolution, p.des_traj_resolution = K, Kd
+        lay = LayoutSpec(pieces, singuls, H=H)
+        out = (C.c_longlong * 8)()
+        assert fn(C.byref(lay.c_struct()), C.byref(p), S, B, 256, out) == 0
+        return dict(zip(("supported", "wave", "threads", "wg_per_cu", "slots", "slice", "lds", "cap"), [int(v) for v in out]))
+
+    # BASELINE configs[2] / [3]: 16 pieces x 33 points, n = 31
+    for B, wave in ((1, 0), (256, 0), (1024, 0), (1280, 0), (1281, 1), (2048, 1), (4096, 1)):
+        q = plan([16], [1], 32, 32, 0, B)
+        assert q["supported"] == 1 and q["wave"] == wave and q["cap"] == 32, (B, q)
+        assert q["lds"] <= 160 * 1024
+        if wave:
+            assert q["threads"] == 512 and q["wg_per_cu"] == 1 and q["slots"] == 256 and q["slice"] == 128   # eight waves per CU
+        else:
+            assert q["threads"] == (128 if B > 768 else 256)
+    # configs[1]: 8 + 8 pieces with a gear shift, n = 33: sums of 40 terms; the 512-register kernels: four waves per CU
+    q = plan([8, 8], [1, -1], 32, 32, 0, 4096)
+    assert q["supported"] == 1 and q["cap"] == 40 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] == 256
+    # configs[4]: 32 pieces x 65 points with four moving obstacles, n = 63
+    q = plan([32], [1], 64, 64, 4, 4096)
+    assert q["supported"] == 1 and q["cap"] == 64 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] <= 256 and q["lds"] <= 160 * 1024
+    # the reference's live case, 12 obstacles (5 H + S + 4 = 36 terms: the 64-bit mask)
+    assert plan([5, 4, 6], [1, -1, 1], 12, 16, 12, 64)["supported"] == 1
+    # outside the mode: more than 64 variables, more than five half-planes, more than 64 terms per point
+    assert plan([40], [1], 8, 8, 0, 1)["supported"] == 0
+    assert plan([8], [1], 8, 8, 0, 1, H=6)["supported"] == 0
+    assert plan([8], [1], 8, 8, 45, 1)["supported"] == 0
