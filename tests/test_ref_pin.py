@@ -316,3 +316,33 @@ def test_packed_sweep_tables_of_the_reference_order_kernel(ref, hiplib, N):
         assert np.array_equal(x, ref.banded_solve(A, 6, 6, b, adjoint=True)[:, 0])
         assert o == nd.value
 
+
+
+@pytest.mark.parametrize("layout,seed", [(([7, 6], [1, -1]), 81), (([5, 4, 6], [1, -1, 1]), 82)])
+def test_live_case_gear_shifts_with_moving_obstacles(ref, oracle, layout, seed):
+    """What the reference's only live caller passes (traj_manager.cpp:604-610): a multi-segment layout AND the moving cars,
+    obstacle clocks that differ from the ego's (traj_optimizer.cpp:1367-1369).  The literal oracle (order 0) is bit-equal
+    to the reference build through the whole solve; order 2 -- the same program with correctly rounded cos / sin / exp /
+    log / pow, the order the GPU's reference-order kernel is held bit-equal to -- stays within 1e-12 of it per evaluation,
+    and the moving-obstacle term is active on the points compared."""
+    pieces, sing = layout
+    B = 4
+    p = oracle.default_params()
+    s = sc.make_scenario(pieces, sing, 12, 16, B, seed=seed, with_moving=True, n_obs=25, start_centre=(-38.0, 5.0))
+    s.surround.start_time[:] = [0.5, 0.0, 1.5, 0.25]
+    s.t_now = 0.6
+    s.apply_resolution(p)
+    rng = np.random.default_rng(seed)
+    active = 0
+    for b in range(B):
+        rr = _compare_problem(ref, oracle, p, s, b)
+        o2 = oracle.OracleProblem(p, s, b, order=2)
+        r = ref.RefProblem(p, s, b)
+        x0 = o2.x0()
+        for x in (x0, x0 + rng.normal(0, 0.25, x0.shape), rr["iter_x"][len(rr["iter_x"]) // 2]):
+            f2, g2 = o2.eval(x)
+            fr, gr = r.eval(x)
+            assert abs(f2 - fr) <= 1e-12 * abs(fr), (layout, b, f2, fr)
+            assert np.abs(g2 - gr).max() <= 1e-12 * max(1.0, np.abs(gr).max())
+            active += o2.cost_terms()[3] > 0.0
+    assert active >= B, active
