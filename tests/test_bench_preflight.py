@@ -131,3 +131,13 @@ def test_every_side_run_of_the_one_gpu_line():
     assert par["lockstep"] == {"failed": par["lockstep"]["failed"]}      # the stand-in keeps no trace: reported, not fatal
     assert out["moving_obstacles_1024"]["reference_order"]["batch"] == 4
     assert out["strong_shard"]["per_gpu"] == 2 and out["strong_shard"]["steps_in_flight"] == 16
+
+
+def test_a_side_run_over_its_time_limit_costs_its_entry_not_the_line():
+    """the watchdog of the other scaling mode (what tests/test_gpu_dist.py checks on the device)"""
+    out = _bench(["--steps", "4", "--warmup", "1", "--batch-per-gpu", "16", "--no-extras", "--cpu-sample", "0"],
+                 env={"DFTPAV_BENCH_FORCE_DIST": "1", "DFTPAV_BENCH_FORCE_OTHER": "1", "MASTER_PORT": str(_port()), "DFTPAV_BENCH_SIDE_LIMIT_S": "0.05"})
+    assert out["value"] > 0 and "time limit" in out["other_scaling"]["error"]
+    out = _bench(["--steps", "4", "--warmup", "1", "--batch-per-gpu", "16", "--no-extras", "--cpu-sample", "0"],
+                 env={"DFTPAV_BENCH_FORCE_DIST": "1", "DFTPAV_BENCH_FORCE_OTHER": "1", "MASTER_PORT": str(_port()), "DFTPAV_BENCH_DEPTH": "4,2"})
+    assert out["other_scaling"]["steps_in_flight"] == 4 and out["other_scaling"]["steps"] >= 8
