@@ -927,6 +927,7 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
     const int n_pairs = sm.dinfo[Npts];
     for (int c0 = 0; c0 < n_pairs; c0 += T) {
       const int i = c0 + tid;
+      const int last = (n_pairs - c0 < T ? n_pairs - c0 : T) - 1; // the thread of the batch's last pair
       if (i < n_pairs) {
         int lo = 0, hi = Npts; // the last point whose first pair index is <= i: it holds pair i
         while (hi - lo > 1) {
@@ -947,6 +948,10 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
           else phi = mid;
         }
         const int p = plo;
+        // pairs are numbered in point order: the batch touches the pieces from its first pair's to its last pair's, and the
+        // chain pass below visits only those (the two padding doubles at the end of dpart's first row carry the bounds)
+        if (tid == 0) sm.dpart[T] = (double)p;
+        if (tid == last) sm.dpart[T + 1] = (double)p;
         const int *pc = sm.pcinfo + 8 * p;
         SampleIn in;
         in.j = pt - pc[0];
@@ -981,7 +986,8 @@ __device__ __forceinline__ void block_eval(const DevBatch &D, const double *cor_
       }
       pr.tick(kPMISC);
       __syncthreads();
-      for (int w = tid; w < 16 * Ntot; w += T) {
+      const int p_first = (int)sm.dpart[T], p_last = (int)sm.dpart[T + 1];
+      for (int w = 16 * p_first + tid; w < 16 * (p_last + 1); w += T) {
         const int p = w >> 4, q = w & 15;
         if (q >= 14) continue;
         const int *pc = sm.pcinfo + 8 * p;
