@@ -477,6 +477,12 @@ def same_solve(a, i, b, j):
                 a["evals"][i] == b["evals"][j] and a["status"][i] == b["status"][j])
 
 
+def same_as_ref_run(r, b, rr):
+    """trajectory b of a device result set against one OptimizeTrajectory run of a reference build (oracle/pyref.py)"""
+    return bool(rr["final_cost"] == r["final_cost"][b] and np.array_equal(rr["x"], r["x"][b]) and rr["iters"] == r["iters"][b] and
+                rr["evals"] == r["evals"][b] and rr["status"] == r["status"][b])
+
+
 def bit_check(po, cores, p2, s2, r2, pick):
     """sampled trajectories of a side run against the device-order oracle: every field bit for bit"""
     ro = po.solve_batch(p2, s2.subset(pick), nthreads=min(len(pick), cores), order=1)
@@ -576,7 +582,7 @@ def side_single(ctx, args, po, cores, cfg, seeds):
     the last bit), so the latency is quoted as the median over the seeded instances, with the per-iteration time beside it"""
     from oracle import pyref as _pr
     p2 = capi.default_params()
-    ms, its, oks, ms_ref, its_ref, eq2, eqb = [], [], [], [], [], [], []
+    ms, its, oks, ms_ref, its_ref, eq2, eqb, eqc = [], [], [], [], [], [], [], []
     for sd in seeds:
         s2 = sc.baseline_config(cfg, B=1, seed=args.seed + 17 * sd)
         s2.apply_resolution(p2)
@@ -601,6 +607,8 @@ def side_single(ctx, args, po, cores, cfg, seeds):
         if _pr.available():
             rr_ = _pr.RefProblem(p2, s2, 0).optimize()
             eqb.append(bool(rr_["final_cost"] == r3["final_cost"][0] and np.array_equal(rr_["x"], r3["x"][0])))
+        if _pr.cr_available():   # the reference's own objects on a correctly rounded libm (oracle/cr_libm.c): must agree on ALL
+            eqc.append(same_as_ref_run(r3, 0, _pr.RefProblem(p2, s2, 0, cr=True).optimize()))
         b2.close(); h2.close()
     ms, its, ms_ref, its_ref = np.array(ms), np.array(its), np.array(ms_ref), np.array(its_ref)
     return {"batch": 1, "instances": len(seeds), "p50_ms_per_solve": float(np.median(ms)), "min_ms": float(ms.min()),
@@ -610,6 +618,7 @@ def side_single(ctx, args, po, cores, cfg, seeds):
                                 "median_iters": float(np.median(its_ref)),
                                 "bit_equal_to_the_reference_program_with_correctly_rounded_cos_sin": int(sum(eq2)),
                                 "bit_equal_to_the_reference_build_on_this_host": (int(sum(eqb)) if eqb else None),
+                                "bit_equal_to_the_reference_build_on_a_correctly_rounded_libm": (int(sum(eqc)) if eqc else None),
                                 "instances": len(seeds)}}
 
 
@@ -633,6 +642,10 @@ def side_configs4_reference_order(ctx, args, po, cores, B=64):
         row = {"batch": B, "kernel_ms": b5.last_solve_ms(), "us_per_iteration_of_the_longest": 1e3 * b5.last_solve_ms() / max(1, int(r5["iters"].max())),
                "bit_equal_to_the_reference_program_with_correctly_rounded_exp_log_pow_on_4_sampled":
                    bool(all(np.array_equal(o5[k_], r5[k_][pick5]) for k_ in SOLVE_FIELDS))}
+        from oracle import pyref as _pr5
+        if _pr5.cr_available():   # one whole solve of the reference's own objects on a correctly rounded libm (seconds on the host)
+            row["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm_on_1_sampled"] = same_as_ref_run(
+                r5, 0, _pr5.RefProblem(p5, s5, 0, cr=True).optimize())
         b5.close(); h5.close()
         return row
     except capi.DftpavError as ex:
@@ -672,6 +685,10 @@ def side_reference_order_other_configs(ctx, args, po, cores):
                 row["against_reference_build"] = {"trajectories": int(sz.B), "bit_equal": eqb_,
                                                   "note": ("every solve must agree" if not libm else
                                                            "agrees where this host's libm rounded every call of the solve correctly")}
+            if libm and _pr2.cr_available():
+                row["against_reference_build_on_a_correctly_rounded_libm"] = {
+                    "trajectories": int(sz.B), "bit_equal": int(sum(same_as_ref_run(rz, i_, _pr2.RefProblem(pz, sz, i_, cr=True).optimize()) for i_ in range(sz.B))),
+                    "note": "the reference's own objects linked against oracle/cr_libm.c: every solve must agree"}
             rows[name_] = row
             bz.close(); hz.close()
         return rows

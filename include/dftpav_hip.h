@@ -303,6 +303,9 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *     - gear shifts TOGETHER WITH moving obstacles -- the reference's live call, traj_manager.cpp:604-610 -- are covered,
  *       including trajtimes[i] = duration of segment i - 1 (traj_optimizer.cpp:230-234) and the extra gdT addends per
  *       previous segment (:1674-1676);
+ *     - with libm calls in the loop the yardstick is the reference's own objects linked against a correctly rounded
+ *       exp / log / pow / sin / cos (oracle/_ref/libdftpav_ref_cr.so, oracle/cr_libm.c: test infrastructure): whole solves of
+ *       this mode are bit-equal to THAT build on all of the three cases above;
  *     - limits: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per constraint point, every gear segment
  *       >= 2 pieces; otherwise DFTPAV_E_UNSUPPORTED, order unchanged.  Choose the order again after the number of
  *       obstacles on the handle changed.  dftpav_batch_trace* is a device-order facility (DFTPAV_E_UNSUPPORTED here).

@@ -21,6 +21,10 @@ _LIB = None
 # dftpav_amd/csrc/host/dropin/traj_optimizer_hip.cpp over libdftpav_hip.so) -- needs a GPU at run time
 _SO_DROPIN = os.path.join(_HERE, "_ref", "libdftpav_dropin.so")
 _LIB_DROPIN = None
+# the reference's objects on a correctly rounded exp / log / pow / sin / cos (oracle/cr_libm.c): what oracle order 2 and the
+# device's reference order are bit-equal to where the reference's loop calls libm
+_SO_CR = os.path.join(_HERE, "_ref", "libdftpav_ref_cr.so")
+_LIB_CR = None
 
 
 def build():
@@ -31,6 +35,21 @@ def build():
 
 def available():
     return os.path.exists(_SO)
+
+
+def cr_available():
+    return os.path.exists(_SO_CR)
+
+
+def cr_lib():
+    global _LIB_CR
+    if _LIB_CR is None:
+        if not cr_available():
+            build()
+        L = C.CDLL(_SO_CR)
+        _bind_common(L)
+        _LIB_CR = L
+    return _LIB_CR
 
 
 def dropin_available():
@@ -107,9 +126,10 @@ class RefProblem:
     """PolyTrajOptimizer of the reference on element b of a Scenario (same inputs as oracle.pyoracle.OracleProblem).
     dropin=True: the same class object with the drop-in's implementation behind it (libdftpav_dropin.so, GPU)."""
 
-    def __init__(self, params, scen, b=0, dropin=False):
+    def __init__(self, params, scen, b=0, dropin=False, cr=False):
+        """cr=True: the reference's objects linked against the correctly rounded libm of oracle/cr_libm.c"""
         from oracle.pyoracle import OracleProblem
-        self._L = dropin_lib() if dropin else lib()
+        self._L = dropin_lib() if dropin else (cr_lib() if cr else lib())
         # reuse the flattening of the oracle's wrapper (plain arrays; nothing of the oracle's arithmetic is involved)
         self._flat = OracleProblem.__new__(OracleProblem)
         lay = scen.layout

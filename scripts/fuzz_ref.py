@@ -2,7 +2,10 @@
 
 Random layouts (1-3 gear segments of 2-12 pieces, sample resolutions 3-24, moving obstacles, random limits / weights /
 help_eps / obstacle clock / L-BFGS memory); x0, f, g at x0, and every field of the whole solve must be bit-identical.
-  python scripts/fuzz_ref.py [n_cases] [first_seed]"""
+  python scripts/fuzz_ref.py [n_cases] [first_seed] [cr]
+cr: oracle order 2 (correctly rounded cos / sin / exp / log / x^3 through binary128) against oracle/_ref/libdftpav_ref_cr.so, the
+reference's own objects linked against the same correctly rounded functions (oracle/cr_libm.c) -- the pin of the order the
+device's reference-order kernel implements; half of the cases then carry moving obstacles."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +14,7 @@ from oracle import pyoracle as po, pyref as pr
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+CR = len(sys.argv) > 3 and sys.argv[3] == "cr"
 bad = 0
 t0 = time.time()
 stat = {}
@@ -23,7 +27,7 @@ for c in range(n_cases):
         sing.append(-sing[-1])
     K = int(rng.integers(3, 25)); Kd = int(rng.integers(3, 25))
     B = int(rng.integers(1, 4))
-    moving = bool(rng.uniform() < 0.3) and sum(pieces) <= 12
+    moving = bool(rng.uniform() < (0.5 if CR else 0.3)) and sum(pieces) <= 12
     p = po.default_params()
     s = sc.make_scenario(pieces, sing, K, Kd, B, seed=5000 + seed0 + c, with_moving=moving, n_obs=int(rng.integers(0, 60)))
     s.apply_resolution(p)
@@ -39,8 +43,8 @@ for c in range(n_cases):
     if moving:
         s.t_now = float(rng.uniform(0.0, 5.0))
     for b in range(B):
-        o = po.OracleProblem(p, s, b, order=0)
-        r = pr.RefProblem(p, s, b)
+        o = po.OracleProblem(p, s, b, order=2 if CR else 0)
+        r = pr.RefProblem(p, s, b, cr=CR)
         rr = r.optimize(trace=True)
         xo, ro = o.solve()
         x0 = o.x0()
@@ -55,5 +59,5 @@ for c in range(n_cases):
             print("MISMATCH case %d b %d: pieces %s singuls %s K %d Kd %d moving %s mem %d eps %g | f0 %r %r | cost %r %r iters %d %d evals %d %d status %d %d" %
                   (c, b, pieces, sing, K, Kd, moving, p.lbfgs_mem_size, s.help_eps, fo, fr, ro.final_cost, rr["final_cost"], ro.iters, rr["iters"],
                    ro.evals, rr["evals"], ro.status, rr["status"]), flush=True)
-print("%d cases, %d mismatches, %.1f s; solver status counts %s" % (n_cases, bad, time.time() - t0, stat))
+print("%s: %d cases, %d mismatches, %.1f s; solver status counts %s" % ("order 2 vs _ref on the correctly rounded libm" if CR else "order 0 vs _ref", n_cases, bad, time.time() - t0, stat))
 sys.exit(1 if bad else 0)

@@ -130,6 +130,11 @@ def test_every_side_run_of_the_one_gpu_line():
     assert par["reference_order"]["overlapped"]["first_batch_equals_the_isolated_solve"] is True
     assert par["lockstep"] == {"failed": par["lockstep"]["failed"]}      # the stand-in keeps no trace: reported, not fatal
     assert out["moving_obstacles_1024"]["reference_order"]["batch"] == 4
+    # the reference's own objects on a correctly rounded libm agree with order 2 (= the stand-in's "device") on every solve
+    assert out["single"]["reference_order"]["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm"] == 9
+    assert out["moving_obstacles_1024"]["reference_order"]["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm_on_1_sampled"] is True
+    live = par["reference_order_other_configs"]["gear_shifts_with_moving_obstacles"]
+    assert live["against_reference_build_on_a_correctly_rounded_libm"]["bit_equal"] == live["trajectories"] == 8
     assert out["strong_shard"]["per_gpu"] == 2 and out["strong_shard"]["steps_in_flight"] == 16
 
 

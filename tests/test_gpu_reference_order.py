@@ -547,3 +547,49 @@ def test_class_mirror_in_reference_order_returns_the_reference_answer(hiplib, or
     assert opt5.last["order"] == hiplib.ORDER_REFERENCE   # moving obstacles: the reference's program with correctly rounded exp / log / pow
     o5 = oracle.solve_batch(p5, s5, nthreads=1, order=2)
     assert opt5.last["final_cost"][0] == o5["final_cost"][0] and np.array_equal(opt5.last["x"][0], o5["x"][0])
+
+
+def _ref_cr():
+    from oracle import pyref
+    return pyref if pyref.cr_available() else None
+
+
+def _same_as_ref(r, b, rr):
+    return bool(rr["final_cost"] == r["final_cost"][b] and np.array_equal(rr["x"], r["x"][b]) and rr["iters"] == r["iters"][b] and
+                rr["evals"] == r["evals"][b] and rr["status"] == r["status"][b] and rr["ok"] == bool(r["success"][b]))
+
+
+def test_reference_order_equals_the_reference_on_a_correctly_rounded_libm(hiplib, oracle):
+    """The bit-level pin of the configurations whose loop calls libm to the reference's OWN CODE.  oracle/_ref/libdftpav_ref_cr.so
+    is traj_optimizer.cpp compiled unmodified (the same two objects as oracle/_ref) linked against a correctly rounded exp /
+    log / pow / sin / cos (oracle/cr_libm.c): the reference's program on the one libm every host agrees on -- the libm the
+    device implements (cr_trig.h).  Whole solves of the device in reference order must be bit-equal to it: BASELINE configs[1]
+    (gear shift, 32 trajectories), the reference's live case (gear shifts with moving obstacles, two layouts, 8 of 64
+    trajectories each), BASELINE configs[4] (one trajectory: binary128 exp / log take seconds per solve on the host)."""
+    pyref = _ref_cr()
+    if pyref is None:
+        pytest.skip("oracle/_ref/libdftpav_ref_cr.so did not travel")
+    cases = [("configs[1]", lambda: sc.baseline_config(2, B=32), range(32)),
+             ("live [7, 6]", lambda: _live_case(([7, 6], [1, -1]), 64, 81), range(0, 64, 8)),
+             ("live [5, 4, 6]", lambda: _live_case(([5, 4, 6], [1, -1, 1]), 64, 82), range(0, 64, 8)),
+             ("configs[4]", lambda: sc.baseline_config(5, B=2), range(1))]
+    for name, mk, pick in cases:
+        p = hiplib.default_params()
+        s = mk()
+        s.apply_resolution(p)
+        h = hiplib.Handle(p)
+        h.set_surround(s.surround)
+        bt = hiplib.Batch(h, s.layout, s.B)
+        bt.upload(s)
+        bt.set_order(hiplib.ORDER_REFERENCE)
+        r = bt.solve()
+        for b in pick:
+            rr = pyref.RefProblem(p, s, b, cr=True).optimize()
+            assert _same_as_ref(r, b, rr), (name, b, r["final_cost"][b], rr["final_cost"], r["iters"][b], rr["iters"])
+        cf, dt = bt.coeffs()           # getMinJerkOptPtr()'s coefficients of the solution (traj_manager.cpp:618-625)
+        rp = pyref.RefProblem(p, s, 0, cr=True)
+        rp.eval(r["x"][0])             # costFunctionCallback of the reference at the solution leaves them in its container
+        co, dto = rp.coeffs()
+        assert np.array_equal(cf[0], co) and np.array_equal(dt[0], dto), name
+        bt.close()
+        h.close()
