@@ -85,3 +85,12 @@ def test_reference_object_gpu_backed_live_case(hiplib, oracle):
         fr, gr = ref.eval(x)
         fg, gg = gpu.eval(x)
         assert abs(fg - fr) <= 1e-12 * abs(fr) and np.abs(gg - gr).max() <= 1e-12 * max(1.0, np.abs(gr).max()), b
+        if pyref.cr_available():
+            # the reference's own objects linked against a correctly rounded libm (oracle/cr_libm.c): THAT object and the GPU-backed
+            # one hand back the same bits -- the whole solve and costFunctionCallback at a common point
+            refc = pyref.RefProblem(p, s, b, cr=True)
+            rc = refc.optimize()
+            assert rg["final_cost"] == rc["final_cost"] and np.array_equal(rg["x"], rc["x"]), b
+            assert (rg["status"], rg["iters"], rg["evals"], bool(rg["ok"])) == (rc["status"], rc["iters"], rc["evals"], bool(rc["ok"])), b
+            fc, gc = refc.eval(x)
+            assert fg == fc and np.array_equal(gg, gc), b
