@@ -8,6 +8,7 @@
 // entry point that needs one fails with DFTPAV_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <atomic>
 #include <mutex>
 
 #include <cmath>
@@ -61,6 +62,13 @@ hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode,
 }
 using namespace dftpav;
 
+// An RCCL communicator and the number of handles that hold it (its creator and the handles it was shared with, each on its own
+// host thread at most): the communicator is destroyed by whichever of them lets go last, in whatever order they do.
+struct CommShared {
+  void *comm;
+  std::atomic<int> holders;
+};
+
 struct dftpav_handle {
   dftpav_params params;
   int device = 0;
@@ -84,7 +92,7 @@ struct dftpav_handle {
   std::vector<struct dftpav_batch *> batches; // every live batch of this handle (obstacle changes finish their chained stragglers)
   // RCCL communicator of dftpav_comm_create (one rank per handle = per GPU), and the staging block of this rank's records
   void *comm = nullptr;
-  bool comm_borrowed = false; // the communicator belongs to another handle of this process (dftpav_comm_share)
+  struct CommShared *comm_ref = nullptr; // the communicator's holders (dftpav_comm_share): destroyed when the last one lets go
   int comm_ranks = 0, comm_rank = 0;
   unsigned char *d_comm_send = nullptr;
   size_t comm_send_bytes = 0;
@@ -1925,10 +1933,13 @@ extern "C" int dftpav_comm_destroy(dftpav_handle *h) {
   if (h->comm) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    if (!h->comm_borrowed) (void)rccl().CommDestroy(h->comm);
+    if (h->comm_ref && h->comm_ref->holders.fetch_sub(1) == 1) { // the last holder (every holder has drained its own stream)
+      (void)rccl().CommDestroy(h->comm_ref->comm);
+      delete h->comm_ref;
+    }
     h->comm = nullptr;
+    h->comm_ref = nullptr;
   }
-  h->comm_borrowed = false;
   if (h->d_comm_send) (void)hipFree(h->d_comm_send);
   h->d_comm_send = nullptr;
   h->comm_send_bytes = 0;
@@ -1946,6 +1957,7 @@ extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const 
   RcclUniqueId u;
   std::memcpy(u.internal, unique_id, DFTPAV_UNIQUE_ID_BYTES);
   RCCLCHK(h, rccl().CommInitRank(&h->comm, nranks, u, rank));
+  h->comm_ref = new CommShared{h->comm, {1}};
   h->comm_ranks = nranks;
   h->comm_rank = rank;
   return DFTPAV_OK;
@@ -1956,13 +1968,15 @@ extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const 
 // same order of collectives on every rank -- which a round-robin over the handles is.
 extern "C" int dftpav_comm_share(dftpav_handle *h, dftpav_handle *owner) {
   if (!h || !owner || h == owner) return DFTPAV_E_INVALID;
-  if (!owner->comm || owner->comm_borrowed || owner->device != h->device) {
-    h->err = "dftpav_comm_share: the owner needs a communicator of its own (dftpav_comm_create) on the same device";
+  if (!owner->comm || !owner->comm_ref || owner->device != h->device) {
+    h->err = "dftpav_comm_share: the other handle needs a communicator (dftpav_comm_create, or shared itself) on the same device";
     return DFTPAV_E_INVALID;
   }
+  if (owner->comm_ref == h->comm_ref) return DFTPAV_OK; // already the same communicator
   if (int rc = dftpav_comm_destroy(h)) return rc;
   h->comm = owner->comm;
-  h->comm_borrowed = true;
+  h->comm_ref = owner->comm_ref;
+  h->comm_ref->holders.fetch_add(1);
   h->comm_ranks = owner->comm_ranks;
   h->comm_rank = owner->comm_rank;
   return DFTPAV_OK;

@@ -421,9 +421,9 @@ int dftpav_batch_records(dftpav_batch *b, void *host_dst);
  *                           channel the host has (MPI, a socket, torch.distributed ...)
  *   dftpav_comm_create      every rank, collectively: ncclCommInitRank on the handle's device
  *   dftpav_comm_share       another handle (= HIP stream) of the same process and device uses the owner's communicator: a host
- *                           with k batches in flight on k handles sets up one communicator per rank, not k.  The owner must
- *                           outlive the borrowers' use; every rank issues its collectives in the same order (round-robin over
- *                           the handles does)
+ *                           with k batches in flight on k handles sets up one communicator per rank, not k.  The communicator
+ *                           is held by all of them and destroyed when the last lets go (dftpav_comm_destroy / dftpav_destroy,
+ *                           any order); every rank issues its collectives in the same order (round-robin over the handles does)
  *   dftpav_comm_layout      the contiguous shard [first, first + count) of a rank out of global_B trajectories, and `block` =
  *                           the largest shard: the gathered buffer holds nranks blocks of `block` records, rank r's shard at
  *                           the start of block r (the pad, at most one record, is zero)

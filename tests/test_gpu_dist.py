@@ -208,8 +208,8 @@ def test_records_are_written_by_the_solve_kernels(hiplib, monkeypatch, mode):
 
 def test_one_communicator_shared_by_several_handles(hiplib):
     """dftpav_comm_share at world size 1: three handles (= HIP streams) of one process, ONE communicator -- the owner's -- and an
-    all-gather of the epilogue-written records on each of the three streams, round-robin, twice; the borrowers are destroyed
-    before the owner.  (What bench.py does at N > 1 instead of a communicator per handle.)"""
+    all-gather of the epilogue-written records on each of the three streams, round-robin, twice; the handle that created the
+    communicator is destroyed FIRST (the communicator is reference-counted).  (What bench.py does at N > 1 instead of a communicator per handle.)"""
     from dftpav_amd import capi, scenarios as sc
     p = capi.default_params()
     B = 9
@@ -236,7 +236,15 @@ def test_one_communicator_shared_by_several_handles(hiplib):
             assert np.array_equal(cost, r["final_cost"]) and np.array_equal(status, r["status"]) and np.array_equal(iters, r["iters"])
     for bt in bts:
         bt.close()
-    for c_ in reversed(comms):
+    # the communicator belongs to its holders together: it lives until the last of them lets go, in whatever order (here the
+    # handle that created it goes first, and a handle shares from a handle that itself only shares)
+    extra = capi.Handle(p, device=0)
+    extra.comm_share(hs[2])
+    comms[0].close()
+    hs[0].close()
+    for c_ in comms[1:]:
         c_.close()
-    for h_ in hs:
+    extra.comm_destroy()
+    extra.close()
+    for h_ in hs[1:]:
         h_.close()
