@@ -1,0 +1,118 @@
+// dense_dir.h -- the L-BFGS search direction d = -H g from a DENSE form of H instead of the two-loop recursion.
+//
+// EXPERIMENTAL (round 4, built and validated on the CPU only; the device path is off unless a batch asks for it through the
+// debug hook dftpav_debug_set_direction): see DESIGN.md section 8.
+//
+// Why.  The reference keeps m = 256 pairs (s_j, y_j) (lbfgs_mem_size, pb.txt:96) for problems of n = 31 .. 63 variables, and
+// its two-loop recursion (lbfgs.hpp:716-739) walks them one after the other: 2 * bound DEPENDENT steps per iteration, each a dot
+// product over n <= 64 elements -- on the device a cross-lane reduction of 300 cycles that nothing else can hide (a third of
+// the throughput kernel's time at 4096 trajectories, half of it for one trajectory alone).  With n << m the operator itself is
+// small: n x n.  H_k = T_{k-1} o ... o T_{k-bound}(gamma I) with T_j(X) = V_j^T X V_j + rho_j s_j s_j^T, V_j = I - rho_j y_j s_j^T
+// (Nocedal & Wright 7.19, the operator the two-loop recursion applies).  A composition of such maps is again of the form
+// X -> A^T X A + C with A = V_old ... V_new (n x n) and C (n x n); composing with one more pair on the right is a rank-1 / rank-2
+// update, O(n^2), and
+//     H g = gamma A^T (A g) + C g
+// is three matrix-vector products whose n results are INDEPENDENT: lane L owns row L, one chain of n multiply-adds, no
+// cross-lane reduction at all.  The window (the oldest pair leaves when the 257th arrives) is kept with the two-stack queue
+// of sliding-window aggregation: the newest pairs are folded into a running `back` aggregate; when the front runs dry the
+// surviving pairs are turned, newest to oldest, into SUFFIX aggregates (one O(n^2) step each, m of them once every m
+// iterations), and dropping the oldest pair is stepping to the next suffix.  With front F = (A_f, C_f) and back B = (A_b, C_b):
+//     H g = A_b^T ( gamma A_f^T (A_f (A_b g)) + C_f (A_b g) ) + C_b g.
+// Numerically this is the BFGS update in product form: measured against the two-loop recursion in 80-bit arithmetic on real
+// solves the direction differs by 1e-14 (median) .. 2e-10 (worst seen) relative, where the fp64 two-loop recursion itself is at
+// 1e-15 .. 3e-13 (tests/test_dense_direction.py).  It is a different device order: same mathematics, its own bits, its own oracle
+// mode (order 3).
+//
+// This header is the ARITHMETIC, shared by the kernel (one lane = one index L) and the device-order oracle (a loop over L):
+// every value is one chain of fused multiply-adds from 0.0 in index order, so the two sides agree bit for bit by construction.
+// Layout of one aggregate ("entry"), pitch np >= n:  Acm[k * np + i] = A[i][k],  Arm[i * np + k] = A[i][k],  Ccm[k * np + i]
+// = C[i][k] -- in each, the lanes of a wave read consecutive doubles.  A is kept twice because both A v (lane = row) and
+// A^T v (lane = column) are wanted; an element is computed by the same expression in both copies, so they hold the same bits.
+#pragma once
+#include "traj_math.h"
+
+namespace dftpav {
+namespace dense {
+
+DFTPAV_HD inline int pitch(int n) { return (n + 7) & ~7; }
+DFTPAV_HD inline size_t entry_doubles(int n) { return 3 * (size_t)pitch(n) * pitch(n); }
+
+struct Entry {
+  double *acm, *arm, *ccm;
+  int np;
+};
+DFTPAV_HD inline Entry entry_at(double *base, int n, size_t index) {
+  const int np = pitch(n);
+  double *p = base + index * entry_doubles(n);
+  Entry e = {p, p + (size_t)np * np, p + 2 * (size_t)np * np, np};
+  return e;
+}
+
+// sum_k M[k * np + L] * v[k]: lane L's chain, k ascending from 0.0
+DFTPAV_HD inline double lane_matvec(const double *M, int np, int n, int L, const double *v) {
+  double acc = 0.0;
+  for (int k = 0; k < n; k++) acc = fma_(M[(size_t)k * np + L], v[k], acc);
+  return acc;
+}
+
+// A = I, C = 0 (lane L writes what it owns)
+DFTPAV_HD inline void set_identity(const Entry &e, int n, int L) {
+  for (int k = 0; k < n; k++) {
+    e.acm[(size_t)k * e.np + L] = k == L ? 1.0 : 0.0;
+    e.arm[(size_t)k * e.np + L] = k == L ? 1.0 : 0.0;
+    e.ccm[(size_t)k * e.np + L] = 0.0;
+  }
+}
+
+// ---- a new pair joins the back aggregate on the right: A <- A V, C <- V^T C V + rho s s^T, V = I - rho y s^T
+//   a = A y, c = C y (lane_matvec on acm / ccm), yCy = y . c (the wave's sum, formed by the caller), beta = rho (rho yCy) + rho
+//   A'[i][k] = A[i][k] - (rho a_i) s_k
+//   C'[i][k] = C[i][k] - (rho s_i) c_k - (rho c_i) s_k + (beta s_i) s_k        (in this order)
+// s, c, ra = rho * a: the whole vectors (LDS on the device); the _L values are lane L's own
+DFTPAV_HD inline double push_beta(double rho, double yCy) { return fma_(rho, rho * yCy, rho); }
+DFTPAV_HD inline void push_update(const Entry &e, int n, int L, const double *s, const double *c, const double *ra, double beta, double rho) {
+  const double s_L = s[L], ra_L = ra[L];
+  const double rs_L = rho * s_L, rc_L = rho * c[L], bs_L = beta * s_L;
+  for (int k = 0; k < n; k++) {
+    const size_t at = (size_t)k * e.np + L;
+    e.acm[at] = fma_(-ra_L, s[k], e.acm[at]);                                          // A[L][k]
+    e.arm[at] = fma_(-ra[k], s_L, e.arm[at]);                                          // A[k][L]
+    e.ccm[at] = fma_(bs_L, s[k], fma_(-rc_L, s[k], fma_(-rs_L, c[k], e.ccm[at])));     // C[L][k]
+  }
+}
+
+// ---- one step of the rebuild: the suffix aggregate that starts at pair j from the one that starts behind it,
+//   (V_j, rho_j s_j s_j^T) o (A, C) = (V_j A, rho_j (A^T s_j)(A^T s_j)^T + C);   w = A^T s_j (lane_matvec on arm, or s itself
+//   when the aggregate behind is the identity: in == nullptr)
+//   C'[i][k] = C[i][k] + (rho w_i) w_k,      A'[i][k] = A[i][k] - (rho y_i) w_k
+DFTPAV_HD inline double rebuild_w(const Entry *in, int n, int L, const double *s) { return in ? lane_matvec(in->arm, in->np, n, L, s) : s[L]; }
+DFTPAV_HD inline void rebuild_step(const Entry *in, const Entry &out, int n, int L, const double *y, const double *w, double rho) {
+  const double w_L = w[L], ry_L = rho * y[L], rw_L = rho * w_L;
+  for (int k = 0; k < n; k++) {
+    const size_t at = (size_t)k * out.np + L;
+    const double a_lk = in ? in->acm[at] : (k == L ? 1.0 : 0.0), a_kl = in ? in->arm[at] : (k == L ? 1.0 : 0.0), c_lk = in ? in->ccm[at] : 0.0;
+    out.ccm[at] = fma_(rw_L, w[k], c_lk);                 // C[L][k]
+    out.acm[at] = fma_(-ry_L, w[k], a_lk);                // A[L][k]
+    out.arm[at] = fma_(-(rho * y[k]), w_L, a_kl);         // A[k][L]
+  }
+}
+
+// ---- the direction.  u = A_b g; with a front: v = A_f u, t = gamma A_f^T v + C_f u, else t = gamma u; d = -(A_b^T t + C_b g).
+// Each stage needs the whole vector of the stage before (LDS on the device): the caller stores a stage's n results, then
+// runs the next.  These are lane L's parts.
+DFTPAV_HD inline double dir_u(const Entry &b, int n, int L, const double *g) { return lane_matvec(b.acm, b.np, n, L, g); }
+DFTPAV_HD inline double dir_v(const Entry &f, int n, int L, const double *u) { return lane_matvec(f.acm, f.np, n, L, u); }
+DFTPAV_HD inline double dir_t_front(const Entry &f, int n, int L, const double *u, const double *v, double gamma) {
+  return fma_(gamma, lane_matvec(f.arm, f.np, n, L, v), lane_matvec(f.ccm, f.np, n, L, u));
+}
+DFTPAV_HD inline double dir_d(const Entry &b, int n, int L, const double *t, const double *g) {
+  return -(lane_matvec(b.arm, b.np, n, L, t) + lane_matvec(b.ccm, b.np, n, L, g));
+}
+
+// ---- the queue's bookkeeping (the same on both sides).  fpos: index of the oldest surviving pair among the m positions of the
+// window as it stood at the last rebuild; m: no front (nothing rebuilt yet, or every suffix used up).
+// A pair is accepted while the window is full (bound_before == m): returns true when the front must be rebuilt first.
+DFTPAV_HD inline bool needs_rebuild(int fpos, int m) { return fpos >= m; }
+
+} // namespace dense
+} // namespace dftpav

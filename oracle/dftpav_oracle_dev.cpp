@@ -35,6 +35,7 @@
 
 #include "oracle_internal.h"
 #include "../dftpav_amd/csrc/traj_math.h"
+#include "../dftpav_amd/csrc/dense_dir.h"
 
 using namespace dftpav;
 
@@ -519,6 +520,19 @@ extern "C" void oracle_dev_coeffs(const oracle_ctx *c, double *coeffs, double *p
   for (int sg = 0; sg < D.L.M; sg++) piece_dt[sg] = D.seg[sg * 16 + 1];
 }
 
+// Test facility of the dense direction (order 3): when switched on, every direction is compared with the plain two-loop recursion
+// over the same window in 80-bit arithmetic.  stats: [0] largest relative difference (max norm), [1] directions compared,
+// [2] of them with a front aggregate in play (window sliding), [3] deepest window
+static thread_local bool g_dense_check = false;
+static thread_local double g_dense_stats[4] = {0.0, 0.0, 0.0, 0.0};
+extern "C" void oracle_dense_check(int on) {
+  g_dense_check = on != 0;
+  for (double &v : g_dense_stats) v = 0.0;
+}
+extern "C" void oracle_dense_stats(double out[4]) {
+  for (int i = 0; i < 4; i++) out[i] = g_dense_stats[i];
+}
+
 // lbfgs_optimize (lbfgs.hpp:440-751) + line_search_lewisoverton (lbfgs.hpp:276-390)
 // with the kernel's reduction order for every dot product.
 static const int kLoopBlock = 8; // stored pairs per block of the two-loop recursion (solver.hip)
@@ -532,6 +546,17 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), ri_h(m, 0.0), alpha_h(m, 0.0);
   std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
   std::vector<double> hU((size_t)m * 8, 0.0), hV((size_t)m * 8, 0.0); // products with the kBand neighbouring pairs
+  // the dense form of H (order 3, dense_dir.h): the back aggregate, the front's suffix aggregates (index = position in the window
+  // at the last rebuild), vectors a lane publishes for the others (LDS on the device)
+  const bool dense_dir = c->dense_dir != 0 && n <= 64;
+  std::vector<double> dn_back, dn_front, dn_c(64, 0.0), dn_ra(64, 0.0), dn_u(64, 0.0), dn_v(64, 0.0), dn_t(64, 0.0), dn_w(64, 0.0);
+  int fpos = m;
+  if (dense_dir) {
+    dn_back.assign(dense::entry_doubles(n), 0.0);
+    dn_front.assign(dense::entry_doubles(n) * (size_t)m, 0.0);
+    const dense::Entry eb = dense::entry_at(dn_back.data(), n, 0);
+    for (int L = 0; L < n; L++) dense::set_identity(eb, n, L);
+  }
   double pf[8];
   int evals = 0, k = 0, end = 0, bound = 0, ret = 0;
   long long hist_sum = 0;
@@ -668,10 +693,88 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
       ri_h[end] = 1.0 / ys;
       double cau = ss * std::sqrt(gpgp) * P.cautious_factor;
       if (ys > cau) {
+        const int bound_before = bound;
         ++bound;
         bound = m < bound ? m : bound;
         end = (end + 1) % m;
-        if (n <= 64 && m >= kLoopBlock) { // the kernel's condition for the blocked form (a block must fit the ring)
+        if (dense_dir) {
+          // ---- d = -H g from the dense form (dense_dir.h); every lane's part as the kernel's lane L runs it
+          const int cs = (end + m - 1) % m; // slot of the pair just stored
+          const double rho = ri_h[cs];
+          const dense::Entry eb = dense::entry_at(dn_back.data(), n, 0);
+          if (bound_before == m) { // the window was full: its oldest pair (already overwritten by this one) leaves
+            if (dense::needs_rebuild(fpos, m)) {
+              // the m - 1 surviving pairs, newest first, into suffix aggregates at positions m - 1 .. 1; the back starts afresh
+              for (int p = m - 1; p >= 1; p--) {
+                const int slot = (cs + m - (m - p)) % m; // position p of the old window = the (m - p)-th pair before the new one
+                const double *sj = &hS[(size_t)slot * n], *yj = &hY[(size_t)slot * n];
+                const dense::Entry out = dense::entry_at(dn_front.data(), n, (size_t)p);
+                const dense::Entry in = dense::entry_at(dn_front.data(), n, (size_t)(p + 1 < m ? p + 1 : p));
+                const dense::Entry *inp = p + 1 < m ? &in : nullptr;
+                for (int L = 0; L < n; L++) dn_w[L] = dense::rebuild_w(inp, n, L, sj);
+                for (int L = 0; L < n; L++) dense::rebuild_step(inp, out, n, L, yj, dn_w.data(), ri_h[slot]);
+              }
+              for (int L = 0; L < n; L++) dense::set_identity(eb, n, L);
+              fpos = 1;
+            } else {
+              fpos++;
+            }
+          }
+          // the new pair joins the back aggregate
+          double prod[64];
+          for (int L = 0; L < 64; L++) prod[L] = 0.0;
+          for (int L = 0; L < n; L++) {
+            const double a = dense::lane_matvec(eb.acm, eb.np, n, L, yc);
+            dn_c[L] = dense::lane_matvec(eb.ccm, eb.np, n, L, yc);
+            dn_ra[L] = rho * a;
+            prod[L] = yc[L] * dn_c[L];
+          }
+          const double yCy = butterfly_sum(prod);
+          const double beta = dense::push_beta(rho, yCy);
+          for (int L = 0; L < n; L++) dense::push_update(eb, n, L, sc, dn_c.data(), dn_ra.data(), beta, rho);
+          // the direction
+          const double gamma = ys / yy;
+          for (int L = 0; L < n; L++) dn_u[L] = dense::dir_u(eb, n, L, g.data());
+          if (fpos < m) {
+            const dense::Entry ef = dense::entry_at(dn_front.data(), n, (size_t)fpos);
+            for (int L = 0; L < n; L++) dn_v[L] = dense::dir_v(ef, n, L, dn_u.data());
+            for (int L = 0; L < n; L++) dn_t[L] = dense::dir_t_front(ef, n, L, dn_u.data(), dn_v.data(), gamma);
+          } else {
+            for (int L = 0; L < n; L++) dn_t[L] = gamma * dn_u[L];
+          }
+          for (int L = 0; L < n; L++) d[L] = dense::dir_d(eb, n, L, dn_t.data(), g.data());
+          if (g_dense_check) {
+            // test facility: the plain two-loop recursion (lbfgs.hpp:716-739) over the same window in 80-bit arithmetic
+            std::vector<long double> q(n), al(m);
+            for (int e = 0; e < n; e++) q[e] = -(long double)g[e];
+            int j = end;
+            for (int i = 0; i < bound; ++i) {
+              j = (j + m - 1) % m;
+              long double acc = 0.0L;
+              for (int e = 0; e < n; e++) acc += (long double)hS[(size_t)j * n + e] * q[e];
+              al[j] = acc / (long double)ys_h[j];
+              for (int e = 0; e < n; e++) q[e] -= al[j] * (long double)hY[(size_t)j * n + e];
+            }
+            for (int e = 0; e < n; e++) q[e] *= (long double)ys / (long double)yy;
+            for (int i = 0; i < bound; ++i) {
+              long double acc = 0.0L;
+              for (int e = 0; e < n; e++) acc += (long double)hY[(size_t)j * n + e] * q[e];
+              const long double cf = al[j] - acc / (long double)ys_h[j];
+              for (int e = 0; e < n; e++) q[e] += cf * (long double)hS[(size_t)j * n + e];
+              j = (j + 1) % m;
+            }
+            long double num = 0.0L, den = 0.0L;
+            for (int e = 0; e < n; e++) {
+              num = std::max(num, std::fabs((long double)d[e] - q[e]));
+              den = std::max(den, std::fabs(q[e]));
+            }
+            const double rel = (double)(num / std::max(den, (long double)1e-300L));
+            g_dense_stats[0] = std::max(g_dense_stats[0], rel);
+            g_dense_stats[1] += 1.0;
+            g_dense_stats[2] += fpos < m ? 1.0 : 0.0;
+            g_dense_stats[3] = std::max(g_dense_stats[3], (double)bound);
+          }
+        } else if (n <= 64 && m >= kLoopBlock) { // the kernel's condition for the blocked form (a block must fit the ring)
           // Two-loop recursion (lbfgs.hpp:716-739) in blocks of kLoopBlock stored pairs, as the kernel runs
           // it: the kLoopBlock dot products of a block are taken against the direction as it stands at the
           // start of the block, and the effect of the block's earlier steps on a later dot product is
