@@ -48,10 +48,27 @@ DFTPAV_HD inline Entry entry_at(double *base, int n, size_t index) {
   return e;
 }
 
-// sum_k M[k * np + L] * v[k]: lane L's chain, k ascending from 0.0
+// sum_k M[k * np + L] * v[k]: lane L's chain, k ascending from 0.0.  The matrix lives in HBM / L2: its elements are requested
+// eight at a time in front of the eight multiply-adds that consume them (the chain itself is the same, in the same order)
+constexpr int kMatvecBatch = 8;
 DFTPAV_HD inline double lane_matvec(const double *M, int np, int n, int L, const double *v) {
   double acc = 0.0;
-  for (int k = 0; k < n; k++) acc = fma_(M[(size_t)k * np + L], v[k], acc);
+  for (int k = 0; k < n; k += kMatvecBatch) {
+    double mv[kMatvecBatch], vv[kMatvecBatch];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int u = 0; u < kMatvecBatch; u++) {
+      const int kk = k + u < n ? k + u : n - 1; // past the end: a valid address, the value is not used
+      mv[u] = M[(size_t)kk * np + L];
+      vv[u] = v[kk];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int u = 0; u < kMatvecBatch; u++)
+      if (k + u < n) acc = fma_(mv[u], vv[u], acc);
+  }
   return acc;
 }
 
@@ -69,15 +86,34 @@ DFTPAV_HD inline void set_identity(const Entry &e, int n, int L) {
 //   A'[i][k] = A[i][k] - (rho a_i) s_k
 //   C'[i][k] = C[i][k] - (rho s_i) c_k - (rho c_i) s_k + (beta s_i) s_k        (in this order)
 // s, c, ra = rho * a: the whole vectors (LDS on the device); the _L values are lane L's own
+constexpr int kUpdateBatch = 4;
 DFTPAV_HD inline double push_beta(double rho, double yCy) { return fma_(rho, rho * yCy, rho); }
 DFTPAV_HD inline void push_update(const Entry &e, int n, int L, const double *s, const double *c, const double *ra, double beta, double rho) {
   const double s_L = s[L], ra_L = ra[L];
   const double rs_L = rho * s_L, rc_L = rho * c[L], bs_L = beta * s_L;
-  for (int k = 0; k < n; k++) {
-    const size_t at = (size_t)k * e.np + L;
-    e.acm[at] = fma_(-ra_L, s[k], e.acm[at]);                                          // A[L][k]
-    e.arm[at] = fma_(-ra[k], s_L, e.arm[at]);                                          // A[k][L]
-    e.ccm[at] = fma_(bs_L, s[k], fma_(-rc_L, s[k], fma_(-rs_L, c[k], e.ccm[at])));     // C[L][k]
+  for (int k = 0; k < n; k += kUpdateBatch) { // the elements of kUpdateBatch steps are read before the first is written back
+    double a1[kUpdateBatch], a2[kUpdateBatch], c1[kUpdateBatch];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int u = 0; u < kUpdateBatch; u++) {
+      const size_t at = (size_t)(k + u < n ? k + u : n - 1) * e.np + L;
+      a1[u] = e.acm[at];
+      a2[u] = e.arm[at];
+      c1[u] = e.ccm[at];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int u = 0; u < kUpdateBatch; u++) {
+      if (k + u < n) {
+        const size_t at = (size_t)(k + u) * e.np + L;
+        const double s_k = s[k + u];
+        e.acm[at] = fma_(-ra_L, s_k, a1[u]);                                          // A[L][k]
+        e.arm[at] = fma_(-ra[k + u], s_L, a2[u]);                                     // A[k][L]
+        e.ccm[at] = fma_(bs_L, s_k, fma_(-rc_L, s_k, fma_(-rs_L, c[k + u], c1[u])));  // C[L][k]
+      }
+    }
   }
 }
 
@@ -88,12 +124,30 @@ DFTPAV_HD inline void push_update(const Entry &e, int n, int L, const double *s,
 DFTPAV_HD inline double rebuild_w(const Entry *in, int n, int L, const double *s) { return in ? lane_matvec(in->arm, in->np, n, L, s) : s[L]; }
 DFTPAV_HD inline void rebuild_step(const Entry *in, const Entry &out, int n, int L, const double *y, const double *w, double rho) {
   const double w_L = w[L], ry_L = rho * y[L], rw_L = rho * w_L;
-  for (int k = 0; k < n; k++) {
-    const size_t at = (size_t)k * out.np + L;
-    const double a_lk = in ? in->acm[at] : (k == L ? 1.0 : 0.0), a_kl = in ? in->arm[at] : (k == L ? 1.0 : 0.0), c_lk = in ? in->ccm[at] : 0.0;
-    out.ccm[at] = fma_(rw_L, w[k], c_lk);                 // C[L][k]
-    out.acm[at] = fma_(-ry_L, w[k], a_lk);                // A[L][k]
-    out.arm[at] = fma_(-(rho * y[k]), w_L, a_kl);         // A[k][L]
+  for (int k = 0; k < n; k += kUpdateBatch) {
+    double a1[kUpdateBatch], a2[kUpdateBatch], c1[kUpdateBatch];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int u = 0; u < kUpdateBatch; u++) {
+      const int kk = k + u < n ? k + u : n - 1;
+      const size_t at = (size_t)kk * out.np + L;
+      a1[u] = in ? in->acm[at] : (kk == L ? 1.0 : 0.0);
+      a2[u] = in ? in->arm[at] : (kk == L ? 1.0 : 0.0);
+      c1[u] = in ? in->ccm[at] : 0.0;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int u = 0; u < kUpdateBatch; u++) {
+      if (k + u < n) {
+        const size_t at = (size_t)(k + u) * out.np + L;
+        const double w_k = w[k + u];
+        out.ccm[at] = fma_(rw_L, w_k, c1[u]);                  // C[L][k]
+        out.acm[at] = fma_(-ry_L, w_k, a1[u]);                 // A[L][k]
+        out.arm[at] = fma_(-(rho * y[k + u]), w_L, a2[u]);     // A[k][L]
+      }
+    }
   }
 }
 

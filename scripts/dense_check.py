@@ -36,6 +36,20 @@ if what in ("parity", "all"):
         print("cfg %d B %d mem %d: %d / %d solves bit-equal to oracle order 3; fields %s; iters max %d" % (cfg, B, mem, nsame, B, eq, int(r["iters"].max())), flush=True)
         bad += nsame != B
         bt.close(); h.close()
+    # the stored vectors (tests/golden/dense.npz, written by the oracle in round 4)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from golden_util import GOLDEN_DIR, load
+    z = np.load(os.path.join(GOLDEN_DIR, "dense.npz"))
+    for name, mem in (("cfg1", 256), ("cfg2", 256), ("cfg3", 256), ("cfg3", 8), ("cfg5", 256)):
+        s, _ = load(name)
+        p = capi.default_params(); p.lbfgs_mem_size = mem
+        s.apply_resolution(p)
+        h, bt = batch(p, s, True)
+        r = bt.solve()
+        ok = all(np.array_equal(r[k], z["%s_m%d_%s" % (name, mem, k)]) for k in KEYS)
+        print("golden %s mem %d: %s" % (name, mem, "bit-equal" if ok else "DIFFERENT"), flush=True)
+        bad += not ok
+        bt.close(); h.close()
     print("PARITY", "OK" if not bad else "FAILED (%d cases)" % bad)
 
 if what in ("time", "all"):

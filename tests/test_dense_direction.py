@@ -88,3 +88,19 @@ def test_only_the_direction_differs(oracle):
     a = oracle.solve_batch(p, s, nthreads=1, order=3)
     b_ = oracle.solve_batch(p, s, nthreads=2, order=3)
     assert np.array_equal(a["x"], b_["x"]) and np.array_equal(a["final_cost"], b_["final_cost"])     # deterministic
+
+
+@pytest.mark.parametrize("name,mem", [("cfg1", 256), ("cfg2", 256), ("cfg3", 256), ("cfg3", 8), ("cfg5", 256)])
+def test_order3_bits_are_pinned(oracle, name, mem):
+    """tests/golden/dense.npz (tests/golden/make_golden_dense.py): the order's arithmetic is portable, so its whole solves are
+    the same bits on every host -- and must stay so when dense_dir.h is restructured (batched reads, other loop shapes)"""
+    import os
+    from golden_util import GOLDEN_DIR, load
+    z = np.load(os.path.join(GOLDEN_DIR, "dense.npz"))
+    s, _ = load(name)
+    p = oracle.default_params()
+    p.lbfgs_mem_size = mem
+    s.apply_resolution(p)
+    r = oracle.solve_batch(p, s, nthreads=2, order=3)
+    for k in ("x", "final_cost", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], z["%s_m%d_%s" % (name, mem, k)]), k
