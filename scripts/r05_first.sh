@@ -11,5 +11,6 @@ cd $R
 SECONDS=0
 timeout 400 python scripts/dense_check.py parity > $O/r05_dense_parity.txt 2>&1; echo "dense parity rc=$? at $SECONDS s"; tail -3 $O/r05_dense_parity.txt
 timeout 300 python scripts/dense_check.py time > $O/r05_dense_time.txt 2>&1; echo "dense time rc=$? at $SECONDS s"; cat $O/r05_dense_time.txt
+DFTPAV_TEST_DENSE=1 timeout 600 python -m pytest tests/test_gpu_dense.py -q 2>&1 | tail -5 > $O/r05_dense_tests.txt; cat $O/r05_dense_tests.txt
 timeout 600 python -m pytest tests/test_gpu_reference_order.py tests/test_gpu_dropin.py tests/test_gpu_dist.py -q -k "correctly_rounded or live_case or one_communicator" 2>&1 | tail -5 > $O/r05_new_tests.txt; echo "new tests rc=$? at $SECONDS s"; cat $O/r05_new_tests.txt
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/r05_gpu_suite.txt; echo "suite rc=$? at $SECONDS s"; cat $O/r05_gpu_suite.txt
