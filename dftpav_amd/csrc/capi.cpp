@@ -1468,8 +1468,9 @@ extern "C" int dftpav_batch_trace_range(dftpav_batch *b, int first, int count, i
 extern "C" int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals) { return dftpav_batch_trace_range(b, traj, 1, max_evals); }
 
 // EXPERIMENTAL, a test hook (not in include/dftpav_hip.h): the device order's search direction from the dense form of H
-// (dense_dir.h, oracle order 3) instead of the two-loop recursion.  dense != 0 allocates [B][mem] aggregates of 3 pitch(n)^2
-// doubles (24 KB each at n = 31: 6.3 MB per trajectory at mem = 256) and selects the DENSE instantiation of the solve kernel;
+// (dense_dir.h, oracle order 3) instead of the two-loop recursion.  dense != 0 allocates per trajectory 2 + 16 + (mem - 1) / 16
+// aggregates of 3 pitch(n)^2 doubles (24 KB each at n = 31: 0.8 MB per trajectory at mem = 256) and selects the DENSE
+// instantiation of the solve kernel;
 // 0 returns to the two-loop recursion.  n <= 64 only; not for the reference order.  Validated on the CPU only this round.
 extern "C" int dftpav_debug_set_direction(dftpav_batch *b, int dense) {
   if (!b) return DFTPAV_E_INVALID;
@@ -1487,7 +1488,7 @@ extern "C" int dftpav_debug_set_direction(dftpav_batch *b, int dense) {
     b->dense_stride = 0;
   }
   if (dense) {
-    b->dense_stride = dense::entry_doubles(b->L.n) * (size_t)b->P.mem_size;
+    b->dense_stride = dense::entry_doubles(b->L.n) * dense::entries_per_trajectory(b->P.mem_size);
     HIPCHK(h, hipMalloc(&b->d_dense, sizeof(double) * b->dense_stride * (size_t)b->B));
   }
   b->dev_version = -1;

@@ -16,7 +16,7 @@
 // cross-lane reduction at all.  The window (the oldest pair leaves when the 257th arrives) is kept with the two-stack queue
 // of sliding-window aggregation: the newest pairs are folded into a running `back` aggregate; when the front runs dry the
 // surviving pairs are turned, newest to oldest, into SUFFIX aggregates (one O(n^2) step each, m of them once every m
-// iterations), and dropping the oldest pair is stepping to the next suffix.  With front F = (A_f, C_f) and back B = (A_b, C_b):
+// iterations; kept as checkpoints + one block, see kBlock below), and dropping the oldest pair is stepping to the next suffix.  With front F = (A_f, C_f) and back B = (A_b, C_b):
 //     H g = A_b^T ( gamma A_f^T (A_f (A_b g)) + C_f (A_b g) ) + C_b g.
 // Numerically this is the BFGS update in product form: measured against the two-loop recursion in 80-bit arithmetic on real
 // solves the direction differs by 1e-14 (median) .. 2e-10 (worst seen) relative, where the fp64 two-loop recursion itself is at
@@ -167,6 +167,32 @@ DFTPAV_HD inline double dir_d(const Entry &b, int n, int L, const double *t, con
 // window as it stood at the last rebuild; m: no front (nothing rebuilt yet, or every suffix used up).
 // A pair is accepted while the window is full (bound_before == m): returns true when the front must be rebuilt first.
 DFTPAV_HD inline bool needs_rebuild(int fpos, int m) { return fpos >= m; }
+
+// The m - 1 suffix aggregates of a rebuild are not all kept (24 KB each at n = 31): the rebuild stores every kBlock-th of them
+// (checkpoints) and the first block; when the front pointer enters the next block, that block is formed again from its
+// checkpoint by the very steps the rebuild took -- the same operations on the same operands, so the same bits -- at twice the
+// rebuild's arithmetic and 1 / 8 of its memory (34 entries per trajectory at m = 256 instead of 256).
+// Entries of one trajectory:  [0] back   [1 .. kBlock] suffixes of the current block (position p at 1 + p % kBlock)
+//                             [1 + kBlock] the rebuild's running aggregate   [2 + kBlock + j] checkpoint = suffix of position (j + 1) kBlock
+constexpr int kBlock = 16;
+DFTPAV_HD inline int checkpoints(int m) { return (m - 1) / kBlock; } // positions kBlock, 2 kBlock, ... <= m - 1
+DFTPAV_HD inline size_t entries_per_trajectory(int m) { return 2 + (size_t)kBlock + (size_t)checkpoints(m); }
+DFTPAV_HD inline size_t idx_block(int p) { return 1 + (size_t)(p % kBlock); }
+DFTPAV_HD inline size_t idx_running() { return 1 + (size_t)kBlock; }
+DFTPAV_HD inline size_t idx_checkpoint(int p) { return 1 + (size_t)kBlock + (size_t)(p / kBlock); } // p a positive multiple of kBlock
+// One rebuild step, position p of the window of size m: which entry it reads (-1: the identity) and which it writes.
+//   whole pass (p = m - 1 .. kBlock): a running aggregate, copied out at the block boundaries;
+//   a block (p = min((q + 1) kBlock, m) - 1 .. max(q kBlock, 1)): from the checkpoint at its end (or the identity) into the block's slots
+DFTPAV_HD inline void pass_step_io(int p, int m, long long &in, size_t &out) {
+  in = p + 1 >= m ? -1LL : ((p + 1) % kBlock == 0 ? (long long)idx_checkpoint(p + 1) : (long long)idx_running());
+  out = p % kBlock == 0 ? idx_checkpoint(p) : idx_running();
+}
+DFTPAV_HD inline void block_step_io(int p, int m, long long &in, size_t &out) {
+  in = p + 1 >= m ? -1LL : ((p + 1) % kBlock == 0 ? (long long)idx_checkpoint(p + 1) : (long long)idx_block(p + 1));
+  out = idx_block(p);
+}
+DFTPAV_HD inline int block_first(int q) { return q * kBlock > 1 ? q * kBlock : 1; }
+DFTPAV_HD inline int block_last(int q, int m) { return ((q + 1) * kBlock < m ? (q + 1) * kBlock : m) - 1; }
 
 } // namespace dense
 } // namespace dftpav

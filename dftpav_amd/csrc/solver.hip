@@ -1773,25 +1773,46 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         const dense::Entry eb = dense::entry_at(dn_b, n, 0);
         int fpos = sm.ist[iDFPOS];
         if (bound_before == m) { // the window was full: its oldest pair (slot `end`, overwritten above) leaves
-          if (dense::needs_rebuild(fpos, m)) {
-            // the m - 1 surviving pairs, newest first, into suffix aggregates at positions m - 1 .. 1; the back starts afresh
-            for (int p = m - 1; p >= 1; p--) {
-              const int slot = end + p < m ? end + p : end + p - m; // position p of the old window
-              const double rho_j = ((gptr_t)hR_b)[2 * (size_t)slot + 1];
-              if (act) {
-                vS[L] = ((gptr_t)hS)[((size_t)slot * npad + L) * 2];
-                vY[L] = ((gptr_t)hS)[((size_t)slot * npad + L) * 2 + 1];
-              }
-              const dense::Entry out = dense::entry_at(dn_b, n, (size_t)p);
-              const dense::Entry in = dense::entry_at(dn_b, n, (size_t)(p + 1 < m ? p + 1 : p));
-              const dense::Entry *inp = p + 1 < m ? &in : nullptr;
-              if (act) vC[L] = dense::rebuild_w(inp, n, L, vS);
-              if (act) dense::rebuild_step(inp, out, n, L, vY, vC, rho_j);
+          // one rebuild step for the pair at window position p (ring slot (base + p) % m), entries by index (-1 = the identity)
+          auto dense_step = [&](int p, int base, long long in_idx, size_t out_idx) {
+            const int slot = base + p < m ? base + p : base + p - m;
+            const double rho_j = ((gptr_t)hR_b)[2 * (size_t)slot + 1];
+            if (act) {
+              vS[L] = ((gptr_t)hS)[((size_t)slot * npad + L) * 2];
+              vY[L] = ((gptr_t)hS)[((size_t)slot * npad + L) * 2 + 1];
             }
+            const dense::Entry out = dense::entry_at(dn_b, n, out_idx);
+            const dense::Entry in = dense::entry_at(dn_b, n, (size_t)(in_idx < 0 ? 0 : in_idx));
+            const dense::Entry *inp = in_idx < 0 ? nullptr : &in;
+            if (act) vC[L] = dense::rebuild_w(inp, n, L, vS);
+            if (act) dense::rebuild_step(inp, out, n, L, vY, vC, rho_j);
+          };
+          auto dense_block = [&](int q, int base) {
+            for (int p = dense::block_last(q, m); p >= dense::block_first(q); p--) {
+              long long in_idx;
+              size_t out_idx;
+              dense::block_step_io(p, m, in_idx, out_idx);
+              dense_step(p, base, in_idx, out_idx);
+            }
+          };
+          if (dense::needs_rebuild(fpos, m)) {
+            // the m - 1 surviving pairs (position p of the old window sits in ring slot (end + p) % m), newest first, into suffix
+            // aggregates: checkpoints at the block boundaries, then the first block; the back starts afresh
+            for (int p = m - 1; p >= dense::kBlock; p--) {
+              long long in_idx;
+              size_t out_idx;
+              dense::pass_step_io(p, m, in_idx, out_idx);
+              dense_step(p, end, in_idx, out_idx);
+            }
+            dense_block(0, end);
             if (act) dense::set_identity(eb, n, L);
             fpos = 1;
           } else {
             fpos++;
+            if (fpos < m && fpos % dense::kBlock == 0) { // the next block, from its checkpoint
+              const int back = (fpos - 1) % m;
+              dense_block(fpos / dense::kBlock, end - back >= 0 ? end - back : end - back + m);
+            }
           }
           if (lane == 0) sm.ist[iDFPOS] = fpos;
         }
@@ -1816,7 +1837,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         if (act) vC[L] = u_L;
         double t_L = gamma * u_L;
         if (fpos < m) {
-          const dense::Entry ef = dense::entry_at(dn_b, n, (size_t)fpos);
+          const dense::Entry ef = dense::entry_at(dn_b, n, dense::idx_block(fpos));
           if (act) vS[L] = dense::dir_v(ef, n, L, vC);
           if (act) t_L = dense::dir_t_front(ef, n, L, vC, vS, gamma);
         }

@@ -549,14 +549,31 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   // the dense form of H (order 3, dense_dir.h): the back aggregate, the front's suffix aggregates (index = position in the window
   // at the last rebuild), vectors a lane publishes for the others (LDS on the device)
   const bool dense_dir = c->dense_dir != 0 && n <= 64;
-  std::vector<double> dn_back, dn_front, dn_c(64, 0.0), dn_ra(64, 0.0), dn_u(64, 0.0), dn_v(64, 0.0), dn_t(64, 0.0), dn_w(64, 0.0);
+  std::vector<double> dn, dn_c(64, 0.0), dn_ra(64, 0.0), dn_u(64, 0.0), dn_v(64, 0.0), dn_t(64, 0.0), dn_w(64, 0.0);
   int fpos = m;
   if (dense_dir) {
-    dn_back.assign(dense::entry_doubles(n), 0.0);
-    dn_front.assign(dense::entry_doubles(n) * (size_t)m, 0.0);
-    const dense::Entry eb = dense::entry_at(dn_back.data(), n, 0);
+    dn.assign(dense::entry_doubles(n) * dense::entries_per_trajectory(m), 0.0); // the trajectory's entries as the kernel lays them out
+    const dense::Entry eb = dense::entry_at(dn.data(), n, 0);
     for (int L = 0; L < n; L++) dense::set_identity(eb, n, L);
   }
+  // one rebuild step for the pair at window position p (ring slot (base + p) % m), entries by index (-1 = the identity)
+  auto dense_step = [&](int p, int base, long long in_idx, size_t out_idx) {
+    const int slot = (base + p) % m;
+    const double *sj = &hS[(size_t)slot * n], *yj = &hY[(size_t)slot * n];
+    const dense::Entry out = dense::entry_at(dn.data(), n, out_idx);
+    const dense::Entry in = dense::entry_at(dn.data(), n, (size_t)(in_idx < 0 ? 0 : in_idx));
+    const dense::Entry *inp = in_idx < 0 ? nullptr : &in;
+    for (int L = 0; L < n; L++) dn_w[L] = dense::rebuild_w(inp, n, L, sj);
+    for (int L = 0; L < n; L++) dense::rebuild_step(inp, out, n, L, yj, dn_w.data(), ri_h[slot]);
+  };
+  auto dense_block = [&](int q, int base) {
+    for (int p = dense::block_last(q, m); p >= dense::block_first(q); p--) {
+      long long in_idx;
+      size_t out_idx;
+      dense::block_step_io(p, m, in_idx, out_idx);
+      dense_step(p, base, in_idx, out_idx);
+    }
+  };
   double pf[8];
   int evals = 0, k = 0, end = 0, bound = 0, ret = 0;
   long long hist_sum = 0;
@@ -701,23 +718,23 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           // ---- d = -H g from the dense form (dense_dir.h); every lane's part as the kernel's lane L runs it
           const int cs = (end + m - 1) % m; // slot of the pair just stored
           const double rho = ri_h[cs];
-          const dense::Entry eb = dense::entry_at(dn_back.data(), n, 0);
+          const dense::Entry eb = dense::entry_at(dn.data(), n, 0);
           if (bound_before == m) { // the window was full: its oldest pair (already overwritten by this one) leaves
             if (dense::needs_rebuild(fpos, m)) {
-              // the m - 1 surviving pairs, newest first, into suffix aggregates at positions m - 1 .. 1; the back starts afresh
-              for (int p = m - 1; p >= 1; p--) {
-                const int slot = (cs + m - (m - p)) % m; // position p of the old window = the (m - p)-th pair before the new one
-                const double *sj = &hS[(size_t)slot * n], *yj = &hY[(size_t)slot * n];
-                const dense::Entry out = dense::entry_at(dn_front.data(), n, (size_t)p);
-                const dense::Entry in = dense::entry_at(dn_front.data(), n, (size_t)(p + 1 < m ? p + 1 : p));
-                const dense::Entry *inp = p + 1 < m ? &in : nullptr;
-                for (int L = 0; L < n; L++) dn_w[L] = dense::rebuild_w(inp, n, L, sj);
-                for (int L = 0; L < n; L++) dense::rebuild_step(inp, out, n, L, yj, dn_w.data(), ri_h[slot]);
+              // the m - 1 surviving pairs (position p of the old window sits in ring slot (cs + p) % m), newest first, into suffix
+              // aggregates: checkpoints at the block boundaries, then the first block; the back starts afresh
+              for (int p = m - 1; p >= dense::kBlock; p--) {
+                long long in_idx;
+                size_t out_idx;
+                dense::pass_step_io(p, m, in_idx, out_idx);
+                dense_step(p, cs, in_idx, out_idx);
               }
+              dense_block(0, cs);
               for (int L = 0; L < n; L++) dense::set_identity(eb, n, L);
               fpos = 1;
             } else {
               fpos++;
+              if (fpos < m && fpos % dense::kBlock == 0) dense_block(fpos / dense::kBlock, (cs - (fpos - 1) % m + m) % m); // the next block, from its checkpoint
             }
           }
           // the new pair joins the back aggregate
@@ -736,7 +753,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           const double gamma = ys / yy;
           for (int L = 0; L < n; L++) dn_u[L] = dense::dir_u(eb, n, L, g.data());
           if (fpos < m) {
-            const dense::Entry ef = dense::entry_at(dn_front.data(), n, (size_t)fpos);
+            const dense::Entry ef = dense::entry_at(dn.data(), n, dense::idx_block(fpos));
             for (int L = 0; L < n; L++) dn_v[L] = dense::dir_v(ef, n, L, dn_u.data());
             for (int L = 0; L < n; L++) dn_t[L] = dense::dir_t_front(ef, n, L, dn_u.data(), dn_v.data(), gamma);
           } else {
