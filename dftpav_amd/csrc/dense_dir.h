@@ -37,13 +37,20 @@ namespace dense {
 DFTPAV_HD inline int pitch(int n) { return (n + 7) & ~7; }
 DFTPAV_HD inline size_t entry_doubles(int n) { return 3 * (size_t)pitch(n) * pitch(n); }
 
+// the matrices live in HBM: on the device their pointers carry the global address space (global_load / global_store instead of
+// flat accesses, which would wait on the LDS counter as well)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) double mat_t;
+#else
+typedef double mat_t;
+#endif
 struct Entry {
-  double *acm, *arm, *ccm;
+  mat_t *acm, *arm, *ccm;
   int np;
 };
 DFTPAV_HD inline Entry entry_at(double *base, int n, size_t index) {
   const int np = pitch(n);
-  double *p = base + index * entry_doubles(n);
+  mat_t *p = (mat_t *)(base + index * entry_doubles(n));
   Entry e = {p, p + (size_t)np * np, p + 2 * (size_t)np * np, np};
   return e;
 }
@@ -51,7 +58,7 @@ DFTPAV_HD inline Entry entry_at(double *base, int n, size_t index) {
 // sum_k M[k * np + L] * v[k]: lane L's chain, k ascending from 0.0.  The matrix lives in HBM / L2: its elements are requested
 // eight at a time in front of the eight multiply-adds that consume them (the chain itself is the same, in the same order)
 constexpr int kMatvecBatch = 8;
-DFTPAV_HD inline double lane_matvec(const double *M, int np, int n, int L, const double *v) {
+DFTPAV_HD inline double lane_matvec(const mat_t *M, int np, int n, int L, const double *v) {
   double acc = 0.0;
   for (int k = 0; k < n; k += kMatvecBatch) {
     double mv[kMatvecBatch], vv[kMatvecBatch];
