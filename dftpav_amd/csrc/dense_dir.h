@@ -170,6 +170,20 @@ DFTPAV_HD inline double dir_d(const Entry &b, int n, int L, const double *t, con
   return -(lane_matvec(b.arm, b.np, n, L, t) + lane_matvec(b.ccm, b.np, n, L, g));
 }
 
+// ---- when the dense form is used.  Forming H explicitly costs accuracy where H is ill-conditioned: a pair with a small
+// curvature y.s has a large |V| = |y| |s| / (y.s), and products of such factors lose what the two-loop recursion (which only
+// ever applies them to one vector) keeps.  Measured over 3 000 random layouts, 587 k directions (scripts/fuzz_dense_cpu.py)
+// against the recursion in 80-bit arithmetic: WITHOUT a gate 70 layouts exceed 1e-8 and five 1e-4 (worst 0.4: gear-shift
+// layouts, a window shorter than n); neither the cancellation of the last product nor the secant equation of the newest pair
+// tells such a direction from a good one, the largest |V| of the window does: below 1e3 the dense direction stays within
+// 5e-10, below 1e4 within 8e-6 (where the fp64 recursion itself is at 2.5e-6 in the worst layout), and 3e-8 on every BASELINE
+// configuration.  So the direction of an iteration comes from the dense form while  max_j |V_j| < kNuGate  over the window,
+// and from the plain recursion otherwise (2.4 % of the fuzz's directions; none on BASELINE configs[0..4]; the aggregates are
+// kept up to date either way).  Gate 3e3: three layouts above 1e-7 instead of seven, but 22 % of configs[1]'s iterations on
+// the slow path; gate 1e3: two, 16 % of all.
+constexpr double kNuGate = 1.0e4;
+DFTPAV_HD inline double pair_nu(double ys, double yy, double ss) { return sqrt(yy * ss) / ys; }
+
 // ---- the queue's bookkeeping (the same on both sides).  fpos: index of the oldest surviving pair among the m positions of the
 // window as it stood at the last rebuild; m: no front (nothing rebuilt yet, or every suffix used up).
 // A pair is accepted while the window is full (bound_before == m): returns true when the front must be rebuilt first.

@@ -1755,6 +1755,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       *reinterpret_cast<d2r_t *>(hR_b + 2 * (size_t)end) = yr; // read back by this wave in the recursion below (fenced there)
     }
     double cau = ss * sqrt(gpgp) * P.cautious_factor;
+    if (DENSE && lane == 0) hU_b[(size_t)end * 8] = dense::pair_nu(ys, yy, ss); // |V| of the pair: the gate of the dense direction
     pr.tick(kPHIST);
     if (ys > cau) {
       const int bound_before = bound;
@@ -1831,19 +1832,55 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
         const double yCy = wave_sum<LV>(act ? ylane * c_L : 0.0);
         const double beta = dense::push_beta(rho, yCy);
         if (act) dense::push_update(eb, n, L, vS, vC, vR, beta, rho);
-        // the direction
+        // the direction: from the dense form while every pair of the window is well conditioned (dense_dir.h: kNuGate), else
+        // the plain recursion
         const double gamma = ys / yy;
-        const double u_L = act ? dense::dir_u(eb, n, L, sm.g) : 0.0;
-        if (act) vC[L] = u_L;
-        double t_L = gamma * u_L;
-        if (fpos < m) {
-          const dense::Entry ef = dense::entry_at(dn_b, n, dense::idx_block(fpos));
-          if (act) vS[L] = dense::dir_v(ef, n, L, vC);
-          if (act) t_L = dense::dir_t_front(ef, n, L, vC, vS, gamma);
+        double numax = 0.0;
+        __threadfence_block(); // lane 0 wrote this pair's |V|, every lane reads the window's below
+        for (int i = lane; i < bound; i += 64) {
+          const int jj = end - i >= 0 ? end - i : end - i + m; // the i-th newest pair (the new one sits in slot `end`)
+          numax = fmax(numax, ((gptr_t)hU_b)[(size_t)jj * 8]);
         }
-        if (act) vR[L] = t_L;
-        const double d_L = act ? dense::dir_d(eb, n, L, vR, sm.g) : 0.0;
-        if (act) sm.d[L] = d_L; // (vC is sm.d: u is dead by now)
+        numax = wave_max<6>(numax); // (a maximum: the same value in whatever order it is formed)
+        if (numax < dense::kNuGate) {
+          const double u_L = act ? dense::dir_u(eb, n, L, sm.g) : 0.0;
+          if (act) vC[L] = u_L;
+          double t_L = gamma * u_L;
+          if (fpos < m) {
+            const dense::Entry ef = dense::entry_at(dn_b, n, dense::idx_block(fpos));
+            if (act) vS[L] = dense::dir_v(ef, n, L, vC);
+            if (act) t_L = dense::dir_t_front(ef, n, L, vC, vS, gamma);
+          }
+          if (act) vR[L] = t_L;
+          const double d_L = act ? dense::dir_d(eb, n, L, vR, sm.g) : 0.0;
+          if (act) sm.d[L] = d_L; // (vC is sm.d: u is dead by now)
+        } else {
+          // lbfgs.hpp:716-739 step by step (the plain form below, with the division by ys as the reference writes it)
+          for (int e = lane; e < n; e += 64) sm.d[e] = -sm.g[e]; // vC (= sm.d) held c
+          int j = ne;
+          for (int i = 0; i < bound; ++i) {
+            j = j == 0 ? m - 1 : j - 1;
+            const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
+            double acc = 0.0;
+            for (int e = lane; e < n; e += 64) acc += sj[2 * e] * sm.d[e];
+            acc = wave_sum<LV>(acc);
+            double a = acc / ((gptr_t)hR_b)[2 * (size_t)j];
+            if (lane == 0) sm.alpha[j] = a;
+            double na = -a;
+            for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[2 * e];
+          }
+          for (int e = lane; e < n; e += 64) sm.d[e] *= gamma;
+          for (int i = 0; i < bound; ++i) {
+            const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
+            double acc = 0.0;
+            for (int e = lane; e < n; e += 64) acc += yj[2 * e] * sm.d[e];
+            acc = wave_sum<LV>(acc);
+            double beta = acc / ((gptr_t)hR_b)[2 * (size_t)j];
+            double cf = sm.alpha[j] - beta;
+            for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[2 * e];
+            j = j == m - 1 ? 0 : j + 1;
+          }
+        }
       } else if (n <= 64 && m >= kLoopBlock) {
         // products of the new y with the s of the kLoopBlock-1 pairs before it (histU / histV)
         double *hU = hU_b, *hV = hV_b;

@@ -29,6 +29,7 @@
  */
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -524,13 +525,13 @@ extern "C" void oracle_dev_coeffs(const oracle_ctx *c, double *coeffs, double *p
 // over the same window in 80-bit arithmetic.  stats: [0] largest relative difference (max norm), [1] directions compared,
 // [2] of them with a front aggregate in play (window sliding), [3] deepest window
 static thread_local bool g_dense_check = false;
-static thread_local double g_dense_stats[4] = {0.0, 0.0, 0.0, 0.0};
+static thread_local double g_dense_stats[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // [4] fp64 two-loop's largest difference, [5] its difference where the dense one is largest, [6] directions taken from the plain recursion (gate closed)
 extern "C" void oracle_dense_check(int on) {
   g_dense_check = on != 0;
   for (double &v : g_dense_stats) v = 0.0;
 }
-extern "C" void oracle_dense_stats(double out[4]) {
-  for (int i = 0; i < 4; i++) out[i] = g_dense_stats[i];
+extern "C" void oracle_dense_stats(double out[7]) {
+  for (int i = 0; i < 7; i++) out[i] = g_dense_stats[i];
 }
 
 // lbfgs_optimize (lbfgs.hpp:440-751) + line_search_lewisoverton (lbfgs.hpp:276-390)
@@ -543,7 +544,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size;
   g_levels = levels_for(n);
-  std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), ri_h(m, 0.0), alpha_h(m, 0.0);
+  std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), ri_h(m, 0.0), alpha_h(m, 0.0), nu_h(m, 0.0);
   std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
   std::vector<double> hU((size_t)m * 8, 0.0), hV((size_t)m * 8, 0.0); // products with the kBand neighbouring pairs
   // the dense form of H (order 3, dense_dir.h): the back aggregate, the front's suffix aggregates (index = position in the window
@@ -708,6 +709,7 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
       double gpgp = wave_dot(gp.data(), gp.data(), n);
       ys_h[end] = ys;
       ri_h[end] = 1.0 / ys;
+      nu_h[end] = dense::pair_nu(ys, yy, ss); // |V| of the pair: the gate of the dense direction (dense_dir.h)
       double cau = ss * std::sqrt(gpgp) * P.cautious_factor;
       if (ys > cau) {
         const int bound_before = bound;
@@ -749,17 +751,48 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
           const double yCy = butterfly_sum(prod);
           const double beta = dense::push_beta(rho, yCy);
           for (int L = 0; L < n; L++) dense::push_update(eb, n, L, sc, dn_c.data(), dn_ra.data(), beta, rho);
-          // the direction
+          // the direction: from the dense form while every pair of the window is well conditioned, else the plain recursion
           const double gamma = ys / yy;
-          for (int L = 0; L < n; L++) dn_u[L] = dense::dir_u(eb, n, L, g.data());
-          if (fpos < m) {
-            const dense::Entry ef = dense::entry_at(dn.data(), n, dense::idx_block(fpos));
-            for (int L = 0; L < n; L++) dn_v[L] = dense::dir_v(ef, n, L, dn_u.data());
-            for (int L = 0; L < n; L++) dn_t[L] = dense::dir_t_front(ef, n, L, dn_u.data(), dn_v.data(), gamma);
-          } else {
-            for (int L = 0; L < n; L++) dn_t[L] = gamma * dn_u[L];
+          double numax = 0.0;
+          {
+            int jj = end;
+            for (int i = 0; i < bound; ++i) {
+              jj = (jj + m - 1) % m;
+              numax = std::fmax(numax, nu_h[jj]);
+            }
           }
-          for (int L = 0; L < n; L++) d[L] = dense::dir_d(eb, n, L, dn_t.data(), g.data());
+          const bool dense_ok = numax < dense::kNuGate;
+          if (dense_ok) {
+            for (int L = 0; L < n; L++) dn_u[L] = dense::dir_u(eb, n, L, g.data());
+            if (fpos < m) {
+              const dense::Entry ef = dense::entry_at(dn.data(), n, dense::idx_block(fpos));
+              for (int L = 0; L < n; L++) dn_v[L] = dense::dir_v(ef, n, L, dn_u.data());
+              for (int L = 0; L < n; L++) dn_t[L] = dense::dir_t_front(ef, n, L, dn_u.data(), dn_v.data(), gamma);
+            } else {
+              for (int L = 0; L < n; L++) dn_t[L] = gamma * dn_u[L];
+            }
+            for (int L = 0; L < n; L++) d[L] = dense::dir_d(eb, n, L, dn_t.data(), g.data());
+          } else {
+            // lbfgs.hpp:716-739 step by step, as the kernel's plain form runs it (wave_dot per step, true divisions)
+            int j = end;
+            for (int i = 0; i < bound; ++i) {
+              j = (j + m - 1) % m;
+              const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
+              double a = wave_dot(sj, d.data(), n) / ys_h[j];
+              alpha_h[j] = a;
+              double na = -a;
+              for (int e = 0; e < n; e++) d[e] += na * yj[e];
+            }
+            for (int e = 0; e < n; e++) d[e] *= gamma;
+            for (int i = 0; i < bound; ++i) {
+              const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
+              double beta = wave_dot(yj, d.data(), n) / ys_h[j];
+              double cf = alpha_h[j] - beta;
+              for (int e = 0; e < n; e++) d[e] += cf * sj[e];
+              j = (j + 1) % m;
+            }
+            g_dense_stats[6] += 1.0;
+          }
           if (g_dense_check) {
             // test facility: the plain two-loop recursion (lbfgs.hpp:716-739) over the same window in 80-bit arithmetic
             std::vector<long double> q(n), al(m);
@@ -786,6 +819,31 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
               den = std::max(den, std::fabs(q[e]));
             }
             const double rel = (double)(num / std::max(den, (long double)1e-300L));
+            {
+              // for scale: the same recursion in plain fp64 against the 80-bit one
+              std::vector<double> q2(n), al2(m);
+              for (int e = 0; e < n; e++) q2[e] = -g[e];
+              int j2 = end;
+              for (int i = 0; i < bound; ++i) {
+                j2 = (j2 + m - 1) % m;
+                double acc = 0.0;
+                for (int e = 0; e < n; e++) acc += hS[(size_t)j2 * n + e] * q2[e];
+                al2[j2] = acc / ys_h[j2];
+                for (int e = 0; e < n; e++) q2[e] -= al2[j2] * hY[(size_t)j2 * n + e];
+              }
+              for (int e = 0; e < n; e++) q2[e] *= ys / yy;
+              for (int i = 0; i < bound; ++i) {
+                double acc = 0.0;
+                for (int e = 0; e < n; e++) acc += hY[(size_t)j2 * n + e] * q2[e];
+                const double cf = al2[j2] - acc / ys_h[j2];
+                for (int e = 0; e < n; e++) q2[e] += cf * hS[(size_t)j2 * n + e];
+                j2 = (j2 + 1) % m;
+              }
+              long double num2 = 0.0L;
+              for (int e = 0; e < n; e++) num2 = std::max(num2, std::fabs((long double)q2[e] - q[e]));
+              g_dense_stats[4] = std::max(g_dense_stats[4], (double)(num2 / std::max(den, (long double)1e-300L)));
+              if (rel > g_dense_stats[0]) g_dense_stats[5] = (double)(num2 / std::max(den, (long double)1e-300L)); // at the worst dense direction
+            }
             g_dense_stats[0] = std::max(g_dense_stats[0], rel);
             g_dense_stats[1] += 1.0;
             g_dense_stats[2] += fpos < m ? 1.0 : 0.0;

@@ -104,3 +104,22 @@ def test_order3_bits_are_pinned(oracle, name, mem):
     r = oracle.solve_batch(p, s, nthreads=2, order=3)
     for k in ("x", "final_cost", "status", "iters", "evals", "hist_sum", "success"):
         assert np.array_equal(r[k], z["%s_m%d_%s" % (name, mem, k)]), k
+
+
+def test_ill_conditioned_windows_go_to_the_plain_recursion():
+    """Forming H explicitly loses accuracy where a pair of the window has a small curvature (|V| = |y||s| / (y.s) large): without
+    the gate of dense_dir.h these layouts of scripts/fuzz_dense_cpu.py had directions 0.4 (relative) away from the recursion.
+    With it the iterations of such windows take the plain recursion: every direction within 1e-5 (the fp64 recursion itself is
+    at 2.5e-6 on the worst of them), and the gate is seen closing."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for n_cases, first in ((8, 3920), (1, 2454), (1, 1615)):       # the fuzz's cases 2920-2927, 1454, 615 of seed block 1000
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_dense_cpu.py"), str(n_cases), str(first)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        line = out.stdout.strip().splitlines()[-1]
+        assert "0 failures" in line, line
+    assert "from the plain recursion" in line
+    closed = int(line.split(" from the plain recursion")[0].split(", ")[-1])
+    assert closed > 0, line          # case 615's third trajectory closes the gate
