@@ -6,6 +6,7 @@ thing to run on a GPU in round 5 -- the device path was written and compiled in 
 python scripts/dense_check.py [parity|time|all]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from dftpav_amd import capi, scenarios as sc
 from oracle import pyoracle as po
@@ -35,6 +36,17 @@ if what in ("parity", "all"):
         nsame = int(sum(bool(r["final_cost"][i] == want["final_cost"][i] and np.array_equal(r["x"][i], want["x"][i])) for i in range(B)))
         print("cfg %d B %d mem %d: %d / %d solves bit-equal to oracle order 3; fields %s; iters max %d" % (cfg, B, mem, nsame, B, eq, int(r["iters"].max())), flush=True)
         bad += nsame != B
+        bt.close(); h.close()
+    # layouts whose windows close the conditioning gate (the plain recursion takes those iterations)
+    from dense_cases import make_case
+    for index in (1615, 2454, 3927, 3542):
+        p, s, pieces = make_case(index)
+        h, bt = batch(p, s, True)
+        r = bt.solve()
+        want = po.solve_batch(p, s, nthreads=2, order=3)
+        ok = all(np.array_equal(r[k], want[k]) for k in KEYS)
+        print("gate case %d (pieces %s, mem %d): %s" % (index, pieces, p.lbfgs_mem_size, "bit-equal" if ok else "DIFFERENT"), flush=True)
+        bad += not ok
         bt.close(); h.close()
     # the stored vectors (tests/golden/dense.npz, written by the oracle in round 4)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

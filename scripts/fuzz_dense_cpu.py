@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dftpav_amd import scenarios as sc
 from oracle import pyoracle as po
+from dense_cases import make_case
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -16,26 +17,8 @@ po.build()
 worst, ndir, nfront, nsolve, bad, nclosed, t0 = 0.0, 0, 0, 0, 0, 0, time.time()
 status = {}
 for c in range(n_cases):
-    rng = np.random.default_rng(31000 + seed0 + c)
-    M = int(rng.choice([1, 1, 2, 3]))
-    pieces = [int(rng.integers(2, 11)) for _ in range(M)]
-    while 2 * (sum(pieces) - M) + M + 3 * (M - 1) > 64:
-        pieces[int(np.argmax(pieces))] -= 1
-    sing = [int(rng.choice([1, -1]))]
-    for _ in range(M - 1):
-        sing.append(-sing[-1])
-    moving = bool(rng.uniform() < 0.25) and sum(pieces) <= 12
-    p = po.default_params()
-    p.lbfgs_mem_size = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 47, 64, 100, 256, 300]))
-    B = int(rng.integers(1, 4))
-    s = sc.make_scenario(pieces, sing, int(rng.integers(3, 21)), int(rng.integers(3, 21)), B, seed=32000 + seed0 + c, with_moving=moving,
-                         n_obs=int(rng.integers(0, 60)))
-    s.apply_resolution(p)
-    if rng.uniform() < 0.4:
-        p.max_forward_vel *= float(rng.uniform(0.3, 1.0)); p.max_forward_acc *= float(rng.uniform(0.2, 1.0)); p.max_forward_cur *= float(rng.uniform(0.2, 1.0))
-        p.wei_obs *= float(rng.uniform(0.1, 10)); p.wei_feas *= float(rng.uniform(0.1, 10)); p.wei_time *= float(rng.uniform(0.1, 10))
-    if moving:
-        s.t_now = float(rng.uniform(0.0, 5.0))
+    p, s, pieces = make_case(seed0 + c)
+    B = s.B
     po.dense_check(True)
     for b in range(B):
         _, r3 = po.OracleProblem(p, s, b, order=3).solve()

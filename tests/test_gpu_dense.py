@@ -93,3 +93,20 @@ def test_throughput_residency_and_the_reference_order_guard(hiplib, oracle):
         bt.set_order(hiplib.ORDER_REFERENCE)
     bt.close()
     h.close()
+
+
+@pytest.mark.parametrize("index", [1615, 2454, 3927, 3542])
+def test_windows_that_close_the_gate(hiplib, oracle, index):
+    """layouts of scripts/fuzz_dense_cpu.py whose windows hold ill-conditioned pairs: those iterations take the plain recursion
+    (dense_dir.h: kNuGate) -- on the device as in oracle order 3, bit for bit"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from dense_cases import make_case
+    p, s, _ = make_case(index)
+    h, bt = _batch(hiplib, s, p)
+    want = oracle.solve_batch(p, s, nthreads=3, order=3)
+    r = bt.solve()
+    for k in KEYS:
+        assert np.array_equal(r[k], want[k]), k
+    bt.close()
+    h.close()
