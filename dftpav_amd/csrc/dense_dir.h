@@ -57,7 +57,10 @@ DFTPAV_HD inline Entry entry_at(double *base, int n, size_t index) {
 
 // sum_k M[k * np + L] * v[k]: lane L's chain, k ascending from 0.0.  The matrix lives in HBM / L2: its elements are requested
 // eight at a time in front of the eight multiply-adds that consume them (the chain itself is the same, in the same order)
-constexpr int kMatvecBatch = 8;
+#ifndef DFTPAV_DENSE_MATVEC_BATCH
+#define DFTPAV_DENSE_MATVEC_BATCH 8 // a tuning knob for scripts/build_variant.sh (the chains, hence the bits, do not depend on it)
+#endif
+constexpr int kMatvecBatch = DFTPAV_DENSE_MATVEC_BATCH;
 DFTPAV_HD inline double lane_matvec(const mat_t *M, int np, int n, int L, const double *v) {
   double acc = 0.0;
   for (int k = 0; k < n; k += kMatvecBatch) {
@@ -93,7 +96,10 @@ DFTPAV_HD inline void set_identity(const Entry &e, int n, int L) {
 //   A'[i][k] = A[i][k] - (rho a_i) s_k
 //   C'[i][k] = C[i][k] - (rho s_i) c_k - (rho c_i) s_k + (beta s_i) s_k        (in this order)
 // s, c, ra = rho * a: the whole vectors (LDS on the device); the _L values are lane L's own
-constexpr int kUpdateBatch = 4;
+#ifndef DFTPAV_DENSE_UPDATE_BATCH
+#define DFTPAV_DENSE_UPDATE_BATCH 4 // likewise
+#endif
+constexpr int kUpdateBatch = DFTPAV_DENSE_UPDATE_BATCH;
 DFTPAV_HD inline double push_beta(double rho, double yCy) { return fma_(rho, rho * yCy, rho); }
 DFTPAV_HD inline void push_update(const Entry &e, int n, int L, const double *s, const double *c, const double *ra, double beta, double rho) {
   const double s_L = s[L], ra_L = ra[L];
