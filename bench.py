@@ -749,40 +749,12 @@ def side_neighbours(ctx, args, po, st, out):
                            Hc[:nchk], po.corridor_rectangles(grid, sc.MAP_RESL, origin, states[:nchk], order=1)))}
 
 
-def side_dense_direction(ctx, args, po, cores, st):
-    """EXPERIMENTAL, only with DFTPAV_BENCH_DENSE=1: the value line's batch, isolated, with the search direction from the dense
-    form of H (csrc/dense_dir.h, dftpav_debug_set_direction) -- kernel time beside the two-loop recursion's `isolated`, and
-    sampled solves against oracle order 3 bit for bit"""
-    shard = st.shard
-    h = capi.Handle(ctx.params, device=ctx.local_rank)
-    h.set_surround(shard.surround)
-    b = capi.Batch(h, shard.layout, shard.B)
-    b.upload(shard)
-    b.debug_set_direction(True)
-    b.solve_async(); b.sync()
-    ms = []
-    for _ in range(3):
-        b.solve_async(); b.sync(); ms.append(b.last_solve_ms())
-    r = b.results()
-    nd = min(32, shard.B)
-    pick = (np.arange(nd) * max(1, shard.B // nd)) % shard.B
-    ro = po.solve_batch(ctx.params, shard.subset(pick), nthreads=min(nd, cores), order=3)
-    row = {"batch": int(shard.B), "kernel_ms": float(np.mean(ms)), "solves_per_s": shard.B / (float(np.mean(ms)) * 1e-3),
-           "mean_iters": float(r["iters"].mean()), "mean_evals": float(r["evals"].mean()), "success_rate": float(r["success"].mean()),
-           "median_cost": float(np.median(r["final_cost"])),
-           "oracle_order3_bit_exact_on_%d_sampled" % nd: bool(all(np.array_equal(ro[k_], r[k_][pick]) for k_ in SOLVE_FIELDS))}
-    b.close(); h.close()
-    return row
-
-
 def side_runs(ctx, args, st, out, cores):
     """the exact BASELINE configs[2] case (batch 256), configs[1] (one gear-shift trajectory), configs[4] (moving cars), the
     reference order on the other configurations, the neighbouring steps of the solve"""
     from oracle import pyoracle as po  # the checker, never the thing measured
     po.build()
     out["isolated"] = side_isolated(st)
-    if os.environ.get("DFTPAV_BENCH_DENSE") == "1":
-        out["dense_direction_isolated"] = side_dense_direction(ctx, args, po, cores, st)
     out["batch256"] = side_batch(ctx, args, po, cores, 3, 256, 3, 8)
     out["single"] = side_single(ctx, args, po, cores, 2, range(9))
     out["moving_obstacles_1024"] = side_batch(ctx, args, po, cores, 5, 1024, 1, 8)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars

@@ -482,13 +482,6 @@ class Batch:
                               iptr(r["collision"]), iptr(r["first_sample"]), dptr(r["states"]), iptr(r["n_valid"])), "plan_cycle_fetch")
         return r
 
-    def debug_set_direction(self, dense=True):
-        """EXPERIMENTAL test hook (dftpav_debug_set_direction): the device order's search direction from the dense form of H
-        (csrc/dense_dir.h; oracle order 3 is its CPU twin) instead of the two-loop recursion.  n <= 64, device order only."""
-        fn = lib().dftpav_debug_set_direction
-        fn.argtypes = [C.c_void_p, C.c_int]
-        self.handle._check(fn(self._b, int(bool(dense))), "debug_set_direction")
-
     def trace(self, traj, max_evals=4096, count=1):
         """Record every evaluation of trajectories traj .. traj + count - 1 during the following solves
         (dftpav_batch_trace_range); max_evals = 0 switches it off."""

@@ -23,7 +23,6 @@
 #include "device_types.h"
 #include "e4_plan.h"
 #include "traj_math.h"
-#include "dense_dir.h"
 #include "cr_trig.h"
 
 namespace dftpav {
@@ -135,8 +134,6 @@ struct dftpav_batch {
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
   unsigned char *d_records = nullptr; // [B + 1][16] result records written by the solver's epilogue (+ one zero record of padding)
-  double *d_dense = nullptr;          // experimental direction mode (dense_dir.h): [B][mem] aggregates; nullptr = two-loop recursion
-  size_t dense_stride = 0;
   DevBatch *d_dev = nullptr; // device copy of the launch descriptor
   int dev_version = -1;
   // pinned host staging of the two descriptors and the event behind their last copy: refreshing the device copies then
@@ -884,7 +881,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt, b->d_records,
                   b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
-                  b->d_f_eval, b->d_trace, b->d_dense, b->d_cor_raw, b->d_ref_tab, b->d_ref_scratch, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
+                  b->d_f_eval, b->d_trace, b->d_cor_raw, b->d_ref_tab, b->d_ref_scratch, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
                   b->pc.d_valid};
   {
     auto &v = b->h->batches;
@@ -1375,8 +1372,6 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.trace_b = b->trace_b;
   D.trace_cap = b->trace_cap;
   D.trace_n = b->trace_n;
-  D.dense = b->d_dense;
-  D.dense_stride = b->dense_stride;
   return D;
 }
 
@@ -1466,34 +1461,6 @@ extern "C" int dftpav_batch_trace_range(dftpav_batch *b, int first, int count, i
   return DFTPAV_OK;
 }
 extern "C" int dftpav_batch_trace(dftpav_batch *b, int traj, int max_evals) { return dftpav_batch_trace_range(b, traj, 1, max_evals); }
-
-// EXPERIMENTAL, a test hook (not in include/dftpav_hip.h): the device order's search direction from the dense form of H
-// (dense_dir.h, oracle order 3) instead of the two-loop recursion.  dense != 0 allocates per trajectory 2 + 16 + (mem - 1) / 16
-// aggregates of 3 pitch(n)^2 doubles (24 KB each at n = 31: 0.8 MB per trajectory at mem = 256) and selects the DENSE
-// instantiation of the solve kernel;
-// 0 returns to the two-loop recursion.  n <= 64 only; not for the reference order.  Validated on the CPU only this round.
-extern "C" int dftpav_debug_set_direction(dftpav_batch *b, int dense) {
-  if (!b) return DFTPAV_E_INVALID;
-  dftpav_handle *h = b->h;
-  if (dense && (b->L.n > 64 || b->order == DFTPAV_ORDER_REFERENCE)) {
-    h->err = "dftpav_debug_set_direction: the dense direction needs n <= 64 and the device order";
-    return DFTPAV_E_UNSUPPORTED;
-  }
-  HIPCHK(h, hipSetDevice(h->device));
-  if (int rc = finish_pending(b)) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (b->d_dense) {
-    HIPCHK(h, hipFree(b->d_dense));
-    b->d_dense = nullptr;
-    b->dense_stride = 0;
-  }
-  if (dense) {
-    b->dense_stride = dense::entry_doubles(b->L.n) * dense::entries_per_trajectory(b->P.mem_size);
-    HIPCHK(h, hipMalloc(&b->d_dense, sizeof(double) * b->dense_stride * (size_t)b->B));
-  }
-  b->dev_version = -1;
-  return DFTPAV_OK;
-}
 
 extern "C" int dftpav_batch_get_trace_of(dftpav_batch *b, int traj, double *out, int *n_evals) {
   if (!b || !n_evals || !b->d_trace || traj < b->trace_b || traj >= b->trace_b + b->trace_n) return DFTPAV_E_INVALID;
@@ -1656,10 +1623,6 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
   if (!b || (order != DFTPAV_ORDER_DEVICE && order != DFTPAV_ORDER_REFERENCE)) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   if (order == b->order && (order == DFTPAV_ORDER_DEVICE || b->ref_S == h->S)) return DFTPAV_OK;
-  if (order == DFTPAV_ORDER_REFERENCE && b->d_dense) { // the dense direction is a variant of the device order
-    h->err = "reference order: switch the experimental dense direction off first (dftpav_debug_set_direction(b, 0))";
-    return DFTPAV_E_UNSUPPORTED;
-  }
   if (order == DFTPAV_ORDER_REFERENCE && b->d_trace) { // the reference-order kernel does not record evaluations
     h->err = "reference order: dftpav_batch_trace is a device-order facility -- switch the trace off first";
     return DFTPAV_E_UNSUPPORTED;
@@ -1772,7 +1735,7 @@ static bool chain_compatible(const dftpav_batch *a, const dftpav_batch *b) {
          a->op_in_lds == b->op_in_lds && a->cor_in_lds == b->cor_in_lds && a->threads2 == b->threads2 &&
          a->hand_over == b->hand_over && a->hand_over > 0 && a->NptsPad == b->NptsPad && a->prof_on == b->prof_on &&
          std::memcmp(&a->L, &b->L, sizeof(DevLayout)) == 0 && std::memcmp(&a->P, &b->P, sizeof(DevParams)) == 0 &&
-         a->t_now == b->t_now && a->epis == b->epis && (a->d_dense != nullptr) == (b->d_dense != nullptr);
+         a->t_now == b->t_now && a->epis == b->epis;
 }
 
 static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {

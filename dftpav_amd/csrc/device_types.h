@@ -159,11 +159,6 @@ struct DevBatch {
   // {f, stp, k, count}
   double *trace;
   int trace_b, trace_cap, trace_n;
-  // EXPERIMENTAL direction mode (dense_dir.h; dftpav_debug_set_direction): per trajectory dense::entries_per_trajectory(mem)
-  // aggregates of 3 pitch^2 doubles (the back, one block of suffix aggregates, the rebuild's running one, checkpoints).
-  // nullptr = two-loop recursion.
-  double *dense;
-  unsigned long long dense_stride; // doubles per trajectory
 };
 
 enum KernelMode { kModeSolve = 0, kModeEval = 1, kModeCoeffs = 2 };

@@ -32,14 +32,13 @@
 #include "device_types.h"
 #include "e4_plan.h"
 #include "traj_math.h"
-#include "dense_dir.h"
 
 namespace dftpav {
 
 // ------------------------------------------------------------------ LDS carve
 // scalar L-BFGS state kept in Smem::st (doubles) and Smem::ist (ints)
 enum { sFX = 0, sFINIT, sDGINIT, sDGTEST, sDSTEST, sMU, sNU, sSTP, sSTEP, sF, sPF0 /* .. sPF0+7 */, sNUM = 24 };
-enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iCUR, iDFPOS /* dense direction: queue front */, iNUM = 16 };
+enum { iCOUNT = 0, iBRACKT, iTOUCHED, iK, iEND, iBOUND, iEVALS, iRET, iPHASE, iACTION, iHISTLO, iHISTHI, iCUR, iNUM = 16 };
 enum { kActEval = 0, kActDone = 1 };
 
 struct Smem {
@@ -1542,11 +1541,9 @@ __device__ __forceinline__ bool begin_iteration(const DevParams &P, const Smem &
 // Everything lbfgs_optimize does between two evaluations (lbfgs.hpp:524-745 with the line
 // search of lbfgs.hpp:312-389 unrolled into it).  Runs on wave 0, every lane computing the same
 // scalars from LDS; sets iACTION to kActEval (a new trial x is in sm.x) or kActDone.
-// DENSE: the search direction from the dense form of H (dense_dir.h; dn_b: this trajectory's aggregates) instead of the two-loop
-// recursion -- experimental, its own instantiation of the kernel so that the default kernels stay what they are.
-template <int LV, bool DENSE>
-__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, double *hS_b, double *hU_b, double *hV_b, double *hR_b, double *dn_b,
-                                              int lane, Prof &pr) {
+template <int LV>
+__device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm, double *hS_b, double *hU_b, double *hV_b, double *hR_b, int lane,
+                                              Prof &pr) {
   // hS_b / hU_b / hV_b: this trajectory's history blocks inside the batch it belongs to
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
@@ -1574,9 +1571,7 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       sm.ist[iHISTLO] = 0;
       sm.ist[iHISTHI] = 0;
       sm.ist[iPHASE] = 1;
-      if (DENSE) sm.ist[iDFPOS] = m; // no front aggregate yet
     }
-    if (DENSE && lane < n) dense::set_identity(dense::entry_at(dn_b, n, 0), n, lane); // the back aggregate starts as (I, 0)
     if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
       if (lane == 0) {
         sm.ist[iRET] = 0; // LBFGS_CONVERGENCE
@@ -1755,133 +1750,12 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Smem &sm,
       *reinterpret_cast<d2r_t *>(hR_b + 2 * (size_t)end) = yr; // read back by this wave in the recursion below (fenced there)
     }
     double cau = ss * sqrt(gpgp) * P.cautious_factor;
-    if (DENSE && lane == 0) hU_b[(size_t)end * 8] = dense::pair_nu(ys, yy, ss); // |V| of the pair: the gate of the dense direction
     pr.tick(kPHIST);
     if (ys > cau) {
-      const int bound_before = bound;
       ++bound;
       bound = m < bound ? m : bound;
       int ne = end + 1 == m ? 0 : end + 1;
-      if constexpr (DENSE) {
-        // ---- d = -H g from the dense form of H (dense_dir.h, mirrored by oracle order 3).  Lane L owns index L of every
-        // vector and row / column L of every matrix: all matrix accesses of a lane are its own (offsets k * pitch + L), only the
-        // vectors travel between lanes, through LDS arrays that are free between two evaluations:
-        double *const vS = sm.xp, *const vY = sm.gp, *const vC = sm.d, *const vR = sm.gdC; // s | v,  y,  c | w | u,  rho a | t
-        const bool act = lane < n;
-        const int L = act ? lane : 0;
-        const double sv_L = act ? sm.x[L] - sm.xp[L] : 0.0; // the same differences as stored in the history above
-        const double rho = 1.0 / ys;
-        const dense::Entry eb = dense::entry_at(dn_b, n, 0);
-        int fpos = sm.ist[iDFPOS];
-        if (bound_before == m) { // the window was full: its oldest pair (slot `end`, overwritten above) leaves
-          // one rebuild step for the pair at window position p (ring slot (base + p) % m), entries by index (-1 = the identity)
-          auto dense_step = [&](int p, int base, long long in_idx, size_t out_idx) {
-            const int slot = base + p < m ? base + p : base + p - m;
-            const double rho_j = ((gptr_t)hR_b)[2 * (size_t)slot + 1];
-            if (act) {
-              vS[L] = ((gptr_t)hS)[((size_t)slot * npad + L) * 2];
-              vY[L] = ((gptr_t)hS)[((size_t)slot * npad + L) * 2 + 1];
-            }
-            const dense::Entry out = dense::entry_at(dn_b, n, out_idx);
-            const dense::Entry in = dense::entry_at(dn_b, n, (size_t)(in_idx < 0 ? 0 : in_idx));
-            const dense::Entry *inp = in_idx < 0 ? nullptr : &in;
-            if (act) vC[L] = dense::rebuild_w(inp, n, L, vS);
-            if (act) dense::rebuild_step(inp, out, n, L, vY, vC, rho_j);
-          };
-          auto dense_block = [&](int q, int base) {
-            for (int p = dense::block_last(q, m); p >= dense::block_first(q); p--) {
-              long long in_idx;
-              size_t out_idx;
-              dense::block_step_io(p, m, in_idx, out_idx);
-              dense_step(p, base, in_idx, out_idx);
-            }
-          };
-          if (dense::needs_rebuild(fpos, m)) {
-            // the m - 1 surviving pairs (position p of the old window sits in ring slot (end + p) % m), newest first, into suffix
-            // aggregates: checkpoints at the block boundaries, then the first block; the back starts afresh
-            for (int p = m - 1; p >= dense::kBlock; p--) {
-              long long in_idx;
-              size_t out_idx;
-              dense::pass_step_io(p, m, in_idx, out_idx);
-              dense_step(p, end, in_idx, out_idx);
-            }
-            dense_block(0, end);
-            if (act) dense::set_identity(eb, n, L);
-            fpos = 1;
-          } else {
-            fpos++;
-            if (fpos < m && fpos % dense::kBlock == 0) { // the next block, from its checkpoint
-              const int back = (fpos - 1) % m;
-              dense_block(fpos / dense::kBlock, end - back >= 0 ? end - back : end - back + m);
-            }
-          }
-          if (lane == 0) sm.ist[iDFPOS] = fpos;
-        }
-        // the new pair joins the back aggregate
-        if (act) {
-          vS[L] = sv_L;
-          vY[L] = ylane;
-        }
-        double c_L = 0.0;
-        if (act) {
-          const double a_L = dense::lane_matvec(eb.acm, eb.np, n, L, vY);
-          c_L = dense::lane_matvec(eb.ccm, eb.np, n, L, vY);
-          vC[L] = c_L;
-          vR[L] = rho * a_L;
-        }
-        const double yCy = wave_sum<LV>(act ? ylane * c_L : 0.0);
-        const double beta = dense::push_beta(rho, yCy);
-        if (act) dense::push_update(eb, n, L, vS, vC, vR, beta, rho);
-        // the direction: from the dense form while every pair of the window is well conditioned (dense_dir.h: kNuGate), else
-        // the plain recursion
-        const double gamma = ys / yy;
-        double numax = 0.0;
-        __threadfence_block(); // lane 0 wrote this pair's |V|, every lane reads the window's below
-        for (int i = lane; i < bound; i += 64) {
-          const int jj = end - i >= 0 ? end - i : end - i + m; // the i-th newest pair (the new one sits in slot `end`)
-          numax = fmax(numax, ((gptr_t)hU_b)[(size_t)jj * 8]);
-        }
-        numax = wave_max<6>(numax); // (a maximum: the same value in whatever order it is formed)
-        if (numax < dense::kNuGate) {
-          const double u_L = act ? dense::dir_u(eb, n, L, sm.g) : 0.0;
-          if (act) vC[L] = u_L;
-          double t_L = gamma * u_L;
-          if (fpos < m) {
-            const dense::Entry ef = dense::entry_at(dn_b, n, dense::idx_block(fpos));
-            if (act) vS[L] = dense::dir_v(ef, n, L, vC);
-            if (act) t_L = dense::dir_t_front(ef, n, L, vC, vS, gamma);
-          }
-          if (act) vR[L] = t_L;
-          const double d_L = act ? dense::dir_d(eb, n, L, vR, sm.g) : 0.0;
-          if (act) sm.d[L] = d_L; // (vC is sm.d: u is dead by now)
-        } else {
-          // lbfgs.hpp:716-739 step by step (the plain form below, with the division by ys as the reference writes it)
-          for (int e = lane; e < n; e += 64) sm.d[e] = -sm.g[e]; // vC (= sm.d) held c
-          int j = ne;
-          for (int i = 0; i < bound; ++i) {
-            j = j == 0 ? m - 1 : j - 1;
-            const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
-            double acc = 0.0;
-            for (int e = lane; e < n; e += 64) acc += sj[2 * e] * sm.d[e];
-            acc = wave_sum<LV>(acc);
-            double a = acc / ((gptr_t)hR_b)[2 * (size_t)j];
-            if (lane == 0) sm.alpha[j] = a;
-            double na = -a;
-            for (int e = lane; e < n; e += 64) sm.d[e] += na * yj[2 * e];
-          }
-          for (int e = lane; e < n; e += 64) sm.d[e] *= gamma;
-          for (int i = 0; i < bound; ++i) {
-            const double *sj = hS + (size_t)j * npad * 2, *yj = hY + (size_t)j * npad * 2;
-            double acc = 0.0;
-            for (int e = lane; e < n; e += 64) acc += yj[2 * e] * sm.d[e];
-            acc = wave_sum<LV>(acc);
-            double beta = acc / ((gptr_t)hR_b)[2 * (size_t)j];
-            double cf = sm.alpha[j] - beta;
-            for (int e = lane; e < n; e += 64) sm.d[e] += cf * sj[2 * e];
-            j = j == m - 1 ? 0 : j + 1;
-          }
-        }
-      } else if (n <= 64 && m >= kLoopBlock) {
+      if (n <= 64 && m >= kLoopBlock) {
         // products of the new y with the s of the kLoopBlock-1 pairs before it (histU / histV)
         double *hU = hU_b, *hV = hV_b;
         {
@@ -2035,7 +1909,7 @@ __device__ inline void state_io(const DevBatch &D, const Smem &sm, int b, int ti
   // (ys and 1 / ys of the stored pairs live in DevBatch::histR, the history in histS: nothing more to move)
 }
 
-template <bool SUR, int LV, int MAXT, bool DENSE = false>
+template <bool SUR, int LV, int MAXT>
 __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict__ Dp, int mode, SchedArgs sched) {
   extern __shared__ double lds_raw[];
   // D0: the launched batch (queue, launch shape, role tables).  Inside a pass D is the batch the trajectory of
@@ -2215,7 +2089,7 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
         // the serial part of the trajectory: the other waves of the workgroup wait for it, the waves this one shares its
         // SIMD with belong to other trajectories -- let the arbiter prefer it
         __builtin_amdgcn_s_setprio(3);
-        lbfgs_advance<LV, DENSE>(D, sm, hS_b, hU_b, hV_b, hR_b, DENSE ? Db.dense + (size_t)b * Db.dense_stride : nullptr, lane, pr);
+        lbfgs_advance<LV>(D, sm, hS_b, hU_b, hV_b, hR_b, lane, pr);
         if (sm.ist[iACTION] == kActEval) prep_durations(D, sm, sm.x, lane); // the trial point is in place
         __builtin_amdgcn_s_setprio(0);
       }
@@ -2305,19 +2179,19 @@ hipError_t launch_adopt(const DevBatch &D, const DevBatch &prev, hipStream_t str
 }
 
 // ------------------------------------------------------------- host launchers
-template <bool SUR, int LV, int MAXT, bool DENSE>
+template <bool SUR, int LV, int MAXT>
 static hipError_t launch_variant(const DevBatch *d_dev, int grid, int mode, int threads, size_t lds, SchedArgs sched, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solver_kernel<SUR, LV, MAXT, DENSE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solver_kernel<SUR, LV, MAXT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((solver_kernel<SUR, LV, MAXT, DENSE>), dim3(grid), dim3(threads), lds, stream, d_dev, mode, sched);
+  hipLaunchKernelGGL((solver_kernel<SUR, LV, MAXT>), dim3(grid), dim3(threads), lds, stream, d_dev, mode, sched);
   return hipGetLastError();
 }
-template <bool SUR, bool DENSE>
+template <bool SUR>
 static hipError_t launch_lv(int n, const DevBatch *d_dev, int grid, int mode, int threads, size_t lds, SchedArgs sched, hipStream_t stream) {
-  if (n <= 16) return launch_variant<SUR, 4, 512, DENSE>(d_dev, grid, mode, threads, lds, sched, stream);
-  if (n <= 32) return launch_variant<SUR, 5, 512, DENSE>(d_dev, grid, mode, threads, lds, sched, stream);
-  return launch_variant<SUR, 6, 512, DENSE>(d_dev, grid, mode, threads, lds, sched, stream);
+  if (n <= 16) return launch_variant<SUR, 4, 512>(d_dev, grid, mode, threads, lds, sched, stream);
+  if (n <= 32) return launch_variant<SUR, 5, 512>(d_dev, grid, mode, threads, lds, sched, stream);
+  return launch_variant<SUR, 6, 512>(d_dev, grid, mode, threads, lds, sched, stream);
 }
 
 // d_dev: device copy of the DevBatch `D` describes; grid: workgroups to launch (D.B unless the launch is scheduled)
@@ -2328,12 +2202,8 @@ hipError_t launch_solver(const DevBatch &D, const DevBatch *d_dev, int mode, int
   if (std::getenv("DFTPAV_VERBOSE"))
     std::fprintf(stderr, "[dftpav] launch mode %d: grid %d x %d threads, %zu B of LDS (%d workgroups per CU by LDS), obstacle coefficients in %s\n", mode, grid,
                  threads, lds, (int)((160 * 1024) / (lds + 64)), D.sur.S > 0 ? (D.sur_coef_lds ? "LDS" : "global memory") : "-");
-  if (D.dense != nullptr && D.L.n <= 64) { // experimental direction mode (dense_dir.h)
-    if (D.sur.S > 0) return launch_lv<true, true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
-    return launch_lv<false, true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
-  }
-  if (D.sur.S > 0) return launch_lv<true, false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
-  return launch_lv<false, false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
+  if (D.sur.S > 0) return launch_lv<true>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
+  return launch_lv<false>(D.L.n, d_dev, grid, mode, threads, lds, sched, stream);
 }
 
 } // namespace dftpav

@@ -718,8 +718,7 @@ oracle_ctx *oracle_prepare(const dftpav_params *p, const oracle_problem *pb, int
 }
 
 void oracle_set_order(oracle_ctx *c, int order) {
-  c->dense_dir = order == 3; /* order 3 = order 1 with the search direction from the dense form of H */
-  c->order = order == 3 ? 1 : order;
+  c->order = order;
   if (c->order == 1 && !c->dev) oracle_dev_init(c);
 }
 

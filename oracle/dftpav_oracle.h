@@ -74,11 +74,7 @@ void oracle_free(oracle_ctx *c);
  *       (OPT:276-281, 312-317) in place of libm's: the program the
  *       reference-order device kernel runs on layouts with a gear shift, where
  *       libm's own bits are a property of the host CPU.  Identical to mode 0 on
- *       single-segment layouts (no such call).
- *   3 = DEVICE ORDER with the L-BFGS search direction from the DENSE form of the inverse-Hessian approximation
- *       (dftpav_amd/csrc/dense_dir.h: H = gamma A^T A + C kept as n x n matrices, window by a two-stack queue) instead of
- *       the two-loop recursion: the same mathematics to 1e-10, other bits -- the experimental direction mode of the kernel
- *       (dftpav_debug_set_direction), n <= 64. */
+ *       single-segment layouts (no such call). */
 void oracle_set_order(oracle_ctx *c, int order);
 /* x0 packing of traj_optimizer.cpp:96-115 */
 void oracle_pack_x0(const oracle_ctx *c, double *x0);

@@ -36,7 +36,6 @@
 
 #include "oracle_internal.h"
 #include "../dftpav_amd/csrc/traj_math.h"
-#include "../dftpav_amd/csrc/dense_dir.h"
 
 using namespace dftpav;
 
@@ -521,19 +520,6 @@ extern "C" void oracle_dev_coeffs(const oracle_ctx *c, double *coeffs, double *p
   for (int sg = 0; sg < D.L.M; sg++) piece_dt[sg] = D.seg[sg * 16 + 1];
 }
 
-// Test facility of the dense direction (order 3): when switched on, every direction is compared with the plain two-loop recursion
-// over the same window in 80-bit arithmetic.  stats: [0] largest relative difference (max norm), [1] directions compared,
-// [2] of them with a front aggregate in play (window sliding), [3] deepest window
-static thread_local bool g_dense_check = false;
-static thread_local double g_dense_stats[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // [4] fp64 two-loop's largest difference, [5] its difference where the dense one is largest, [6] directions taken from the plain recursion (gate closed)
-extern "C" void oracle_dense_check(int on) {
-  g_dense_check = on != 0;
-  for (double &v : g_dense_stats) v = 0.0;
-}
-extern "C" void oracle_dense_stats(double out[7]) {
-  for (int i = 0; i < 7; i++) out[i] = g_dense_stats[i];
-}
-
 // lbfgs_optimize (lbfgs.hpp:440-751) + line_search_lewisoverton (lbfgs.hpp:276-390)
 // with the kernel's reduction order for every dot product.
 static const int kLoopBlock = 8; // stored pairs per block of the two-loop recursion (solver.hip)
@@ -544,37 +530,9 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
   const DevParams &P = D.P;
   const int n = D.L.n, m = P.mem_size;
   g_levels = levels_for(n);
-  std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), ri_h(m, 0.0), alpha_h(m, 0.0), nu_h(m, 0.0);
+  std::vector<double> g(n), xp(n), gp(n), d(n), ys_h(m, 0.0), ri_h(m, 0.0), alpha_h(m, 0.0);
   std::vector<double> hS((size_t)m * n, 0.0), hY((size_t)m * n, 0.0);
   std::vector<double> hU((size_t)m * 8, 0.0), hV((size_t)m * 8, 0.0); // products with the kBand neighbouring pairs
-  // the dense form of H (order 3, dense_dir.h): the back aggregate, the front's suffix aggregates (index = position in the window
-  // at the last rebuild), vectors a lane publishes for the others (LDS on the device)
-  const bool dense_dir = c->dense_dir != 0 && n <= 64;
-  std::vector<double> dn, dn_c(64, 0.0), dn_ra(64, 0.0), dn_u(64, 0.0), dn_v(64, 0.0), dn_t(64, 0.0), dn_w(64, 0.0);
-  int fpos = m;
-  if (dense_dir) {
-    dn.assign(dense::entry_doubles(n) * dense::entries_per_trajectory(m), 0.0); // the trajectory's entries as the kernel lays them out
-    const dense::Entry eb = dense::entry_at(dn.data(), n, 0);
-    for (int L = 0; L < n; L++) dense::set_identity(eb, n, L);
-  }
-  // one rebuild step for the pair at window position p (ring slot (base + p) % m), entries by index (-1 = the identity)
-  auto dense_step = [&](int p, int base, long long in_idx, size_t out_idx) {
-    const int slot = (base + p) % m;
-    const double *sj = &hS[(size_t)slot * n], *yj = &hY[(size_t)slot * n];
-    const dense::Entry out = dense::entry_at(dn.data(), n, out_idx);
-    const dense::Entry in = dense::entry_at(dn.data(), n, (size_t)(in_idx < 0 ? 0 : in_idx));
-    const dense::Entry *inp = in_idx < 0 ? nullptr : &in;
-    for (int L = 0; L < n; L++) dn_w[L] = dense::rebuild_w(inp, n, L, sj);
-    for (int L = 0; L < n; L++) dense::rebuild_step(inp, out, n, L, yj, dn_w.data(), ri_h[slot]);
-  };
-  auto dense_block = [&](int q, int base) {
-    for (int p = dense::block_last(q, m); p >= dense::block_first(q); p--) {
-      long long in_idx;
-      size_t out_idx;
-      dense::block_step_io(p, m, in_idx, out_idx);
-      dense_step(p, base, in_idx, out_idx);
-    }
-  };
   double pf[8];
   int evals = 0, k = 0, end = 0, bound = 0, ret = 0;
   long long hist_sum = 0;
@@ -709,147 +667,12 @@ extern "C" void oracle_dev_solve(oracle_ctx *c, double *x, oracle_result *res) {
       double gpgp = wave_dot(gp.data(), gp.data(), n);
       ys_h[end] = ys;
       ri_h[end] = 1.0 / ys;
-      nu_h[end] = dense::pair_nu(ys, yy, ss); // |V| of the pair: the gate of the dense direction (dense_dir.h)
       double cau = ss * std::sqrt(gpgp) * P.cautious_factor;
       if (ys > cau) {
-        const int bound_before = bound;
         ++bound;
         bound = m < bound ? m : bound;
         end = (end + 1) % m;
-        if (dense_dir) {
-          // ---- d = -H g from the dense form (dense_dir.h); every lane's part as the kernel's lane L runs it
-          const int cs = (end + m - 1) % m; // slot of the pair just stored
-          const double rho = ri_h[cs];
-          const dense::Entry eb = dense::entry_at(dn.data(), n, 0);
-          if (bound_before == m) { // the window was full: its oldest pair (already overwritten by this one) leaves
-            if (dense::needs_rebuild(fpos, m)) {
-              // the m - 1 surviving pairs (position p of the old window sits in ring slot (cs + p) % m), newest first, into suffix
-              // aggregates: checkpoints at the block boundaries, then the first block; the back starts afresh
-              for (int p = m - 1; p >= dense::kBlock; p--) {
-                long long in_idx;
-                size_t out_idx;
-                dense::pass_step_io(p, m, in_idx, out_idx);
-                dense_step(p, cs, in_idx, out_idx);
-              }
-              dense_block(0, cs);
-              for (int L = 0; L < n; L++) dense::set_identity(eb, n, L);
-              fpos = 1;
-            } else {
-              fpos++;
-              if (fpos < m && fpos % dense::kBlock == 0) dense_block(fpos / dense::kBlock, (cs - (fpos - 1) % m + m) % m); // the next block, from its checkpoint
-            }
-          }
-          // the new pair joins the back aggregate
-          double prod[64];
-          for (int L = 0; L < 64; L++) prod[L] = 0.0;
-          for (int L = 0; L < n; L++) {
-            const double a = dense::lane_matvec(eb.acm, eb.np, n, L, yc);
-            dn_c[L] = dense::lane_matvec(eb.ccm, eb.np, n, L, yc);
-            dn_ra[L] = rho * a;
-            prod[L] = yc[L] * dn_c[L];
-          }
-          const double yCy = butterfly_sum(prod);
-          const double beta = dense::push_beta(rho, yCy);
-          for (int L = 0; L < n; L++) dense::push_update(eb, n, L, sc, dn_c.data(), dn_ra.data(), beta, rho);
-          // the direction: from the dense form while every pair of the window is well conditioned, else the plain recursion
-          const double gamma = ys / yy;
-          double numax = 0.0;
-          {
-            int jj = end;
-            for (int i = 0; i < bound; ++i) {
-              jj = (jj + m - 1) % m;
-              numax = std::fmax(numax, nu_h[jj]);
-            }
-          }
-          const bool dense_ok = numax < dense::kNuGate;
-          if (dense_ok) {
-            for (int L = 0; L < n; L++) dn_u[L] = dense::dir_u(eb, n, L, g.data());
-            if (fpos < m) {
-              const dense::Entry ef = dense::entry_at(dn.data(), n, dense::idx_block(fpos));
-              for (int L = 0; L < n; L++) dn_v[L] = dense::dir_v(ef, n, L, dn_u.data());
-              for (int L = 0; L < n; L++) dn_t[L] = dense::dir_t_front(ef, n, L, dn_u.data(), dn_v.data(), gamma);
-            } else {
-              for (int L = 0; L < n; L++) dn_t[L] = gamma * dn_u[L];
-            }
-            for (int L = 0; L < n; L++) d[L] = dense::dir_d(eb, n, L, dn_t.data(), g.data());
-          } else {
-            // lbfgs.hpp:716-739 step by step, as the kernel's plain form runs it (wave_dot per step, true divisions)
-            int j = end;
-            for (int i = 0; i < bound; ++i) {
-              j = (j + m - 1) % m;
-              const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-              double a = wave_dot(sj, d.data(), n) / ys_h[j];
-              alpha_h[j] = a;
-              double na = -a;
-              for (int e = 0; e < n; e++) d[e] += na * yj[e];
-            }
-            for (int e = 0; e < n; e++) d[e] *= gamma;
-            for (int i = 0; i < bound; ++i) {
-              const double *sj = &hS[(size_t)j * n], *yj = &hY[(size_t)j * n];
-              double beta = wave_dot(yj, d.data(), n) / ys_h[j];
-              double cf = alpha_h[j] - beta;
-              for (int e = 0; e < n; e++) d[e] += cf * sj[e];
-              j = (j + 1) % m;
-            }
-            g_dense_stats[6] += 1.0;
-          }
-          if (g_dense_check) {
-            // test facility: the plain two-loop recursion (lbfgs.hpp:716-739) over the same window in 80-bit arithmetic
-            std::vector<long double> q(n), al(m);
-            for (int e = 0; e < n; e++) q[e] = -(long double)g[e];
-            int j = end;
-            for (int i = 0; i < bound; ++i) {
-              j = (j + m - 1) % m;
-              long double acc = 0.0L;
-              for (int e = 0; e < n; e++) acc += (long double)hS[(size_t)j * n + e] * q[e];
-              al[j] = acc / (long double)ys_h[j];
-              for (int e = 0; e < n; e++) q[e] -= al[j] * (long double)hY[(size_t)j * n + e];
-            }
-            for (int e = 0; e < n; e++) q[e] *= (long double)ys / (long double)yy;
-            for (int i = 0; i < bound; ++i) {
-              long double acc = 0.0L;
-              for (int e = 0; e < n; e++) acc += (long double)hY[(size_t)j * n + e] * q[e];
-              const long double cf = al[j] - acc / (long double)ys_h[j];
-              for (int e = 0; e < n; e++) q[e] += cf * (long double)hS[(size_t)j * n + e];
-              j = (j + 1) % m;
-            }
-            long double num = 0.0L, den = 0.0L;
-            for (int e = 0; e < n; e++) {
-              num = std::max(num, std::fabs((long double)d[e] - q[e]));
-              den = std::max(den, std::fabs(q[e]));
-            }
-            const double rel = (double)(num / std::max(den, (long double)1e-300L));
-            {
-              // for scale: the same recursion in plain fp64 against the 80-bit one
-              std::vector<double> q2(n), al2(m);
-              for (int e = 0; e < n; e++) q2[e] = -g[e];
-              int j2 = end;
-              for (int i = 0; i < bound; ++i) {
-                j2 = (j2 + m - 1) % m;
-                double acc = 0.0;
-                for (int e = 0; e < n; e++) acc += hS[(size_t)j2 * n + e] * q2[e];
-                al2[j2] = acc / ys_h[j2];
-                for (int e = 0; e < n; e++) q2[e] -= al2[j2] * hY[(size_t)j2 * n + e];
-              }
-              for (int e = 0; e < n; e++) q2[e] *= ys / yy;
-              for (int i = 0; i < bound; ++i) {
-                double acc = 0.0;
-                for (int e = 0; e < n; e++) acc += hY[(size_t)j2 * n + e] * q2[e];
-                const double cf = al2[j2] - acc / ys_h[j2];
-                for (int e = 0; e < n; e++) q2[e] += cf * hS[(size_t)j2 * n + e];
-                j2 = (j2 + 1) % m;
-              }
-              long double num2 = 0.0L;
-              for (int e = 0; e < n; e++) num2 = std::max(num2, std::fabs((long double)q2[e] - q[e]));
-              g_dense_stats[4] = std::max(g_dense_stats[4], (double)(num2 / std::max(den, (long double)1e-300L)));
-              if (rel > g_dense_stats[0]) g_dense_stats[5] = (double)(num2 / std::max(den, (long double)1e-300L)); // at the worst dense direction
-            }
-            g_dense_stats[0] = std::max(g_dense_stats[0], rel);
-            g_dense_stats[1] += 1.0;
-            g_dense_stats[2] += fpos < m ? 1.0 : 0.0;
-            g_dense_stats[3] = std::max(g_dense_stats[3], (double)bound);
-          }
-        } else if (n <= 64 && m >= kLoopBlock) { // the kernel's condition for the blocked form (a block must fit the ring)
+        if (n <= 64 && m >= kLoopBlock) { // the kernel's condition for the blocked form (a block must fit the ring)
           // Two-loop recursion (lbfgs.hpp:716-739) in blocks of kLoopBlock stored pairs, as the kernel runs
           // it: the kLoopBlock dot products of a block are taken against the direction as it stands at the
           // start of the block, and the effect of the block's earlier steps on a later dot product is

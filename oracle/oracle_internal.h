@@ -48,7 +48,6 @@ struct oracle_ctx {
   int evals;
   double cost_terms[5];
   int order;   /* 0 literal (reference statement order), 1 device order (replays the kernel) */
-  int dense_dir; /* device order only: the search direction from the dense form of H (dftpav_amd/csrc/dense_dir.h); set by order 3 */
   void *dev;   /* device-order state, dftpav_oracle_dev.cpp */
 };
 

@@ -174,22 +174,6 @@ class OracleProblem:
 
 
 LITERAL, DEVICE_ORDER = 0, 1
-DEVICE_ORDER_DENSE = 3   # device order with the search direction from the dense form of H (dftpav_amd/csrc/dense_dir.h)
-
-
-def dense_check(on=True):
-    """order 3's test facility (this thread): compare every direction with the plain two-loop recursion in 80-bit arithmetic"""
-    lib().oracle_dense_check(int(bool(on)))
-
-
-def dense_stats():
-    """-> dict(max_rel_d, directions, with_front, deepest_window) since dense_check(True)"""
-    out = np.zeros(7)
-    fn = lib().oracle_dense_stats
-    fn.argtypes = [c_double_p]
-    fn(dptr(out))
-    return dict(max_rel_d=float(out[0]), directions=int(out[1]), with_front=int(out[2]), deepest_window=int(out[3]),
-                two_loop_fp64_max_rel_d=float(out[4]), two_loop_fp64_rel_d_at_the_worst=float(out[5]), gate_closed=int(out[6]))
 
 
 def solve_batch(params, scen, nthreads=1, order=0):

@@ -7,7 +7,7 @@ name=$1; expr=$2; shift 2 || true
 cd "$(dirname "$0")/../dftpav_amd/csrc"
 mkdir -p ../variants /tmp/variant_$name
 sed "$expr" solver.hip > /tmp/variant_$name/solver.hip
-cp device_types.h traj_math.h dense_dir.h cr_trig.h rs_math.h e4_plan.h /tmp/variant_$name/
+cp device_types.h traj_math.h cr_trig.h rs_math.h e4_plan.h /tmp/variant_$name/
 if [ -n "$VARIANT_TRAJ_MATH" ]; then cp "$VARIANT_TRAJ_MATH" /tmp/variant_$name/traj_math.h; fi   # another traj_math.h for the solve kernel
 /opt/rocm/bin/hipcc -O2 -mllvm -amdgpu-sched-strategy=max-ilp -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed "$@" \
   -c /tmp/variant_$name/solver.hip -o /tmp/variant_$name/solver.o

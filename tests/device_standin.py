@@ -98,9 +98,6 @@ class Batch:
     def set_order(self, order):
         self.order = 2 if order == ORDER_REFERENCE else 1
 
-    def debug_set_direction(self, dense=True):
-        self.order = 3 if dense else 1      # oracle order 3 = the dense direction
-
     def upload(self, scen, with_corridor=True):
         assert scen.B == self.B and scen.layout.n_vars == self.n
         self.scen, self.r = scen, None

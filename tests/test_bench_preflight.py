@@ -116,9 +116,8 @@ def test_world_size_one_through_the_collective_path():
 def test_every_side_run_of_the_one_gpu_line():
     """the default N = 1 line with all its side runs, at sizes the oracle finishes in half a minute: no side run fails, every
     entry the documents quote is there"""
-    out = _bench(["--steps", "2", "--warmup", "1", "--batch-per-gpu", "16", "--cpu-sample", "16"], timeout=900, env={"DFTPAV_BENCH_DENSE": "1"})
+    out = _bench(["--steps", "2", "--warmup", "1", "--batch-per-gpu", "16", "--cpu-sample", "16"], timeout=900)
     assert "side_run_errors" not in out, out.get("side_run_errors")
-    assert out["dense_direction_isolated"]["oracle_order3_bit_exact_on_16_sampled"] is True      # (opt-in entry: DFTPAV_BENCH_DENSE=1)
     for k in ("strong_shard", "isolated", "batch256", "single", "moving_obstacles_1024", "validate", "readout", "shots", "corridor",
               "cpu_baseline", "with_upload", "parity"):
         assert k in out, k
