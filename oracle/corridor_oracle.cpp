@@ -14,7 +14,9 @@
 // order 0: cos / sin of libm, as the reference.  order 1: the portable cos / sin of
 // dftpav_amd/csrc/traj_math.h, which is what the HIP kernel evaluates; every other operation is a
 // correctly rounded IEEE operation in the reference's order, so order 1 is bit-identical to the GPU.
-// Parity unpinned against the real reference (it cannot be built here).
+// PINNED (round 5): order 0 is bit-equal to the reference's own code -- the cited functions cut verbatim out of
+// /root/reference (oracle/ref_slices.py) and compiled into oracle/_ref/libdftpav_ref_next.so (oracle/ref_next_driver.cpp) --
+// on the scenarios the GPU tests of this step use (tests/test_ref_pin.py::test_corridor_oracle_is_bit_equal_to_getRectangleConst).
 #include <cmath>
 #include <cstdint>
 

@@ -1,8 +1,11 @@
 /*
  * dftpav_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see dftpav_oracle.h).
  *
- * fp64 CPU restatement of the Dftpav solve path.  PARITY UNPINNED: the
- * reference has no golden vectors for this path and cannot be built here.
+ * fp64 CPU restatement of the Dftpav solve path.  PINNED: bit-equal to the
+ * reference's own sources compiled unmodified (oracle/_ref, oracle/Makefile.ref;
+ * tests/test_ref_pin.py: L-BFGS, BandedSystem, MinJerkOpt, every evaluation and
+ * whole solves of every BASELINE config; order 2 against the same objects on a
+ * correctly rounded libm).  The reference itself holds no golden vectors.
  *
  * Shorthand for citations:
  *   OPT   = src/Plan/traj_planner/src/traj_optimizer.cpp
@@ -12,8 +15,8 @@
  * Arithmetic is written scalar-by-scalar in the reference's left-to-right
  * operator order.  Eigen's internal summation order inside fixed-size
  * products/reductions is not pinned by the reference (Eigen version unpinned,
- * TP/CMakeLists.txt:14), so agreement with a real build of the reference is
- * expected at rounding level, not bit level.  Build with -ffp-contract=off
+ * TP/CMakeLists.txt:14): the pin is against the build over oracle/ref_shim's
+ * Eigen stand-in (sequential reductions; its contract is stated in that file).  Build with -ffp-contract=off
  * (the reference is built -O3 without -march, i.e. no FMA contraction).
  */
 #include "oracle_internal.h"

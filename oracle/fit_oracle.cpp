@@ -12,7 +12,10 @@
 //
 // order 0: as the reference — libm cos / sin, the banded system solved for the actual right-hand side.
 // order 1: what the HIP kernel evaluates — portable cos / sin, the right-hand side times the dense operator
-// (A_N^{-1} applied to unit vectors with the same banded LU), columns in ascending order.  Parity unpinned.
+// (A_N^{-1} applied to unit vectors with the same banded LU), columns in ascending order.
+// PINNED (round 5): order 0 is bit-equal to the reference's own code -- the cited functions cut verbatim out of
+// /root/reference (oracle/ref_slices.py) and compiled into oracle/_ref/libdftpav_ref_next.so (oracle/ref_next_driver.cpp) --
+// on the scenarios the GPU tests of this step use (tests/test_ref_pin.py::test_fit_oracle_is_bit_equal_to_ConverSurroundTrajFromPoints).
 #include <cmath>
 #include <vector>
 

@@ -16,7 +16,10 @@
 //
 // order 0: libm cos / sin / tan, as the reference.  order 1: the portable cos / sin of traj_math.h (tan = sin / cos),
 // which is what the HIP kernel evaluates; all else is correctly rounded IEEE arithmetic in the reference's order.
-// Parity unpinned against the real reference.
+// PINNED (round 5): order 0 is bit-equal to the reference's own code -- the cited functions cut verbatim out of
+// /root/reference (oracle/ref_slices.py) and compiled into oracle/_ref/libdftpav_ref_next.so (oracle/ref_next_driver.cpp) --
+// on the scenarios the GPU tests of this step use (tests/test_ref_pin.py::test_frontend_oracle_is_bit_equal_to_getKinoNode_and_RunMINCOParking).
+// (From SampleTraj on: the A* nodes and the OMPL shot that build SampleTraj are outside what can be compiled here.)
 #include <algorithm>
 #include <cmath>
 #include <vector>

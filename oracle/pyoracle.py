@@ -259,8 +259,45 @@ def minco_generate(inner, dT, head, tail):
                                     dptr(np.ascontiguousarray(tail, dtype=np.float64)), dptr(c))
     return c, J
 
+_REF_NEXT = None
 
-def corridor_rectangles(grid, resolution, origin, states, veh=(1.90, 4.88, 1.015), order=0):
+
+def ref_next_lib():
+    """oracle/_ref/libdftpav_ref_next.so: the REFERENCE'S OWN code of the steps either side of the solve path (functions cut
+    verbatim out of /root/reference by oracle/ref_slices.py, compiled by oracle/ref_next_driver.cpp; recipe oracle/Makefile.ref).
+    The wrappers below take `ref=True` to run it in the restatement's place (order 0 only): what tests/test_ref_pin.py compares."""
+    global _REF_NEXT
+    if _REF_NEXT is None:
+        so = os.path.join(_HERE, "_ref", "libdftpav_ref_next.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-f", "Makefile.ref", "-s"])
+        _REF_NEXT = C.CDLL(so)
+    return _REF_NEXT
+
+
+def ref_next_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libdftpav_ref_next.so")) or os.path.exists("/root/reference/src/Plan/traj_planner/src/traj_manager.cpp")
+
+
+def _step_fn(name, ref):
+    """oracle_<name> of the restatement, or ref_<name> of the reference's own code (returns 0, or < 0 where the reference
+    hard-codes what the restatement takes as an argument)"""
+    if not ref:
+        fn = getattr(lib(), "oracle_" + name)
+        fn.restype = None
+        return fn
+    raw = getattr(ref_next_lib(), "ref_" + name)
+    raw.restype = C.c_int
+
+    def call(*a):
+        rc = raw(*a)
+        if rc != 0:
+            raise ValueError("ref_%s: the reference's code does not take these arguments (rc %d)" % (name, rc))
+    call.raw = raw
+    return call
+
+
+def corridor_rectangles(grid, resolution, origin, states, veh=(1.90, 4.88, 1.015), order=0, ref=False):
     """getRectangleConst (traj_manager.cpp:1213-1469) on an occupancy grid.
 
     grid: uint8 [size_y][size_x] (cell (ix, iy) at grid[iy, ix], 80 = occupied); states: [n][3] (x, y, yaw).
@@ -269,9 +306,8 @@ def corridor_rectangles(grid, resolution, origin, states, veh=(1.90, 4.88, 1.015
     g = np.ascontiguousarray(grid, dtype=np.uint8)
     st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 3)
     out = np.zeros((st.shape[0], 4, 4), dtype=np.float64)
-    fn = L.oracle_corridor_rectangles
-    fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int,
+    fn = _step_fn("corridor_rectangles", ref)
+    (fn.raw if ref else fn).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int,
                    C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
     fn(g.ctypes.data, g.shape[1], g.shape[0], float(resolution), float(origin[0]), float(origin[1]), st.ctypes.data,
        st.shape[0], float(veh[0]), float(veh[1]), float(veh[2]), int(order), out.ctypes.data)
@@ -279,7 +315,7 @@ def corridor_rectangles(grid, resolution, origin, states, veh=(1.90, 4.88, 1.015
 
 
 def validate_trajectories(grid, resolution, origin, coeffs, piece_dt, piece_nums, singuls, veh=(1.90, 4.88, 1.015),
-                          sample_dt=0.05, vertex_res=0.1, order=0):
+                          sample_dt=0.05, vertex_res=0.1, order=0, ref=False):
     """The collision re-check of CheckReplan (traj_server_ros.cpp:385-397) for B trajectories.
 
     coeffs: [B][Ntot][6][2] (entry [k][d] = coefficient of s^k), piece_dt: [B][M].  Returns (collision [B], first_sample [B])."""
@@ -292,9 +328,8 @@ def validate_trajectories(grid, resolution, origin, coeffs, piece_dt, piece_nums
     sg = np.ascontiguousarray(singuls, dtype=np.int32)
     col = np.zeros(B, dtype=np.int32)
     first = np.zeros(B, dtype=np.int32)
-    fn = L.oracle_validate_trajectories
-    fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+    fn = _step_fn("validate_trajectories", ref)
+    (fn.raw if ref else fn).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                    C.c_void_p, C.c_void_p]
     fn(g.ctypes.data, g.shape[1], g.shape[0], float(resolution), float(origin[0]), float(origin[1]), co.ctypes.data,
@@ -304,7 +339,7 @@ def validate_trajectories(grid, resolution, origin, coeffs, piece_dt, piece_nums
 
 
 def sample_states(coeffs, piece_dt, piece_nums, singuls, t0=0.0, sample_dt=0.01, n_samples=100, filter_singularity=True,
-                  wheel_base=2.85, order=0):
+                  wheel_base=2.85, order=0, ref=False):
     """Trajectory::GetState over a time grid, played back as the server does (states_oracle.cpp): returns
     (states [B][n_samples][8], n_valid [B])."""
     L = lib()
@@ -315,9 +350,8 @@ def sample_states(coeffs, piece_dt, piece_nums, singuls, t0=0.0, sample_dt=0.01,
     sg = np.ascontiguousarray(singuls, dtype=np.int32)
     st = np.zeros((B, int(n_samples), 8))
     nv = np.zeros(B, dtype=np.int32)
-    fn = L.oracle_sample_states
-    fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+    fn = _step_fn("sample_states", ref)
+    (fn.raw if ref else fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     fn(co.ctypes.data, dt.ctypes.data, pn.ctypes.data, sg.ctypes.data, len(pn), B, float(wheel_base), float(t0),
        float(sample_dt), int(n_samples), int(bool(filter_singularity)), int(order), st.ctypes.data, nv.ctypes.data)
@@ -375,22 +409,21 @@ RS_TYPE_KINDS = np.array([[1, 3, 1, 0, 0], [3, 1, 3, 0, 0], [1, 3, 1, 3, 0], [3,
                          dtype=np.int32)
 
 
-def fit_surround(states, order=0):
+def fit_surround(states, order=0, ref=False):
     """ConverSurroundTrajFromPoints (traj_manager.cpp:743-789): states [S][n][7] (x, y, angle, velocity, acceleration,
     curvature, time_stamp) -> dict(durations [S][n-1], coeffs [S][n-1][12], total [S], start [S])."""
     L = lib()
     st = np.ascontiguousarray(states, dtype=np.float64)
     S, n = st.shape[0], st.shape[1]
     out = dict(durations=np.zeros((S, n - 1)), coeffs=np.zeros((S, n - 1, 12)), total=np.zeros(S), start=np.zeros(S))
-    fn = L.oracle_fit_surround
-    fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn = _step_fn("fit_surround", ref)
+    (fn.raw if ref else fn).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     fn(st.ctypes.data, S, n, int(order), out["durations"].ctypes.data, out["coeffs"].ctypes.data, out["total"].ctypes.data,
        out["start"].ctypes.data)
     return out
 
 
-def frontend_resample(paths, path_len, start_states, end_states, start_ctrl, fparams=None, order=0, **caps):
+def frontend_resample(paths, path_len, start_states, end_states, start_ctrl, fparams=None, order=0, ref=False, **caps):
     """getKinoNode (from SampleTraj on) + the resampling of RunMINCOParking (kino_astar.cpp:606-795, traj_manager.cpp:531-568).
     paths [n_hyp][max_path][3]; returns the dict of padded arrays of dftpav_amd.pods.FrontendOut."""
     from dftpav_amd.pods import FrontendParams, FrontendOut
@@ -403,9 +436,8 @@ def frontend_resample(paths, path_len, start_states, end_states, start_ctrl, fpa
     sc_ = np.ascontiguousarray(start_ctrl, dtype=np.float64)
     fp = fparams if fparams is not None else FrontendParams.default()
     out = FrontendOut(n_hyp, **caps)
-    fn = L.oracle_frontend_resample
-    fn.restype = None
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    fn = _step_fn("frontend_resample", ref)
+    (fn.raw if ref else fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     fn(C.byref(fp), P.ctypes.data, pl.ctypes.data, max_path, ss.ctypes.data, es.ctypes.data, sc_.ctypes.data, n_hyp, int(order),
        C.byref(out.c))
     return out.arrays()

@@ -7,8 +7,9 @@
 //   SemanticMapManager::CheckCollisionUsingPosAndYaw  semantic_map_manager.cc:639-662
 //
 // order 0: libm sin / cos / atan2, as OMPL and the reference use them.  order 1: the portable functions of
-// traj_math.h, which is what the HIP kernel evaluates -- bit-identical to the GPU.  Parity unpinned against OMPL
-// itself (absent here); the pins are properties: the interpolated path ends on the goal, its pieces respect the
+// traj_math.h, which is what the HIP kernel evaluates -- bit-identical to the GPU.  PARITY UNPINNED against OMPL
+// itself (not vendored by the reference, absent here: the one step of SURVEY §8(f) that can only stay property-pinned; the
+// collision test it ends in IS pinned, through validate_oracle.cpp); the pins are properties: the interpolated path ends on the goal, its pieces respect the
 // turning radius, no other word is shorter, and the symmetries of the problem (tests/test_shot_oracle.py).
 #include <cmath>
 #include <cstdint>

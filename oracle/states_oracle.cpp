@@ -18,7 +18,10 @@
 // order 0: libm atan2 / atan / pow / tan, as the reference.  order 1: the portable atan2 / atan of
 // traj_math.h, v*v*v for pow(v, 3) and the constant tan(M_PI / 4) = 0x1.fffffffffffffp-1 (what glibc returns),
 // which is what the HIP kernel evaluates; everything else is correctly rounded IEEE arithmetic in the
-// reference's order, so order 1 is bit-identical to the GPU.  Parity unpinned against the real reference.
+// reference's order, so order 1 is bit-identical to the GPU.  
+// PINNED (round 5): order 0 is bit-equal to the reference's own code -- the cited functions cut verbatim out of
+// /root/reference (oracle/ref_slices.py) and compiled into oracle/_ref/libdftpav_ref_next.so (oracle/ref_next_driver.cpp) --
+// on the scenarios the GPU tests of this step use (tests/test_ref_pin.py::test_states_oracle_is_bit_equal_to_GetState_and_the_servers_playback).
 #include <cmath>
 #include <cstdint>
 

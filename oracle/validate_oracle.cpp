@@ -15,7 +15,10 @@
 //
 // order 0: libm cos / sin / atan2, as the reference.  order 1: the portable functions of traj_math.h that
 // the HIP kernel evaluates; everything else is correctly rounded IEEE arithmetic in the reference's order,
-// so order 1 is bit-identical to the GPU.  Parity unpinned against the real reference.
+// so order 1 is bit-identical to the GPU.  
+// PINNED (round 5): order 0 is bit-equal to the reference's own code -- the cited functions cut verbatim out of
+// /root/reference (oracle/ref_slices.py) and compiled into oracle/_ref/libdftpav_ref_next.so (oracle/ref_next_driver.cpp) --
+// on the scenarios the GPU tests of this step use (tests/test_ref_pin.py::test_validate_oracle_is_bit_equal_to_CheckReplan).
 #include <cmath>
 #include <cstdint>
 

@@ -1,6 +1,7 @@
 """CPU checks of the corridor-generation oracle (oracle/corridor_oracle.cpp): the
 restatement of TrajPlanner::getRectangleConst (traj_manager.cpp:1213-1469).  The reference holds no
-golden vectors for it (parity unpinned); the pins are properties of the algorithm."""
+golden vectors for it; these are property checks -- the pin against the reference's own code is
+tests/test_ref_pin.py::test_corridor_oracle_is_bit_equal_to_getRectangleConst."""
 import numpy as np
 import pytest
 

@@ -1,5 +1,6 @@
 """CPU checks of the moving-obstacle fit oracle (oracle/fit_oracle.cpp): ConverSurroundTrajFromPoints
-(traj_manager.cpp:743-789).  No golden vectors in the reference (parity unpinned); the pins are the MINCO invariants."""
+(traj_manager.cpp:743-789).  No golden vectors in the reference; these are the MINCO invariants -- the pin against the
+reference's own code is tests/test_ref_pin.py::test_fit_oracle_is_bit_equal_to_ConverSurroundTrajFromPoints."""
 import numpy as np
 
 from dftpav_amd import scenarios as sc

@@ -1,6 +1,7 @@
 """CPU checks of the front-end resampling oracle (oracle/frontend_oracle.cpp): getKinoNode from
 SampleTraj on (kino_astar.cpp:606-795) and the resampling of RunMINCOParking (traj_manager.cpp:531-568).  The
-reference holds no golden vectors for it (parity unpinned); the pins are properties of the algorithm."""
+reference holds no golden vectors for it; these are property checks -- the pin against the reference's own code is
+tests/test_ref_pin.py::test_frontend_oracle_is_bit_equal_to_getKinoNode_and_RunMINCOParking."""
 import numpy as np
 import pytest
 

@@ -973,6 +973,35 @@ def test_golden_steps_on_device(hiplib):
     h.close()
 
 
+def test_step_kernels_against_the_reference_builds_vectors(hiplib):
+    """The kernels of the steps around the solve against vectors written by the REFERENCE'S OWN CODE (tests/golden/ref_steps.npz:
+    getRectangleConst, getKinoNode + RunMINCOParking's resampling, ConverSurroundTrajFromPoints cut out of /root/reference and
+    compiled, tests/golden/make_golden_ref_steps.py).  The reference calls libm's cos / sin where the device evaluates its own
+    portable ones, so the bar is the rounding of those calls: discrete outputs identical, continuous ones to 1e-11; a corridor
+    side may stop one 0.3 m step apart where an ulp moves a line sample across a cell boundary (none does on these 60 poses)."""
+    import os
+    from dftpav_amd.pods import FrontendParams
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    Z, R = np.load(os.path.join(g, "steps.npz")), np.load(os.path.join(g, "ref_steps.npz"))
+    h = hiplib.Handle(hiplib.default_params())
+    h.set_grid_map(Z["grid"], sc.MAP_RESL, tuple(Z["origin"]))
+    H = h.corridor_rectangles(Z["cor_states"])
+    assert np.abs(H - R["cor_out"]).max() < 1e-11
+    fe = h.frontend_resample(Z["fe_paths"], Z["fe_len"], Z["fe_ss"], Z["fe_es"], Z["fe_ct"], FrontendParams.default(K=6, Kd=9))
+    for k in ("n_seg", "singul", "piece_nums", "n_states"):
+        assert np.array_equal(fe[k], R["fe_out_" + k]), k
+    for k in ("piece_dt", "ini_states", "fin_states", "inner_pts", "states"):
+        assert np.abs(fe[k] - R["fe_out_" + k]).max() < 1e-11, k
+    h.fit_surround(Z["fit_states"])
+    gs = h.get_surround()
+    S, ns = Z["fit_states"].shape[0], Z["fit_states"].shape[1]
+    assert np.array_equal(gs["durations"].reshape(S, -1), R["fit_dur"]) and np.array_equal(gs["total"], R["fit_total"])
+    assert np.array_equal(gs["start"], R["fit_start"])
+    scale = np.abs(R["fit_coef"]).max()
+    assert np.abs(gs["coeffs"].reshape(S, ns - 1, 12) - R["fit_coef"]).max() < 1e-11 * scale
+    h.close()
+
+
 def test_overlapped_streams_and_hand_over_zero(hiplib, monkeypatch):
     """bench.py's default schedule: two handles (two HIP streams), hand-over 0 so that every trajectory finishes in its
     queue launch, batches launched alternately without waiting for the previous one -- results equal the plain

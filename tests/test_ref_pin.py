@@ -423,3 +423,204 @@ def test_order2_is_bit_equal_to_the_reference_on_a_correctly_rounded_libm_config
     s = sc.baseline_config(5, B=1)
     s.apply_resolution(p)
     _compare_order2_with_the_reference_on_a_correctly_rounded_libm(ref, oracle, p, s, 0, np.random.default_rng(5))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The steps either side of the solve path: the restatements oracle/{corridor,validate,states,fit,frontend}_oracle.cpp
+# against the reference's OWN code -- oracle/_ref/libdftpav_ref_next.so = the functions cut verbatim out of /root/reference by
+# oracle/ref_slices.py (traj_manager.cpp, map_adapter.cpp, kino_astar.cpp, traj_server_ros.cpp, the simulator's grid / outline
+# code) compiled by oracle/ref_next_driver.cpp.  Same process, same libm: order 0 of every restatement must agree BIT FOR BIT, on
+# the scenarios the GPU tests of these steps use (tests/test_gpu_parity.py).  The device's own order (order 1: portable
+# transcendentals) is tied to order 0 by the existing oracle tests.
+@pytest.fixture(scope="module")
+def refnext():
+    from oracle import pyoracle as po
+    if os.path.exists(REF_SRC):
+        from oracle import pyref
+        pyref.build()
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libdftpav_ref_next.so")):
+        pytest.skip("oracle/_ref/libdftpav_ref_next.so is not built here and /root/reference is absent")
+    po.ref_next_lib()
+    return po
+
+
+def test_ref_next_is_cut_from_the_reference_tree_by_line_range(refnext):
+    """every slice is where the manifest says, none of it is in the repository, and the library holds the five entry points"""
+    import subprocess
+    import sys
+    if os.path.exists(REF_SRC):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_slices.py"), "/root/reference", os.path.join(ROOT, "oracle", "_ref", "slices")],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+    tracked = subprocess.run(["git", "-C", ROOT, "ls-files", "oracle/_ref"], capture_output=True, text=True).stdout.strip()
+    assert tracked == ""
+    L = refnext.ref_next_lib()
+    for name in ("corridor_rectangles", "validate_trajectories", "sample_states", "fit_surround", "frontend_resample"):
+        assert hasattr(L, "ref_" + name)
+
+
+def _corridor_scene(seed):  # tests/test_gpu_parity.py::_corridor_scene
+    rng = np.random.default_rng(seed)
+    obs = np.column_stack([rng.uniform(-25, 25, 60), rng.uniform(-25, 25, 60), rng.uniform(0.5, 1.5, 60)])
+    grid, origin = sc.occupancy_grid(obs, arena=80.0)
+    states = np.column_stack([rng.uniform(-22, 22, 1500), rng.uniform(-22, 22, 1500), rng.uniform(-7.0, 7.0, 1500)])
+    return grid, origin, states
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_corridor_oracle_is_bit_equal_to_getRectangleConst(refnext, seed):
+    """§8(f)-1: corridor_oracle.cpp == TrajPlanner::getRectangleConst (traj_manager.cpp:1213-1469) over
+    TrajPlannerAdapter::CheckIfCollisionUsingLine (map_adapter.cpp:117-129) and the simulator's GridMapND"""
+    po = refnext
+    grid, origin, states = _corridor_scene(seed)
+    want = po.corridor_rectangles(grid, sc.MAP_RESL, origin, states, ref=True)
+    got = po.corridor_rectangles(grid, sc.MAP_RESL, origin, states, order=0)
+    assert np.array_equal(got, want)
+    # the rectangles are not trivial: sides stop at obstacles at many different lengths
+    ext = np.einsum("pki,pki->pk", want[:, :, :2], want[:, :, 2:] - states[:, None, :2])
+    assert len(np.unique(np.round(ext, 6))) > 50
+    # a pose outside the map (every sample out of range counts as free), an empty map of another resolution
+    far = np.array([[500.0, -300.0, 0.7]])
+    assert np.array_equal(po.corridor_rectangles(grid, sc.MAP_RESL, origin, far, order=0), po.corridor_rectangles(grid, sc.MAP_RESL, origin, far, ref=True))
+    empty = np.full((50, 70), 127, dtype=np.uint8)
+    assert np.array_equal(po.corridor_rectangles(empty, 0.25, (-3.0, -4.0), states[:40], order=0),
+                          po.corridor_rectangles(empty, 0.25, (-3.0, -4.0), states[:40], ref=True))
+    # the path poses of a BASELINE scenario on its own map (the corridor the solver's inputs are made of)
+    s = sc.baseline_config(3, B=4)
+    st = s.meta["states"]
+    c = (0.5 * (st[..., 0].min() + st[..., 0].max()), 0.5 * (st[..., 1].min() + st[..., 1].max()))
+    g2, o2 = sc.occupancy_grid(s.meta["obstacles"], arena=120.0, centre=c)
+    assert np.array_equal(po.corridor_rectangles(g2, sc.MAP_RESL, o2, st.reshape(-1, 3), order=0),
+                          po.corridor_rectangles(g2, sc.MAP_RESL, o2, st.reshape(-1, 3), ref=True))
+
+
+def _solved(po, cfg, B):
+    """optimised trajectories of a BASELINE config (the restatement's own solves): coefficients, piece durations, scenario"""
+    p = po.default_params()
+    s = sc.baseline_config(cfg, B=B)
+    s.apply_resolution(p)
+    r = po.solve_batch(p, s, nthreads=4, order=1)
+    co, dts = [], []
+    for b in range(s.B):
+        pr = po.OracleProblem(p, s, b, order=1)
+        pr.eval(r["x"][b])
+        a, d = pr.coeffs()
+        co.append(a)
+        dts.append(d)
+    return np.array(co), np.array(dts), s, p
+
+
+@pytest.mark.parametrize("cfg,B", [(3, 24), (2, 6)])
+def test_validate_oracle_is_bit_equal_to_CheckReplan(refnext, cfg, B):
+    """§8(f)-2: validate_oracle.cpp == the collision loop of TrajPlannerServer::CheckReplan (traj_server_ros.cpp:385-397) over
+    Trajectory::getPos / getAngle, SemanticMapManager::CheckCollisionUsingPosAndYaw (semantic_map_manager.cc:639-662) and
+    ShapeUtils::GetDenseVerticesOfOrientedBoundingBox (shapes.cc:110-149)"""
+    po = refnext
+    co, dts, s, _ = _solved(po, cfg, B)
+    lay = s.layout
+    st = s.meta["states"]
+    c = (0.5 * (st[..., 0].min() + st[..., 0].max()), 0.5 * (st[..., 1].min() + st[..., 1].max()))
+    obs = s.meta["obstacles"]
+    grid, origin = sc.occupancy_grid(obs, arena=140.0, centre=c)
+    a = po.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, lay.piece_nums, lay.singuls, order=0)
+    b = po.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, lay.piece_nums, lay.singuls, ref=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # obstacles dropped onto the nominal paths: most trajectories flagged, at the same first sample
+    rng = np.random.default_rng(cfg)
+    extra = [[st[h, k, 0], st[h, k, 1], 0.8] for h in range(st.shape[0]) for k in rng.choice(np.arange(st.shape[1] // 3, st.shape[1]), 3, replace=False)]
+    grid2, origin2 = sc.occupancy_grid(np.vstack([obs, np.array(extra)]), arena=140.0, centre=c)
+    a = po.validate_trajectories(grid2, sc.MAP_RESL, origin2, co, dts, lay.piece_nums, lay.singuls, order=0)
+    b = po.validate_trajectories(grid2, sc.MAP_RESL, origin2, co, dts, lay.piece_nums, lay.singuls, ref=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert b[0].mean() > 0.5 and (b[1][b[0] == 1] > 0).all() and len(np.unique(b[1])) > 1
+    # the server's 0.05 s and the outline's 0.1 m are constants of the reference: its code takes no others
+    with pytest.raises(ValueError):
+        po.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, lay.piece_nums, lay.singuls, sample_dt=0.21, ref=True)
+
+
+@pytest.mark.parametrize("cfg,B", [(2, 6), (3, 16)])
+def test_states_oracle_is_bit_equal_to_GetState_and_the_servers_playback(refnext, cfg, B):
+    """§8(f)-2, the read-out: states_oracle.cpp == Trajectory::GetState (poly_traj_utils.hpp:378-406) driven by the playback tick
+    of TrajPlannerServer::PublishData (traj_server_ros.cpp:248-259) with FilterSingularityState (:335-356), the segments chained
+    by TrajContainer::addSingulTraj as traj_manager.cpp:618-625 does"""
+    po = refnext
+    co, dts, s, p = _solved(po, cfg, B)
+    lay = s.layout
+    total = (dts * lay.piece_nums[None, :]).sum(axis=1)
+    for t0, dt, n, filt in [(0.0, 0.01, int(total.max() / 0.01) + 40, True), (0.0, 0.01, 300, False), (-0.3, 0.037, 600, True),
+                            (2.5, 0.2, 7, True)]:
+        a, na = po.sample_states(co, dts, lay.piece_nums, lay.singuls, t0=t0, sample_dt=dt, n_samples=n, filter_singularity=filt, order=0)
+        b, nb = po.sample_states(co, dts, lay.piece_nums, lay.singuls, t0=t0, sample_dt=dt, n_samples=n, filter_singularity=filt, ref=True)
+        assert np.array_equal(na, nb)
+        assert np.array_equal(a, b)
+    assert (nb > 0).all()
+    # a standstill where the filter acts: a reversing segment entered at zero speed (the heading jumps by pi between samples)
+    co2 = np.zeros((1, 5, 6, 2))
+    for q in range(3):
+        co2[0, q, 0] = [1.0 * q, 0.0]
+        co2[0, q, 1] = [1.0, 0.0]
+    for q in range(2):
+        co2[0, 3 + q, 0] = [3.0 - 0.05 * 1.5 * q, 0.0]
+        co2[0, 3 + q, 1] = [-0.05, 1e-9]
+    a, na = po.sample_states(co2, [[1.0, 1.5]], [3, 2], [1, -1], sample_dt=0.01, n_samples=700, order=0)
+    b, nb = po.sample_states(co2, [[1.0, 1.5]], [3, 2], [1, -1], sample_dt=0.01, n_samples=700, ref=True)
+    assert np.array_equal(na, nb) and np.array_equal(a, b)
+
+
+def test_fit_oracle_is_bit_equal_to_ConverSurroundTrajFromPoints(refnext):
+    """§8(f)-4: fit_oracle.cpp == TrajPlanner::ConverSurroundTrajFromPoints + state_to_flat_output (traj_manager.cpp:743-789,
+    139-158) over MinJerkOpt::reset / generate / getTraj"""
+    po = refnext
+    st = sc.predicted_states()
+    a, b = po.fit_surround(st, order=0), po.fit_surround(st, ref=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    rng = np.random.default_rng(5)
+    st2 = sc.predicted_states(pre_time=9.0, deltatime=0.75, cars=[(rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(1, 6),
+                                                                   rng.uniform(3, 20), rng.uniform(0, 6.28)) for _ in range(7)])
+    for sub in (st2, st2[:1], st2[:, :3]):
+        a, b = po.fit_surround(sub, order=0), po.fit_surround(sub, ref=True)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    z = st.copy()
+    z[:, 0, 3] = 0.0  # a car at rest: the 1e-5 speed rule of state_to_flat_output
+    a, b = po.fit_surround(z, order=0), po.fit_surround(z, ref=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("gears,K,Kd", [((1, -1), 16, 32), ((-1, 1, -1, 1), 32, 32), ((1,), 7, 11)])
+def test_frontend_oracle_is_bit_equal_to_getKinoNode_and_RunMINCOParking(refnext, gears, K, Kd):
+    """§8(f)-3: frontend_oracle.cpp == KinoAstar::getKinoNode from SampleTraj on (kino_astar.cpp:613-743), evaluatePos (:468-521),
+    evaluateDuration / evaluateLength (:744-795), getFlatState (:834-857) and the resampling loop of TrajPlanner::RunMINCOParking
+    (traj_manager.cpp:531-568).  (What builds SampleTraj -- the A* nodes and the OMPL Reeds-Shepp shot -- is not in the reference
+    tree's reach here: oracle/shot_oracle*.cpp stay property-pinned.)"""
+    from dftpav_amd.pods import FrontendParams
+    po = refnext
+    P, pl, ss, es, ct = sc.searched_paths(40, seed=len(gears) + K, gears=gears, seg_duration=6.0)
+    fp = FrontendParams.default(K=K, Kd=Kd)
+    a = po.frontend_resample(P, pl, ss, es, ct, fp, order=0)
+    b = po.frontend_resample(P, pl, ss, es, ct, fp, ref=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert (b["n_seg"] == len(gears)).all() and (b["n_states"][:, :len(gears)] > 0).all()
+    # fewer segments than gear changes: the counts are reported, nothing else is produced
+    a = po.frontend_resample(P, pl, ss, es, ct, fp, order=0, max_seg=max(1, len(gears) - 1))
+    b = po.frontend_resample(P, pl, ss, es, ct, fp, ref=True, max_seg=max(1, len(gears) - 1))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_step_oracles_reproduce_the_reference_codes_vectors(oracle):
+    """anywhere (no /root/reference needed): order 0 of the five restatements against tests/golden/ref_steps.npz, written by the
+    reference's own code on the inputs of tests/golden/steps.npz (tests/golden/make_golden_ref_steps.py).  Same libm as the
+    writer's (this image): bit equality."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_ref_steps", os.path.join(GOLDEN_DIR, "make_golden_ref_steps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    Z, R = np.load(os.path.join(GOLDEN_DIR, "steps.npz")), np.load(os.path.join(GOLDEN_DIR, "ref_steps.npz"))
+    got = mod.run(Z, order=0)
+    assert set(got) == set(R.files)
+    for k in got:
+        assert np.array_equal(got[k], R[k]), k

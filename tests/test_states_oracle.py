@@ -1,7 +1,8 @@
 """CPU checks of the trajectory read-out oracle (oracle/states_oracle.cpp): Trajectory::GetState
 (poly_traj_utils.hpp:378-406) over a time grid, played back as TrajPlannerServer::PublishData does
 (traj_server_ros.cpp:244-259) with FilterSingularityState (:335-356).  The reference holds no expected values for
-this step (parity unpinned); the pins are properties."""
+this step; these are property checks -- the pin against the reference's own code is
+tests/test_ref_pin.py::test_states_oracle_is_bit_equal_to_GetState_and_the_servers_playback."""
 import numpy as np
 
 

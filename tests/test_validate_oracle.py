@@ -1,6 +1,7 @@
 """CPU checks of the trajectory-validation oracle (oracle/validate_oracle.cpp): the collision
 re-check of TrajPlannerServer::CheckReplan (traj_server_ros.cpp:385-397).  No golden vectors exist in the
-reference (parity unpinned); the pins are properties."""
+reference; these are property checks -- the pin against the reference's own code is
+tests/test_ref_pin.py::test_validate_oracle_is_bit_equal_to_CheckReplan."""
 import numpy as np
 
 from dftpav_amd import scenarios as sc
