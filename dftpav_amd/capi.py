@@ -34,7 +34,7 @@ EXPORTS = [
     "dftpav_reeds_shepp_shots", "dftpav_mark", "dftpav_marks_elapsed_ms", "dftpav_batch_set_hand_over", "dftpav_batch_solve_chained", "dftpav_batch_finish", "dftpav_wire_size", "dftpav_wire_pack", "dftpav_wire_info", "dftpav_wire_unpack", "dftpav_set_surround_wire",
     "dftpav_batch_trace", "dftpav_batch_get_trace", "dftpav_plan_cycle", "dftpav_plan_cycle_fetch", "dftpav_batch_create_shaped",
     "dftpav_batch_set_order", "dftpav_batch_get_order", "dftpav_batch_trace_range", "dftpav_batch_get_trace_of",
-    "dftpav_comm_unique_id", "dftpav_comm_create", "dftpav_comm_destroy", "dftpav_comm_share", "dftpav_comm_layout", "dftpav_batch_allgather_results",
+    "dftpav_comm_available", "dftpav_comm_unique_id", "dftpav_comm_create", "dftpav_comm_destroy", "dftpav_comm_share", "dftpav_comm_layout", "dftpav_batch_allgather_results",
 ]
 
 
@@ -47,6 +47,14 @@ def comm_unique_id():
     if rc != OK:
         raise DftpavError(rc, "comm_unique_id: RCCL is not loadable")
     return buf
+
+
+def comm_available():
+    """is RCCL loadable behind the C-ABI?  (dftpav_comm_available: dlopen only -- no bootstrap root is started)"""
+    fn = lib().dftpav_comm_available
+    fn.argtypes = []
+    fn.restype = C.c_int
+    return bool(fn())
 
 
 def comm_layout(global_B, nranks, rank):

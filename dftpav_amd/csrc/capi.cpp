@@ -63,11 +63,17 @@ hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode,
 using namespace dftpav;
 
 // An RCCL communicator and the number of handles that hold it (its creator and the handles it was shared with, each on its own
-// host thread at most): the communicator is destroyed by whichever of them lets go last, in whatever order they do.
+// host thread at most): the communicator is destroyed by whichever of them lets go last, in whatever order they do.  An RCCL
+// communicator does not take concurrent enqueues: `mu` is held around every call on it (the holders' threads serialise there;
+// the ORDER of the collectives across ranks stays the host's business -- same order on every rank).  Taking and dropping a
+// reference (share / destroy / create) happens under g_comm_mu, so a handle never reads another's comm_ref while that one
+// lets go of it.
 struct CommShared {
   void *comm;
   std::atomic<int> holders;
+  std::mutex mu;
 };
+static std::mutex g_comm_mu;
 
 struct dftpav_handle {
   dftpav_params params;
@@ -1928,13 +1934,19 @@ extern "C" int dftpav_comm_unique_id(void *id) {
   std::memcpy(id, u.internal, DFTPAV_UNIQUE_ID_BYTES);
   return DFTPAV_OK;
 }
+// Is RCCL loadable here?  (dlopen + dlsym only: no bootstrap root is started, unlike dftpav_comm_unique_id.)
+extern "C" int dftpav_comm_available(void) { return rccl().ok ? 1 : 0; }
 extern "C" int dftpav_comm_destroy(dftpav_handle *h) {
   if (!h) return DFTPAV_E_INVALID;
   if (h->comm) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    std::lock_guard<std::mutex> reg(g_comm_mu);
     if (h->comm_ref && h->comm_ref->holders.fetch_sub(1) == 1) { // the last holder (every holder has drained its own stream)
-      (void)rccl().CommDestroy(h->comm_ref->comm);
+      {
+        std::lock_guard<std::mutex> lk(h->comm_ref->mu);
+        (void)rccl().CommDestroy(h->comm_ref->comm);
+      }
       delete h->comm_ref;
     }
     h->comm = nullptr;
@@ -1957,7 +1969,12 @@ extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const 
   RcclUniqueId u;
   std::memcpy(u.internal, unique_id, DFTPAV_UNIQUE_ID_BYTES);
   RCCLCHK(h, rccl().CommInitRank(&h->comm, nranks, u, rank));
-  h->comm_ref = new CommShared{h->comm, {1}};
+  {
+    std::lock_guard<std::mutex> reg(g_comm_mu);
+    h->comm_ref = new CommShared;
+    h->comm_ref->comm = h->comm;
+    h->comm_ref->holders.store(1);
+  }
   h->comm_ranks = nranks;
   h->comm_rank = rank;
   return DFTPAV_OK;
@@ -1968,12 +1985,16 @@ extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const 
 // same order of collectives on every rank -- which a round-robin over the handles is.
 extern "C" int dftpav_comm_share(dftpav_handle *h, dftpav_handle *owner) {
   if (!h || !owner || h == owner) return DFTPAV_E_INVALID;
-  if (!owner->comm || !owner->comm_ref || owner->device != h->device) {
+  {
+    std::lock_guard<std::mutex> reg(g_comm_mu);
+    if (owner->comm && owner->comm_ref && owner->comm_ref == h->comm_ref) return DFTPAV_OK; // already the same communicator
+  }
+  if (int rc = dftpav_comm_destroy(h)) return rc;  // (takes g_comm_mu itself)
+  std::lock_guard<std::mutex> reg(g_comm_mu);
+  if (!owner->comm || !owner->comm_ref || owner->device != h->device) { // read under the lock: the owner may be letting go
     h->err = "dftpav_comm_share: the other handle needs a communicator (dftpav_comm_create, or shared itself) on the same device";
     return DFTPAV_E_INVALID;
   }
-  if (owner->comm_ref == h->comm_ref) return DFTPAV_OK; // already the same communicator
-  if (int rc = dftpav_comm_destroy(h)) return rc;
   h->comm = owner->comm;
   h->comm_ref = owner->comm_ref;
   h->comm_ref->holders.fetch_add(1);
@@ -2008,6 +2029,7 @@ extern "C" int dftpav_batch_allgather_results(dftpav_batch *b, int global_B, voi
   if (block <= b->B + 1) {
     // the send buffer IS the batch's record array (its epilogue-written records, one zero record of padding behind them for
     // the ranks whose shard is one short of the block): nothing of ours runs between the solve and the collective
+    std::lock_guard<std::mutex> lk(h->comm_ref->mu);
     RCCLCHK(h, rccl().AllGather(b->d_records, all_records, bytes, kNcclUint8, h->comm, h->stream));
     return DFTPAV_OK;
   }
@@ -2019,6 +2041,7 @@ extern "C" int dftpav_batch_allgather_results(dftpav_batch *b, int global_B, voi
   }
   HIPCHK(h, hipMemsetAsync(h->d_comm_send, 0, bytes, h->stream));
   HIPCHK(h, hipMemcpyAsync(h->d_comm_send, b->d_records, (size_t)16 * count, hipMemcpyDeviceToDevice, h->stream));
+  std::lock_guard<std::mutex> lk(h->comm_ref->mu);
   RCCLCHK(h, rccl().AllGather(h->d_comm_send, all_records, bytes, kNcclUint8, h->comm, h->stream));
   return DFTPAV_OK;
 }

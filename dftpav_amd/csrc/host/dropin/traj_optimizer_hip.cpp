@@ -69,7 +69,9 @@ struct Backend {
   // the last solve, as lbfgs_optimize leaves it in OptimizeTrajectory's locals (traj_optimizer.cpp:159-175)
   std::vector<double> x;
   double final_cost = 0.0;
-  int status = 0, success = 0, iters = 0, evals = 0, order = DFTPAV_ORDER_REFERENCE;
+  int status = 0, success = 0, iters = 0, evals = 0, order = DFTPAV_ORDER_REFERENCE; // order: the one the last solve RAN in
+  int order_wanted = -1;            // the order the cached batch was created for (the cache key)
+  bool ref_unsupported = false;     // this layout is outside the reference-order kernel's limits: do not ask again
   bool solved = false;
   ~Backend() {
     if (b) dftpav_batch_destroy(b);
@@ -245,7 +247,7 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
 
   const int S_now = surround_trajs_ ? (int)surround_trajs_->size() : 0;
   const int order = wanted_order();
-  if (!be->b || be->piece_nums != piece_nums || be->singuls != singuls || be->H != H || be->S_at_create != S_now || be->order != order) {
+  if (!be->b || be->piece_nums != piece_nums || be->singuls != singuls || be->H != H || be->S_at_create != S_now || be->order_wanted != order) {
     if (be->b) dftpav_batch_destroy(be->b);
     be->b = nullptr;
     dftpav_layout lay{M, piece_nums.data(), singuls.data(), H};
@@ -259,7 +261,8 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
     be->singuls = singuls;
     be->H = H;
     be->S_at_create = S_now;
-    be->order = order;
+    be->order_wanted = order;
+    be->ref_unsupported = false;
   }
   dftpav_batch_data d;
   std::memset(&d, 0, sizeof(d));
@@ -271,13 +274,15 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
   d.t_now = now;
   d.help_eps = help_eps;
   int rc = dftpav_batch_upload(be->b, &d);
-  if (rc == DFTPAV_OK && order == DFTPAV_ORDER_REFERENCE) {
+  be->order = order;
+  if (rc == DFTPAV_OK && order == DFTPAV_ORDER_REFERENCE && !be->ref_unsupported) {
     rc = dftpav_batch_set_order(be->b, DFTPAV_ORDER_REFERENCE);
     if (rc == DFTPAV_E_UNSUPPORTED) { // a layout outside the reference-order kernel's limits: the throughput order solves it
-      rc = DFTPAV_OK;
-      be->order = DFTPAV_ORDER_DEVICE;
+      rc = DFTPAV_OK;                 // (remembered with the cached batch: the 20 Hz cycle neither recreates it nor asks again)
+      be->ref_unsupported = true;
     }
   }
+  if (be->ref_unsupported) be->order = DFTPAV_ORDER_DEVICE;
   if (rc == DFTPAV_OK) rc = dftpav_batch_solve_async(be->b);
   dftpav_layout lay{M, piece_nums.data(), singuls.data(), H};
   const int n = dftpav_num_vars(&lay);

@@ -84,9 +84,12 @@ class RcclComm:
             dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         uid, ok = np.zeros(128, dtype=np.uint8), 1
         try:
-            probe = capi.comm_unique_id()      # loads RCCL behind the C-ABI; every rank probes, rank 0's id is the one used
+            # every rank probes that RCCL loads behind the C-ABI (dlopen only); rank 0 alone makes an id -- ncclGetUniqueId starts
+            # a bootstrap root (a listening socket and a thread) that only the id's maker should own
+            if not capi.comm_available():
+                raise RuntimeError("RCCL (librccl.so.1) is not loadable")
             if self.rank == 0:
-                uid = probe
+                uid = capi.comm_unique_id()
         except Exception as ex:  # noqa: BLE001
             ok, self._err = 0, str(ex)
         if self.world > 1:

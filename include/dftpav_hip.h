@@ -417,13 +417,16 @@ int dftpav_batch_records(dftpav_batch *b, void *host_dst);
 /* The collective itself behind the C-ABI, for a C++ host (the reference's caller is one: TrajPlanner::RunMINCOParking,
  * traj_manager.cpp:608-610) that shards its restarts / hypotheses over the GPUs of a node, one process (or thread) and one
  * dftpav_handle per GPU: ONE RCCL all-gather of the 16-byte records over xGMI, enqueued on the handle's stream.
+ *   dftpav_comm_available   1 where RCCL is loadable (dlopen only; every rank may ask), else 0
  *   dftpav_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands the bytes to the other ranks by whatever
  *                           channel the host has (MPI, a socket, torch.distributed ...)
  *   dftpav_comm_create      every rank, collectively: ncclCommInitRank on the handle's device
  *   dftpav_comm_share       another handle (= HIP stream) of the same process and device uses the owner's communicator: a host
  *                           with k batches in flight on k handles sets up one communicator per rank, not k.  The communicator
  *                           is held by all of them and destroyed when the last lets go (dftpav_comm_destroy / dftpav_destroy,
- *                           any order); every rank issues its collectives in the same order (round-robin over the handles does)
+ *                           any order); every rank issues its collectives in the same order (round-robin over the handles does).
+ *                           The holders may live on different host threads: the library serialises its calls on the shared
+ *                           communicator with a lock (RCCL takes no concurrent enqueues); the ORDER is still the host's to keep
  *   dftpav_comm_layout      the contiguous shard [first, first + count) of a rank out of global_B trajectories, and `block` =
  *                           the largest shard: the gathered buffer holds nranks blocks of `block` records, rank r's shard at
  *                           the start of block r (the pad, at most one record, is zero)
@@ -437,6 +440,7 @@ int dftpav_batch_records(dftpav_batch *b, void *host_dst);
  * starts (the default is 4 hardware queues per process: the fifth stream's launch waits for one of the first four to drain,
  * which halves the throughput of 8 batches in flight and lets a collective queue behind an unrelated batch). */
 #define DFTPAV_UNIQUE_ID_BYTES 128
+int dftpav_comm_available(void);
 int dftpav_comm_unique_id(void *id128);
 int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const void *id128);
 int dftpav_comm_destroy(dftpav_handle *h);
