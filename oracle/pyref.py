@@ -25,6 +25,9 @@ _LIB_DROPIN = None
 # device's reference order are bit-equal to where the reference's loop calls libm
 _SO_CR = os.path.join(_HERE, "_ref", "libdftpav_ref_cr.so")
 _LIB_CR = None
+# the reference over the stand-in Eigen with the reductions of dynamic vectors in Eigen 3.3's SSE2 order (DFTPAV_SHIM_EIGEN_REDUX=1)
+_SO_EIGEN = os.path.join(_HERE, "_ref", "libdftpav_ref_eigen.so")
+_LIB_EIGEN = None
 
 
 def build():
@@ -50,6 +53,17 @@ def cr_lib():
         _bind_common(L)
         _LIB_CR = L
     return _LIB_CR
+
+
+def eigen_lib():
+    global _LIB_EIGEN
+    if _LIB_EIGEN is None:
+        if not os.path.exists(_SO_EIGEN):
+            build()
+        L = C.CDLL(_SO_EIGEN)
+        _bind_common(L)
+        _LIB_EIGEN = L
+    return _LIB_EIGEN
 
 
 def dropin_available():
@@ -126,10 +140,11 @@ class RefProblem:
     """PolyTrajOptimizer of the reference on element b of a Scenario (same inputs as oracle.pyoracle.OracleProblem).
     dropin=True: the same class object with the drop-in's implementation behind it (libdftpav_dropin.so, GPU)."""
 
-    def __init__(self, params, scen, b=0, dropin=False, cr=False):
-        """cr=True: the reference's objects linked against the correctly rounded libm of oracle/cr_libm.c"""
+    def __init__(self, params, scen, b=0, dropin=False, cr=False, eigen_redux=False):
+        """cr=True: the reference's objects linked against the correctly rounded libm of oracle/cr_libm.c;
+        eigen_redux=True: the build whose dynamic-vector reductions add in Eigen 3.3's SSE2 order"""
         from oracle.pyoracle import OracleProblem
-        self._L = dropin_lib() if dropin else (cr_lib() if cr else lib())
+        self._L = dropin_lib() if dropin else (cr_lib() if cr else (eigen_lib() if eigen_redux else lib()))
         # reuse the flattening of the oracle's wrapper (plain arrays; nothing of the oracle's arithmetic is involved)
         self._flat = OracleProblem.__new__(OracleProblem)
         lay = scen.layout

@@ -624,3 +624,28 @@ def test_step_oracles_reproduce_the_reference_codes_vectors(oracle):
     assert set(got) == set(R.files)
     for k in got:
         assert np.array_equal(got[k], R[k]), k
+
+
+def test_eigen_redux_build_differs_only_in_the_dynamic_reductions(ref):
+    """oracle/_ref/libdftpav_ref_eigen.so (the stand-in Eigen's reductions of dynamic vectors in Eigen 3.3's SSE2 order,
+    scripts/eigen_redux_cpu.py): costFunctionCallback has no such reduction -- same bits as the sequential build on every
+    evaluation -- while lbfgs_optimize's dot products do, so whole solves part ways (profiles/r05_eigen_redux_cpu.json: 0 of 2048
+    keep their bits, with the spread of a one-ulp perturbation)."""
+    if not os.path.exists(REF_SRC):
+        pytest.skip("needs /root/reference to build the variant")
+    from oracle import pyoracle as po
+    p = po.default_params()
+    s = sc.baseline_config(3, B=3, seed=20240)
+    s.apply_resolution(p)
+    parted = 0
+    for b in range(3):
+        a, e = ref.RefProblem(p, s, b), ref.RefProblem(p, s, b, eigen_redux=True)
+        ra, re_ = a.optimize(trace=True), e.optimize(trace=True)
+        assert np.array_equal(ra["eval_x"][0], re_["eval_x"][0])
+        assert ra["eval_f"][0] == re_["eval_f"][0] and np.array_equal(ra["eval_g"][0], re_["eval_g"][0])
+        x = ra["x"]
+        fa, ga = a.eval(x)
+        fe, ge = e.eval(x)
+        assert fa == fe and np.array_equal(ga, ge)
+        parted += int(not np.array_equal(ra["x"], re_["x"]))
+    assert parted >= 2
