@@ -582,7 +582,7 @@ def side_single(ctx, args, po, cores, cfg, seeds):
     the last bit), so the latency is quoted as the median over the seeded instances, with the per-iteration time beside it"""
     from oracle import pyref as _pr
     p2 = capi.default_params()
-    ms, its, oks, ms_ref, its_ref, eq2, eqb, eqc = [], [], [], [], [], [], [], []
+    ms, its, oks, ms_ref, its_ref, eq2, eqb, eqc, best64 = [], [], [], [], [], [], [], [], []
     for sd in seeds:
         s2 = sc.baseline_config(cfg, B=1, seed=args.seed + 17 * sd)
         s2.apply_resolution(p2)
@@ -609,6 +609,20 @@ def side_single(ctx, args, po, cores, cfg, seeds):
             eqb.append(bool(rr_["final_cost"] == r3["final_cost"][0] and np.array_equal(rr_["x"], r3["x"][0])))
         if _pr.cr_available():   # the reference's own objects on a correctly rounded libm (oracle/cr_libm.c): must agree on ALL
             eqc.append(same_as_ref_run(r3, 0, _pr.RefProblem(p2, s2, 0, cr=True).optimize()))
+        # one trajectory leaves 255 CUs idle: the same call as slot 0 of a batch of 64 with 63 seeded restarts in the SAME launch
+        # (what the drop-in does with DFTPAV_DROPIN_RESTARTS=64): time to the best of 64, slot 0's bits untouched
+        sK = s2.with_restarts(h2, 64, seed=args.seed)
+        bK = capi.Batch(h2, sK.layout, 64)
+        bK.upload(sK)
+        bK.set_order(capi.ORDER_REFERENCE)
+        bK.solve_async(); bK.sync()
+        bK.solve_async(); bK.sync()
+        rK = bK.results()
+        okK = rK["success"] != 0
+        best64.append({"kernel_ms": bK.last_solve_ms(), "slot0_bit_equal_to_the_lone_solve": bool(all(np.array_equal(rK[k_][0], r3[k_][0]) for k_ in SOLVE_FIELDS)),
+                       "slot0_cost": float(rK["final_cost"][0]), "best_cost": float(rK["final_cost"][okK].min()) if okK.any() else None,
+                       "successes": int(okK.sum()), "lone_solve_ms": ms_ref[-1]})
+        bK.close()
         b2.close(); h2.close()
     ms, its, ms_ref, its_ref = np.array(ms), np.array(its), np.array(ms_ref), np.array(its_ref)
     return {"batch": 1, "instances": len(seeds), "p50_ms_per_solve": float(np.median(ms)), "min_ms": float(ms.min()),
@@ -619,7 +633,12 @@ def side_single(ctx, args, po, cores, cfg, seeds):
                                 "bit_equal_to_the_reference_program_with_correctly_rounded_cos_sin": int(sum(eq2)),
                                 "bit_equal_to_the_reference_build_on_this_host": (int(sum(eqb)) if eqb else None),
                                 "bit_equal_to_the_reference_build_on_a_correctly_rounded_libm": (int(sum(eqc)) if eqc else None),
-                                "instances": len(seeds)}}
+                                "instances": len(seeds),
+                                "best_of_64_restarts_in_one_launch": {
+                                    "p50_ms": float(np.median([r_["kernel_ms"] for r_ in best64])), "p50_ms_of_the_lone_solve": float(np.median([r_["lone_solve_ms"] for r_ in best64])),
+                                    "slot0_bit_equal_to_the_lone_solve_on_all": bool(all(r_["slot0_bit_equal_to_the_lone_solve"] for r_ in best64)),
+                                    "median_cost_ratio_best_over_slot0": float(np.median([r_["best_cost"] / r_["slot0_cost"] for r_ in best64 if r_["best_cost"] is not None])),
+                                    "mean_successes_of_64": float(np.mean([r_["successes"] for r_ in best64]))}}}
 
 
 def side_configs4_reference_order(ctx, args, po, cores, B=64):

@@ -26,6 +26,13 @@
 // one trajectory per 20 Hz cycle (traj_server_ros.cpp:100), and the reference order reproduces the CPU planner's decision
 // bit for bit (for gear shifts / moving obstacles: the reference's program with correctly rounded cos / sin / exp / log /
 // pow in place of libm's host-dependent ones).
+//
+// One trajectory per call leaves 255 of 256 CUs idle.  Opt-in, DFTPAV_DROPIN_RESTARTS=K (2 .. 1024): the call's problem goes
+// into slot 0 of a batch of K, slots 1 .. K-1 are seeded restarts of it (dftpav_sample_restarts: waypoints moved by N(0, 0.3^2) m,
+// segment durations scaled by U[0.8, 1.25] -- SURVEY.md section 8(d) "Restarts"), all solved in the same launch; with a map given
+// (dftpav_dropin_set_map) the candidates are re-checked for collisions on the device (CheckReplan's loop, dftpav_batch_validate).
+// The best successful, collision-free candidate fills jerkOpt_container; slot 0 -- the reference's own solve, same bits as
+// without restarts -- stays readable through dftpav_dropin_last_solve, the choice through dftpav_dropin_last_choice.
 // (every standard header the reference's headers pull in comes first: the access lift below must not reach libstdc++)
 #include <algorithm>
 #include <cassert>
@@ -73,6 +80,10 @@ struct Backend {
   int order_wanted = -1;            // the order the cached batch was created for (the cache key)
   bool ref_unsupported = false;     // this layout is outside the reference-order kernel's limits: do not ask again
   bool solved = false;
+  // restarts (DFTPAV_DROPIN_RESTARTS): size of the cached batch; the candidate OptimizeTrajectory returned and what it cost
+  int K = 1, chosen = 0, n_success = 0, n_colliding = 0;
+  double chosen_cost = 0.0, solve_ms = 0.0;
+  bool have_map = false;
   ~Backend() {
     if (b) dftpav_batch_destroy(b);
     if (h) dftpav_destroy(h);
@@ -102,6 +113,11 @@ void drop_backend(const void *obj) {
     delete it->second;
     r.erase(it);
   }
+}
+int wanted_restarts() {
+  const char *e = std::getenv("DFTPAV_DROPIN_RESTARTS");
+  const int k = e ? std::atoi(e) : 1;
+  return k < 1 ? 1 : (k > 1024 ? 1024 : k);
 }
 int wanted_order() {
   const char *e = std::getenv("DFTPAV_DROPIN_ORDER");
@@ -247,11 +263,13 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
 
   const int S_now = surround_trajs_ ? (int)surround_trajs_->size() : 0;
   const int order = wanted_order();
-  if (!be->b || be->piece_nums != piece_nums || be->singuls != singuls || be->H != H || be->S_at_create != S_now || be->order_wanted != order) {
+  const int K = wanted_restarts();
+  if (!be->b || be->piece_nums != piece_nums || be->singuls != singuls || be->H != H || be->S_at_create != S_now || be->order_wanted != order ||
+      be->K != K) {
     if (be->b) dftpav_batch_destroy(be->b);
     be->b = nullptr;
     dftpav_layout lay{M, piece_nums.data(), singuls.data(), H};
-    int rc = dftpav_batch_create(be->h, &lay, 1, &be->b);
+    int rc = dftpav_batch_create(be->h, &lay, K, &be->b);
     if (rc != DFTPAV_OK) {
       ROS_ERROR("dftpav_batch_create: %d %s", rc, dftpav_last_error(be->h));
       be->b = nullptr;
@@ -263,13 +281,38 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
     be->S_at_create = S_now;
     be->order_wanted = order;
     be->ref_unsupported = false;
+    be->K = K;
+  }
+  std::vector<double> Ts(initTs.data(), initTs.data() + M);
+  if (K > 1) { // slot 0: the call's problem; slots 1 .. K-1: its seeded restarts, same boundary states and corridor
+    const int n_inner = (int)inner.size();
+    std::vector<double> rin((size_t)K * n_inner), rts((size_t)K * M);
+    unsigned long long seed = 20240;
+    if (const char *e = std::getenv("DFTPAV_DROPIN_SEED")) seed = std::strtoull(e, nullptr, 10);
+    int rc = dftpav_sample_restarts(be->h, inner.data(), Ts.data(), 1, K, n_inner, M, 0.3, 0.8, 1.25, seed, rin.data(), rts.data());
+    if (rc != DFTPAV_OK) {
+      ROS_ERROR("dftpav_sample_restarts: %d %s", rc, dftpav_last_error(be->h));
+      return false;
+    }
+    for (int k = 1; k < K; k++) // a restart's duration must stay above mini_T as the call's own must (traj_optimizer.cpp:30)
+      for (int i = 0; i < M; i++) rts[(size_t)k * M + i] = std::max(rts[(size_t)k * M + i], mini_T);
+    auto tile = [&](std::vector<double> &v) {
+      const size_t n1 = v.size();
+      v.resize(n1 * K);
+      for (int k = 1; k < K; k++) std::copy(v.begin(), v.begin() + n1, v.begin() + (size_t)k * n1);
+    };
+    tile(ini);
+    tile(fin);
+    tile(cor);
+    inner.swap(rin);
+    Ts.swap(rts);
   }
   dftpav_batch_data d;
   std::memset(&d, 0, sizeof(d));
   d.ini_states = ini.data();
   d.fin_states = fin.data();
   d.inner_pts = inner.data();
-  d.init_Ts = initTs.data();
+  d.init_Ts = Ts.data();
   d.corridor = cor.data();
   d.t_now = now;
   d.help_eps = help_eps;
@@ -288,20 +331,45 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
   const int n = dftpav_num_vars(&lay);
   variable_num_ = n;
   be->x.assign(n, 0.0);
-  if (rc == DFTPAV_OK)
-    rc = dftpav_batch_results(be->b, be->x.data(), &be->final_cost, &be->status, &be->success, &be->iters, &be->evals, nullptr, nullptr);
+  std::vector<double> xs((size_t)K * n), costs(K);
+  std::vector<int> status(K), success(K), iters(K), evals(K), colliding(K, 0), first(K, -1);
+  if (rc == DFTPAV_OK) rc = dftpav_batch_results(be->b, xs.data(), costs.data(), status.data(), success.data(), iters.data(), evals.data(), nullptr, nullptr);
+  if (rc == DFTPAV_OK && K > 1 && be->have_map) rc = dftpav_batch_validate(be->b, 0.05, 0.1, colliding.data(), first.data()); // traj_server_ros.cpp:385-397
   if (rc != DFTPAV_OK) {
     ROS_ERROR("dftpav: %d %s", rc, dftpav_last_error(be->h));
     return false;
   }
+  // slot 0 is the reference's own solve
+  std::copy(xs.begin(), xs.begin() + n, be->x.begin());
+  be->final_cost = costs[0];
+  be->status = status[0];
+  be->success = success[0];
+  be->iters = iters[0];
+  be->evals = evals[0];
   iter_num_ = be->iters;
   be->solved = true;
+  // the candidate that is returned: the cheapest successful one that does not collide (slot 0 when there is none, or no restarts)
+  int chosen = 0;
+  be->n_success = be->n_colliding = 0;
+  for (int k = 0; k < K; k++) {
+    be->n_success += success[k] != 0;
+    be->n_colliding += colliding[k] != 0;
+    const bool ok_k = success[k] != 0 && colliding[k] == 0, ok_c = success[chosen] != 0 && colliding[chosen] == 0;
+    if (ok_k && (!ok_c || costs[k] < costs[chosen])) chosen = k;
+  }
+  be->chosen = chosen;
+  be->chosen_cost = costs[chosen];
+  {
+    float ms = 0.0f;
+    (void)dftpav_batch_last_solve_ms(be->b, &ms);
+    be->solve_ms = ms;
+  }
 
   // jerkOpt_container: what getMinJerkOptPtr() hands to traj_manager.cpp:618-625 -- per gear segment the coefficients and the
   // piece duration of the solution, regenerated on the device from the final x (dftpav_batch_coeffs)
   int Ntot = 0;
   for (int i = 0; i < M; i++) Ntot += piece_nums[i];
-  std::vector<double> cf((size_t)12 * Ntot), dt(M);
+  std::vector<double> cf((size_t)12 * Ntot * K), dt((size_t)M * K);
   rc = dftpav_batch_coeffs(be->b, cf.data(), dt.data());
   if (rc != DFTPAV_OK) {
     ROS_ERROR("dftpav_batch_coeffs: %d %s", rc, dftpav_last_error(be->h));
@@ -309,7 +377,7 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
   }
   jerkOpt_container.clear();
   jerkOpt_container.resize(M);
-  size_t off = 0;
+  size_t off = (size_t)12 * Ntot * chosen;
   for (int i = 0; i < M; i++) {
     plan_utils::MinJerkOpt &mj = jerkOpt_container[i];
     const int N = piece_nums[i];
@@ -319,11 +387,11 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
       for (int dd = 0; dd < 2; dd++) mj.c(r, dd) = cf[off + 2 * r + dd];
     off += (size_t)12 * N;
     mj.t(0) = 1.0;
-    mj.t(1) = dt[i];
+    mj.t(1) = dt[(size_t)M * chosen + i];
     mj.headPVA = iniStates[i];
     mj.tailPVA = finStates[i];
   }
-  return be->success != 0;
+  return success[chosen] != 0;
 }
 
 // traj_optimizer.cpp:206-350 -- lbfgs_evaluate_t (lbfgs.hpp:200-202): one evaluation of the cost and its gradient at x for the
@@ -352,4 +420,35 @@ extern "C" int dftpav_dropin_last_solve(const void *optimizer, int *n, const dou
   if (evals) *evals = be->evals;
   if (order) *order = be->order;
   return 1;
+}
+
+// With DFTPAV_DROPIN_RESTARTS=K: which candidate the last OptimizeTrajectory returned (0 = the call's own problem), its cost, how
+// many of the K succeeded / were rejected by the collision re-check, and the device time of the launch.  Returns K (0: no solve).
+extern "C" int dftpav_dropin_last_choice(const void *optimizer, int *chosen, double *chosen_cost, int *n_success, int *n_colliding, double *solve_ms) {
+  Backend *be = backend_of(optimizer, false);
+  if (!be || !be->solved) return 0;
+  if (chosen) *chosen = be->chosen;
+  if (chosen_cost) *chosen_cost = be->chosen_cost;
+  if (n_success) *n_success = be->n_success;
+  if (n_colliding) *n_colliding = be->n_colliding;
+  if (solve_ms) *solve_ms = be->solve_ms;
+  return be->K;
+}
+// The occupancy grid the candidates are re-checked on (the planner has it: TrajPlannerMapItf::GetObstacleMap, map_interface.h:52);
+// grid[ix + size_x * iy], 80 = occupied.  Without it the restarts are ranked by cost alone.
+extern "C" int dftpav_dropin_set_map(const void *optimizer, const unsigned char *grid, int size_x, int size_y, double resolution, double origin_x,
+                                     double origin_y) {
+  Backend *be = backend_of(optimizer, false);
+  if (!be || !be->h) return DFTPAV_E_INVALID;
+  dftpav_grid_map m;
+  std::memset(&m, 0, sizeof(m));
+  m.cells = grid;
+  m.size_x = size_x;
+  m.size_y = size_y;
+  m.resolution = resolution;
+  m.origin_x = origin_x;
+  m.origin_y = origin_y;
+  const int rc = dftpav_set_grid_map(be->h, &m);
+  be->have_map = rc == DFTPAV_OK;
+  return rc;
 }

@@ -73,6 +73,16 @@ class Scenario:
                         np.ascontiguousarray(self.corridor[idx]), self.t_now, self.help_eps, self.surround,
                         dict(self.meta))
 
+    def with_restarts(self, handle, K, b=0, sigma=0.3, lo=0.8, hi=1.25, seed=20240):
+        """Element b of this batch as slot 0 of a batch of K, slots 1 .. K-1 its seeded restarts from the device's sampler
+        (dftpav_sample_restarts: waypoints moved by N(0, sigma^2), durations scaled by U[lo, hi]) -- what the drop-in builds with
+        DFTPAV_DROPIN_RESTARTS=K (csrc/host/dropin/traj_optimizer_hip.cpp); boundary states and corridor are shared."""
+        inner, durs = handle.sample_restarts(self.inner_pts[b:b + 1], self.init_Ts[b:b + 1], K, sigma=sigma, lo=lo, hi=hi, seed=seed)
+        rep = lambda a: np.ascontiguousarray(np.repeat(a[b:b + 1], K, axis=0))
+        return Scenario(self.name + "+restarts", self.layout, self.K, self.Kd, K, rep(self.ini_states), rep(self.fin_states),
+                        np.ascontiguousarray(inner), np.ascontiguousarray(durs), rep(self.corridor), self.t_now, self.help_eps, self.surround,
+                        dict(self.meta))
+
 
 # --------------------------------------------------------------------------
 # nominal ("front-end") path: a kinematic car driven by a seeded control script

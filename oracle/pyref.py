@@ -192,6 +192,20 @@ class RefProblem:
         self.result = r
         return r
 
+    def last_choice(self):
+        """drop-in only (DFTPAV_DROPIN_RESTARTS=K): dict(K, chosen, chosen_cost, n_success, n_colliding, solve_ms) of the last optimize()"""
+        ch, ns, nc = C.c_int(0), C.c_int(0), C.c_int(0)
+        cost, ms = C.c_double(0), C.c_double(0)
+        K = self._L.ref_dropin_last_choice(C.c_void_p(self.ctx), C.byref(ch), C.byref(cost), C.byref(ns), C.byref(nc), C.byref(ms))
+        return dict(K=K, chosen=ch.value, chosen_cost=cost.value, n_success=ns.value, n_colliding=nc.value, solve_ms=ms.value)
+
+    def set_map(self, grid, resolution, origin):
+        """drop-in only: the occupancy grid the restarts' candidates are re-checked on (uint8 [size_y][size_x], 80 = occupied)"""
+        g = np.ascontiguousarray(grid, dtype=np.uint8)
+        self._keep["grid"] = g
+        return self._L.ref_dropin_set_map(C.c_void_p(self.ctx), g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], C.c_double(resolution),
+                                          C.c_double(origin[0]), C.c_double(origin[1]))
+
     def eval(self, x):
         """costFunctionCallback at x (runs OptimizeTrajectory once first: its set-up lives in the object's members)."""
         if self.result is None:

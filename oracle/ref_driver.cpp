@@ -24,6 +24,8 @@
 using plan_manage::PolyTrajOptimizer;
 #ifdef DFTPAV_DROPIN
 extern "C" int dftpav_dropin_last_solve(const void *optimizer, int *n, const double **x, double *final_cost, int *status, int *iters, int *evals, int *order);
+extern "C" int dftpav_dropin_last_choice(const void *optimizer, int *chosen, double *chosen_cost, int *n_success, int *n_colliding, double *solve_ms);
+extern "C" int dftpav_dropin_set_map(const void *optimizer, const unsigned char *grid, int size_x, int size_y, double resolution, double origin_x, double origin_y);
 #endif
 
 namespace {
@@ -115,6 +117,13 @@ extern "C" {
 int ref_abi_version(void) { return 1; }
 #ifdef DFTPAV_DROPIN
 int ref_is_dropin(void) { return 1; }
+// the drop-in's restarts (DFTPAV_DROPIN_RESTARTS): which candidate the last OptimizeTrajectory returned, and the map they are re-checked on
+int ref_dropin_last_choice(void *h, int *chosen, double *chosen_cost, int *n_success, int *n_colliding, double *solve_ms) {
+  return dftpav_dropin_last_choice(&static_cast<RefCtx *>(h)->opt, chosen, chosen_cost, n_success, n_colliding, solve_ms);
+}
+int ref_dropin_set_map(void *h, const unsigned char *grid, int size_x, int size_y, double resolution, double origin_x, double origin_y) {
+  return dftpav_dropin_set_map(&static_cast<RefCtx *>(h)->opt, grid, size_x, size_y, resolution, origin_x, origin_y);
+}
 #else
 int ref_is_dropin(void) { return 0; }
 #endif

@@ -74,6 +74,9 @@ class Handle:
         return self._timed(po.reeds_shepp_shots, from_, to, max_cur=max_cur, checkl=checkl, max_samples=max_samples, grid=g,
                            resolution=res, origin=org, vertex_res=vertex_res, order=1)
 
+    def sample_restarts(self, inner, durs, n_restarts, sigma=0.3, lo=0.8, hi=1.25, seed=0):
+        return po.sample_restarts(inner, durs, n_restarts, sigma=sigma, lo=lo, hi=hi, seed=seed)
+
     def comm_create(self, nranks, rank, unique_id):
         if os.environ.get("STANDIN_COMM") == "fail_rank1" and rank == 1:   # one rank cannot set its communicator up
             raise DftpavError(real.E_COMM, "stand-in: no communicator on rank 1")

@@ -94,3 +94,46 @@ def test_reference_object_gpu_backed_live_case(hiplib, oracle):
             assert (rg["status"], rg["iters"], rg["evals"], bool(rg["ok"])) == (rc["status"], rc["iters"], rc["evals"], bool(rc["ok"])), b
             fc, gc = refc.eval(x)
             assert fg == fc and np.array_equal(gg, gc), b
+
+
+def test_restarts_behind_the_reference_entry_point(hiplib, oracle, monkeypatch):
+    """DFTPAV_DROPIN_RESTARTS=64: the planner's one call becomes a batch of 64 in the same launch -- slot 0 the call's own problem,
+    63 seeded restarts of it (north_star's batch dimension behind OptimizeTrajectory).  Slot 0 stays BIT-EQUAL to the reference
+    build's solve (the restarts change nothing for it); the returned candidate is the cheapest successful one, collision-checked on
+    the device when the map is given; getMinJerkOptPtr() hands out the chosen candidate's coefficients."""
+    pyref = _pyref()
+    p, s = _scenario(oracle, hiplib, "cfg3", 3)
+    st = s.meta["states"]
+    c = (0.5 * (st[..., 0].min() + st[..., 0].max()), 0.5 * (st[..., 1].min() + st[..., 1].max()))
+    grid, origin = sc.occupancy_grid(s.meta["obstacles"], arena=140.0, centre=c)
+    lay = s.layout
+    for b in range(3):
+        ref = pyref.RefProblem(p, s, b)
+        rr = ref.optimize()
+        monkeypatch.delenv("DFTPAV_DROPIN_RESTARTS", raising=False)
+        gpu = pyref.RefProblem(p, s, b, dropin=True)
+        r1 = gpu.optimize()
+        ch1 = gpu.last_choice()
+        assert ch1["K"] == 1 and ch1["chosen"] == 0 and ch1["chosen_cost"] == r1["final_cost"]
+        monkeypatch.setenv("DFTPAV_DROPIN_RESTARTS", "64")
+        assert gpu.set_map(grid, sc.MAP_RESL, origin) == 0
+        rk = gpu.optimize()
+        ch = gpu.last_choice()
+        # slot 0: the reference's own solve, bit for bit
+        assert rk["final_cost"] == rr["final_cost"] and np.array_equal(rk["x"], rr["x"])
+        assert (rk["status"], rk["iters"], rk["evals"]) == (rr["status"], rr["iters"], rr["evals"])
+        # the choice
+        assert ch["K"] == 64 and 0 <= ch["chosen"] < 64 and ch["n_success"] >= 1 and ch["solve_ms"] > 0.0
+        assert rk["ok"] is True
+        if rr["ok"]:
+            assert ch["chosen_cost"] <= rr["final_cost"]
+        # what getMinJerkOptPtr() exposes is the chosen candidate: it passes the oracle's collision re-check on the same map
+        cg, dtg = gpu.coeffs()
+        col, _ = oracle.validate_trajectories(grid, sc.MAP_RESL, origin, cg[None], dtg[None], lay.piece_nums, lay.singuls, order=1)
+        assert col[0] == 0
+        if ch["chosen"] == 0 and rr["status"] >= 0:
+            cr, dtr = ref.coeffs()
+            assert np.array_equal(cg, cr) and np.array_equal(dtg, dtr)
+        # the same seed gives the same choice; the cached batch is reused
+        rk2 = gpu.optimize()
+        assert gpu.last_choice()["chosen"] == ch["chosen"] and gpu.last_choice()["chosen_cost"] == ch["chosen_cost"] and np.array_equal(rk2["x"], rk["x"])
