@@ -641,12 +641,15 @@ def side_single(ctx, args, po, cores, cfg, seeds):
                                     "mean_successes_of_64": float(np.mean([r_["successes"] for r_ in best64]))}}}
 
 
-def side_configs4_reference_order(ctx, args, po, cores, B=64):
-    """BASELINE configs[4] in reference order: dynamicObsGradCostP statement by statement with the correctly rounded exp / log /
-    x^3 (libm's own bits there belong to the host); checked against that program on the CPU (oracle order 2)"""
+def side_reference_order_batch(ctx, args, po, cores, cfg, B, golden):
+    """A BASELINE configuration in reference order AT ITS OWN BATCH SIZE (configs[4]: 1024, moving cars -- dynamicObsGradCostP
+    statement by statement with the correctly rounded exp / log / x^3; configs[1]: the gear shift at 4096).  Checked against the
+    reference's program with correctly rounded libm calls: 64 sampled trajectories whose expected results were computed where the
+    cores are (tests/golden/ref_order_batches.npz: oracle order 2, the first 8 also by the reference's own objects on a correctly
+    rounded libm), or, for other sizes and seeds, 4 sampled by oracle order 2 here."""
     try:
         p5 = capi.default_params()
-        s5 = sc.baseline_config(5, B=B, seed=args.seed)
+        s5 = sc.baseline_config(cfg, B=B, seed=args.seed)
         s5.apply_resolution(p5)
         h5 = capi.Handle(p5, device=ctx.local_rank)
         h5.set_surround(s5.surround)
@@ -656,15 +659,25 @@ def side_configs4_reference_order(ctx, args, po, cores, B=64):
         b5.solve_async(); b5.sync()
         b5.solve_async(); b5.sync()
         r5 = b5.results()
-        pick5 = np.array([0, B // 3, 2 * B // 3, B - 1])
-        o5 = po.solve_batch(p5, s5.subset(pick5), nthreads=min(4, cores), order=2)
-        row = {"batch": B, "kernel_ms": b5.last_solve_ms(), "us_per_iteration_of_the_longest": 1e3 * b5.last_solve_ms() / max(1, int(r5["iters"].max())),
-               "bit_equal_to_the_reference_program_with_correctly_rounded_exp_log_pow_on_4_sampled":
-                   bool(all(np.array_equal(o5[k_], r5[k_][pick5]) for k_ in SOLVE_FIELDS))}
-        from oracle import pyref as _pr5
-        if _pr5.cr_available():   # one whole solve of the reference's own objects on a correctly rounded libm (seconds on the host)
-            row["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm_on_1_sampled"] = same_as_ref_run(
-                r5, 0, _pr5.RefProblem(p5, s5, 0, cr=True).optimize())
+        ms5 = b5.last_solve_ms()
+        lay5 = s5.layout
+        ab5 = float(algorithmic_bytes(lay5, s5.n_points, lay5.H, lay5.M, r5["iters"], r5["evals"], r5["hist_sum"]).sum())
+        row = {"batch": B, "kernel_ms": ms5, "solves_per_s": B / (ms5 * 1e-3), "mean_iters": float(r5["iters"].mean()), "success_rate": float(r5["success"].mean()),
+               "us_per_iteration_of_the_longest": 1e3 * ms5 / max(1, int(r5["iters"].max())),
+               "roofline": {"bound": "hbm", "achieved": ab5 / (ms5 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "isolated": True}}
+        gz = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "ref_order_batches.npz")
+        Z = np.load(gz) if os.path.exists(gz) else None
+        if Z is not None and golden + "_pick" in Z.files and int(Z["seed"]) == args.seed and int(Z[golden + "_pick"].max()) < B and golden.endswith("_b%d" % B):
+            pk = Z[golden + "_pick"]
+            row["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_%d_sampled" % len(pk)] = bool(
+                all(np.array_equal(Z[golden + "_" + k_], r5[k_][pk]) for k_ in SOLVE_FIELDS))
+            row["of_them_solved_by_the_reference_build_on_a_correctly_rounded_libm"] = int(Z["n_checked_against_the_reference_objects_on_a_correctly_rounded_libm"])
+        else:
+            pick5 = np.array([0, B // 3, 2 * B // 3, B - 1])
+            o5 = po.solve_batch(p5, s5.subset(pick5), nthreads=min(4, cores), order=2)
+            row["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] = bool(
+                all(np.array_equal(o5[k_], r5[k_][pick5]) for k_ in SOLVE_FIELDS))
         b5.close(); h5.close()
         return row
     except capi.DftpavError as ex:
@@ -777,7 +790,8 @@ def side_runs(ctx, args, st, out, cores):
     out["batch256"] = side_batch(ctx, args, po, cores, 3, 256, 3, 8)
     out["single"] = side_single(ctx, args, po, cores, 2, range(9))
     out["moving_obstacles_1024"] = side_batch(ctx, args, po, cores, 5, 1024, 1, 8)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
-    out["moving_obstacles_1024"]["reference_order"] = side_configs4_reference_order(ctx, args, po, cores)
+    out["moving_obstacles_1024"]["reference_order"] = side_reference_order_batch(ctx, args, po, cores, 5, 1024, "cfg5_b1024")
+    out["gear_shift_4096_reference_order"] = side_reference_order_batch(ctx, args, po, cores, 2, 4096, "cfg2_b4096")
     out.setdefault("parity", {})["reference_order_other_configs"] = side_reference_order_other_configs(ctx, args, po, cores)
     side_neighbours(ctx, args, po, st, out)
 

@@ -165,10 +165,15 @@ typedef unsigned short __attribute__((address_space(3))) *ldsh_t;
 // has n = 33 -- 40 dependent additions per sum instead of 64.
 __host__ __device__ inline int ref_cap_of(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 40 ? 40 : (n <= 48 ? 48 : 64))); }
 
+// WAVE shape: the kernels up to this width are built for 256 registers (two waves per SIMD, eight trajectories per CU), the wider
+// ones take what they need (378-414 registers, no spills, four per CU).  Round 5, measured on configs[1]'s gear shift at 4096
+// (n = 33: the 40-term kernel, profiles/r05_reference_order_baseline_batches.txt): 256 registers with 176 spilled against 414
+// with none -- 450 against 467 ms, same bits: residency wins, by 3.7 %.  48 and 64 terms stay wide (not measured without
+// moving obstacles; with them the kernel needs 512 either way).
 #ifndef DFTPAV_REF_NARROW_CAP
-#define DFTPAV_REF_NARROW_CAP 32
+#define DFTPAV_REF_NARROW_CAP 40
 #endif
-constexpr int kNarrowCap = DFTPAV_REF_NARROW_CAP; // WAVE shape: the kernels up to this width are built for 256 registers, eight waves per CU
+constexpr int kNarrowCap = DFTPAV_REF_NARROW_CAP;
 
 struct Shape {
   int wave;     // 1: one wave per trajectory

@@ -39,8 +39,8 @@ dist.init_process_group = init_gloo
 # side runs at sizes a CPU finishes in seconds
 _side_batch = bench.side_batch
 bench.side_batch = lambda ctx, args, po, cores, cfg, B, reps, n_check: _side_batch(ctx, args, po, cores, cfg, min(B, 8), reps, min(n_check, 2))
-_cfg4 = bench.side_configs4_reference_order
-bench.side_configs4_reference_order = lambda ctx, args, po, cores: _cfg4(ctx, args, po, cores, B=4)
+_refb = bench.side_reference_order_batch
+bench.side_reference_order_batch = lambda ctx, args, po, cores, cfg, B, golden: _refb(ctx, args, po, cores, cfg, min(B, 4), golden)
 bench.live_pmc = lambda args, schedule: (None, "stand-in: no counters")
 
 if os.environ.get("STANDIN_TIMES") == "1":   # where the time of a full run goes
@@ -55,7 +55,7 @@ if os.environ.get("STANDIN_TIMES") == "1":   # where the time of a full run goes
             print("[standin] %-40s %7.1f s" % (name, time.perf_counter() - t0), file=sys.stderr, flush=True)
             return r
         setattr(bench, name, w)
-    for n_ in ("run_strong_shard", "side_isolated", "side_batch", "side_single", "side_configs4_reference_order", "side_reference_order_other_configs",
+    for n_ in ("run_strong_shard", "side_isolated", "side_batch", "side_single", "side_reference_order_batch", "side_reference_order_other_configs",
                "side_neighbours", "cpu_baseline", "parity_device_order", "parity_reference_order", "parity_literal", "parity_lockstep", "with_upload"):
         timed(n_)
 

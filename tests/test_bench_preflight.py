@@ -132,7 +132,11 @@ def test_every_side_run_of_the_one_gpu_line():
     assert out["moving_obstacles_1024"]["reference_order"]["batch"] == 4
     # the reference's own objects on a correctly rounded libm agree with order 2 (= the stand-in's "device") on every solve
     assert out["single"]["reference_order"]["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm"] == 9
-    assert out["moving_obstacles_1024"]["reference_order"]["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm_on_1_sampled"] is True
+    for k in ("moving_obstacles_1024", ):
+        assert out[k]["reference_order"]["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] is True
+    ro = out["gear_shift_4096_reference_order"]
+    assert ro["batch"] == 4 and ro["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] is True and ro["roofline"]["frac"] > 0
+    assert out["single"]["reference_order"]["best_of_64_restarts_in_one_launch"]["slot0_bit_equal_to_the_lone_solve_on_all"] is True
     live = par["reference_order_other_configs"]["gear_shifts_with_moving_obstacles"]
     assert live["against_reference_build_on_a_correctly_rounded_libm"]["bit_equal"] == live["trajectories"] == 8
     assert out["strong_shard"]["per_gpu"] == 2 and out["strong_shard"]["steps_in_flight"] == 16

@@ -593,3 +593,30 @@ def test_reference_order_equals_the_reference_on_a_correctly_rounded_libm(hiplib
         assert np.array_equal(cf[0], co) and np.array_equal(dt[0], dto), name
         bt.close()
         h.close()
+
+
+@pytest.mark.parametrize("name,cfg,B", [("cfg5_b1024", 5, 1024), ("cfg2_b4096", 2, 4096)])
+def test_reference_order_at_the_baseline_batch_sizes(hiplib, name, cfg, B):
+    """BASELINE configs[4] at ITS batch (1024 trajectories among the four moving cars, 63 variables: the 64-term kernel) and
+    configs[1]'s gear shift at 4096 (33 variables: the 40-term kernel), whole batches in reference order; 64 sampled trajectories
+    of each against the reference's program with correctly rounded libm calls -- expected results computed where the cores are
+    (tests/golden/make_golden_ref_order_batches.py: oracle order 2; the first 8 of each were also solved by the reference's OWN
+    objects on the correctly rounded libm, oracle/_ref/libdftpav_ref_cr.so, and agreed bit for bit)."""
+    import os
+    Z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_order_batches.npz"))
+    p = hiplib.default_params()
+    s = sc.baseline_config(cfg, B=B, seed=int(Z["seed"]))
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    h.set_surround(s.surround)
+    bt = hiplib.Batch(h, s.layout, B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    r = bt.solve()
+    pk = Z[name + "_pick"]
+    assert len(pk) == 64 and int(Z["n_checked_against_the_reference_objects_on_a_correctly_rounded_libm"]) >= 8
+    for k in ("final_cost", "x", "status", "iters", "evals"):
+        assert np.array_equal(r[k][pk], Z[name + "_" + k]), (name, k)
+    assert r["success"].mean() > 0.95
+    bt.close()
+    h.close()
