@@ -17,7 +17,8 @@ import bench  # noqa: E402
 import device_standin as standin  # noqa: E402
 
 # the device: tensors on the host, no streams to wait for
-bench.DEV = "cpu"
+import benchlib.common as _common  # noqa: E402
+_common.DEV = bench.DEV = "cpu"
 torch.cuda.set_device = lambda d: None
 torch.cuda.synchronize = lambda *a: None
 torch.cuda.get_device_properties = lambda d: types.SimpleNamespace(multi_processor_count=256)
@@ -41,7 +42,8 @@ _side_batch = bench.side_batch
 bench.side_batch = lambda ctx, args, po, cores, cfg, B, reps, n_check: _side_batch(ctx, args, po, cores, cfg, min(B, 8), reps, min(n_check, 2))
 _refb = bench.side_reference_order_batch
 bench.side_reference_order_batch = lambda ctx, args, po, cores, cfg, B, golden: _refb(ctx, args, po, cores, cfg, min(B, 4), golden)
-bench.live_pmc = lambda args, schedule: (None, "stand-in: no counters")
+import benchlib.counters as _counters  # noqa: E402  (hbm_traffic looks live_pmc up in its own module)
+_counters.live_pmc = bench.live_pmc = lambda args, schedule: (None, "stand-in: no counters")
 
 if os.environ.get("STANDIN_TIMES") == "1":   # where the time of a full run goes
     import time

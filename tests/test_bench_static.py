@@ -31,6 +31,8 @@ def _check(path):
 
 def test_every_global_name_bench_reads_is_defined():
     assert _check(os.path.join(ROOT, "bench.py")) == []
+    for part in ("common", "stream", "counters", "side", "parity"):   # bench.py's parts (benchlib/)
+        assert _check(os.path.join(ROOT, "benchlib", part + ".py")) == [], part
 
 
 def test_the_same_for_the_entry_points_and_the_host_modules():
