@@ -16,8 +16,8 @@
 //     per cost -- add the records in the reference's sample -> vertex -> plane order;
 //   * lbfgs_optimize / line_search_lewisoverton (lbfgs.hpp:276-390, 440-751): sequential dot products (the products are
 //     formed by the lanes, the sum is one chain from the first element) and the plain two-loop recursion (:716-739);
-//   * no fused multiply-add anywhere except inside a division by a stored reciprocal (div_by_rcp: the correctly rounded
-//     quotient, i.e. the bits of a / b); contraction is off for the file.
+//   * no fused multiply-add anywhere except inside a division by a stored reciprocal (div_by_rcp: equal to a / b on everything
+//     it has been compared on -- an empirical claim, see there; DFTPAV_REF_EXACT_DIV=1 divides); contraction is off for the file.
 //
 // Scope: n <= 64 decision variables, at most 64 terms per constraint point (5 H + S + 4), any number of gear segments with or
 // without moving obstacles (the reference's live call, traj_manager.cpp:604-610, installs both).  With ONE gear segment and no
@@ -69,9 +69,14 @@ typedef int __attribute__((address_space(3))) *ldsi_t;
 typedef const double __attribute__((address_space(1))) *gcd_t;
 typedef double __attribute__((address_space(1))) *gd_t;
 
-// a / b from y = 1 / b (Markstein): the correctly rounded quotient, i.e. the bits of a / b (solver.hip: checked on 2^31
-// pairs on gfx950 against the division) -- as long as nothing under- or overflows on the way, which takes a divisor or a
-// dividend beyond 2^+-500.  The divisors are stored quantities: the y . s of a stored pair only has to exceed a `cau` that can be
+// a / b from y = 1 / b (Markstein's correction step): q0 = a y, r = a - b q0 (exact in an FMA), q = q0 + r y.  With y the correctly
+// rounded reciprocal this is the correctly rounded quotient whenever q0 is a FAITHFUL rounding of a / b (Markstein's theorem); RN(a y)
+// can be up to ~1.5 ulp off, so the theorem does not cover every operand pair and the claim made here is an EMPIRICAL one: equal to
+// the division on 2^31 random pairs on gfx950 (solver.hip), on every solve ever compared with the reference build (the GPU fuzz: 16 197
+// solves; every bench run: 64 + 685 sampled), and on a test that runs the recursion with true divisions beside it.  A pair that
+// broke it would show as one differing bit in one alpha.  DFTPAV_REF_EXACT_DIV=1 (and any divisor outside [2^-500, 2^500], below)
+// takes the true division; the direction of the sweeps' diagonals is checked on the host.  Nothing may under- or overflow on the
+// way, which takes a divisor or a dividend beyond 2^+-500.  The divisors are stored quantities: the y . s of a stored pair only has to exceed a `cau` that can be
 // tiny, so the solver notes the first one outside [2^-500, 2^500] in its state (iSLOWDIV) and runs the recursion with true
 // divisions (EXACT = true) from then on, as the reference does; the LU diagonals of the band system are checked on the host
 // (reference_order_tables refuses a system with such a diagonal).  Dividends -- sums of products of O(1e-30 .. 1e20) quantities
