@@ -187,9 +187,14 @@ def test_launch_shapes_of_the_reference_order(hiplib):
             assert q["threads"] == 512 and q["wg_per_cu"] == 1 and q["slots"] == 256 and q["slice"] == 128   # eight waves per CU
         else:
             assert q["threads"] == (128 if B > 768 else 256)
-    # configs[1]: 8 + 8 pieces with a gear shift, n = 33: sums of 40 terms; the 512-register kernels: four waves per CU
+    # configs[1]: 8 + 8 pieces with a gear shift, n = 33: sums of 40 terms.  Since round 5 that kernel is built for 256 registers too
+    # (kNarrowCap = 40: residency won over a spill-free 414 registers, 450 against 467 ms at 4096); two segments' tables and state
+    # leave room for seven waves in the 160 KB
     q = plan([8, 8], [1, -1], 32, 32, 0, 4096)
-    assert q["supported"] == 1 and q["cap"] == 40 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] == 256
+    assert q["supported"] == 1 and q["cap"] == 40 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] == 448 and q["lds"] <= 160 * 1024
+    # 48 terms and more: the wide kernels, four waves per CU
+    q = plan([11, 12], [1, -1], 16, 16, 0, 4096)
+    assert q["supported"] == 1 and q["cap"] == 48 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] <= 256
     # configs[4]: 32 pieces x 65 points with four moving obstacles, n = 63
     q = plan([32], [1], 64, 64, 4, 4096)
     assert q["supported"] == 1 and q["cap"] == 64 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] <= 256 and q["lds"] <= 160 * 1024
