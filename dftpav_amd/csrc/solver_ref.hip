@@ -1904,8 +1904,67 @@ __device__ __forceinline__ void wave_lds_order() { __builtin_amdgcn_fence(__ATOM
 // CAP = 16 / 32 / 64 >= n values are fetched in one go (the reads go out together, the chain starts when the first
 // arrives); lanes from n on contribute -0.0, and x + (-0.0) == x for EVERY x (both zeros included), so the chain may
 // simply run to CAP.
+// Round 5: the chain WITHOUT the trip through LDS.  v_fmac_f64 has a DPP form whose first operand
+// can be lane K of the reader's own row of 16 (row_newbcast:K), and fma(p, 1.0, acc) is acc + p, rounded once: the same bits as
+// the addition.  So the sixteen terms of row 0 are sixteen dependent one-instruction steps in which every lane of row 0 adds
+// term K; terms 16 .. 31 (row 1) are first moved under row 0 by one v_permlane16_swap per register half, then chained the same
+// way, rows 2 and 3 after a v_permlane32_swap.  No store, no fence, no sixteen broadcast reads: 832 -> 477 cycles per step of the
+// two-loop recursion at 4096, 370 -> 316 ms per batch, the same bits.  (A VALU write followed by a DPP read of the register needs two wait
+// states, and EXEC is not touched here: s_nop 1 in front, the inline-asm block is opaque to the hazard recogniser.)
+#ifndef DFTPAV_REF_DPP_CHAIN
+#define DFTPAV_REF_DPP_CHAIN 1
+#endif
+#define DFTPAV_FMAC_BCAST(K) "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define DFTPAV_FMAC_BCAST16 \
+  DFTPAV_FMAC_BCAST(0) DFTPAV_FMAC_BCAST(1) DFTPAV_FMAC_BCAST(2) DFTPAV_FMAC_BCAST(3) DFTPAV_FMAC_BCAST(4) DFTPAV_FMAC_BCAST(5) DFTPAV_FMAC_BCAST(6) \
+  DFTPAV_FMAC_BCAST(7) DFTPAV_FMAC_BCAST(8) DFTPAV_FMAC_BCAST(9) DFTPAV_FMAC_BCAST(10) DFTPAV_FMAC_BCAST(11) DFTPAV_FMAC_BCAST(12) \
+  DFTPAV_FMAC_BCAST(13) DFTPAV_FMAC_BCAST(14) DFTPAV_FMAC_BCAST(15)
+#define DFTPAV_FMAC_BCAST8 \
+  DFTPAV_FMAC_BCAST(0) DFTPAV_FMAC_BCAST(1) DFTPAV_FMAC_BCAST(2) DFTPAV_FMAC_BCAST(3) DFTPAV_FMAC_BCAST(4) DFTPAV_FMAC_BCAST(5) DFTPAV_FMAC_BCAST(6) \
+  DFTPAV_FMAC_BCAST(7)
+// row r of v moved under row 0: v_permlane16_swap exchanges vdst's odd rows with src's even rows, v_permlane32_swap vdst's upper
+// half with src's lower half; with both operands = v the SECOND result holds v's row 1 (rows 2, 3) in row 0 (rows 0, 1)
+__device__ __forceinline__ double row1_to_row0(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double upper_to_lower(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[1], lo[1]);
+}
+template <int CAP>
+__device__ __forceinline__ double seq_sum_dpp(double p, int n, int lane) {
+  static_assert(CAP == 16 || CAP == 32 || CAP == 40 || CAP == 48 || CAP == 64, "whole rows, or half of row 2");
+  const double v = lane < n ? p : -0.0; // terms n .. CAP-1 are -0.0, as in the LDS form (lanes >= CAP hold anything: nobody chains them)
+  double acc = 0.0;
+  const double one = 1.0;
+  asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST16 : "+v"(acc) : "v"(v), "v"(one)); // terms 0 .. 15
+  if (CAP >= 32) {
+    const double w = row1_to_row0(v);
+    asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST16 : "+v"(acc) : "v"(w), "v"(one)); // 16 .. 31
+  }
+  if (CAP > 32) {
+    const double u = upper_to_lower(v); // rows 2, 3 under rows 0, 1
+    if (CAP == 40) {
+      asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST8 : "+v"(acc) : "v"(u), "v"(one)); // 32 .. 39
+    } else {
+      asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST16 : "+v"(acc) : "v"(u), "v"(one)); // 32 .. 47
+    }
+    if (CAP == 64) {
+      const double w3 = row1_to_row0(u);
+      asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST16 : "+v"(acc) : "v"(w3), "v"(one)); // 48 .. 63
+    }
+  }
+  const int rl = __builtin_amdgcn_readfirstlane(__double2loint(acc)), rh = __builtin_amdgcn_readfirstlane(__double2hiint(acc));
+  return __hiloint2double(rh, rl);
+}
 template <int CAP>
 __device__ __forceinline__ double seq_sum(double p, int n, ldsd_t buf, int lane) {
+#if DFTPAV_REF_DPP_CHAIN
+  return seq_sum_dpp<CAP>(p, n, lane);
+#endif
   if (lane < CAP) buf[lane] = lane < n ? p : -0.0;
   wave_lds_order();
   double s = 0.0;
