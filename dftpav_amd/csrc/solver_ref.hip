@@ -1330,7 +1330,8 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
   const gd_t stage_b = rec_b + (size_t)Npts * nterm * kRec;                         // moving obstacles: a point's records as surround_terms leaves them
   int *glist = reinterpret_cast<int *>((double *)(stage_b + (size_t)Npts * nS * kRec)); // entries beyond the LDS window
   int base = 0;
-  // (requesting the half-planes one round ahead was tried: 40 more live registers, 100 -> 116 k cycles per evaluation)
+  // (requesting the half-planes one round ahead was tried twice: 40 more live registers; round 4: 100 -> 116 k cycles per evaluation,
+  // round 5 on the DPP-chain kernel: 92.6 -> 112.7 k, 310 -> 317 ms per 4096 -- docs/HISTORY.md)
   for (int r0 = 0; r0 < Npts; r0 += 64) {
     const int pt = r0 + tid;
     const bool in = pt < Npts;
