@@ -55,6 +55,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--depth", type=int, default=4,
+                    help="overlap schedule: steps in flight = resident batches = HIP streams per GPU (a step launches one batch and "
+                         "takes delivery of the one launched DEPTH - 1 steps earlier); 2 was the value line until round 4")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config (1-based) used as the workload")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="trajectories timed on the host cores (-1 = 4 per core, 0 = skip)")
@@ -110,8 +113,9 @@ def run_strong_shard(ctx, args):
 
 
 SCHEDULE_NOTE = {
-    "overlap": "overlap: two batches alternate on two HIP streams, every trajectory finishes in its queue launch, "
-               "the next launch takes the slots the previous one frees; the last batch completes inside the timed region",
+    "overlap": "overlap: --depth batches resident, each on its own HIP stream, launched in turn; every trajectory finishes in its "
+               "queue launch, the next launches take the slots an earlier one frees; the timed region starts on an idle device and "
+               "ends when the last batch is delivered",
     "chain": "chain: one stream, the stragglers of a batch finish inside the next batch's queue launch, the last "
              "batch is flushed inside the timed region",
     "plain": "plain: every batch finishes on its own"}
@@ -137,7 +141,7 @@ def value_line(ctx, args, st, res, B_total):
                                (shard.name, args.batch_per_gpu, "/GPU" if args.scaling == "weak" else " in all", lay.n_pieces, shard.K + 1),
                    "global_batch": B_total, "pieces": lay.n_pieces, "pts_per_piece": shard.K + 1,
                    "n_vars": lay.n_vars, "parallelism": "batch-sharded x%d, 1 all-gather of 16B records" % world,
-                   "allgather_via": st.via},
+                   "steps_in_flight": st.D, "allgather_via": st.via},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_uncorrected": traffic_raw,
                      "traffic_source": traffic_source,

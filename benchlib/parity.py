@@ -148,11 +148,11 @@ def parity_reference_order(ctx, args, po, st, r, sample, out, B_total):
             ro["slowdown_vs_device_order_isolated"] = ref_ms / out["isolated"]["kernel_ms"]
         ro["isolated_solves_per_s"] = ro["solves_per_s"]
         out["parity"]["reference_order"] = ro
-        # the same stream of planning cycles as the value line -- two resident batches on two HIP streams, one launched
+        # the same stream of planning cycles as the value line -- --depth resident batches on as many HIP streams, one launched
         # while the other thins out -- in the REFERENCE'S order: the throughput of the bit-equal mode
         bR.close(); hR.close()
         try:
-            stR = Stream(ctx, B_total, args.config, args.seed, depth=2, order=capi.ORDER_REFERENCE)
+            stR = Stream(ctx, B_total, args.config, args.seed, depth=args.depth, order=capi.ORDER_REFERENCE)
             k_ref = max(4, min(args.steps, 8))
             rR = stR.run(k_ref, 2)
             same = bool(np.array_equal(rR["rs"][0]["final_cost"], ref_gpu["final_cost"])) if stR.shards[0].B == shard.B else None

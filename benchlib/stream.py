@@ -1,4 +1,4 @@
-"""bench.py, part: the timed object: a stream of planning cycles on this rank (two resident batches solved alternately on two HIP streams) and the shard schedules."""
+"""bench.py, part: the timed object: a stream of planning cycles on this rank (--depth resident batches, each on its own HIP stream, launched in turn) and the shard schedules."""
 import os
 import time
 
@@ -15,9 +15,9 @@ from benchlib.common import (HBM_PEAK_GBS, SOLVE_FIELDS, Ctx, algorithmic_bytes,
 
 
 class Stream:
-    """A stream of planning cycles on this rank: two resident batches of different problems, solved alternately.  A step
-    launches one batch and delivers the records of the batch that this completes (pack + all-gather); after the last step
-    the outstanding batch is completed and delivered INSIDE the timed region, so K steps deliver K batches.
+    """A stream of planning cycles on this rank: `depth` resident batches of different problems, launched in turn.  A step
+    launches one batch and delivers the records of the batch launched depth - 1 steps earlier (pack + all-gather); after the
+    last step the outstanding batches are completed and delivered INSIDE the timed region, so K steps deliver K batches.
       overlap (default): each batch on its own handle = HIP stream, hand-over 0: every trajectory finishes in its queue
         launch, and while that launch thins out the other stream's launch takes the freed workgroup slots.
       chain: one stream; the last trajectories of a batch are adopted by the next batch's queue launch
@@ -28,7 +28,7 @@ class Stream:
         self.c = ctx
         # every rank generates its own shard from (seed, rank) — trajectories are independent, nothing is scattered
         # (SURVEY §8e); rank r owns global trajectories [r*B/G, (r+1)*B/G)
-        # depth: resident batches = steps in flight (overlap schedule only; 2 for the value line).  A shard too small to
+        # depth: resident batches = steps in flight (overlap schedule only; --depth for the value line).  A shard too small to
         # fill the device alone (512 of a strong-scaled 4096) is run deeper, in the throughput residency, so that a GPU
         # holds as many trajectories as it does at 4096 per step.
         self.D = D = depth if self.c.schedule == "overlap" else 2
@@ -185,12 +185,13 @@ class Stream:
 
 
 def shard_schedule(args, schedule, per_gpu):
-    """steps in flight and residency for a per-GPU shard: a shard that is a fraction of --batch-per-gpu runs as many steps
-    deep as it takes to hold 2 x --batch-per-gpu trajectories per GPU (what the value line holds), at most 16, in the
+    """steps in flight and residency for a per-GPU shard: --depth for a full shard; a shard that is a fraction of --batch-per-gpu runs
+    as many steps deep as it takes to hold --depth x --batch-per-gpu trajectories per GPU (what the value line holds), at most 16, in the
     throughput residency (several workgroups per CU)"""
     if os.environ.get("DFTPAV_BENCH_DEPTH"):   # developer knob: "depth[,residency]"
         v = os.environ["DFTPAV_BENCH_DEPTH"].split(",")
         return int(v[0]), (int(v[1]) if len(v) > 1 else None)
+    depth = max(2, getattr(args, "depth", 2))
     if per_gpu >= args.batch_per_gpu or schedule != "overlap":
-        return 2, None
-    return max(2, min(16, 2 * args.batch_per_gpu // max(1, per_gpu))), 2
+        return depth, None
+    return max(2, min(16, depth * args.batch_per_gpu // max(1, per_gpu))), 2

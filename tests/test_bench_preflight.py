@@ -60,6 +60,7 @@ def test_one_rank_line_and_step_count():
     out = _bench(["--steps", "3", "--warmup", "2", "--batch-per-gpu", "6", "--no-extras", "--cpu-sample", "0"])
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 6 and out["config"]["allgather_via"].startswith("none")
+    assert out["config"]["steps_in_flight"] == 4                                # --depth's default
     assert _count(out, "solve", 6) == 5 and _count(out, "allgather") == 0     # warm-up + timed steps, one solve each; no collective
     assert "other_scaling" not in out and "cpu_baseline" not in out
 
@@ -67,8 +68,9 @@ def test_one_rank_line_and_step_count():
 @pytest.mark.parametrize("nproc", [2, 4])
 def test_ranks_weak_value_line_and_the_strong_side_run(nproc):
     B = 8
-    out = _bench(["--steps", "3", "--warmup", "1", "--batch-per-gpu", str(B), "--no-extras", "--cpu-sample", "0"], nproc=nproc)
+    out = _bench(["--steps", "3", "--warmup", "1", "--batch-per-gpu", str(B), "--depth", "2", "--no-extras", "--cpu-sample", "0"], nproc=nproc)
     assert out["n_gpus"] == nproc and out["scaling"] == "weak" and out["config"]["global_batch"] == nproc * B
+    assert out["config"]["steps_in_flight"] == 2
     assert "dftpav_batch_allgather_results" in out["config"]["allgather_via"]
     o = out["other_scaling"]
     assert o["scaling"] == "strong" and o["global_batch"] == B and o["per_gpu"] == B // nproc
