@@ -26,7 +26,7 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 # The HIP runtime multiplexes a process's streams onto 4 hardware queues by default: the fifth batch in flight waits for one of
 # the first four to END, however empty the device is.  The side runs that keep 8..16 small batches in flight (a 512-trajectory
 # shard of a strong-scaled 4096, 8 planner threads of 256) want as many queues as streams: 19 k -> 33 k solves/s on 512-
-# trajectory steps.  Read once, when the runtime initialises; no effect on the value line (two streams).  INTEGRATION.md §5.
+# trajectory steps.  Read once, when the runtime initialises; no effect on the value line (--depth = 4 streams).  INTEGRATION.md §5.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
