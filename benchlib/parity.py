@@ -153,10 +153,10 @@ def parity_reference_order(ctx, args, po, st, r, sample, out, B_total):
         bR.close(); hR.close()
         try:
             stR = Stream(ctx, B_total, args.config, args.seed, depth=args.depth, order=capi.ORDER_REFERENCE)
-            k_ref = max(4, min(args.steps, 8))
-            rR = stR.run(k_ref, 2)
+            k_ref, w_ref = max(4, min(args.steps, 20)), max(2, min(args.warmup, 5))   # the value line's K and W at the driver's settings
+            rR = stR.run(k_ref, w_ref)
             same = bool(np.array_equal(rR["rs"][0]["final_cost"], ref_gpu["final_cost"])) if stR.shards[0].B == shard.B else None
-            ro["overlapped"] = {"solves_per_s": rR["value"], "ms_per_step": rR["ms_per_step"], "steps": k_ref, "warmup": 2,
+            ro["overlapped"] = {"solves_per_s": rR["value"], "ms_per_step": rR["ms_per_step"], "steps": k_ref, "warmup": w_ref,
                                 "schedule": ctx.schedule, "first_batch_equals_the_isolated_solve": same}
             ro["solves_per_s"] = rR["value"]
             ro["solves_per_s_is"] = "the overlapped stream of %d steps (as the value line); isolated_solves_per_s: one batch alone" % k_ref

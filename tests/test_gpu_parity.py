@@ -1002,19 +1002,20 @@ def test_step_kernels_against_the_reference_builds_vectors(hiplib):
     h.close()
 
 
-def test_overlapped_streams_and_hand_over_zero(hiplib, monkeypatch):
-    """bench.py's default schedule: two handles (two HIP streams), hand-over 0 so that every trajectory finishes in its
-    queue launch, batches launched alternately without waiting for the previous one -- results equal the plain
-    solves bit for bit; the marker events give the device time across the two streams."""
+@pytest.mark.parametrize("D", [2, 4])
+def test_overlapped_streams_and_hand_over_zero(hiplib, monkeypatch, D):
+    """bench.py's schedule (--depth D; 4 is its default, 2 was until round 4): D handles (D HIP streams), hand-over 0 so that
+    every trajectory finishes in its queue launch, batches launched in turn without waiting for the previous ones -- results
+    equal the plain solves bit for bit; the marker events give the device time across the streams."""
     monkeypatch.setenv("DFTPAV_SCHED", "1")
     monkeypatch.setenv("DFTPAV_SLOTS", "8")
     monkeypatch.setenv("DFTPAV_SLICE", "7")
     p = hiplib.default_params()
     B = 36
-    scen = [sc.baseline_config(3, B=B, seed=4242 + 17 * k) for k in range(2)]
+    scen = [sc.baseline_config(3, B=B, seed=4242 + 17 * k) for k in range(D)]
     for s in scen:
         s.apply_resolution(p)
-    hs = [hiplib.Handle(p), hiplib.Handle(p)]
+    hs = [hiplib.Handle(p) for _ in range(D)]
     bts = []
     for h, s in zip(hs, scen):
         bt = hiplib.Batch(h, s.layout, B)
@@ -1025,13 +1026,15 @@ def test_overlapped_streams_and_hand_over_zero(hiplib, monkeypatch):
     for bt in bts:
         bt.set_hand_over(0)
     hs[0].mark(0)
-    for k in range(6):
-        bts[k % 2].solve_async()
-        if k:
-            bts[(k - 1) % 2].sync()
-    bts[1].sync()
-    hs[1].mark(1)
-    assert hs[1].elapsed_since(hs[0], 0, 1) > 0.0
+    nb = 3 * D
+    for k in range(nb):
+        bts[k % D].solve_async()
+        if k >= D - 1:
+            bts[(k - D + 1) % D].sync()
+    for k in range(nb - D + 1, nb):
+        bts[k % D].sync()
+    hs[(nb - 1) % D].mark(1)
+    assert hs[(nb - 1) % D].elapsed_since(hs[0], 0, 1) > 0.0
     for bt, ref in zip(bts, plain):
         got = bt.results()
         for k in keys:
