@@ -1556,10 +1556,19 @@ extern "C" int dftpav_debug_cr_sincos(int n, const double *x, double *s, double 
   for (int i = 0; i < n; i++) dftpav::crt::sincos(x[i], s[i], c[i]);
   return DFTPAV_OK;
 }
-// test hook (host only): which = 0 exp, 1 log, 2 x^3 -- the correctly rounded functions of cr_trig.h for n arguments
+// test hook (host only): which = 0 exp, 1 log, 2 x^3 -- the correctly rounded functions of cr_trig.h for n arguments; 3 / 4: exp / log
+// by their accurate phase alone (what the quick phase with its rounding test stands in front of)
 extern "C" int dftpav_debug_cr_fn(int which, int n, const double *x, double *y) {
-  if (n < 0 || !x || !y || which < 0 || which > 2) return DFTPAV_E_INVALID;
-  for (int i = 0; i < n; i++) y[i] = which == 0 ? dftpav::crt::exp_cr(x[i]) : (which == 1 ? dftpav::crt::log_cr(x[i]) : dftpav::crt::cube_cr(x[i]));
+  if (n < 0 || !x || !y || which < 0 || which > 4) return DFTPAV_E_INVALID;
+  for (int i = 0; i < n; i++) {
+    switch (which) {
+      case 0: y[i] = dftpav::crt::exp_cr(x[i]); break;
+      case 1: y[i] = dftpav::crt::log_cr(x[i]); break;
+      case 2: y[i] = dftpav::crt::cube_cr(x[i]); break;
+      case 3: y[i] = dftpav::crt::exp_cr_impl<false>(x[i]); break;
+      default: y[i] = dftpav::crt::log_cr_impl<false>(x[i]); break;
+    }
+  }
   return DFTPAV_OK;
 }
 // test hook (host only): the sweep tables of a segment of N pieces, [4][6N][8]; returns 1 if the middle blocks have the assumed pattern

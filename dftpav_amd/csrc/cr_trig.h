@@ -17,6 +17,17 @@
 #pragma once
 #include "device_types.h"
 
+// (scripts/cr_quick_check.cpp counts how often the quick phases of exp / log hand over to the accurate ones)
+#ifndef DFTPAV_CR_FALLBACK
+#define DFTPAV_CR_FALLBACK(which) ((void)0)
+#endif
+// what the quick phases' rounding tests ask for, relative.  Their error bounds are 2^-67 (exp) and 2^-68 (log); built with a
+// smaller number here, the check above finds no mismatch at 2^-67 (1.4e9 arguments), the first ones of exp at 2^-69 and of log at
+// 2^-71 (2e8 arguments per range) -- the bounds are real, and 2^-64 is eight times the larger one (7e9 arguments: none).
+#ifndef DFTPAV_CR_QUICK_REL
+#define DFTPAV_CR_QUICK_REL 0x1.0p-64
+#endif
+
 namespace dftpav {
 namespace crt {
 
@@ -225,10 +236,28 @@ DFTPAV_HD inline double scale2(double v, int k) { // v 2^k, in two steps so that
   b.u = (unsigned long long)(1023 + k2) << 52;
   return (v * a.d) * b.d;
 }
-// exp x: x = k ln2 + r (ln2 in three 33-bit chunks and a tail), exp(r / 16) by its Taylor series in double-double, four squarings.
+// Ziv's rounding test.  e (normalised) approximates a value v to within rel |e.hi|: when e.hi + (e.lo - d) and e.hi + (e.lo + d),
+// d = rel |e.hi|, round to the same double, every number between them does (rounding is monotonic), v among them: that double IS v
+// correctly rounded.  (The two inner sums are themselves rounded, by at most 2^-106 |e.hi|: the callers' rel leaves a factor of
+// four for it.)
+DFTPAV_HD inline bool round_if_certain(dd e, double rel, double &out) {
+  const double d = rel * (e.hi < 0.0 ? -e.hi : e.hi);
+  const double a = e.hi + (e.lo - d), b = e.hi + (e.lo + d);
+  out = a;
+  return a == b;
+}
+// exp x: x = k ln2 + r (ln2 in three 33-bit chunks and a tail), then two phases (Ziv):
+//   quick     s = r / 32 (|s| <= 0.0109): exp s = 1 + s + s^2 / 2 in double-double + s^3 (1/6 + s/24 + ... + s^5 / 8!) in plain fp64
+//             (the tail is below 2^-22, its error -- a few ulp of it, the neglected s.lo, the series' remainder s^9 / 9! -- below
+//             2^-72), five squarings (error x 32: 2^-67 relative); the rounding test asks for 2^-64.  It fails for about one
+//             argument in 1 000, which then takes
+//   accurate  exp(r / 16) by its Taylor series in double-double to ~2^-100, four squarings (all there was until round 5).
+// Both return the correctly rounded value, so which phase answered cannot be seen in the result (tests/test_cr_trig.py: the two
+// against each other and against binary128).
 // Results below the normal range (x < -708.4) go through a second rounding in scale2 (the reference's sums absorb them:
 // they are weights relative to a term that is exactly 1).
-DFTPAV_HD inline double exp_cr(double x) {
+template <bool QUICK>
+DFTPAV_HD inline double exp_cr_impl(double x) {
   if (x != x) return x; // NaN in, NaN out (before the conversion to int below, which is undefined for a NaN on the host)
   if (x < -745.2) return 0.0;
   if (x > 709.8) return 1.0e308 * 1.0e308;
@@ -242,6 +271,27 @@ DFTPAV_HD inline double exp_cr(double x) {
   r = dd_add_d(r, -(kd * l2));
   r = dd_add_d(r, -(kd * l3));
   r = dd_add(r, dd_neg(two_prod(kd, l4)));
+  if (QUICK) {
+    const dd s{r.hi * 0.03125, r.lo * 0.03125}; // r / 32, exact
+    const double sh = s.hi;
+    double P = 0x1.a01a01a01a01ap-16;              // 1 / 8!
+    P = __builtin_fma(P, sh, 0x1.a01a01a01a01ap-13); // 1 / 7!
+    P = __builtin_fma(P, sh, 0x1.6c16c16c16c17p-10); // 1 / 6!
+    P = __builtin_fma(P, sh, 0x1.1111111111111p-7);  // 1 / 5!
+    P = __builtin_fma(P, sh, 0x1.5555555555555p-5);  // 1 / 4!
+    P = __builtin_fma(P, sh, 0x1.5555555555555p-3);  // 1 / 3!
+    const double T = sh * sh * sh * P;
+    dd h = dd_mul(s, s);
+    h.hi *= 0.5;
+    h.lo *= 0.5;
+    h = dd_add(s, h);
+    h = dd_add_d(h, T);
+    dd e = dd_add_d(h, 1.0);
+    for (int q = 0; q < 5; q++) e = dd_mul(e, e);
+    double out;
+    if (round_if_certain(e, DFTPAV_CR_QUICK_REL, out)) return scale2(out, k);
+    DFTPAV_CR_FALLBACK(0);
+  }
   r.hi *= 0.0625; // r / 16, exact
   r.lo *= 0.0625;
   dd p = inv_fact(14);
@@ -251,8 +301,15 @@ DFTPAV_HD inline double exp_cr(double x) {
   for (int q = 0; q < 4; q++) e = dd_mul(e, e);
   return scale2(e.hi, k);
 }
-// log x: x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh((m - 1) / (m + 1)) by its series in double-double
-DFTPAV_HD inline double log_cr(double x) {
+DFTPAV_HD inline double exp_cr(double x) { return exp_cr_impl<true>(x); }
+// log x: x = m 2^e with m in [sqrt(1/2), sqrt(2)); log m = 2 atanh z, z = (m - 1) / (m + 1) in double-double (|z| <= 0.1716,
+// w = z^2 <= 0.0295), again in two phases:
+//   quick     2 z (1 + w (1/3 + w/5 + w^2 Q(w))) with Q = 1/7 + w/9 + ... + w^9 / 25 in plain fp64 and the rest in double-double:
+//             w^3 Q is below 2^-18 of the result, its error (a few ulp of it, the remainder w^10 / 27) below 2^-68; e ln2 is at
+//             least twice log m when e != 0, so nothing cancels; the rounding test asks for 2^-64;
+//   accurate  the whole series in double-double (all there was until round 5).
+template <bool QUICK>
+DFTPAV_HD inline double log_cr_impl(double x) {
   const double t[21][2] = {
       {0x1.5555555555555p-2, 0x1.5555555555555p-56},  {0x1.999999999999ap-3, -0x1.999999999999ap-57}, {0x1.2492492492492p-3, 0x1.2492492492492p-57},
       {0x1.c71c71c71c71cp-4, 0x1.c71c71c71c71cp-58},  {0x1.745d1745d1746p-4, -0x1.745d1745d1746p-59}, {0x1.3b13b13b13b14p-4, -0x1.3b13b13b13b14p-58},
@@ -283,18 +340,33 @@ DFTPAV_HD inline double log_cr(double x) {
   const dd den = two_sum(m, 1.0);         // exact as a double-double
   const dd z = dd_div(num, den);
   const dd w = dd_mul(z, z);
+  const double ed = (double)e;
+  dd el = two_sum(ed * l1, ed * l2); // e ln2: exact products (|e| <= 1074)
+  el = dd_add_d(el, ed * l3);
+  el = dd_add(el, two_prod(ed, l4));
+  if (QUICK) {
+    const double wh = w.hi;
+    double Q = t[11][0];                          // 1 / 25
+    for (int n = 10; n >= 2; n--) Q = __builtin_fma(Q, wh, t[n][0]); // ... 1/9, 1/7
+    const double U = wh * wh * Q;
+    dd in = dd_mul(w, dd{t[1][0], t[1][1]});      // w / 5
+    in = dd_add(in, dd{t[0][0], t[0][1]});        // + 1/3
+    in = dd_add_d(in, U);
+    dd sq = dd_add(z, dd_mul(dd_mul(in, w), z));  // z + z w (1/3 + w/5 + w^2 Q)
+    sq.hi *= 2.0;
+    sq.lo *= 2.0;
+    double out;
+    if (round_if_certain(dd_add(el, sq), DFTPAV_CR_QUICK_REL, out)) return out;
+    DFTPAV_CR_FALLBACK(1);
+  }
   dd acc = dd{t[20][0], t[20][1]};
   for (int n = 19; n >= 0; n--) acc = dd_add(dd{t[n][0], t[n][1]}, dd_mul(acc, w)); // 1/3 + w (1/5 + w (...))
   dd sres = dd_add(z, dd_mul(dd_mul(acc, w), z)); // z + z^3 (1/3 + ...)
   sres.hi *= 2.0;
   sres.lo *= 2.0;
-  const double ed = (double)e;
-  dd r = two_sum(ed * l1, ed * l2); // exact products (|e| <= 1074)
-  r = dd_add_d(r, ed * l3);
-  r = dd_add(r, two_prod(ed, l4));
-  r = dd_add(r, sres);
-  return r.hi;
+  return dd_add(el, sres).hi;
 }
+DFTPAV_HD inline double log_cr(double x) { return log_cr_impl<true>(x); }
 // x^3, correctly rounded (the reference: pow(x, 3))
 DFTPAV_HD inline double cube_cr(double x) {
   const double plain = x * x * x;
