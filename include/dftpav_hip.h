@@ -315,7 +315,7 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *       counter-example in 2^31 random pairs nor in any solve compared with the reference build, none ruled out.  The
  *       environment variable DFTPAV_REF_EXACT_DIV=1 makes the recursion divide (slower; the bits have never differed).
  *   Launch shape by batch size: up to five trajectories per CU one workgroup each (lowest latency); beyond, one WAVE per
- *   trajectory, eight per CU, popped from the batch's ring in slices of 128 iterations (20 k solves/s at 4096 on MI355X). */
+ *   trajectory, eight per CU, popped from the batch's ring in slices of 128 iterations (20.7 k solves/s at 4096 on MI355X). */
 #define DFTPAV_ORDER_DEVICE 0
 #define DFTPAV_ORDER_REFERENCE 1
 int dftpav_batch_set_order(dftpav_batch *b, int order);
