@@ -117,3 +117,22 @@ def test_cr_exp_log_cube_equal_binary128_rounded(hiplib):
             off[which] += int(sum(lib(v) != w for v, w in zip(x[:20000], yq[:20000])))
     print("this host's libm differs from the correctly rounded value: exp %d, log %d, pow(x, 3) %d of 80000 / 100000 / 60000 arguments" %
           (off[0], off[1], off[2]))
+
+
+def test_quick_phases_never_disagree_with_the_accurate_ones(tmp_path):
+    """scripts/cr_quick_check.cpp (the header compiled for the host, OpenMP): exp / log through their quick phase + rounding test
+    against the double-double series alone on 2M random arguments per range -- no mismatch, and the quick phase hands over for
+    about one argument in 1 400 (a test that never hands over would not be a test)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cr_quick_check")
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "dftpav_amd", "csrc"),
+                           os.path.join(root, "scripts", "cr_quick_check.cpp"), "-o", exe])
+    out = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    lines = [ln for ln in out.stdout.splitlines() if "arguments" in ln]
+    assert len(lines) == 7
+    for ln in lines:
+        assert " 0 mismatches" in ln, ln
+        handed = int(ln.split("handed over")[1].split()[0])
+        if "e^[" not in ln:   # (the logarithm of a correctly rounded exponential sits next to a double: its rounding is never in doubt)
+            assert 2000000 / 3000 < handed < 2000000 / 700, ln
