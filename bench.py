@@ -64,8 +64,8 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-256 / single-trajectory side runs (profiling)")
     ap.add_argument("--schedule", choices=["overlap", "chain", "plain"], default="overlap",
-                    help="overlap: two batches on two HIP streams, every trajectory stays in its queue launch, the next batch's "
-                         "launch fills the slots the previous one frees (default); chain: one stream, the stragglers of a batch are "
+                    help="overlap: --depth batches resident, each on its own HIP stream, every trajectory stays in its queue launch, the next "
+                         "launches fill the slots an earlier one frees (default); chain: one stream, the stragglers of a batch are "
                          "adopted by the next batch's launch; plain: isolated solves (the tail of each batch runs on a nearly empty device)")
     ap.add_argument("--no-chain", action="store_true", help="same as --schedule plain")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
