@@ -56,7 +56,12 @@ size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S);
 size_t reference_order_table_doubles(int N);
 void reference_order_pack_tables(int N, const double *full, double *packed);
 int reference_order_interior_mask(int sweep, int row_mod_6);
-RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu);
+RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu, bool allow_quad = true);
+// the QUAD shape (solver_ref4.hip): four trajectories per wave; its copy of the corridor and its launches
+size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B);
+hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t stream);
+hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, const double *cor_t, double *scratch, const RefPlan &pl,
+                              int scheduled, hipStream_t stream);
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
                              hipStream_t stream);
 }
@@ -157,6 +162,9 @@ struct dftpav_batch {
   int ref_S = 0; // moving obstacles on the handle when the reference order was chosen (the term records are sized for them)
   double *d_ref_tab = nullptr, *d_ref_scratch = nullptr;
   RefPlan ref_plan{}; // its launch shape (chosen with the order)
+  RefPlan ref_plan_wt{}; // QUAD shape: the TEAM / WAVE plan of the same batch (what the QUAD kernel leaves to solver_ref.hip: the coefficient read-out)
+  double *d_cor_t = nullptr; // QUAD shape: the corridor as [B][4 H][Kmax + 1][16] (solver_ref4.hip), refreshed when the corridor changes
+  bool cor_t_dirty = true;
   // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
   struct PlanCycle {
     double *d_poses = nullptr, *d_t = nullptr, *d_v = nullptr, *d_rd = nullptr;
@@ -887,7 +895,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
                   b->d_x_in, b->d_x_out, b->d_f, b->d_g, b->d_status, b->d_success, b->d_iters, b->d_evals,
                   b->d_hist, b->d_ticks, b->d_prof, b->d_dev, b->d_coef, b->d_dt, b->d_records,
                   b->d_queue, b->d_stragglers, b->d_stragglers2, b->d_sflag, b->d_iota, b->d_qctl, b->d_state, b->d_dev2,
-                  b->d_f_eval, b->d_trace, b->d_cor_raw, b->d_ref_tab, b->d_ref_scratch, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
+                  b->d_f_eval, b->d_trace, b->d_cor_raw, b->d_ref_tab, b->d_ref_scratch, b->d_cor_t, b->pc.d_poses, b->pc.d_t, b->pc.d_v, b->pc.d_rd, b->pc.d_col, b->pc.d_first,
                   b->pc.d_valid};
   {
     auto &v = b->h->batches;
@@ -1258,6 +1266,7 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
     HIPCHK(h, launch_corridor_layout(b->d_cor_raw, b->d_corridor, B, L.Npts, L.H, b->NptsPad, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream)); // the caller's buffer is free again when this returns
     b->have_corridor = true;
+    b->cor_t_dirty = true;
   }
   b->t_now = d->t_now;
   b->epis = d->help_eps;
@@ -1276,7 +1285,10 @@ extern "C" int dftpav_batch_corridor_from_hypotheses(dftpav_batch *b, const doub
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   int rc = run_corridor(h, states, (b->B / n_restarts) * b->L.Npts, nullptr, b->d_corridor, b->L.Npts, b->NptsPad, n_restarts);
-  if (rc == DFTPAV_OK) b->have_corridor = true;
+  if (rc == DFTPAV_OK) {
+    b->have_corridor = true;
+    b->cor_t_dirty = true;
+  }
   return rc;
 }
 extern "C" int dftpav_batch_corridor_from_states(dftpav_batch *b, const double *states) {
@@ -1499,8 +1511,19 @@ extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals
 }
 
 // every launch of the solve kernel for a batch goes through here: the reference-order kernel when the batch asks for it
+static hipError_t launch_ref(dftpav_batch *b, const DevBatch &D, int mode, int scheduled) {
+  if (b->ref_plan.quad && mode != kModeCoeffs) {
+    if (b->cor_t_dirty) { // the QUAD shape reads its own layout of the corridor
+      const hipError_t e = launch_quad_corridor(D, b->d_cor_t, b->h->stream);
+      if (e != hipSuccess) return e;
+      b->cor_t_dirty = false;
+    }
+    return launch_solver_ref4(D, b->d_dev, mode, b->d_ref_tab, b->d_cor_t, b->d_ref_scratch, b->ref_plan, scheduled, b->h->stream);
+  }
+  return launch_solver_ref(D, b->d_dev, mode, b->d_ref_tab, b->d_ref_scratch, b->ref_plan.quad ? b->ref_plan_wt : b->ref_plan, scheduled, b->h->stream);
+}
 static hipError_t launch_for(dftpav_batch *b, const DevBatch &D, int mode) {
-  if (b->order == DFTPAV_ORDER_REFERENCE) return launch_solver_ref(D, b->d_dev, mode, b->d_ref_tab, b->d_ref_scratch, b->ref_plan, 0, b->h->stream);
+  if (b->order == DFTPAV_ORDER_REFERENCE) return launch_ref(b, D, mode, 0);
   return launch_solver(D, b->d_dev, mode, b->threads, b->B, SchedArgs{0, 0, 0, nullptr}, b->h->stream);
 }
 
@@ -1660,6 +1683,15 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
         return DFTPAV_E_HIP;
       }
       b->ref_plan = pl;
+      if (pl.quad) {
+        b->ref_plan_wt = reference_order_plan(b->L, b->P, h->S, b->B, n_cu, false);
+        if (!b->d_cor_t && hipMalloc(&b->d_cor_t, sizeof(double) * reference_order_quad_corridor_doubles(b->L, b->B)) != hipSuccess) {
+          (void)hipGetLastError();
+          h->err = "reference order: no device memory for the QUAD shape's copy of the corridor";
+          return DFTPAV_E_HIP;
+        }
+        b->cor_t_dirty = true;
+      }
     }
     if (!b->d_ref_tab || !b->d_ref_scratch || b->ref_S != h->S) {
       std::vector<double> tab; // the tables of the segments, one after the other
@@ -1764,13 +1796,14 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
   if (b->order == DFTPAV_ORDER_REFERENCE) {
-    if (b->ref_plan.wave && b->ref_plan.slots > 0 && b->ref_plan.slots * (b->ref_plan.threads / 64) < b->B && b->ref_plan.slice > 0) {
+    const int per_wave = b->ref_plan.quad ? 4 : 1; // trajectories a wave holds
+    if (b->ref_plan.wave && b->ref_plan.slots > 0 && b->ref_plan.slots * (b->ref_plan.threads / 64) * per_wave < b->B && b->ref_plan.slice > 0) {
       // more trajectories than resident waves: persistent workgroups whose waves pop trajectories from the ring and run them a
       // slice of iterations at a time (solver_ref.hip); queue = all trajectories, flags cleared, counters reset on the stream
       HIPCHK(h, hipMemcpyAsync(b->d_queue, b->d_iota, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToDevice, h->stream));
       HIPCHK(h, hipMemsetAsync(b->d_sflag, 0, sizeof(int) * (size_t)b->B, h->stream));
       HIPCHK(h, hipMemcpyAsync(b->d_qctl, b->d_qctl + 8, sizeof(unsigned) * 8, hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(h, launch_solver_ref(D, b->d_dev, kModeSolve, b->d_ref_tab, b->d_ref_scratch, b->ref_plan, 1, h->stream));
+      HIPCHK(h, launch_ref(b, D, kModeSolve, 1));
     } else {
       HIPCHK(h, launch_for(b, D, kModeSolve)); // every trajectory has its team from the start
     }
@@ -2225,6 +2258,7 @@ extern "C" int dftpav_plan_cycle(dftpav_batch *b, const dftpav_batch_data *d, co
                             pc.d_poses, (int)n_poses, h->params.veh_width, h->params.veh_length, h->params.veh_d_cr, h->d_dl, h->n_dl,
                             nullptr, b->d_corridor, b->L.Npts, b->NptsPad, n_restarts, h->stream));
   b->have_corridor = true;
+  b->cor_t_dirty = true;
   if (int rc = solve_impl(b, nullptr, false)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;

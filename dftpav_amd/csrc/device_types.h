@@ -179,6 +179,7 @@ inline int solver_state_doubles(const DevLayout &L, const DevParams &P) { (void)
 // launch shape of a reference-order batch (solver_ref.hip: reference_order_plan)
 struct RefPlan {
   int wave;      // 1: one wave per trajectory, several per workgroup (throughput); 0: one workgroup per trajectory (latency)
+  int quad;      // 1 (with wave = 1): FOUR trajectories per wave, one per row of 16 lanes (solver_ref4.hip)
   int threads;   // workgroup size
   int wg_per_cu; // WAVE shape: resident workgroups per CU
   int slots;     // WAVE shape: persistent workgroups of a scheduled solve

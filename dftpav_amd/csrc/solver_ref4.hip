@@ -1,0 +1,1019 @@
+// solver_ref4.hip — the reference order in the QUAD shape: FOUR trajectories per wave, one per row of 16 lanes (gfx950).
+//
+// solver_ref.hip's WAVE shape gives a trajectory a wave of its own.  Its sequential sums are chains of v_fmac_f64_dpp
+// row_newbcast:K, and such an instruction costs the same whether one row of the wave wants its result or all four do; its band
+// substitutions run on 2 of 64 lanes.  A wave there serves ONE trajectory per instruction, and the kernel is issue-bound
+// (profiles/r05_*: 15.0 M vector instructions per solve, two-loop recursion at its issue rate).  Here a row of 16 lanes is a
+// trajectory, so every chain instruction, every step of a substitution and every step of the line search serves four:
+//
+//   * lane l of a row OWNS PIECE l of its trajectory (one gear segment of at most 16 pieces): the piece's six rows of the band
+//     system (both dimensions), its coefficients c, its gdC and its adjoint live in that lane's REGISTERS -- no LDS copy of
+//     b / c / gdC / adj at all (they were 6.1 of the WAVE shape's 18.2 KB per trajectory);
+//   * BandedSystem::solve / solveAdj (poly_traj_utils.hpp:805-852): the row sweeps of solver_ref.hip, piece by piece -- at step s
+//     the lane that owns block s takes the six results of the previous block from its neighbour's registers (DPP row_shr / row_shl)
+//     and computes its own six rows, both dimensions side by side; the row's multiply-subtract pairs in the reference's order;
+//   * addPVAGradCost2CT (traj_optimizer.cpp:486-705): lane l walks the K + 1 constraint points of ITS piece in order (the running
+//     s1 += step of :513 is a register), and what an active term adds to gdC goes straight into the lane's own gdC registers --
+//     the order a gdC entry receives its additions in is (point, term) order within the piece, which is all the reference's order
+//     says about it.  No 16-double records, no chain pass.  Only what the term adds to the segment's gdT and to the two costs
+//     (three doubles) is parked, per piece, and chained afterwards over the pieces in order;
+//   * the corridor is read from a copy laid out [component][j][piece]: the 16 lanes of a row read 128 contiguous bytes;
+//   * lbfgs_optimize / line_search_lewisoverton (lbfgs.hpp:276-390, 440-751): solver_ref.hip's lbfgs_advance, per row; a vector of
+//     n <= 32 variables is two registers per lane (elements l and 16 + l), a sequential dot product is the 32-step DPP chain --
+//     each row chains its own sixteen lanes, no permlane swap -- and the two-loop recursion (:716-739) runs the four rows' history
+//     steps in the same instructions (a row that is still in its line search, or has the shorter history, is masked).
+//
+// Same bits as the TEAM / WAVE shapes (every sum is the same chain; tests/test_gpu_reference_order.py compares the shapes with one
+// another, with the restatement and with the golden vectors).  Scope: one gear segment, N <= 16 pieces, n <= 32, no moving
+// obstacles, H <= 5 -- the BASELINE configs[2] / [3] workload; everything else stays with solver_ref.hip.
+//
+// Residency: 4.1 KB of LDS per trajectory (x, g, the boundary states, the scalars of the line search, alpha[mem], the first three
+// parked terms of every piece), four waves per workgroup sharing the sweep tables: 79 KB, two workgroups = 32 trajectories per CU
+// at 256 registers (8 in the WAVE shape).  Scheduling as the WAVE shape: the rows pop trajectories from the batch's ring, run them
+// a slice of evaluations and push them back unfinished, so that a wave's rows stay filled until the batch runs out.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+
+#include "ref_order_common.h"
+
+namespace dftpav {
+namespace reford {
+
+constexpr int kQLcap = 3; // parked terms of a piece kept in LDS (the rest in global scratch)
+
+// LDS of one trajectory (a row)
+struct Q4 {
+  ldsd_t xs, gs;  // [32] the trial point, the gradient (the interface between the evaluation and the solver)
+  ldsd_t bnd;     // [12] iniS [6], finS [6] as uploaded (clamped)
+  ldsd_t st;      // [sNUM]
+  ldsd_t alpha;   // [mem]
+  ldsd_t tl;      // [16][kQLcap][3] parked terms of a piece: what they add to gdT, to the corridor cost, to the feasibility cost
+  ldsi_t ist;     // [iNUM]
+  ldsi_t tcnt;    // [16] parked terms of a piece
+};
+__host__ __device__ inline size_t q4_team_doubles(int mem) { return 32 + 32 + 12 + sNUM + (size_t)mem + 16 * kQLcap * 3; }
+__host__ __device__ inline size_t q4_team_bytes(int mem) { return (q4_team_doubles(mem) * sizeof(double) + (iNUM + 16) * sizeof(int) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t q4_shared_bytes(int N) { return ((size_t)pk_segment_doubles(N) * sizeof(double) + 15) & ~(size_t)15; }
+__device__ inline void q4_carve(Q4 &q, char *team, int mem) {
+  ldsd_t p = (ldsd_t)reinterpret_cast<double *>(team);
+  q.xs = p; p += 32;
+  q.gs = p; p += 32;
+  q.bnd = p; p += 12;
+  q.st = p; p += sNUM;
+  q.alpha = p; p += mem;
+  q.tl = p; p += 16 * kQLcap * 3;
+  ldsi_t i = (ldsi_t)p;
+  q.ist = i; i += iNUM;
+  q.tcnt = i;
+}
+
+// acc + v[lane 0 of the row] + v[lane 1] + ... + v[lane 15]: sixteen dependent additions, every lane of a row ends with its
+// row's sum.  (fma(v, 1.0, acc) == acc + v rounded once.  A VALU write followed by a DPP read needs two wait states and the asm
+// block is opaque to the hazard recogniser: s_nop 1 in front.)
+__device__ __forceinline__ double row_chain16(double acc, double v) {
+  const double one = 1.0;
+  asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST16 : "+v"(acc) : "v"(v), "v"(one));
+  return acc;
+}
+// acc + v[lane 0 of the row]
+__device__ __forceinline__ double row_add_lane0(double acc, double v) {
+  const double one = 1.0;
+  asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST(0) : "+v"(acc) : "v"(v), "v"(one));
+  return acc;
+}
+// 0.0 + p[0] + p[1] + ... + p[n-1] for a vector held as (element l, element 16 + l); elements from n on contribute -0.0, and
+// x + (-0.0) == x for every x: the second half of the chain is left out when it has nothing but those
+__device__ __forceinline__ double row_sum32(double p0, double p1, int n, int l) {
+  double acc = row_chain16(0.0, l < n ? p0 : -0.0);
+  if (n > 16) acc = row_chain16(acc, 16 + l < n ? p1 : -0.0); // (uniform)
+  return acc;
+}
+// max over the 16 lanes of a row (order-free), the same value in every lane of the row
+__device__ __forceinline__ double row_max16(double v) {
+  v = fmax(v, mov_dpp<0xB1>(v));
+  v = fmax(v, mov_dpp<0x4E>(v));
+  v = fmax(v, mov_dpp<0x141>(v));
+  v = fmax(v, mov_dpp<0x140>(v));
+  return v;
+}
+// the neighbour's value: lane l - 1 (row_shr:1) / lane l + 1 (row_shl:1) of the same row; 0.0 where there is none
+template <int CTRL> __device__ __forceinline__ double nb_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// One substitution sweep over the 6 N rows of the band system (solver_ref.hip: sweep / rows_end / rows_pack -- the same rows, the
+// same order of a row's updates), the rows in registers: bq[2 r + d] = row 6 l + r, dimension d, of this lane's piece.  Step s of
+// the traversal belongs to piece s (ascending sweeps) or N - 1 - s (descending); the six previous results it starts from are the
+// finished rows of the previous step's piece, i.e. the neighbour lane's registers.  tab: this sweep's table (blocks in traversal
+// order: whole rows at the two ends, the interior pattern's coefficients in between).
+template <int Q>
+__device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int l) {
+  constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
+  ldscd_t ip = tab + 48;
+#pragma unroll 1
+  for (int s = 0; s < N; s++) {
+    const int p = DESC ? N - 1 - s : s;
+    // traversal row r of a block is natural row r (ascending) or 5 - r (descending) of the piece
+    double w[6][2];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const double nb = DESC ? nb_dpp<0x101>(bq[2 * (5 - r) + d]) : nb_dpp<0x111>(bq[2 * r + d]);
+        w[r][d] = s == 0 ? 0.0 : nb;
+      }
+    if (s == 0 || s == N - 1) { // (uniform) a block of the ends: every coefficient is tested, as the reference does (`if (a != 0.0)`)
+      const ldscv2_t a = (ldscv2_t)(s == 0 ? tab : ip + (N - 2) * pk_size(Q));
+      if (l == p) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          v2d_t c[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) c[u] = a[4 * r + u];
+          const int rr = DESC ? 5 - r : r;
+#pragma unroll
+          for (int d = 0; d < 2; d++) {
+            double acc = bq[2 * rr + d];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+              const double ck = (k & 1) ? c[k >> 1].y : c[k >> 1].x;
+              const double t = ck * w[(r + k) % 6][d];
+              acc = ck != 0.0 ? acc - t : acc;
+            }
+            if (DIV) acc = div_by_rcp(acc, c[3].x, c[3].y);
+            w[r][d] = acc;
+            bq[2 * rr + d] = acc;
+          }
+        }
+      }
+    } else { // an interior block: the non-zero terms only, no test
+      const ldscv2_t a = (ldscv2_t)(ip + (s - 1) * pk_size(Q));
+      if (l == p) {
+        v2d_t c[pk_size(Q) / 2];
+#pragma unroll
+        for (int u = 0; u < pk_size(Q) / 2; u++) c[u] = a[u];
+        auto at = [&](int o) { return (o & 1) ? c[o >> 1].y : c[o >> 1].x; };
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const int rr = DESC ? 5 - r : r;
+#pragma unroll
+          for (int d = 0; d < 2; d++) {
+            double acc = bq[2 * rr + d];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+              if (pk_mask(Q, r) & (1 << k)) acc = acc - at(pk_off(Q, r, k)) * w[(r + k) % 6][d];
+            if (DIV) acc = div_by_rcp(acc, at(pk_diag0(Q) + 2 * r), at(pk_diag0(Q) + 2 * r + 1));
+            w[r][d] = acc;
+            bq[2 * rr + d] = acc;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350), one gear segment
+// x (q.xs) -> g (q.gs), returns f.  The statements are solver_ref.hip's ref_eval, stage by stage; what changes is where a value
+// lives.  cor: &cor_t[b][0][0][l] (component pitch cpitch = 16 (Kmax + 1), a round's 16 pieces contiguous); ovf: this
+// trajectory's global scratch for the parked terms beyond the LDS window.
+__device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_t tab, gcd_t cor, size_t cpitch, gd_t ovf, int l, Prof &pr) {
+  const DevLayout &L = D.L;
+  const DevParams &P = D.P;
+  const int N = L.Ntot, H = L.H, nterm = 5 * H + 4, t0 = 5 * H;
+  // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966)
+  const double vt = q.xs[L.x_tau0];
+  const double Tr = vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + P.mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + P.mini_T;
+  const double t1 = Tr / N, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
+  const double tI[6] = {1.0 / 1.0, 1.0 / t1, 1.0 / t2, 1.0 / t3, 1.0 / t4, 1.0 / t5};
+  double hv[6], tv[6];
+#pragma unroll
+  for (int u = 0; u < 6; u++) {
+    hv[u] = q.bnd[u];
+    tv[u] = q.bnd[6 + u];
+  }
+  // ---- right-hand sides (poly_traj_utils.hpp:968-977): the rows of this lane's piece
+  double bq[12];
+#pragma unroll
+  for (int u = 0; u < 12; u++) bq[u] = 0.0;
+  if (l == 0) {
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      bq[0 + d] = hv[d];
+      bq[2 + d] = hv[2 + d] * t1;
+      bq[4 + d] = hv[4 + d] * t2;
+    }
+  }
+  if (l == N - 1) {
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      bq[6 + d] = tv[d];
+      bq[8 + d] = tv[2 + d] * t1;
+      bq[10 + d] = tv[4 + d] * t2;
+    }
+  } else if (l < N - 1) {
+    bq[10] = q.xs[2 * l];
+    bq[11] = q.xs[2 * l + 1];
+  }
+  // ---- BandedSystem::solve (poly_traj_utils.hpp:805-826)
+  sweep4<0>(tab, bq, N, l);
+  sweep4<1>(tab + pk_sweep_offset(1, N), bq, N, l);
+  pr.tick(0);
+  // ---- c = b * tInv (:979-984)
+  double cc[12];
+#pragma unroll
+  for (int u = 0; u < 12; u++) cc[u] = bq[u] * tI[u >> 1];
+  // ---- initSmGradCost / getTrajJerkCost per piece (poly_traj_utils.hpp:998-1035)
+  double gdC[12], pE, pG;
+  {
+    const double *c = cc;
+    const double t[6] = {1.0, t1, t2, t3, t4, t5};
+    const double n33 = c[6] * c[6] + c[7] * c[7], n44 = c[8] * c[8] + c[9] * c[9], n55 = c[10] * c[10] + c[11] * c[11];
+    const double d43 = c[8] * c[6] + c[9] * c[7], d53 = c[10] * c[6] + c[11] * c[7], d54 = c[10] * c[8] + c[11] * c[9];
+    pE = 36.0 * n33 * t[1] + 144.0 * d43 * t[2] + 192.0 * n44 * t[3] + 240.0 * d53 * t[3] + 720.0 * d54 * t[4] + 720.0 * n55 * t[5];
+    pG = 36.0 * n33 + 288.0 * d43 * t[1] + 576.0 * n44 * t[2] + 720.0 * d53 * t[2] + 2880.0 * d54 * t[3] + 3600.0 * n55 * t[4];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      const double c3 = c[6 + d], c4 = c[8 + d], c5 = c[10 + d];
+      gdC[10 + d] = 240.0 * c3 * t[3] + 720.0 * c4 * t[4] + 1440.0 * c5 * t[5];
+      gdC[8 + d] = 144.0 * c3 * t[2] + 384.0 * c4 * t[3] + 720.0 * c5 * t[4];
+      gdC[6 + d] = 72.0 * c3 * t[1] + 144.0 * c4 * t[2] + 240.0 * c5 * t[3];
+      gdC[d] = 0.0;
+      gdC[2 + d] = 0.0;
+      gdC[4 + d] = 0.0;
+    }
+  }
+  pr.tick(1);
+  // ---- the constraint points of this lane's piece, in order (traj_optimizer.cpp:486-705)
+  const bool piece = l < N;
+  const int Kl = (l == 0 || l == N - 1) ? L.Kd : L.K;
+  const int pt0 = l == 0 ? 0 : (L.Kd + 1) + (l - 1) * (L.K + 1); // the piece's first constraint point
+  const double step = t1 / Kl;
+  const int singul_ = L.singuls[0];
+  double s1 = 0.0;
+  int cnt = 0;
+  const gd_t ovf_l = ovf + (size_t)pt0 * nterm * 3;
+#pragma unroll 1
+  for (int j = 0; j <= L.Kmax; j++) {
+    unsigned m = 0u;
+    PtState pst;
+    const gcd_t cj = cor + (size_t)j * 16;
+    if (piece && j <= Kl) {
+      double pl[20];
+      load_planes(cj, cpitch, H, pl);
+      m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, D.epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
+    }
+    s1 += step; // the running sum of traj_optimizer.cpp:513
+    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue; // (uniform) nothing active in this round
+    for (unsigned mm = m; mm;) {
+      const int t = __builtin_ctz(mm);
+      mm &= mm - 1;
+      double r_[16];
+      point_emit(P, pst, t, H, t0, cj, cpitch, (double *)r_);
+#pragma unroll
+      for (int u = 0; u < 12; u++) gdC[u] += r_[u];
+      // what the term adds to gdT and to its cost, parked (the other cost gets -0.0: x + (-0.0) == x)
+      const bool corr = t < t0;
+      const double e0 = r_[12], e1 = corr ? r_[13] : -0.0, e2 = corr ? -0.0 : r_[13];
+      if (cnt < kQLcap) {
+        ldsd_t e = q.tl + (l * kQLcap + cnt) * 3;
+        e[0] = e0;
+        e[1] = e1;
+        e[2] = e2;
+      } else {
+        gd_t e = ovf_l + (size_t)cnt * 3;
+        e[0] = e0;
+        e[1] = e1;
+        e[2] = e2;
+      }
+      cnt++;
+    }
+  }
+  q.tcnt[l] = piece ? cnt : 0;
+  __threadfence_block(); // parked terms beyond the LDS window went to global memory; the counts are read by the other lanes
+  pr.tick(2);
+  // ---- the per-segment chains: `gdT +=`, `energy +=` over the pieces in order from 0.0, then the parked terms in (piece, point,
+  // term) order (every lane of the row forms them for itself: the same bits)
+  double gdT = row_chain16(0.0, piece ? pG : -0.0);
+  const double en = row_chain16(0.0, piece ? pE : -0.0);
+  double cost0 = 0.0, cost2 = 0.0;
+  {
+    int total = 0;
+    for (int p = 0; p < N; p++) total += q.tcnt[p];
+    pr.count(9, total);
+    if (total > 0) {
+      for (int p = 0; p < N; p++) {
+        const int c = q.tcnt[p];
+        if (c == 0) continue;
+        const int pp0 = p == 0 ? 0 : (L.Kd + 1) + (p - 1) * (L.K + 1);
+        const gcd_t og = (gcd_t)(ovf + (size_t)pp0 * nterm * 3);
+        for (int i = 0; i < c; i++) {
+          double e0, e1, e2;
+          if (i < kQLcap) {
+            ldscd_t e = q.tl + (p * kQLcap + i) * 3;
+            e0 = e[0];
+            e1 = e[1];
+            e2 = e[2];
+          } else {
+            e0 = og[(size_t)i * 3];
+            e1 = og[(size_t)i * 3 + 1];
+            e2 = og[(size_t)i * 3 + 2];
+          }
+          gdT += e0;
+          cost0 += e1;
+          cost2 += e2;
+        }
+      }
+    }
+  }
+  pr.tick(3);
+  // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
+  double pA;
+  {
+    const double gdtInv[6] = {0.0, -1.0 * tI[2], -2.0 * tI[3], -3.0 * tI[4], -4.0 * tI[5], -5.0 * tI[5] * tI[1]};
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const double gdcol = gdC[2 * k] * bq[2 * k] + gdC[2 * k + 1] * bq[2 * k + 1];
+      acc += gdtInv[k] * gdcol;
+    }
+    pA = acc;
+  }
+  double adj[12];
+#pragma unroll
+  for (int u = 0; u < 12; u++) adj[u] = gdC[u] * tI[u >> 1];
+  sweep4<2>(tab + pk_sweep_offset(2, N), adj, N, l);
+  sweep4<3>(tab + pk_sweep_offset(3, N), adj, N, l);
+  pr.tick(4);
+  // ---- gradient and cost (traj_optimizer.cpp:299-344)
+  if (l < N - 1) { // gdP: rows 6 i + 5 of the adjoint
+    q.gs[2 * l] = adj[10];
+    q.gs[2 * l + 1] = adj[11];
+  }
+  {
+    // the duration gradient (poly_traj_utils.hpp:1050-1064, VirtualTGradCost :405-419): the head terms live in lane 0, the tail
+    // terms in lane N - 1 (every other lane hands the chain a -0.0)
+    const double h1 = hv[2] * adj[2] + hv[3] * adj[3];
+    const double h2 = (hv[4] * adj[4] + hv[5] * adj[5]) * 2.0 * t1;
+    const double g1 = tv[2] * adj[8] + tv[3] * adj[9];
+    const double g2 = (tv[4] * adj[10] + tv[5] * adj[11]) * 2.0 * t1;
+    gdT = row_add_lane0(gdT, h1);
+    gdT = row_add_lane0(gdT, h2);
+    gdT = row_chain16(gdT, l == N - 1 ? g1 : -0.0);
+    gdT = row_chain16(gdT, l == N - 1 ? g2 : -0.0);
+    gdT = row_chain16(gdT, piece ? pA : -0.0);
+    double gdVT2Rt;
+    if (vt > 0) {
+      gdVT2Rt = vt + 1.0;
+    } else {
+      const double denSqrt = (0.5 * vt - 1.0) * vt + 1.0;
+      gdVT2Rt = (1.0 - vt) / (denSqrt * denSqrt);
+    }
+    if (l == 0) q.gs[L.x_tau0] = (gdT / N + P.wei_time) * gdVT2Rt;
+  }
+  double total_smcost = 0.0, total_timecost = 0.0, penalty_cost = 0.0;
+  total_smcost += en;
+  penalty_cost += (cost0 + 0.0) + cost2; // (the moving-obstacle cost of a segment without obstacles is its start value 0.0)
+  total_timecost += Tr * P.wei_time;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // g is read by other lanes of the row
+  pr.tick(5);
+  return total_smcost + total_timecost + penalty_cost;
+}
+
+// ------------------------------------------------ L-BFGS, per row
+struct QVec { // the solver's vectors that live in registers: element l and element 16 + l
+  double xp0, xp1, gp0, gp1, d0, d1;
+};
+
+// Start of an outer iteration (lbfgs.hpp:559-574, 290-315): xp = x, gp = g, dginit = gp . d, first trial point
+__device__ __forceinline__ bool q4_begin_iteration(const DevParams &P, const Q4 &q, QVec &v, int n, int l) {
+  const bool e0 = l < n, e1 = 16 + l < n;
+  v.xp0 = e0 ? q.xs[l] : 0.0;
+  v.xp1 = e1 ? q.xs[16 + l] : 0.0;
+  v.gp0 = e0 ? q.gs[l] : 0.0;
+  v.gp1 = e1 ? q.gs[16 + l] : 0.0;
+  const double dginit = row_sum32(v.gp0 * v.d0, v.gp1 * v.d1, n, l);
+  const double step = q.st[sSTEP];
+  if (!(step > 0.0)) {
+    if (l == 0) q.ist[iRET] = -1006;
+    return false;
+  }
+  if (0.0 < dginit) {
+    if (l == 0) q.ist[iRET] = -1005;
+    return false;
+  }
+  if (l == 0) {
+    q.st[sFINIT] = q.st[sFX];
+    q.st[sDGINIT] = dginit;
+    q.st[sDGTEST] = P.f_dec_coeff * dginit;
+    q.st[sDSTEST] = P.s_curv_coeff * dginit;
+    q.st[sMU] = 0.0;
+    q.st[sNU] = P.max_step;
+    q.st[sSTP] = step;
+    q.ist[iCOUNT] = 0;
+    q.ist[iBRACKT] = 0;
+    q.ist[iTOUCHED] = 0;
+  }
+  if (e0) q.xs[l] = v.xp0 + step * v.d0;
+  if (e1) q.xs[16 + l] = v.xp1 + step * v.d1;
+  return true;
+}
+
+// The two-loop recursion (lbfgs.hpp:716-739) over `bound` stored pairs of this row's trajectory, the newest in slot ne - 1;
+// d = -g on entry (elements from n on: 0.0).  The four rows run their steps in the same instructions; bound, the ring position
+// and the division mode belong to the row.  History rows: (s, y) interleaved per element at pitch npad; (ys, 1 / ys) per pair.
+constexpr int kQB = 4; // stored pairs per register block (the next block is in flight while one is worked on)
+struct QBlk {
+  d2_t a[kQB], b[kQB]; // (s, y) of elements l and 16 + l
+  d2_t yr[kQB];        // (ys, 1 / ys)
+};
+typedef double __attribute__((ext_vector_type(2))) qd2_t;
+template <int DIR>
+__device__ __forceinline__ void q4_load_blk(QBlk &R, gcd2_t hS, gcd2_t hR, int npad, int m, int la, int lb, int &jl) {
+#pragma unroll
+  for (int u = 0; u < kQB; u++) {
+    R.a[u] = hS[(size_t)jl * npad + la];
+    R.b[u] = hS[(size_t)jl * npad + lb];
+    R.yr[u] = hR[jl];
+    if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
+    else jl = jl == m - 1 ? 0 : jl + 1;
+  }
+}
+__device__ __forceinline__ void q4_pin_blk(QBlk &R) {
+#pragma unroll
+  for (int u = 0; u < kQB; u++)
+    asm volatile("" : "+v"(R.a[u].x), "+v"(R.a[u].y), "+v"(R.b[u].x), "+v"(R.b[u].y), "+v"(R.yr[u].x), "+v"(R.yr[u].y));
+}
+__device__ __forceinline__ void q4_first_steps(const QBlk &R, const Q4 &q, int i0, int bound, int m, int n, int l, bool exact, int &j, double &d0, double &d1) {
+#pragma unroll
+  for (int u = 0; u < kQB; u++) {
+    if (i0 + u < bound) { // (row-uniform)
+      j = j == 0 ? m - 1 : j - 1;
+      const double dot = row_sum32(R.a[u].x * d0, R.b[u].x * d1, n, l);
+      const double a = exact ? dot / R.yr[u].x : div_by_rcp<false>(dot, R.yr[u].x, R.yr[u].y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
+      if (l == 0) q.alpha[j] = a;
+      const double na = -a;
+      d0 = d0 + na * R.a[u].y; // d += (-alpha) * lm_y.col(j)
+      d1 = d1 + na * R.b[u].y;
+    }
+  }
+}
+__device__ __forceinline__ void q4_second_steps(const QBlk &R, const Q4 &q, int i0, int bound, int m, int n, int l, bool exact, int &j, double &d0, double &d1) {
+#pragma unroll
+  for (int u = 0; u < kQB; u++) {
+    if (i0 + u < bound) { // (row-uniform)
+      const double al = q.alpha[j];
+      const double dot = row_sum32(R.a[u].y * d0, R.b[u].y * d1, n, l);
+      const double beta = exact ? dot / R.yr[u].x : div_by_rcp<false>(dot, R.yr[u].x, R.yr[u].y);
+      const double cf = al - beta;
+      d0 = d0 + cf * R.a[u].x; // d += (alpha - beta) * lm_s.col(j)
+      d1 = d1 + cf * R.b[u].x;
+      j = j == m - 1 ? 0 : j + 1;
+    }
+  }
+}
+__device__ __forceinline__ void q4_two_loop(const Q4 &q, gcd2_t hS, gcd2_t hR, int npad, int m, int n, int l, int bound, int ne, bool exact, double sc0, double &d0,
+                                            double &d1) {
+  const int la = l < n ? l : 0, lb = 16 + l < n ? 16 + l : 0;
+  QBlk A, B;
+  int j = ne;
+  int jl = ne == 0 ? m - 1 : ne - 1;
+  q4_load_blk<-1>(A, hS, hR, npad, m, la, lb, jl);
+#pragma unroll 1
+  for (int i0 = 0; i0 < bound; i0 += 2 * kQB) {
+    q4_pin_blk(A);
+    q4_load_blk<-1>(B, hS, hR, npad, m, la, lb, jl);
+    q4_first_steps(A, q, i0, bound, m, n, l, exact, j, d0, d1);
+    q4_pin_blk(B);
+    q4_load_blk<-1>(A, hS, hR, npad, m, la, lb, jl);
+    q4_first_steps(B, q, i0 + kQB, bound, m, n, l, exact, j, d0, d1);
+  }
+  d0 = d0 * sc0;
+  d1 = d1 * sc0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // alpha written by lane 0 of the row, read by all below
+  jl = j;
+  q4_load_blk<+1>(A, hS, hR, npad, m, la, lb, jl);
+#pragma unroll 1
+  for (int i0 = 0; i0 < bound; i0 += 2 * kQB) {
+    q4_pin_blk(A);
+    q4_load_blk<+1>(B, hS, hR, npad, m, la, lb, jl);
+    q4_second_steps(A, q, i0, bound, m, n, l, exact, j, d0, d1);
+    q4_pin_blk(B);
+    q4_load_blk<+1>(A, hS, hR, npad, m, la, lb, jl);
+    q4_second_steps(B, q, i0 + kQB, bound, m, n, l, exact, j, d0, d1);
+  }
+}
+
+// Everything lbfgs_optimize does between two evaluations (lbfgs.hpp:524-745 with the line search of :312-389 unrolled into it):
+// solver_ref.hip's lbfgs_advance for the trajectory of this row; f: the cost of the evaluation just made; sets iACTION.
+__device__ __forceinline__ void q4_advance(const DevBatch &D, const Q4 &q, QVec &v, double f, gd_t hS, gd_t hR, int l, Prof &pr) {
+  const DevParams &P = D.P;
+  const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
+  const bool e0 = l < n, e1 = 16 + l < n;
+  int action = kActEval;
+  if (q.ist[iPHASE] == 0) { // after the first evaluation: lbfgs.hpp:524-551
+    const double g0 = e0 ? q.gs[l] : 0.0, g1 = e1 ? q.gs[16 + l] : 0.0;
+    const double x0 = e0 ? q.xs[l] : 0.0, x1 = e1 ? q.xs[16 + l] : 0.0;
+    v.d0 = e0 ? -g0 : 0.0;
+    v.d1 = e1 ? -g1 : 0.0;
+    const double gmax = row_max16(fmax(fabs(g0), fabs(g1))), xmax = row_max16(fmax(fabs(x0), fabs(x1)));
+    const double dd = row_sum32((-g0) * (-g0), (-g1) * (-g1), n, l);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (l == 0) {
+      q.st[sFX] = f;
+      q.st[sPF0] = f;
+      q.ist[iEVALS] = 1;
+      q.ist[iEND] = 0;
+      q.ist[iBOUND] = 0;
+      q.ist[iHISTLO] = 0;
+      q.ist[iHISTHI] = 0;
+      q.ist[iPHASE] = 1;
+    }
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      if (l == 0) {
+        q.ist[iRET] = 0;
+        q.ist[iK] = 0;
+      }
+      action = kActDone;
+    } else {
+      if (l == 0) {
+        q.st[sSTEP] = 1.0 / sqrt(dd);
+        q.ist[iK] = 1;
+      }
+      __threadfence_block();
+      if (!q4_begin_iteration(P, q, v, n, l)) action = kActDone;
+    }
+    if (l == 0) q.ist[iACTION] = action;
+    return;
+  }
+
+  // ---- after a line-search trial: lbfgs.hpp:317-389
+  const double fx = f;
+  const double finit = q.st[sFINIT];
+  double stp = q.st[sSTP];
+  const int count = q.ist[iCOUNT] + 1;
+  int ls = 0;
+  bool decided = false;
+  const int evals_before = q.ist[iEVALS];
+  __threadfence_block();
+  if (l == 0) {
+    q.st[sFX] = fx;
+    q.ist[iEVALS] = evals_before + 1;
+    q.ist[iCOUNT] = count;
+  }
+  if (isinf(fx) || isnan(fx)) {
+    ls = -1012;
+    decided = true;
+  } else if (P.past > 0 && fabs(finit - fx) / (fabs(finit) + 1.0) < P.delta / P.past) { // lbfgs.hpp:326-329
+    ls = count;
+    decided = true;
+  } else {
+    double mu = q.st[sMU], nu = q.st[sNU];
+    bool brackt = q.ist[iBRACKT] != 0;
+    const int touched = q.ist[iTOUCHED];
+    if (fx > finit + stp * q.st[sDGTEST]) {
+      nu = stp;
+      brackt = true;
+    } else {
+      const double g0 = e0 ? q.gs[l] : 0.0, g1 = e1 ? q.gs[16 + l] : 0.0;
+      const double gs = row_sum32(g0 * v.d0, g1 * v.d1, n, l);
+      if (gs < q.st[sDSTEST]) {
+        mu = stp;
+      } else {
+        ls = count;
+        decided = true;
+      }
+    }
+    bool touch_now = false;
+    if (!decided) {
+      if (P.max_linesearch <= count) {
+        ls = -1009;
+        decided = true;
+      } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+        ls = -1007;
+        decided = true;
+      } else {
+        if (brackt) stp = 0.5 * (mu + nu);
+        else stp *= 2.0;
+        if (stp < P.min_step) {
+          ls = -1011;
+          decided = true;
+        } else if (stp > P.max_step) {
+          if (touched) {
+            ls = -1010;
+            decided = true;
+          } else {
+            touch_now = true;
+            stp = P.max_step;
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    if (l == 0) {
+      q.st[sMU] = mu;
+      q.st[sNU] = nu;
+      q.ist[iBRACKT] = brackt ? 1 : 0;
+      q.st[sSTP] = stp;
+      if (touch_now) q.ist[iTOUCHED] = 1;
+    }
+    if (!decided) {
+      if (e0) q.xs[l] = v.xp0 + stp * v.d0;
+      if (e1) q.xs[16 + l] = v.xp1 + stp * v.d1;
+      if (l == 0) q.ist[iACTION] = kActEval;
+      pr.tick(6);
+      return;
+    }
+  }
+  if (l == 0) q.st[sSTEP] = stp; // lbfgs.hpp:574 passes `step` by reference
+  if (ls < 0) { // lbfgs.hpp:604-611: x, g reverted; fx is not
+    if (e0) {
+      q.xs[l] = v.xp0;
+      q.gs[l] = v.gp0;
+    }
+    if (e1) {
+      q.xs[16 + l] = v.xp1;
+      q.gs[16 + l] = v.gp1;
+    }
+    if (l == 0) {
+      q.ist[iRET] = ls;
+      q.ist[iACTION] = kActDone;
+    }
+    return;
+  }
+
+  // ---- convergence / stopping tests (lbfgs.hpp:628-666)
+  const double x0 = e0 ? q.xs[l] : 0.0, x1 = e1 ? q.xs[16 + l] : 0.0;
+  const double g0 = e0 ? q.gs[l] : 0.0, g1 = e1 ? q.gs[16 + l] : 0.0;
+  int k = q.ist[iK];
+  {
+    const double gmax = row_max16(fmax(fabs(g0), fabs(g1))), xmax = row_max16(fmax(fabs(x0), fabs(x1)));
+    const int kGoOn = 12345;
+    int ret = kGoOn;
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      ret = 0;
+    } else {
+      if (0 < P.past) {
+        const int slot = k % P.past;
+        const double pf = q.st[sPF0 + slot];
+        __threadfence_block();
+        if (P.past <= k) {
+          const double rate = fabs(pf - fx) / fmax(1.0, fabs(fx));
+          if (rate < P.delta) ret = 1;
+        }
+        if (ret == kGoOn && l == 0) q.st[sPF0 + slot] = fx;
+      }
+      if (ret == kGoOn && P.max_iterations != 0 && P.max_iterations <= k) ret = -1008;
+    }
+    if (ret != kGoOn) {
+      if (l == 0) {
+        q.ist[iRET] = ret;
+        q.ist[iACTION] = kActDone;
+      }
+      return;
+    }
+  }
+  ++k;
+  pr.tick(6);
+  const int end = q.ist[iEND];
+  int bound = q.ist[iBOUND];
+  __threadfence_block();
+  if (l == 0) q.ist[iK] = k;
+
+  // ---- history update + two-loop recursion (lbfgs.hpp:676-740); (s, y) interleaved per element
+  const double sv0 = e0 ? x0 - v.xp0 : 0.0, sv1 = e1 ? x1 - v.xp1 : 0.0;
+  const double yv0 = e0 ? g0 - v.gp0 : 0.0, yv1 = e1 ? g1 - v.gp1 : 0.0;
+  if (e0) {
+    d2_t sy;
+    sy.x = sv0;
+    sy.y = yv0;
+    ((gd2_t)hS)[(size_t)end * npad + l] = sy;
+  }
+  if (e1) {
+    d2_t sy;
+    sy.x = sv1;
+    sy.y = yv1;
+    ((gd2_t)hS)[(size_t)end * npad + 16 + l] = sy;
+  }
+  v.d0 = e0 ? -g0 : 0.0;
+  v.d1 = e1 ? -g1 : 0.0;
+  // the four dot products of lbfgs.hpp:683-694
+  const double ys = row_sum32(yv0 * sv0, yv1 * sv1, n, l);
+  const double yy = row_sum32(yv0 * yv0, yv1 * yv1, n, l);
+  const double ss = row_sum32(sv0 * sv0, sv1 * sv1, n, l);
+  const double gpgp = row_sum32(v.gp0 * v.gp0, v.gp1 * v.gp1, n, l);
+  if (l == 0) {
+    d2_t yr;
+    yr.x = ys;
+    yr.y = 1.0 / ys;
+    ((gd2_t)hR)[end] = yr;
+    if (!rcp_route_ok(ys)) q.ist[iSLOWDIV] = 1; // from here on the recursion divides (see div_by_rcp)
+  }
+  const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+  pr.tick(7);
+  if (ys > cau) {
+    ++bound;
+    bound = m < bound ? m : bound;
+    const int ne = end + 1 == m ? 0 : end + 1;
+    __threadfence_block(); // the newest pair's row and (ys, 1 / ys) are read back below
+    const bool exact = q.ist[iSLOWDIV] != 0;
+    double d0 = v.d0, d1 = v.d1;
+    q4_two_loop(q, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, l, bound, ne, exact, ys / yy, d0, d1);
+    v.d0 = e0 ? d0 : 0.0;
+    v.d1 = e1 ? d1 : 0.0;
+    if (l == 0) {
+      q.ist[iEND] = ne;
+      q.ist[iBOUND] = bound;
+      long long hs = ((long long)q.ist[iHISTHI] << 32) | (unsigned int)q.ist[iHISTLO];
+      hs += bound;
+      q.ist[iHISTLO] = (int)(hs & 0xffffffffLL);
+      q.ist[iHISTHI] = (int)(hs >> 32);
+    }
+  }
+  if (l == 0) q.st[sSTEP] = 1.0; // lbfgs.hpp:743
+  pr.tick(8);
+  __threadfence_block();
+  const bool ok = q4_begin_iteration(P, q, v, n, l);
+  if (l == 0) q.ist[iACTION] = ok ? kActEval : kActDone;
+  pr.tick(6);
+}
+
+// solver state of a suspended trajectory <-> its record in DevBatch::state (the layout of solver_ref.hip's state_io: five vectors at
+// pitch npad -- x, xp, g, gp, d --, the scalars, the integers)
+__device__ inline void q4_state_io(const DevBatch &D, const Q4 &q, QVec &v, int b, int l, bool save) {
+  const int n = D.L.n, npad = D.L.npad;
+  double *rec = D.state + (size_t)b * D.state_stride;
+  for (int h = 0; h < 2; h++) {
+    const int e = 16 * h + l;
+    if (e >= n) {
+      if (!save) {
+        q.xs[e] = 0.0;
+        q.gs[e] = 0.0;
+        if (h == 0) { v.xp0 = 0.0; v.gp0 = 0.0; v.d0 = 0.0; } else { v.xp1 = 0.0; v.gp1 = 0.0; v.d1 = 0.0; }
+      }
+      continue;
+    }
+    if (save) {
+      rec[0 * npad + e] = q.xs[e];
+      rec[1 * npad + e] = h == 0 ? v.xp0 : v.xp1;
+      rec[2 * npad + e] = q.gs[e];
+      rec[3 * npad + e] = h == 0 ? v.gp0 : v.gp1;
+      rec[4 * npad + e] = h == 0 ? v.d0 : v.d1;
+    } else {
+      q.xs[e] = rec[0 * npad + e];
+      q.gs[e] = rec[2 * npad + e];
+      if (h == 0) {
+        v.xp0 = rec[1 * npad + e];
+        v.gp0 = rec[3 * npad + e];
+        v.d0 = rec[4 * npad + e];
+      } else {
+        v.xp1 = rec[1 * npad + e];
+        v.gp1 = rec[3 * npad + e];
+        v.d1 = rec[4 * npad + e];
+      }
+    }
+  }
+  double *r2 = rec + 5 * npad;
+  for (int w = l; w < sNUM; w += 16) {
+    if (save) r2[w] = q.st[w];
+    else q.st[w] = r2[w];
+  }
+  int *ri = reinterpret_cast<int *>(r2 + 24);
+  for (int w = l; w < iNUM; w += 16) {
+    if (save) ri[w] = q.ist[w];
+    else q.ist[w] = ri[w];
+  }
+}
+
+// ------------------------------------------------ the kernel
+// source bit 0: the rows pop trajectories from the batch's ring (solves; DevBatch::queue as solver_ref.hip uses it) -- otherwise row
+// r of wave w of workgroup i takes trajectory (i W + w) 4 + r; bit 1: test hook, true divisions in the recursion from the start.
+// slice: evaluations of a wave after which its unfinished trajectories go back to the ring (all four rows together, so that the
+// rows of a wave are refilled together and the last trajectories of a batch gather in few waves).
+__global__ void __launch_bounds__(256, 2)
+    ref4_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, const double *__restrict__ cor_t, double *__restrict__ scratch, int source,
+                int slice) {
+  extern __shared__ double lds_raw[];
+  const DevBatch &D = *Dp;
+  const DevLayout &L = D.L;
+  const int tidb = threadIdx.x, Tb = blockDim.x, lane = tidb & 63, wv = tidb >> 6, W = Tb >> 6, row = lane >> 4, l = lane & 15;
+  const int n = L.n, N = L.Ntot, H = L.H, mem = D.P.mem_size;
+  Q4 q;
+  q4_carve(q, reinterpret_cast<char *>(lds_raw) + q4_shared_bytes(N) + (size_t)(wv * 4 + row) * q4_team_bytes(mem), mem);
+  const ldscd_t tab = (ldscd_t)lds_raw;
+  for (int i = tidb; i < pk_segment_doubles(N); i += Tb) ((ldsd_t)lds_raw)[i] = tabs[i];
+  __syncthreads(); // the only time the waves of the workgroup meet
+  const bool ring = mode == kModeSolve && (source & 1) != 0;
+  const bool force_exact_div = (source & 2) != 0;
+  const int nterm = 5 * H + 4, JP = L.Kmax + 1;
+  const size_t cpitch = (size_t)JP * 16;
+  const size_t scratch_per_traj = (size_t)L.Npts * nterm * kRec + (size_t)L.Npts * nterm; // reference_order_scratch_per_traj, no obstacles
+  Prof pr;
+  pr.on = false;
+  pr.acc = nullptr;
+  pr.last = 0;
+  QVec v{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int b = -1;
+  bool act = false, resumed = false;
+  long long tick0 = 0;
+  int steps = 0;
+
+  for (int pass = 0;; pass++) {
+    // ---- rows without a trajectory take one
+    if (!act) {
+      int id = -1;
+      if (ring) {
+        for (int r = 0; r < 4; r++) // one row after the other (the rows of a wave would otherwise race each other for the head)
+          if (row == r && l == 0) id = ring_pop(D.qctl, D.queue, D.qcap);
+        id = __shfl(id, lane & 48);
+      } else if (pass == 0) {
+        id = ((int)blockIdx.x * W + wv) * 4 + row;
+        if (id >= D.B) id = -1;
+      }
+      if (id >= 0) {
+        b = id;
+        act = true;
+        resumed = ring && D.sflag[b] == 1;
+        if (resumed) {
+          q4_state_io(D, q, v, b, l, false);
+        } else {
+          const double *xsrc = (mode == kModeSolve) ? D.x0 : D.x_in;
+          for (int h = 0; h < 2; h++) {
+            const int e = 16 * h + l;
+            q.xs[e] = e < n ? xsrc[(size_t)b * n + e] : 0.0;
+            q.gs[e] = 0.0;
+          }
+          v = QVec{0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+          q.ist[l] = (l == iSLOWDIV && force_exact_div) ? 1 : 0; // (iNUM == 16 lanes)
+        }
+        if (l < 12) q.bnd[l] = l < 6 ? D.iniS[(size_t)b * 6 + l] : D.finS[(size_t)b * 6 + (l - 6)];
+        tick0 = wall_clock64();
+        pr.start(D.prof != nullptr && mode == kModeSolve && l == 0, D.prof + (size_t)b * 12, resumed);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(act) == 0ull) break; // (uniform) this wave has nothing left to do
+    if (act) {
+      const gcd_t cor = (gcd_t)(cor_t + (size_t)b * L.H * 4 * cpitch + l);
+      const gd_t ovf = (gd_t)(scratch + (size_t)b * scratch_per_traj);
+      const double f = q4_eval(D, q, tab, cor, cpitch, ovf, l, pr);
+      if (mode == kModeEval) {
+        for (int h = 0; h < 2; h++) {
+          const int e = 16 * h + l;
+          if (e < n) D.g_out[(size_t)b * n + e] = q.gs[e];
+        }
+        if (l == 0) D.f_eval[b] = f;
+        act = false;
+      } else {
+        const gd_t hS = (gd_t)(D.histS + (size_t)b * mem * L.npad * 2);
+        const gd_t hR = (gd_t)(D.histR + (size_t)b * mem * 2);
+        q4_advance(D, q, v, f, hS, hR, l, pr);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (q.ist[iACTION] == kActDone) { // the epilogue of solver_ref.hip
+          for (int h = 0; h < 2; h++) {
+            const int e = 16 * h + l;
+            if (e < n) D.x_out[(size_t)b * n + e] = q.xs[e];
+          }
+          if (l == 0) {
+            const double fx = q.st[sFX];
+            const int ret = q.ist[iRET];
+            D.f_out[b] = fx;
+            D.status[b] = ret;
+            D.iters[b] = q.ist[iK];
+            D.evals[b] = q.ist[iEVALS];
+            D.hist_sum[b] = ((long long)q.ist[iHISTHI] << 32) | (unsigned int)q.ist[iHISTLO];
+            {
+              double *rec = reinterpret_cast<double *>(D.records + (size_t)16 * b); // the all-gather record
+              rec[0] = fx;
+              int *ri = reinterpret_cast<int *>(rec + 1);
+              ri[0] = ret;
+              ri[1] = q.ist[iK];
+            }
+            D.ticks[b] = (resumed ? D.ticks[b] : 0) + (wall_clock64() - tick0); // time in service
+            int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
+            if (fx >= D.P.fail_cost) ok = 0;
+            D.success[b] = ok;
+            if (ring) {
+              D.sflag[b] = 2;
+              atomicSub(&D.qctl[3], 1u);
+            }
+          }
+          act = false;
+        }
+      }
+    }
+    if (!ring) {
+      if (mode == kModeEval) break;
+      continue;
+    }
+    // ---- end of a slice: the wave's unfinished trajectories go back to the ring
+    steps++;
+    if (slice > 0 && steps >= slice) { // (uniform)
+      steps = 0;
+      if (act) {
+        q4_state_io(D, q, v, b, l, true);
+        __threadfence(); // the record and the history rows of this slice are out before the id is handed on
+        if (l == 0) {
+          D.ticks[b] = (resumed ? D.ticks[b] : 0) + (wall_clock64() - tick0);
+          D.sflag[b] = 1;
+        }
+      }
+      for (int r = 0; r < 4; r++)
+        if (act && row == r && l == 0) ring_push(D.qctl, D.queue, D.qcap, b);
+      act = false;
+    }
+  }
+}
+
+// the corridor of a batch [B][4 H][NptsPad] -> [B][4 H][Kmax + 1][16]: element (j, p) = the value at constraint point j of piece p
+// (0.0 where the piece has no such point), so that the 16 lanes of a row read a round's half-planes as 128 contiguous bytes
+__global__ void q4_corridor_kernel(const double *__restrict__ cor, double *__restrict__ out, int B, int H4, int NptsPad, int N, int K, int Kd, int JP) {
+  const size_t total = (size_t)B * H4 * JP * 16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i & 15);
+    const size_t r = i >> 4;
+    const int j = (int)(r % JP);
+    const size_t bc = r / JP; // b * H4 + component
+    double v = 0.0;
+    if (p < N) {
+      const int Kp = (p == 0 || p == N - 1) ? Kd : K;
+      const int pt0 = p == 0 ? 0 : (Kd + 1) + (p - 1) * (K + 1);
+      if (j <= Kp) v = cor[bc * NptsPad + pt0 + j];
+    }
+    out[i] = v;
+  }
+}
+
+} // namespace reford
+
+// ---- host side
+// what the layout must satisfy for the QUAD shape (header)
+bool reference_order_quad_supported(const DevLayout &L, const DevParams &P, int S) {
+  if (L.M != 1 || S != 0 || L.n > 32 || L.Ntot > 16 || L.Ntot < 2 || L.H < 1 || L.H > 5) return false;
+  return reford::q4_shared_bytes(L.Ntot) + 4 * reford::q4_team_bytes(P.mem_size) <= 160 * 1024;
+}
+size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B) { return (size_t)B * L.H * 4 * (L.Kmax + 1) * 16; }
+// fills RefPlan for the QUAD shape: as many waves per workgroup (at most 4) and workgroups per CU as the LDS holds, eight waves
+// per CU at most (256 registers)
+void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int n_cu, RefPlan &pl) {
+  const size_t shared = reford::q4_shared_bytes(L.Ntot), team = reford::q4_team_bytes(P.mem_size), budget = 160 * 1024;
+  int best_w = 1, best_wg = 1, best_res = 0;
+  for (int w = 4; w >= 1; w--) {
+    const size_t lds = shared + (size_t)w * 4 * team;
+    if (lds > budget) continue;
+    const int wg = (int)std::min<size_t>((size_t)(8 / w), budget / lds);
+    if (wg * w > best_res) {
+      best_res = wg * w;
+      best_w = w;
+      best_wg = wg;
+    }
+  }
+  if (const char *e = std::getenv("DFTPAV_REF_QUAD_WAVES")) { // developer knob: waves per workgroup
+    const int w = std::atoi(e);
+    if (w >= 1 && w <= 4 && shared + (size_t)w * 4 * team <= budget) {
+      best_w = w;
+      best_wg = (int)std::min<size_t>((size_t)(8 / w), budget / (shared + (size_t)w * 4 * team));
+    }
+  }
+  pl.quad = 1;
+  pl.wave = 1;
+  pl.threads = 64 * best_w;
+  pl.lds = shared + (size_t)best_w * 4 * team;
+  pl.wg_per_cu = best_wg;
+  pl.slots = n_cu * best_wg;
+  pl.slice = 256;
+  if (const char *e = std::getenv("DFTPAV_REF_SLICE")) pl.slice = std::atoi(e);
+  if (const char *e = std::getenv("DFTPAV_REF_SLOTS")) pl.slots = std::max(1, std::atoi(e));
+}
+hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t stream) {
+  const DevLayout &L = D.L;
+  const size_t total = reference_order_quad_corridor_doubles(L, D.B);
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(reford::q4_corridor_kernel, dim3(grid), dim3(256), 0, stream, D.corridor, cor_t, D.B, L.H * 4, D.NptsPad, L.Ntot, L.K, L.Kd, L.Kmax + 1);
+  return hipGetLastError();
+}
+// scheduled != 0: a solve whose rows pop from the batch's ring (the caller has reset it)
+hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, const double *cor_t, double *scratch, const RefPlan &pl,
+                              int scheduled, hipStream_t stream) {
+  const int W = pl.threads / 64;
+  int grid = (D.B + 4 * W - 1) / (4 * W), source = 0, slice = 0;
+  if (scheduled && mode == kModeSolve) {
+    grid = pl.slots < grid ? pl.slots : grid;
+    source = 1;
+    slice = pl.slice;
+  }
+  if (const char *e = std::getenv("DFTPAV_REF_EXACT_DIV"))
+    if (std::atoi(e) != 0) source |= 2;
+  if (std::getenv("DFTPAV_VERBOSE"))
+    std::fprintf(stderr, "[dftpav] reference order, QUAD shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", grid, pl.threads, pl.lds, source, slice);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(reford::ref4_kernel, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice);
+  return hipGetLastError();
+}
+
+} // namespace dftpav
