@@ -834,8 +834,9 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
 // The record of an active static term t (not a moving-obstacle term) of a point: what the term adds to gdC (12), gdT [12] and the
 // cost [13], exactly the expressions of traj_optimizer.cpp:600-705.  t0 = 5 H + S: the first feasibility term.  R: any pointer
 // type (global records of the TEAM shape, LDS / flat records of the WAVE shape).
-template <typename R>
-__device__ __forceinline__ void point_emit(const DevParams &P, const PtState &st, int t, int H, int t0, gcd_t cor, size_t pitch, R r_) {
+// planes(k, n0, n1, q0, q1): the half-plane k of this point (what point_masks tested)
+template <typename R, typename PF>
+__device__ __forceinline__ void point_emit_pf(const DevParams &P, const PtState &st, int t, int H, int t0, PF planes, R r_) {
   const double s1 = st.s1;
   const double s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1; // the expressions of point_masks: the same bits
   const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
@@ -851,9 +852,9 @@ __device__ __forceinline__ void point_emit(const DevParams &P, const PtState &st
 #pragma unroll
     for (int q = 1; q < 5; q++) v += t >= q * H ? 1 : 0;
     const int k = t - v * H;
-    // the half-plane and the vertex of this term, fetched again (they are what point_masks tested)
-    const double on0 = cor[(size_t)(4 * k + 0) * pitch], on1 = cor[(size_t)(4 * k + 1) * pitch];
-    const double q0 = cor[(size_t)(4 * k + 2) * pitch], q1 = cor[(size_t)(4 * k + 3) * pitch];
+    // the half-plane and the vertex of this term (they are what point_masks tested)
+    double on0, on1, q0, q1;
+    planes(k, on0, on1, q0, q1);
     double le0 = P.vec_le[0][0], le1 = P.vec_le[0][1];
 #pragma unroll
     for (int q = 1; q < 5; q++) {
@@ -947,6 +948,19 @@ __device__ __forceinline__ void point_emit(const DevParams &P, const PtState &st
     }
     r_[13] = omg * step * P.wei_feas * 10.0 * pena;
   }
+}
+
+// the half-plane fetched again from the corridor (TEAM / WAVE shapes: the point's planes are not kept across the numbering)
+template <typename R>
+__device__ __forceinline__ void point_emit(const DevParams &P, const PtState &st, int t, int H, int t0, gcd_t cor, size_t pitch, R r_) {
+  point_emit_pf(P, st, t, H, t0,
+                [&](int k, double &on0, double &on1, double &q0, double &q1) {
+                  on0 = cor[(size_t)(4 * k + 0) * pitch];
+                  on1 = cor[(size_t)(4 * k + 1) * pitch];
+                  q0 = cor[(size_t)(4 * k + 2) * pitch];
+                  q1 = cor[(size_t)(4 * k + 3) * pitch];
+                },
+                r_);
 }
 
 // TEAM shape: the point's tests, then a record per active term in the point's own slots rec[t][kRec] (global scratch)

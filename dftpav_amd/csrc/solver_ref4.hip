@@ -42,18 +42,26 @@ namespace dftpav {
 namespace reford {
 
 constexpr int kQLcap = 3; // parked terms of a piece kept in LDS (the rest in global scratch)
+// Waves per SIMD the kernel is built for.  At 2 (256 registers) it spills 205 of them and its scratch traffic alone is HBM-sized
+// (measured: the point loop 3 x slower than at 1); at 1 the allocator takes 455 registers, nothing goes to scratch, and four waves
+// per CU hold 16 trajectories -- twice the WAVE shape's 8 -- each of them at the speed of a wave that has its SIMD to itself.
+#ifndef DFTPAV_Q4_WAVES_PER_EU
+#define DFTPAV_Q4_WAVES_PER_EU 1
+#endif
+constexpr int kQ4WavesPerCU = 4 * DFTPAV_Q4_WAVES_PER_EU;
 
 // LDS of one trajectory (a row)
 struct Q4 {
   ldsd_t xs, gs;  // [32] the trial point, the gradient (the interface between the evaluation and the solver)
   ldsd_t bnd;     // [12] iniS [6], finS [6] as uploaded (clamped)
+  ldsd_t tw;      // [6] 1 / t^k of the piece duration of the evaluation in progress
   ldsd_t st;      // [sNUM]
   ldsd_t alpha;   // [mem]
   ldsd_t tl;      // [16][kQLcap][3] parked terms of a piece: what they add to gdT, to the corridor cost, to the feasibility cost
   ldsi_t ist;     // [iNUM]
   ldsi_t tcnt;    // [16] parked terms of a piece
 };
-__host__ __device__ inline size_t q4_team_doubles(int mem) { return 32 + 32 + 12 + sNUM + (size_t)mem + 16 * kQLcap * 3; }
+__host__ __device__ inline size_t q4_team_doubles(int mem) { return 32 + 32 + 12 + 6 + sNUM + (size_t)mem + 16 * kQLcap * 3; }
 __host__ __device__ inline size_t q4_team_bytes(int mem) { return (q4_team_doubles(mem) * sizeof(double) + (iNUM + 16) * sizeof(int) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t q4_shared_bytes(int N) { return ((size_t)pk_segment_doubles(N) * sizeof(double) + 15) & ~(size_t)15; }
 __device__ inline void q4_carve(Q4 &q, char *team, int mem) {
@@ -61,6 +69,7 @@ __device__ inline void q4_carve(Q4 &q, char *team, int mem) {
   q.xs = p; p += 32;
   q.gs = p; p += 32;
   q.bnd = p; p += 12;
+  q.tw = p; p += 6;
   q.st = p; p += sNUM;
   q.alpha = p; p += mem;
   q.tl = p; p += 16 * kQLcap * 3;
@@ -115,6 +124,20 @@ template <int Q>
 __device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int l) {
   constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
   ldscd_t ip = tab + 48;
+  // the table of this lane's own block (an interior block: pk_size(Q) doubles), read once, in front of the traversal
+  v2d_t c[pk_size(Q) / 2];
+  {
+    const int sl = DESC ? N - 1 - l : l; // the step this lane's piece is taken in
+    const int bi = sl >= 1 && sl <= N - 2 ? sl - 1 : 0;
+    const ldscv2_t a = (ldscv2_t)(ip + bi * pk_size(Q));
+    if (N > 2) {
+#pragma unroll
+      for (int u = 0; u < pk_size(Q) / 2; u++) c[u] = a[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < pk_size(Q) / 2; u++) c[u] = v2d_t{0.0, 0.0};
+    }
+  }
 #pragma unroll 1
   for (int s = 0; s < N; s++) {
     const int p = DESC ? N - 1 - s : s;
@@ -132,31 +155,27 @@ __device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int
       if (l == p) {
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-          v2d_t c[4];
+          v2d_t ce[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) c[u] = a[4 * r + u];
+          for (int u = 0; u < 4; u++) ce[u] = a[4 * r + u];
           const int rr = DESC ? 5 - r : r;
 #pragma unroll
           for (int d = 0; d < 2; d++) {
             double acc = bq[2 * rr + d];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-              const double ck = (k & 1) ? c[k >> 1].y : c[k >> 1].x;
+              const double ck = (k & 1) ? ce[k >> 1].y : ce[k >> 1].x;
               const double t = ck * w[(r + k) % 6][d];
               acc = ck != 0.0 ? acc - t : acc;
             }
-            if (DIV) acc = div_by_rcp(acc, c[3].x, c[3].y);
+            if (DIV) acc = div_by_rcp(acc, ce[3].x, ce[3].y);
             w[r][d] = acc;
             bq[2 * rr + d] = acc;
           }
         }
       }
     } else { // an interior block: the non-zero terms only, no test
-      const ldscv2_t a = (ldscv2_t)(ip + (s - 1) * pk_size(Q));
       if (l == p) {
-        v2d_t c[pk_size(Q) / 2];
-#pragma unroll
-        for (int u = 0; u < pk_size(Q) / 2; u++) c[u] = a[u];
         auto at = [&](int o) { return (o & 1) ? c[o >> 1].y : c[o >> 1].x; };
 #pragma unroll
         for (int r = 0; r < 6; r++) {
@@ -189,13 +208,7 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   const double vt = q.xs[L.x_tau0];
   const double Tr = vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + P.mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + P.mini_T;
   const double t1 = Tr / N, t2 = t1 * t1, t3 = t2 * t1, t4 = t2 * t2, t5 = t4 * t1;
-  const double tI[6] = {1.0 / 1.0, 1.0 / t1, 1.0 / t2, 1.0 / t3, 1.0 / t4, 1.0 / t5};
-  double hv[6], tv[6];
-#pragma unroll
-  for (int u = 0; u < 6; u++) {
-    hv[u] = q.bnd[u];
-    tv[u] = q.bnd[6 + u];
-  }
+  pr.tick(10); // (what a pass of the kernel's loop does around the evaluation)
   // ---- right-hand sides (poly_traj_utils.hpp:968-977): the rows of this lane's piece
   double bq[12];
 #pragma unroll
@@ -203,17 +216,17 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   if (l == 0) {
 #pragma unroll
     for (int d = 0; d < 2; d++) {
-      bq[0 + d] = hv[d];
-      bq[2 + d] = hv[2 + d] * t1;
-      bq[4 + d] = hv[4 + d] * t2;
+      bq[0 + d] = q.bnd[d];
+      bq[2 + d] = q.bnd[2 + d] * t1;
+      bq[4 + d] = q.bnd[4 + d] * t2;
     }
   }
   if (l == N - 1) {
 #pragma unroll
     for (int d = 0; d < 2; d++) {
-      bq[6 + d] = tv[d];
-      bq[8 + d] = tv[2 + d] * t1;
-      bq[10 + d] = tv[4 + d] * t2;
+      bq[6 + d] = q.bnd[6 + d];
+      bq[8 + d] = q.bnd[8 + d] * t1;
+      bq[10 + d] = q.bnd[10 + d] * t2;
     }
   } else if (l < N - 1) {
     bq[10] = q.xs[2 * l];
@@ -225,8 +238,15 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   pr.tick(0);
   // ---- c = b * tInv (:979-984)
   double cc[12];
+  {
+    const double tI[6] = {1.0 / 1.0, 1.0 / t1, 1.0 / t2, 1.0 / t3, 1.0 / t4, 1.0 / t5};
 #pragma unroll
-  for (int u = 0; u < 12; u++) cc[u] = bq[u] * tI[u >> 1];
+    for (int u = 0; u < 12; u++) cc[u] = bq[u] * tI[u >> 1];
+    if (l == 0) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) q.tw[u] = tI[u]; // kept for calGrads_PT (six divisions, not six registers across the point loop)
+    }
+  }
   // ---- initSmGradCost / getTrajJerkCost per piece (poly_traj_utils.hpp:998-1035)
   double gdC[12], pE, pG;
   {
@@ -257,23 +277,35 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   double s1 = 0.0;
   int cnt = 0;
   const gd_t ovf_l = ovf + (size_t)pt0 * nterm * 3;
+  // a round's half-planes are requested one round ahead (the copy holds zeros where a piece has no such point: every lane
+  // loads, whatever its piece): 33 rounds of a dependent HBM round trip each were 3/4 of this kernel's time
+  double pl[20];
+  load_planes(cor, cpitch, H, pl);
 #pragma unroll 1
   for (int j = 0; j <= L.Kmax; j++) {
     unsigned m = 0u;
     PtState pst;
-    const gcd_t cj = cor + (size_t)j * 16;
-    if (piece && j <= Kl) {
-      double pl[20];
-      load_planes(cj, cpitch, H, pl);
+    double nx[20];
+    load_planes(cor + (size_t)(j < L.Kmax ? j + 1 : j) * 16, cpitch, H, nx);
+    if (piece && j <= Kl)
       m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, D.epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
-    }
     s1 += step; // the running sum of traj_optimizer.cpp:513
-    if (__builtin_amdgcn_ballot_w64(m != 0u) == 0ull) continue; // (uniform) nothing active in this round
     for (unsigned mm = m; mm;) {
       const int t = __builtin_ctz(mm);
       mm &= mm - 1;
       double r_[16];
-      point_emit(P, pst, t, H, t0, cj, cpitch, (double *)r_);
+      point_emit_pf(P, pst, t, H, t0,
+                    [&](int k, double &on0, double &on1, double &q0, double &q1) { // the planes point_masks tested, still in registers
+                      on0 = pl[0]; on1 = pl[1]; q0 = pl[2]; q1 = pl[3];
+#pragma unroll
+                      for (int u = 1; u < 5; u++) {
+                        on0 = k == u ? pl[4 * u] : on0;
+                        on1 = k == u ? pl[4 * u + 1] : on1;
+                        q0 = k == u ? pl[4 * u + 2] : q0;
+                        q1 = k == u ? pl[4 * u + 3] : q1;
+                      }
+                    },
+                    (double *)r_);
 #pragma unroll
       for (int u = 0; u < 12; u++) gdC[u] += r_[u];
       // what the term adds to gdT and to its cost, parked (the other cost gets -0.0: x + (-0.0) == x)
@@ -292,6 +324,8 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
       }
       cnt++;
     }
+#pragma unroll
+    for (int u = 0; u < 20; u++) pl[u] = nx[u];
   }
   q.tcnt[l] = piece ? cnt : 0;
   __threadfence_block(); // parked terms beyond the LDS window went to global memory; the counts are read by the other lanes
@@ -333,6 +367,9 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   pr.tick(3);
   // ---- calGrads_PT (poly_traj_utils.hpp:1037-1066): adj = gdC * tInv, solveAdj, the duration gradient
   double pA;
+  double tI[6];
+#pragma unroll
+  for (int u = 0; u < 6; u++) tI[u] = q.tw[u];
   {
     const double gdtInv[6] = {0.0, -1.0 * tI[2], -2.0 * tI[3], -3.0 * tI[4], -4.0 * tI[5], -5.0 * tI[5] * tI[1]};
     double acc = 0.0;
@@ -357,6 +394,12 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   {
     // the duration gradient (poly_traj_utils.hpp:1050-1064, VirtualTGradCost :405-419): the head terms live in lane 0, the tail
     // terms in lane N - 1 (every other lane hands the chain a -0.0)
+    double hv[6], tv[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++) {
+      hv[u] = q.bnd[u];
+      tv[u] = q.bnd[6 + u];
+    }
     const double h1 = hv[2] * adj[2] + hv[3] * adj[3];
     const double h2 = (hv[4] * adj[4] + hv[5] * adj[5]) * 2.0 * t1;
     const double g1 = tv[2] * adj[8] + tv[3] * adj[9];
@@ -794,7 +837,7 @@ __device__ inline void q4_state_io(const DevBatch &D, const Q4 &q, QVec &v, int 
 // r of wave w of workgroup i takes trajectory (i W + w) 4 + r; bit 1: test hook, true divisions in the recursion from the start.
 // slice: evaluations of a wave after which its unfinished trajectories go back to the ring (all four rows together, so that the
 // rows of a wave are refilled together and the last trajectories of a batch gather in few waves).
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     ref4_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, const double *__restrict__ cor_t, double *__restrict__ scratch, int source,
                 int slice) {
   extern __shared__ double lds_raw[];
@@ -962,11 +1005,11 @@ size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B) { return
 void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int n_cu, RefPlan &pl) {
   const size_t shared = reford::q4_shared_bytes(L.Ntot), team = reford::q4_team_bytes(P.mem_size), budget = 160 * 1024;
   int best_w = 1, best_wg = 1, best_res = 0;
-  for (int w = 4; w >= 1; w--) {
+  for (int w = std::min(4, reford::kQ4WavesPerCU); w >= 1; w--) {
     const size_t lds = shared + (size_t)w * 4 * team;
     if (lds > budget) continue;
-    const int wg = (int)std::min<size_t>((size_t)(8 / w), budget / lds);
-    if (wg * w > best_res) {
+    const int wg = (int)std::min<size_t>((size_t)(reford::kQ4WavesPerCU / w), budget / lds);
+    if (wg * w >= best_res) { // ties: the smaller workgroup (it leaves sooner at the end of a launch)
       best_res = wg * w;
       best_w = w;
       best_wg = wg;
@@ -976,7 +1019,7 @@ void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int n_cu,
     const int w = std::atoi(e);
     if (w >= 1 && w <= 4 && shared + (size_t)w * 4 * team <= budget) {
       best_w = w;
-      best_wg = (int)std::min<size_t>((size_t)(8 / w), budget / (shared + (size_t)w * 4 * team));
+      best_wg = (int)std::min<size_t>((size_t)(reford::kQ4WavesPerCU / w), budget / (shared + (size_t)w * 4 * team));
     }
   }
   pl.quad = 1;
