@@ -963,7 +963,7 @@ extern "C" int dftpav_debug_reference_plan(const dftpav_layout *layout, const df
   fill_dev_params(*p, P);
   out[0] = reference_order_supported(L, P, S) ? 1 : 0;
   const RefPlan pl = reference_order_plan(L, P, S, B, n_cu);
-  out[1] = pl.wave;
+  out[1] = pl.wave | (pl.quad << 1); // 0: TEAM, 1: WAVE, 3: QUAD
   out[2] = pl.threads;
   out[3] = pl.wg_per_cu;
   out[4] = pl.slots;

@@ -1580,7 +1580,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 25
 #define DFTPAV_REF_PART 0
 #endif
 bool reference_order_quad_supported(const DevLayout &L, const DevParams &P, int S); // solver_ref4.hip
-void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int n_cu, RefPlan &pl);
+void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int B, int n_cu, RefPlan &pl);
 #if DFTPAV_REF_PART != 2
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
@@ -1686,7 +1686,7 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
   }
   pl.quad = 0;
   if (quad) {
-    reference_order_quad_plan(L, P, n_cu, pl);
+    reference_order_quad_plan(L, P, B, n_cu, pl);
     return pl;
   }
   pl.wave = wave ? 1 : 0;

@@ -1002,7 +1002,7 @@ bool reference_order_quad_supported(const DevLayout &L, const DevParams &P, int 
 size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B) { return (size_t)B * L.H * 4 * (L.Kmax + 1) * 16; }
 // fills RefPlan for the QUAD shape: as many waves per workgroup (at most 4) and workgroups per CU as the LDS holds, eight waves
 // per CU at most (256 registers)
-void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int n_cu, RefPlan &pl) {
+void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int B, int n_cu, RefPlan &pl) {
   const size_t shared = reford::q4_shared_bytes(L.Ntot), team = reford::q4_team_bytes(P.mem_size), budget = 160 * 1024;
   int best_w = 1, best_wg = 1, best_res = 0;
   for (int w = std::min(4, reford::kQ4WavesPerCU); w >= 1; w--) {
@@ -1027,8 +1027,15 @@ void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int n_cu,
   pl.threads = 64 * best_w;
   pl.lds = shared + (size_t)best_w * 4 * team;
   pl.wg_per_cu = best_wg;
-  pl.slots = n_cu * best_wg;
-  pl.slice = 256;
+  // Persistent workgroups of a scheduled solve: a wave's rows are only refilled while the batch's ring holds waiting
+  // trajectories, so a launch takes HALF as many rows as the batch has trajectories (two per row) -- the rows stay busy until half
+  // of the batch is done, the rest gathers in ever fewer waves (slices), and the waves that leave make room for the next batch's
+  // launch on another stream.  Measured on the bench's stream of 4096-batches, four in flight (gpurun_out/q4.log, round 6): 256 / 512 /
+  // 768 waves per launch -> 22.7 / 28.0 / 27.1 k solves/s; a launch as wide as the device (every trajectory its own row from the
+  // start, no refill): 19.3 k.
+  const int per_wg = 4 * best_w;
+  pl.slots = std::max(1, std::min(n_cu * best_wg, (B + 2 * per_wg - 1) / (2 * per_wg)));
+  pl.slice = 64; // evaluations between two visits to the ring (64 / 256: 28.0 / 26.0 k solves/s)
   if (const char *e = std::getenv("DFTPAV_REF_SLICE")) pl.slice = std::atoi(e);
   if (const char *e = std::getenv("DFTPAV_REF_SLOTS")) pl.slots = std::max(1, std::atoi(e));
 }
