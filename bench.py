@@ -1,6 +1,11 @@
 #!/usr/bin/env python
 """bench.py — batched trajectory solves/sec of the MINCO/L-BFGS solve path on MI355X.
 
+The value line runs in the REFERENCE ORDER (dftpav_batch_set_order(DFTPAV_ORDER_REFERENCE): every sum in the order the reference
+executes it, whole solves bit-equal to the CPU restatement -- the mode that meets north_star's "final cost within 1e-5 relative of
+CPU", with 0.0); the device order (reassociated sums, faster, equal to the reference only statistically) is timed beside it under
+"device_order" (--order device makes it the value line).
+
 A "step" = one pass of the hot path over one resident batch: every rank launches the
 persistent solve kernel on its shard (inputs already in HBM), packs {cost,status,iters}
 records on the device and — for N>1 — joins the single RCCL all-gather of SURVEY §8(e).
@@ -44,7 +49,7 @@ from benchlib.common import (HBM_PEAK_GBS, DEV, SOLVE_FIELDS, Ctx, algorithmic_b
 from benchlib.stream import Stream, shard_schedule  # noqa: E402,F401
 from benchlib.counters import live_pmc, hbm_traffic  # noqa: E402,F401
 from benchlib.side import (side_isolated, side_batch, side_single, side_reference_order_batch, side_reference_order_other_configs,  # noqa: E402,F401
-                           side_neighbours)
+                           side_neighbours, side_device_order)
 from benchlib.parity import (cpu_baseline, parity_device_order, reference_order_batch, paired, parity_reference_order, parity_bias,  # noqa: E402,F401
                              restart_stats, parity_literal, parity_lockstep, with_upload)
 
@@ -59,6 +64,9 @@ def parse_args(argv=None):
                     help="overlap schedule: steps in flight = resident batches = HIP streams per GPU (a step launches one batch and "
                          "takes delivery of the one launched DEPTH - 1 steps earlier); 2 was the value line until round 4")
     ap.add_argument("--config", type=int, default=3, help="BASELINE config (1-based) used as the workload")
+    ap.add_argument("--order", choices=["reference", "device"], default="reference",
+                    help="floating-point order of the value line: reference (bit-equal to the CPU restatement of the reference; default) or "
+                         "device (reassociated sums; statistically equal only)")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="trajectories timed on the host cores (-1 = 4 per core, 0 = skip)")
     ap.add_argument("--seed", type=int, default=20240)
@@ -89,8 +97,10 @@ def init_job(args):
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    return Ctx("plain" if args.no_chain else args.schedule, rank, world, local_rank, distributed, capi.default_params(),
-               n_cu=torch.cuda.get_device_properties(local_rank).multi_processor_count)
+    ctx = Ctx("plain" if args.no_chain else args.schedule, rank, world, local_rank, distributed, capi.default_params(),
+              n_cu=torch.cuda.get_device_properties(local_rank).multi_processor_count)
+    ctx.order = capi.ORDER_REFERENCE if args.order == "reference" else None   # what every Stream of the value line's order is created with
+    return ctx
 
 
 def run_strong_shard(ctx, args):
@@ -98,11 +108,11 @@ def run_strong_shard(ctx, args):
     strong-scaling expectation is on record before the driver measures it -- two steps in flight (the value line's
     schedule: the device is a quarter full) and as many as hold the value line's 8192 trajectories (16 steps of 512)"""
     per = max(1, args.batch_per_gpu // 8)
-    s_stream = Stream(ctx, per, args.config, args.seed + 2)
+    s_stream = Stream(ctx, per, args.config, args.seed + 2, order=ctx.order)
     sr = s_stream.run(max(args.steps, 8), max(args.warmup, 2))
     s_stream.close()
     d_s, r_s = shard_schedule(args, ctx.schedule, per)
-    s_stream = Stream(ctx, per, args.config, args.seed + 2, depth=d_s, residency=r_s)
+    s_stream = Stream(ctx, per, args.config, args.seed + 2, depth=d_s, residency=r_s, order=ctx.order)
     sd = s_stream.run(max(args.steps, 4 * d_s), max(args.warmup, d_s))
     s_stream.close()
     return {"per_gpu": per, "solves_per_s": sd["value"], "ms_per_step": sd["ms_per_step"], "steps": sd["steps"],
@@ -131,13 +141,16 @@ def value_line(ctx, args, st, res, B_total):
     kms = res["gpu_ms"] / args.steps  # device time of the timed region (marker events on the library's streams) per step
     achieved = ebytes_steps / args.steps / (kms * 1e-3) / 1e9
     traffic, traffic_raw, traffic_source, valu_per_solve = hbm_traffic(ctx, args, shard.B)
+    ref = ctx.order is not None
     out = {
+        "order": ("reference: every sum in the order the reference executes it; whole solves bit-equal to the CPU restatement "
+                  "(parity.reference_order)" if ref else "device: reassociated sums, bit-equal to its own CPU replay only (parity.bias: the distance to the reference)"),
         "metric": "trajectory solves/sec (batched), 16-piece MINCO",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]/[3] problem (%s): %d trajectories%s x %d pieces x %d pts/piece, "
-                               "50 static obstacles, H=4 rectangle corridor per trajectory, fp64 bit-exact mode" %
+                               "50 static obstacles, H=4 rectangle corridor per trajectory, fp64" %
                                (shard.name, args.batch_per_gpu, "/GPU" if args.scaling == "weak" else " in all", lay.n_pieces, shard.K + 1),
                    "global_batch": B_total, "pieces": lay.n_pieces, "pts_per_piece": shard.K + 1,
                    "n_vars": lay.n_vars, "parallelism": "batch-sharded x%d, 1 all-gather of 16B records" % world,
@@ -145,7 +158,7 @@ def value_line(ctx, args, st, res, B_total):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_uncorrected": traffic_raw,
                      "traffic_source": traffic_source,
-                     "kernel": "solver_kernel", "kernel_ms": kms,
+                     "kernel": ("ref4_kernel (reference order, QUAD shape: four trajectories per wave)" if ref else "solver_kernel"), "kernel_ms": kms,
                      "launches_per_step": 1 if (ctx.schedule == "overlap" or shard.B < 4 * ctx.n_cu) else 2,
                      "algorithmic_bytes_per_launch": ebytes_steps / args.steps},
         "schedule": SCHEDULE_NOTE[ctx.schedule],
@@ -187,12 +200,14 @@ def strong_shard_entry(strong_shard, value):
 # (oracle/pyoracle.py, oracle/pyref.py): never the thing measured.
 
 
-def side_runs(ctx, args, st, out, cores):
+def side_runs(ctx, args, st, out, cores, B_total, rs0=None):
     """the exact BASELINE configs[2] case (batch 256), configs[1] (one gear-shift trajectory), configs[4] (moving cars), the
     reference order on the other configurations, the neighbouring steps of the solve"""
     from oracle import pyoracle as po  # the checker, never the thing measured
     po.build()
-    out["isolated"] = side_isolated(st)
+    out["isolated"] = side_isolated(st, rs0)
+    if ctx.order is not None:   # the device order on the same stream of cycles, at the value line's depth and at depth 2
+        out["device_order"] = side_device_order(ctx, args, B_total)
     out["batch256"] = side_batch(ctx, args, po, cores, 3, 256, 3, 8)
     out["single"] = side_single(ctx, args, po, cores, 2, range(9))
     out["moving_obstacles_1024"] = side_batch(ctx, args, po, cores, 5, 1024, 1, 8)  # BASELINE configs[4]: 32 pieces x 65 pts, 4 moving cars
@@ -207,16 +222,22 @@ def side_runs(ctx, args, st, out, cores):
 
 
 def cpu_baseline_and_parity(ctx, args, st, r, out, cpu, B_total):
+    """r: the results of the value line's first batch (in the value line's order)"""
     from oracle import pyoracle as po
     from oracle import pyref
     po.build()
     torch.set_num_threads(1)
     cores, shard = cpu["effective"], st.shard
     sample = cpu_baseline(ctx, args, po, pyref, shard, cpu, out)
-    out["parity"] = dict(out.get("parity", {}), **parity_device_order(ctx, po, shard, r, cores))
-    ref_gpu = parity_reference_order(ctx, args, po, st, r, sample, out, B_total)
-    out["parity"]["literal"] = parity_literal(ctx, po, shard, r, ref_gpu, cores)
-    out["parity"]["lockstep"] = parity_lockstep(ctx, po, shard)
+    out.setdefault("parity", {})
+    # the device order's solves of the same batch: the value line's when it runs in that order, else the side run's
+    r_dev = r if ctx.order is None else (out.get("device_order") or {}).pop("_results", None)
+    if r_dev is not None:
+        out["parity"].update(parity_device_order(ctx, po, shard, r_dev, cores))
+    ref_gpu = parity_reference_order(ctx, args, po, st, r if ctx.order is not None else None, r_dev, sample, out, B_total)
+    if r_dev is not None:
+        out["parity"]["literal"] = parity_literal(ctx, po, shard, r_dev, ref_gpu, cores)
+        out["parity"]["lockstep"] = parity_lockstep(ctx, po, shard)
     out["with_upload"] = with_upload(st)
 
 
@@ -246,7 +267,7 @@ def other_scaling(ctx, args, out):
         B_other = args.batch_per_gpu if args.scaling == "weak" else args.batch_per_gpu * ctx.world
         d_o, r_o = shard_schedule(args, ctx.schedule, B_other // ctx.world)
         d_o = min(d_o, 8)
-        o_stream = Stream(ctx, B_other, args.config, args.seed + 1, depth=d_o, residency=r_o)
+        o_stream = Stream(ctx, B_other, args.config, args.seed + 1, depth=d_o, residency=r_o, order=ctx.order)
         o = o_stream.run(max(args.steps, 2 * d_o), max(args.warmup, d_o))
         o_stream.close()
         if ctx.rank == 0:
@@ -266,7 +287,7 @@ def main(argv=None):
     # the value line: weak = --batch-per-gpu on every GPU, strong = --batch-per-gpu in all (BASELINE configs[3] as written)
     B_total = args.batch_per_gpu * world if args.scaling == "weak" else args.batch_per_gpu
     d_main, r_main = shard_schedule(args, ctx.schedule, B_total // world)
-    st = Stream(ctx, B_total, args.config, args.seed, depth=d_main, residency=r_main)
+    st = Stream(ctx, B_total, args.config, args.seed, depth=d_main, residency=r_main, order=ctx.order)
     res = st.run(args.steps, args.warmup)
     side = world == 1 and not args.no_extras
     strong_shard = run_strong_shard(ctx, args) if side and args.scaling == "weak" else None
@@ -277,12 +298,13 @@ def main(argv=None):
             out["strong_shard"] = strong_shard_entry(strong_shard, res["value"])
         cpu = effective_cores()
         if side:
-            guarded(out, "extras", side_runs, ctx, args, st, out, cpu["effective"])
+            guarded(out, "extras", side_runs, ctx, args, st, out, cpu["effective"], B_total, res["rs"][0])
         if world == 1 and args.cpu_sample != 0:
             guarded(out, "cpu_baseline_and_parity", cpu_baseline_and_parity, ctx, args, st, res["rs"][0], out, cpu, B_total)
     if world > 1 or (ctx.distributed and os.environ.get("DFTPAV_BENCH_FORCE_OTHER") == "1"):  # (forced: the one-GPU test of this code)
         other_scaling(ctx, args, out)
     if ctx.rank == 0:
+        (out.get("device_order") or {}).pop("_results", None)
         print(json.dumps(out), flush=True)
     st.close()
     if ctx.distributed:

@@ -47,6 +47,7 @@ class Ctx:
     def __init__(self, schedule, rank, world, local_rank, distributed, params, n_cu=256):
         self.schedule, self.rank, self.world, self.local_rank, self.distributed, self.params = schedule, rank, world, local_rank, distributed, params
         self.n_cu = n_cu   # compute units of this rank's device
+        self.order = None  # floating-point order of the value line's streams (None: device order; capi.ORDER_REFERENCE)
 
 
 SOLVE_FIELDS = ("final_cost", "x", "iters", "evals", "status")

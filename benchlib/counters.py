@@ -28,7 +28,9 @@ def live_pmc(args, schedule):
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
         return None, "this run is itself profiled: no nested collection"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-sample", "0",
-             "--batch-per-gpu", str(args.batch_per_gpu), "--config", str(args.config), "--seed", str(args.seed), "--schedule", schedule]
+             "--batch-per-gpu", str(args.batch_per_gpu), "--config", str(args.config), "--seed", str(args.seed), "--schedule", schedule,
+             "--order", getattr(args, "order", "reference"), "--depth", str(getattr(args, "depth", 4))]
+    names = ("ref4_kernel", "ref_kernel") if getattr(args, "order", "reference") == "reference" else ("solver_kernel",)
     env = dict(os.environ, TMPDIR="/tmp")
     got, t0 = {}, time.perf_counter()
     for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
@@ -41,10 +43,10 @@ def live_pmc(args, schedule):
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "solver_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                    if any(nm in r["Kernel_Name"] for nm in names) and r["Counter_Name"] == ctr:
                         rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
             if not rows:
-                return (got or None), "no %s rows for solver_kernel" % ctr
+                return (got or None), "no %s rows for %s" % (ctr, " / ".join(names))
             gmax = max(g for g, _ in rows)
             got[ctr] = sum(v for _, v in rows) / sum(1 for g, _ in rows if g == gmax)
         except Exception as ex:  # noqa: BLE001
@@ -63,6 +65,8 @@ def hbm_traffic(ctx, args, shard_B):
     if os.path.exists(pmc):
         try:
             pj = json.load(open(pmc))
+            if pj.get("order", "device") != getattr(args, "order", "reference"):   # a collection of the other order says nothing about this line
+                raise ValueError("other order")
             traffic = pj.get("hbm_bytes_per_launch")
             valu_per_solve = pj.get("valu_instructions_per_solve")
             traffic_source = "profiles/pmc_latest.json: separate rocprofv3 --pmc passes of `%s` (%s)" % (

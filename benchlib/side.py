@@ -13,13 +13,42 @@ from benchlib.common import (HBM_PEAK_GBS, DEV, SOLVE_FIELDS, Ctx, algorithmic_b
 from benchlib.stream import Stream, shard_schedule  # noqa: F401
 
 
-def side_isolated(st):
-    """the value line's batch as isolated solves (no chaining: its tail runs on a nearly empty device)"""
+def side_isolated(st, rs0=None):
+    """the value line's batch as isolated solves (no chaining: its tail runs on a nearly empty device); rs0: what the stream's solve
+    of the same batch returned (the schedule moves no bit)"""
     bt, iso = st.bts[0], []
     bt.set_hand_over(-1)  # the plan's default end game (the overlap schedule runs with 0)
     for _ in range(3):
         bt.solve_async(); bt.sync(); iso.append(bt.last_solve_ms())
-    return {"batch": int(st.shard.B), "kernel_ms": float(np.mean(iso)), "solves_per_s": st.shard.B / (float(np.mean(iso)) * 1e-3)}
+    out = {"batch": int(st.shard.B), "kernel_ms": float(np.mean(iso)), "solves_per_s": st.shard.B / (float(np.mean(iso)) * 1e-3)}
+    if rs0 is not None:
+        ri = bt.results()
+        out["same_bits_as_the_stream"] = bool(all(np.array_equal(ri[k_], rs0[k_]) for k_ in SOLVE_FIELDS))
+    return out
+
+
+def side_device_order(ctx, args, B_total):
+    """The DEVICE order (solver.hip: reassociated sums) on the value line's stream of cycles -- same seeds, same batches -- at the value
+    line's depth and at depth 2 (the schedule of rounds 3-4), so that a change of schedule cannot read as a change of kernel.  Its
+    results of the first batch go to the parity legs ("_results", removed before the line is printed)."""
+    out = {"note": "reassociated sums: faster, bit-equal only to its own CPU replay; against the reference see parity.bias"}
+    k, w = max(4, min(args.steps, 20)), max(2, min(args.warmup, 5))
+    for depth in sorted({2, max(2, args.depth)}):
+        stD = Stream(ctx, B_total, args.config, args.seed, depth=depth)
+        rD = stD.run(k, w)
+        lay, sh, rs = stD.shard.layout, stD.shard, rD["rs"]
+        eb = [float(algorithmic_bytes(lay, sh.n_points, lay.H, lay.M, q["iters"], q["evals"], q["hist_sum"]).sum()) if q is not None else 0.0 for q in rs]
+        eb_steps = sum(eb[(stD.k - k + j) % stD.D] for j in range(k))
+        kms = rD["gpu_ms"] / k
+        ent = {"solves_per_s": rD["value"], "ms_per_step": rD["ms_per_step"], "steps": k, "warmup": w, "time_to_result_ms": rD["to_result_ms"],
+               "roofline_frac": eb_steps / k / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "solver_kernel"}
+        out["depth_%d" % depth] = ent
+        if depth == max(2, args.depth):
+            out.update(ent)
+            out["steps_in_flight"] = depth
+            out["_results"] = rs[0]
+        stD.close()
+    return out
 
 
 def side_batch(ctx, args, po, cores, cfg, B, reps, n_check):
@@ -155,8 +184,8 @@ def side_single(ctx, args, po, cores, cfg, seeds):
             "reference_order": {"p50_ms_per_solve": float(np.median(ms_ref)), "us_per_iteration": float(1e3 * ms_ref.sum() / its_ref.sum()),
                                 "median_iters": float(np.median(its_ref)),
                                 "bit_equal_to_the_reference_program_with_correctly_rounded_cos_sin": int(sum(eq2)),
-                                "bit_equal_to_the_reference_build_on_this_host": (int(sum(eqb)) if eqb else None),
-                                "bit_equal_to_the_reference_build_on_a_correctly_rounded_libm": (int(sum(eqc)) if eqc else None),
+                                "bit_equal_to_the_retired_standin_build_on_this_host": (int(sum(eqb)) if eqb else None),
+                                "bit_equal_to_the_retired_standin_build_on_a_correctly_rounded_libm": (int(sum(eqc)) if eqc else None),
                                 "instances": len(seeds),
                                 "best_of_64_restarts_in_one_launch": {
                                     "p50_ms": float(np.median([r_["kernel_ms"] for r_ in best64])), "p50_ms_of_the_lone_solve": float(np.median([r_["lone_solve_ms"] for r_ in best64])),
@@ -196,7 +225,7 @@ def side_reference_order_batch(ctx, args, po, cores, cfg, B, golden):
             pk = Z[golden + "_pick"]
             row["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_%d_sampled" % len(pk)] = bool(
                 all(np.array_equal(Z[golden + "_" + k_], r5[k_][pk]) for k_ in SOLVE_FIELDS))
-            row["of_them_solved_by_the_reference_build_on_a_correctly_rounded_libm"] = int(Z["n_checked_against_the_reference_objects_on_a_correctly_rounded_libm"])
+            row["of_them_also_solved_by_the_retired_standin_build_in_round_5"] = int(Z["n_checked_against_the_reference_objects_on_a_correctly_rounded_libm"])
         else:
             pick5 = np.array([0, B // 3, 2 * B // 3, B - 1])
             o5 = po.solve_batch(p5, s5.subset(pick5), nthreads=min(4, cores), order=2)
@@ -238,11 +267,11 @@ def side_reference_order_other_configs(ctx, args, po, cores):
                 for i_ in range(sz.B):
                     rr_ = _pr2.RefProblem(pz, sz, i_).optimize()
                     eqb_ += int(rr_["final_cost"] == rz["final_cost"][i_] and np.array_equal(rr_["x"], rz["x"][i_]) and rr_["iters"] == rz["iters"][i_])
-                row["against_reference_build"] = {"trajectories": int(sz.B), "bit_equal": eqb_,
+                row["against_retired_standin_build"] = {"trajectories": int(sz.B), "bit_equal": eqb_,
                                                   "note": ("every solve must agree" if not libm else
                                                            "agrees where this host's libm rounded every call of the solve correctly")}
             if libm and _pr2.cr_available():
-                row["against_reference_build_on_a_correctly_rounded_libm"] = {
+                row["against_retired_standin_build_on_a_correctly_rounded_libm"] = {
                     "trajectories": int(sz.B), "bit_equal": int(sum(same_as_ref_run(rz, i_, _pr2.RefProblem(pz, sz, i_, cr=True).optimize()) for i_ in range(sz.B))),
                     "note": "the reference's own objects linked against oracle/cr_libm.c: every solve must agree"}
             rows[name_] = row

@@ -56,7 +56,7 @@ size_t reference_order_scratch_doubles(const DevLayout &L, int B, int S);
 size_t reference_order_table_doubles(int N);
 void reference_order_pack_tables(int N, const double *full, double *packed);
 int reference_order_interior_mask(int sweep, int row_mod_6);
-RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu, bool allow_quad = true);
+RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu, bool allow_quad = true, bool throughput = false);
 // the QUAD shape (solver_ref4.hip): four trajectories per wave; its copy of the corridor and its launches
 size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B);
 hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t stream);
@@ -165,6 +165,7 @@ struct dftpav_batch {
   RefPlan ref_plan_wt{}; // QUAD shape: the TEAM / WAVE plan of the same batch (what the QUAD kernel leaves to solver_ref.hip: the coefficient read-out)
   double *d_cor_t = nullptr; // QUAD shape: the corridor as [B][4 H][Kmax + 1][16] (solver_ref4.hip), refreshed when the corridor changes
   bool cor_t_dirty = true;
+  int residency = -1; // the caller's residency hint (dftpav_batch_create_shaped); 2 = many such batches in flight: the throughput shapes whatever B
   // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
   struct PlanCycle {
     double *d_poses = nullptr, *d_t = nullptr, *d_v = nullptr, *d_rd = nullptr;
@@ -996,6 +997,7 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
   auto *b = new dftpav_batch();
   b->h = h;
   b->B = B;
+  b->residency = residency;
   DevLayout &L = b->L;
   fill_dev_layout(*layout, p.traj_resolution, p.des_traj_resolution, L);
   if (L.n > 256 || L.Ntot > 1024 || L.Npts > 32767) {
@@ -1677,14 +1679,14 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
       int n_cu = 256;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-      const RefPlan pl = reference_order_plan(b->L, b->P, h->S, b->B, n_cu);
+      const RefPlan pl = reference_order_plan(b->L, b->P, h->S, b->B, n_cu, true, b->residency == 2);
       if (pl.wave && ensure_ring_buffers(b) != hipSuccess) {
         h->err = "reference order: no device memory for the ring of this batch";
         return DFTPAV_E_HIP;
       }
       b->ref_plan = pl;
       if (pl.quad) {
-        b->ref_plan_wt = reference_order_plan(b->L, b->P, h->S, b->B, n_cu, false);
+        b->ref_plan_wt = reference_order_plan(b->L, b->P, h->S, b->B, n_cu, false, b->residency == 2);
         if (!b->d_cor_t && hipMalloc(&b->d_cor_t, sizeof(double) * reference_order_quad_corridor_doubles(b->L, b->B)) != hipSuccess) {
           (void)hipGetLastError();
           h->err = "reference order: no device memory for the QUAD shape's copy of the corridor";

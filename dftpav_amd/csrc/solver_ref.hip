@@ -1647,7 +1647,8 @@ int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kIn
 // parallel stages finish sooner: 70 against 73 ms at batch 32, 133 against 140 at 256), two for more.  WAVE: as many waves per
 // workgroup as keep the most trajectories resident on a CU -- 8 waves of 256 registers (4 for the kernels that take 512), the
 // LDS of the shared tables plus a team's part per wave.
-RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu, bool allow_quad) {
+// throughput: the caller keeps many such batches in flight (dftpav_batch_create_shaped, residency 2) -- the throughput shapes whatever B
+RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int B, int n_cu, bool allow_quad, bool throughput) {
   RefPlan pl{};
   const bool narrow = reford::ref_cap_of(L.n) <= reford::kNarrowCap && S == 0; // the kernels built for 256 registers (two waves per SIMD)
   const int max_waves_cu = narrow ? 8 : 4;
@@ -1667,7 +1668,7 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
   }
   // up to four per CU the TEAM shape (128 threads, 34 KB of LDS with the compact tables) holds them all at once, each one faster:
   // 171 against 195 ms at 1024, 133 against 189 at 512; at 2048 the WAVE shape is ahead, 262 against 320 ms
-  bool wave = best_w > 0 && B > 5 * n_cu;
+  bool wave = best_w > 0 && (B > 5 * n_cu || throughput);
   if (const char *e = std::getenv("DFTPAV_REF_SHAPE")) { // developer knob: "team" / "wave"
     if (e[0] == 't') wave = false;
     if (e[0] == 'w' && best_w > 0) wave = true;

@@ -179,14 +179,21 @@ def test_launch_shapes_of_the_reference_order(hiplib):
         return dict(zip(("supported", "wave", "threads", "wg_per_cu", "slots", "slice", "lds", "cap"), [int(v) for v in out]))
 
     # BASELINE configs[2] / [3]: 16 pieces x 33 points, n = 31
-    for B, wave in ((1, 0), (256, 0), (1024, 0), (1280, 0), (1281, 1), (2048, 1), (4096, 1)):
+    # (beyond five trajectories per CU this layout -- one gear segment, 16 pieces, n = 31, no moving obstacles -- takes the QUAD shape
+    # of solver_ref4.hip: "wave" = 3, four trajectories per wave, workgroups of one wave, four per CU at one wave per SIMD; a launch
+    # takes half as many rows as the batch has trajectories, at most the device's 1024 waves)
+    for B, wave in ((1, 0), (256, 0), (1024, 0), (1280, 0), (1281, 3), (2048, 3), (4096, 3), (16384, 3)):
         q = plan([16], [1], 32, 32, 0, B)
         assert q["supported"] == 1 and q["wave"] == wave and q["cap"] == 32, (B, q)
         assert q["lds"] <= 160 * 1024
         if wave:
-            assert q["threads"] == 512 and q["wg_per_cu"] == 1 and q["slots"] == 256 and q["slice"] == 128   # eight waves per CU
+            assert q["threads"] == 64 and q["wg_per_cu"] == 4 and q["slots"] == min(1024, (B + 7) // 8) and q["slice"] == 64
+            assert q["wg_per_cu"] * q["lds"] <= 160 * 1024
         else:
             assert q["threads"] == (128 if B > 768 else 256)
+    # 8 + 9 pieces in ONE segment do not fit a row of 16 lanes: the WAVE shape, as before
+    q = plan([17], [1], 16, 16, 0, 4096)
+    assert q["supported"] == 1 and q["wave"] == 1 and q["cap"] == 40
     # configs[1]: 8 + 8 pieces with a gear shift, n = 33: sums of 40 terms.  Since round 5 that kernel is built for 256 registers too
     # (kNarrowCap = 40: residency won over a spill-free 414 registers, 450 against 467 ms at 4096); two segments' tables and state
     # leave room for seven waves in the 160 KB

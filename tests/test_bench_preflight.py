@@ -57,7 +57,10 @@ def _count(out, what, arg=None):
 
 
 def test_one_rank_line_and_step_count():
+    out = _bench(["--steps", "3", "--warmup", "2", "--batch-per-gpu", "6", "--no-extras", "--cpu-sample", "0", "--order", "device"])
+    assert out["order"].startswith("device") and out["roofline"]["kernel"] == "solver_kernel"
     out = _bench(["--steps", "3", "--warmup", "2", "--batch-per-gpu", "6", "--no-extras", "--cpu-sample", "0"])
+    assert out["order"].startswith("reference")
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 6 and out["config"]["allgather_via"].startswith("none")
     assert out["config"]["steps_in_flight"] == 4                                # --depth's default
@@ -121,26 +124,33 @@ def test_every_side_run_of_the_one_gpu_line():
     out = _bench(["--steps", "2", "--warmup", "1", "--batch-per-gpu", "16", "--cpu-sample", "16"], timeout=900)
     assert "side_run_errors" not in out, out.get("side_run_errors")
     for k in ("strong_shard", "isolated", "batch256", "single", "moving_obstacles_1024", "validate", "readout", "shots", "corridor",
-              "cpu_baseline", "with_upload", "parity"):
+              "cpu_baseline", "with_upload", "parity", "device_order", "order"):
         assert k in out, k
+    assert out["order"].startswith("reference") and "ref4_kernel" in out["roofline"]["kernel"]       # the parity-grade order is the value line
+    do = out["device_order"]
+    assert do["solves_per_s"] > 0 and "depth_2" in do and "depth_4" in do and do["steps_in_flight"] == 4 and "_results" not in do
     cb = out["cpu_baseline"]
-    assert cb["kind"] in ("reference", "port") and cb["unit"] == "solves/s" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    assert cb["kind"] == "port" and cb["unit"] == "solves/s" and cb["value"] > 0 and cb["cores"] == 1 and "sample" in cb   # the reference cannot be built here
     par = out["parity"]
     for k in ("reference_order", "reference_order_other_configs", "bias", "literal", "lockstep"):
         assert k in par, k
     assert par["reference_order"]["bit_equal"] == par["reference_order"]["trajectories"] == 16
-    assert par["reference_order"]["overlapped"]["first_batch_equals_the_isolated_solve"] is True
+    assert par["reference_order"]["frac_within_1e-5_of_cpu"] == 1.0 and par["reference_order"]["solves_per_s"] == out["value"]
+    assert par["reference_order"]["first_batch_equals_the_isolated_solve"] is True
     assert par["lockstep"] == {"failed": par["lockstep"]["failed"]}      # the stand-in keeps no trace: reported, not fatal
     assert out["moving_obstacles_1024"]["reference_order"]["batch"] == 4
-    # the reference's own objects on a correctly rounded libm agree with order 2 (= the stand-in's "device") on every solve
-    assert out["single"]["reference_order"]["bit_equal_to_the_reference_build_on_a_correctly_rounded_libm"] == 9
+    # (the stand-in build of the reference's sources is retired, oracle/pyref.py: its entries stay empty)
+    assert out["single"]["reference_order"]["bit_equal_to_the_retired_standin_build_on_a_correctly_rounded_libm"] is None
+    assert out["single"]["reference_order"]["bit_equal_to_the_reference_program_with_correctly_rounded_cos_sin"] == 9
+    assert "standin_build_of_the_reference_sources" not in out["cpu_baseline"]
     for k in ("moving_obstacles_1024", ):
         assert out[k]["reference_order"]["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] is True
     ro = out["gear_shift_4096_reference_order"]
     assert ro["batch"] == 4 and ro["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] is True and ro["roofline"]["frac"] > 0
     assert out["single"]["reference_order"]["best_of_64_restarts_in_one_launch"]["slot0_bit_equal_to_the_lone_solve_on_all"] is True
     live = par["reference_order_other_configs"]["gear_shifts_with_moving_obstacles"]
-    assert live["against_reference_build_on_a_correctly_rounded_libm"]["bit_equal"] == live["trajectories"] == 8
+    assert live["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls"] == live["trajectories"] == 8
+    assert "against_retired_standin_build" not in live
     assert out["strong_shard"]["per_gpu"] == 2 and out["strong_shard"]["steps_in_flight"] == 16
 
 

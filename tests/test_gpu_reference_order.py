@@ -300,6 +300,84 @@ def test_wave_shape_and_ring_are_bit_identical(hiplib, oracle, monkeypatch, case
     monkeypatch.delenv("DFTPAV_REF_SLICE")
 
 
+@pytest.mark.parametrize("cfg,B,slots,slice_", [(3, 40, 0, 0), (3, 41, 2, 5), (3, 23, 1, 64), (1, 37, 3, 2), (1, 9, 0, 0)])
+def test_quad_shape_and_its_ring_are_bit_identical(hiplib, oracle, monkeypatch, cfg, B, slots, slice_):
+    """The QUAD shape of the reference order (solver_ref4.hip): FOUR trajectories per wave, one per row of 16 lanes, a piece per lane,
+    the band system / c / gdC / adjoint in registers, 32-step row chains for the dot products.  Forced on small batches -- cfg 3
+    (16 pieces x 33 points, n = 31: BASELINE configs[2] / [3]) and cfg 1 (8 pieces, K = 16 / Kd = 32: the end pieces are longer than
+    the inner ones, half the lanes of a row idle) -- once with every trajectory in a row of its own from the start, then with 1-3
+    persistent waves whose rows pop from the batch's ring and suspend after a slice of 2 / 5 / 64 evaluations (batch sizes that leave
+    rows empty): every evaluation and every field of every solve equal to the restatement's, the coefficient read-out (left to
+    solver_ref.hip) too.  No sum depends on the shape; suspending and resuming moves no bit."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(cfg, B=B)
+    s.apply_resolution(p)
+    want = oracle.solve_batch(p, s, nthreads=8, order=0)
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    monkeypatch.setenv("DFTPAV_REF_SHAPE", "quad")
+    monkeypatch.setenv("DFTPAV_REF_QUAD_WAVES", "1")
+    if slots:
+        monkeypatch.setenv("DFTPAV_REF_SLOTS", str(slots))
+        monkeypatch.setenv("DFTPAV_REF_SLICE", str(slice_))
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    rng = np.random.default_rng(4)
+    for x in (bt.x0(), bt.x0() + rng.normal(0, 0.2, bt.x0().shape), bt.x0() + rng.normal(0, 0.7, bt.x0().shape)):
+        f, g = bt.eval(x)
+        for b in range(0, s.B, 4):
+            fo, go = oracle.OracleProblem(p, s, b, order=0).eval(x[b])
+            assert f[b] == fo and np.array_equal(g[b], go), (cfg, b)
+    for rep in range(2):                   # twice: the ring is reset by every solve
+        r = bt.solve()
+        for k in keys:
+            assert np.array_equal(r[k], want[k]), (cfg, slots, rep, k)
+    c, dt = bt.coeffs()
+    lp = oracle.OracleProblem(p, s, s.B - 1, order=0)
+    lp.eval(r["x"][s.B - 1])
+    co, dto = lp.coeffs()
+    assert np.array_equal(c[s.B - 1], co) and np.array_equal(dt[s.B - 1], dto)
+    # a new upload (other half-planes) reaches the QUAD shape's own copy of the corridor
+    s2 = sc.baseline_config(cfg, B=B, seed=977)
+    s2.apply_resolution(p)
+    bt.upload(s2)
+    r2 = bt.solve()
+    want2 = oracle.solve_batch(p, s2, nthreads=8, order=0)
+    for k in keys:
+        assert np.array_equal(r2[k], want2[k]), (cfg, "second upload", k)
+    bt.close()
+    h.close()
+
+
+def test_quad_shape_is_what_a_full_batch_takes_and_equals_the_other_shapes(hiplib, oracle, monkeypatch):
+    """BASELINE configs[3] at 4096 on one GPU: the plan picks the QUAD shape on its own (dftpav_debug_reference_plan), its scheduled
+    launch (512 persistent waves for 4096 trajectories, slices of 64 evaluations) gives every trajectory the bits the WAVE shape gives
+    it, and 24 sampled trajectories the restatement's."""
+    p = hiplib.default_params()
+    s = sc.baseline_config(3, B=4096)
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    rq = bt.solve()
+    bt.set_order(hiplib.ORDER_DEVICE)
+    monkeypatch.setenv("DFTPAV_REF_SHAPE", "wave")
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    monkeypatch.delenv("DFTPAV_REF_SHAPE")
+    rw = bt.solve()
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    for k in keys:
+        assert np.array_equal(rq[k], rw[k]), k
+    pick = (np.arange(24) * 170 + 11) % s.B
+    want = oracle.solve_batch(p, s.subset(pick), nthreads=8, order=0)
+    for k in keys:
+        assert np.array_equal(rq[k][pick], want[k]), k
+    bt.close()
+    h.close()
+
+
 @pytest.mark.parametrize("shape", ["team", "wave"])
 def test_recursion_with_true_divisions_gives_the_same_bits(hiplib, oracle, monkeypatch, shape):
     """The two-loop recursion divides by the stored y . s of a pair through its stored reciprocal (Markstein's correctly rounded
