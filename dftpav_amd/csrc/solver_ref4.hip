@@ -200,10 +200,14 @@ __device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int
 // x (q.xs) -> g (q.gs), returns f.  The statements are solver_ref.hip's ref_eval, stage by stage; what changes is where a value
 // lives.  cor: &cor_t[b][0][0][l] (component pitch cpitch = 16 (Kmax + 1), a round's 16 pieces contiguous); ovf: this
 // trajectory's global scratch for the parked terms beyond the LDS window.
+// FAST: the live path's constants known at compile time -- H = 4 half-planes per point (rectangles, traj_manager.cpp:1225) and
+// help_eps = 0.0 (:610): the fifth plane slot and the second reciprocal of the curvature term drop out of the point loop.
+template <bool FAST>
 __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_t tab, gcd_t cor, size_t cpitch, gd_t ovf, int l, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
-  const int N = L.Ntot, H = L.H, nterm = 5 * H + 4, t0 = 5 * H;
+  const int N = L.Ntot, H = FAST ? 4 : L.H, nterm = 5 * H + 4, t0 = 5 * H;
+  const double epis = FAST ? 0.0 : D.epis;
   // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966)
   const double vt = q.xs[L.x_tau0];
   const double Tr = vt > 0.0 ? ((0.5 * vt + 1.0) * vt + 1.0) + P.mini_T : 1.0 / ((0.5 * vt - 1.0) * vt + 1.0) + P.mini_T;
@@ -288,7 +292,7 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
     double nx[20];
     load_planes(cor + (size_t)(j < L.Kmax ? j + 1 : j) * 16, cpitch, H, nx);
     if (piece && j <= Kl)
-      m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, D.epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
+      m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
     s1 += step; // the running sum of traj_optimizer.cpp:513
     for (unsigned mm = m; mm;) {
       const int t = __builtin_ctz(mm);
@@ -469,7 +473,7 @@ __device__ __forceinline__ bool q4_begin_iteration(const DevParams &P, const Q4 
 // The two-loop recursion (lbfgs.hpp:716-739) over `bound` stored pairs of this row's trajectory, the newest in slot ne - 1;
 // d = -g on entry (elements from n on: 0.0).  The four rows run their steps in the same instructions; bound, the ring position
 // and the division mode belong to the row.  History rows: (s, y) interleaved per element at pitch npad; (ys, 1 / ys) per pair.
-constexpr int kQB = 4; // stored pairs per register block (the next block is in flight while one is worked on)
+constexpr int kQB = 8; // stored pairs per register block (the next block is in flight while one is worked on)
 struct QBlk {
   d2_t a[kQB], b[kQB]; // (s, y) of elements l and 16 + l
   d2_t yr[kQB];        // (ys, 1 / ys)
@@ -837,6 +841,7 @@ __device__ inline void q4_state_io(const DevBatch &D, const Q4 &q, QVec &v, int 
 // r of wave w of workgroup i takes trajectory (i W + w) 4 + r; bit 1: test hook, true divisions in the recursion from the start.
 // slice: evaluations of a wave after which its unfinished trajectories go back to the ring (all four rows together, so that the
 // rows of a wave are refilled together and the last trajectories of a batch gather in few waves).
+template <bool FAST>
 __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     ref4_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, const double *__restrict__ cor_t, double *__restrict__ scratch, int source,
                 int slice) {
@@ -903,7 +908,7 @@ __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     if (act) {
       const gcd_t cor = (gcd_t)(cor_t + (size_t)b * L.H * 4 * cpitch + l);
       const gd_t ovf = (gd_t)(scratch + (size_t)b * scratch_per_traj);
-      const double f = q4_eval(D, q, tab, cor, cpitch, ovf, l, pr);
+      const double f = q4_eval<FAST>(D, q, tab, cor, cpitch, ovf, l, pr);
       if (mode == kModeEval) {
         for (int h = 0; h < 2; h++) {
           const int e = 16 * h + l;
@@ -1060,9 +1065,12 @@ hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode
     if (std::atoi(e) != 0) source |= 2;
   if (std::getenv("DFTPAV_VERBOSE"))
     std::fprintf(stderr, "[dftpav] reference order, QUAD shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", grid, pl.threads, pl.lds, source, slice);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  const bool fast = D.L.H == 4 && D.epis == 0.0 && !std::getenv("DFTPAV_REF_QUAD_GENERIC"); // the live path's constants (q4_eval)
+  const void *fn = fast ? reinterpret_cast<const void *>(&reford::ref4_kernel<true>) : reinterpret_cast<const void *>(&reford::ref4_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reford::ref4_kernel, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice);
+  if (fast) hipLaunchKernelGGL(reford::ref4_kernel<true>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice);
+  else hipLaunchKernelGGL(reford::ref4_kernel<false>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice);
   return hipGetLastError();
 }
 
