@@ -61,7 +61,7 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
 size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B);
 hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t stream);
 hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, const double *cor_t, double *scratch, const RefPlan &pl,
-                              int scheduled, hipStream_t stream);
+                              int scheduled, int slots, int hand, hipStream_t stream);
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
                              hipStream_t stream);
 }
@@ -1520,7 +1520,16 @@ static hipError_t launch_ref(dftpav_batch *b, const DevBatch &D, int mode, int s
       if (e != hipSuccess) return e;
       b->cor_t_dirty = false;
     }
-    return launch_solver_ref4(D, b->d_dev, mode, b->d_ref_tab, b->d_cor_t, b->d_ref_scratch, b->ref_plan, scheduled, b->h->stream);
+    // A batch that has the device to itself (the default; dftpav_batch_set_hand_over(b, 0) says that other batches follow on other
+    // streams) takes every wave slot and hands its last trajectories to the WAVE shape: a launch of solver_ref.hip's kernel queued
+    // behind this one pops them from the same ring and resumes them from the same records (a wave per trajectory is 2-3 x faster
+    // per iteration once the device is emptying).  In a stream of batches the launch is half as wide as the batch (solver_ref4.hip).
+    const bool alone = b->hand_over != 0 && scheduled && mode == kModeSolve;
+    const int slots = alone ? b->ref_plan.slots_wide : b->ref_plan.slots;
+    const int hand = alone && b->ref_plan_wt.wave ? std::min(b->ref_plan.hand, b->B / 2) : 0;
+    hipError_t e = launch_solver_ref4(D, b->d_dev, mode, b->d_ref_tab, b->d_cor_t, b->d_ref_scratch, b->ref_plan, scheduled, slots, hand, b->h->stream);
+    if (e == hipSuccess && hand > 0) e = launch_solver_ref(D, b->d_dev, kModeSolve, b->d_ref_tab, b->d_ref_scratch, b->ref_plan_wt, 1, b->h->stream);
+    return e;
   }
   return launch_solver_ref(D, b->d_dev, mode, b->d_ref_tab, b->d_ref_scratch, b->ref_plan.quad ? b->ref_plan_wt : b->ref_plan, scheduled, b->h->stream);
 }
@@ -1686,7 +1695,7 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
       }
       b->ref_plan = pl;
       if (pl.quad) {
-        b->ref_plan_wt = reference_order_plan(b->L, b->P, h->S, b->B, n_cu, false, b->residency == 2);
+        b->ref_plan_wt = reference_order_plan(b->L, b->P, h->S, b->B, n_cu, false, true); // (the WAVE shape whatever B: it finishes the QUAD shape's last trajectories)
         if (!b->d_cor_t && hipMalloc(&b->d_cor_t, sizeof(double) * reference_order_quad_corridor_doubles(b->L, b->B)) != hipSuccess) {
           (void)hipGetLastError();
           h->err = "reference order: no device memory for the QUAD shape's copy of the corridor";
@@ -1798,8 +1807,8 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   if (int rc = sync_dev(b, D)) return rc;
   HIPCHK(h, hipEventRecord(b->ev0, h->stream));
   if (b->order == DFTPAV_ORDER_REFERENCE) {
-    const int per_wave = b->ref_plan.quad ? 4 : 1; // trajectories a wave holds
-    if (b->ref_plan.wave && b->ref_plan.slots > 0 && b->ref_plan.slots * (b->ref_plan.threads / 64) * per_wave < b->B && b->ref_plan.slice > 0) {
+    // (the QUAD shape always runs from the ring: its rows take a new trajectory as soon as one ends)
+    if (b->ref_plan.wave && b->ref_plan.slots > 0 && b->ref_plan.slice > 0 && (b->ref_plan.quad || b->ref_plan.slots * (b->ref_plan.threads / 64) < b->B)) {
       // more trajectories than resident waves: persistent workgroups whose waves pop trajectories from the ring and run them a
       // slice of iterations at a time (solver_ref.hip); queue = all trajectories, flags cleared, counters reset on the stream
       HIPCHK(h, hipMemcpyAsync(b->d_queue, b->d_iota, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToDevice, h->stream));

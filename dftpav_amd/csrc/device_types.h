@@ -184,6 +184,8 @@ struct RefPlan {
   int wg_per_cu; // WAVE shape: resident workgroups per CU
   int slots;     // WAVE shape: persistent workgroups of a scheduled solve
   int slice;     // WAVE shape: iterations after which an unfinished trajectory goes back to the ring
+  int slots_wide; // QUAD shape: persistent workgroups of a launch that has the device to itself (dftpav_batch_set_hand_over != 0)
+  int hand;       // QUAD shape, such a launch: unfinished trajectories at which its waves leave theirs to a follow-up launch in the WAVE shape
   size_t lds;    // dynamic LDS per workgroup
 };
 

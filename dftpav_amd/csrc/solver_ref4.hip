@@ -840,11 +840,11 @@ __device__ inline void q4_state_io(const DevBatch &D, const Q4 &q, QVec &v, int 
 // source bit 0: the rows pop trajectories from the batch's ring (solves; DevBatch::queue as solver_ref.hip uses it) -- otherwise row
 // r of wave w of workgroup i takes trajectory (i W + w) 4 + r; bit 1: test hook, true divisions in the recursion from the start.
 // slice: evaluations of a wave after which its unfinished trajectories go back to the ring (all four rows together, so that the
-// rows of a wave are refilled together and the last trajectories of a batch gather in few waves).
+// rows of a wave are refilled together and the last trajectories of a batch gather in few waves).  hand: see the slice's end.
 template <bool FAST>
 __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     ref4_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, const double *__restrict__ cor_t, double *__restrict__ scratch, int source,
-                int slice) {
+                int slice, int hand) {
   extern __shared__ double lds_raw[];
   const DevBatch &D = *Dp;
   const DevLayout &L = D.L;
@@ -962,6 +962,10 @@ __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     steps++;
     if (slice > 0 && steps >= slice) { // (uniform)
       steps = 0;
+      // hand: once no more than this many trajectories of the batch are unfinished, the waves put theirs back and LEAVE -- the host
+      // has a launch of the WAVE shape (solver_ref.hip: a wave per trajectory, 2-3 x faster per iteration on a device that is
+      // emptying) queued behind this one, which pops them from the same ring and resumes them from the same records
+      const bool leave = hand > 0 && __hip_atomic_load(&D.qctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= (unsigned)hand;
       if (act) {
         q4_state_io(D, q, v, b, l, true);
         __threadfence(); // the record and the history rows of this slice are out before the id is handed on
@@ -973,6 +977,7 @@ __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
       for (int r = 0; r < 4; r++)
         if (act && row == r && l == 0) ring_push(D.qctl, D.queue, D.qcap, b);
       act = false;
+      if (leave) break;
     }
   }
 }
@@ -1041,8 +1046,11 @@ void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int B, in
   const int per_wg = 4 * best_w;
   pl.slots = std::max(1, std::min(n_cu * best_wg, (B + 2 * per_wg - 1) / (2 * per_wg)));
   pl.slice = 64; // evaluations between two visits to the ring (64 / 256: 28.0 / 26.0 k solves/s)
+  pl.slots_wide = n_cu * best_wg; // a batch with the device to itself: every wave slot
+  pl.hand = 768;                  // ... and its last trajectories finish in the WAVE shape (launch_ref, capi.cpp)
+  if (const char *e = std::getenv("DFTPAV_REF_QUAD_HANDOVER")) pl.hand = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("DFTPAV_REF_SLICE")) pl.slice = std::atoi(e);
-  if (const char *e = std::getenv("DFTPAV_REF_SLOTS")) pl.slots = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("DFTPAV_REF_SLOTS")) pl.slots = pl.slots_wide = std::max(1, std::atoi(e)); // developer knob: persistent workgroups
 }
 hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t stream) {
   const DevLayout &L = D.L;
@@ -1052,25 +1060,28 @@ hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t st
   return hipGetLastError();
 }
 // scheduled != 0: a solve whose rows pop from the batch's ring (the caller has reset it)
+// slots: persistent workgroups of this launch; hand: unfinished trajectories at which the waves leave theirs to a follow-up launch
 hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, const double *cor_t, double *scratch, const RefPlan &pl,
-                              int scheduled, hipStream_t stream) {
+                              int scheduled, int slots, int hand, hipStream_t stream) {
   const int W = pl.threads / 64;
   int grid = (D.B + 4 * W - 1) / (4 * W), source = 0, slice = 0;
   if (scheduled && mode == kModeSolve) {
-    grid = pl.slots < grid ? pl.slots : grid;
+    grid = slots < grid ? slots : grid;
     source = 1;
     slice = pl.slice;
+  } else {
+    hand = 0;
   }
   if (const char *e = std::getenv("DFTPAV_REF_EXACT_DIV"))
     if (std::atoi(e) != 0) source |= 2;
   if (std::getenv("DFTPAV_VERBOSE"))
-    std::fprintf(stderr, "[dftpav] reference order, QUAD shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", grid, pl.threads, pl.lds, source, slice);
+    std::fprintf(stderr, "[dftpav] reference order, QUAD shape: grid %d x %d threads, %zu B of LDS, source %d slice %d hand-over at %d\n", grid, pl.threads, pl.lds, source, slice, hand);
   const bool fast = D.L.H == 4 && D.epis == 0.0 && !std::getenv("DFTPAV_REF_QUAD_GENERIC"); // the live path's constants (q4_eval)
   const void *fn = fast ? reinterpret_cast<const void *>(&reford::ref4_kernel<true>) : reinterpret_cast<const void *>(&reford::ref4_kernel<false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
   if (e != hipSuccess) return e;
-  if (fast) hipLaunchKernelGGL(reford::ref4_kernel<true>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice);
-  else hipLaunchKernelGGL(reford::ref4_kernel<false>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice);
+  if (fast) hipLaunchKernelGGL(reford::ref4_kernel<true>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice, hand);
+  else hipLaunchKernelGGL(reford::ref4_kernel<false>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice, hand);
   return hipGetLastError();
 }
 
