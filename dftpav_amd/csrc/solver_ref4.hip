@@ -483,8 +483,9 @@ template <int DIR>
 __device__ __forceinline__ void q4_load_blk(QBlk &R, gcd2_t hS, gcd2_t hR, int npad, int m, int la, int lb, int &jl) {
 #pragma unroll
   for (int u = 0; u < kQB; u++) {
-    R.a[u] = hS[(size_t)jl * npad + la];
-    R.b[u] = hS[(size_t)jl * npad + lb];
+    const gcd2_t row = hS + (size_t)jl * npad + la; // (element 16 + l sits 16 entries on: rows are npad >= 32 long, what lies beyond n is never used)
+    R.a[u] = row[0];
+    R.b[u] = row[16];
     R.yr[u] = hR[jl];
     if (DIR < 0) jl = jl == 0 ? m - 1 : jl - 1;
     else jl = jl == m - 1 ? 0 : jl + 1;
@@ -495,13 +496,15 @@ __device__ __forceinline__ void q4_pin_blk(QBlk &R) {
   for (int u = 0; u < kQB; u++)
     asm volatile("" : "+v"(R.a[u].x), "+v"(R.a[u].y), "+v"(R.b[u].x), "+v"(R.b[u].y), "+v"(R.yr[u].x), "+v"(R.yr[u].y));
 }
+template <bool EXACT>
 __device__ __forceinline__ void q4_first_steps(const QBlk &R, const Q4 &q, int i0, int bound, int m, int n, int l, bool exact, int &j, double &d0, double &d1) {
 #pragma unroll
   for (int u = 0; u < kQB; u++) {
     if (i0 + u < bound) { // (row-uniform)
       j = j == 0 ? m - 1 : j - 1;
       const double dot = row_sum32(R.a[u].x * d0, R.b[u].x * d1, n, l);
-      const double a = exact ? dot / R.yr[u].x : div_by_rcp<false>(dot, R.yr[u].x, R.yr[u].y); // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
+      // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]  (EXACT: some row of the wave divides -- only its lanes take the division's result)
+      const double a = EXACT && exact ? dot / R.yr[u].x : div_by_rcp<false>(dot, R.yr[u].x, R.yr[u].y);
       if (l == 0) q.alpha[j] = a;
       const double na = -a;
       d0 = d0 + na * R.a[u].y; // d += (-alpha) * lm_y.col(j)
@@ -509,13 +512,14 @@ __device__ __forceinline__ void q4_first_steps(const QBlk &R, const Q4 &q, int i
     }
   }
 }
+template <bool EXACT>
 __device__ __forceinline__ void q4_second_steps(const QBlk &R, const Q4 &q, int i0, int bound, int m, int n, int l, bool exact, int &j, double &d0, double &d1) {
 #pragma unroll
   for (int u = 0; u < kQB; u++) {
     if (i0 + u < bound) { // (row-uniform)
       const double al = q.alpha[j];
       const double dot = row_sum32(R.a[u].y * d0, R.b[u].y * d1, n, l);
-      const double beta = exact ? dot / R.yr[u].x : div_by_rcp<false>(dot, R.yr[u].x, R.yr[u].y);
+      const double beta = EXACT && exact ? dot / R.yr[u].x : div_by_rcp<false>(dot, R.yr[u].x, R.yr[u].y);
       const double cf = al - beta;
       d0 = d0 + cf * R.a[u].x; // d += (alpha - beta) * lm_s.col(j)
       d1 = d1 + cf * R.b[u].x;
@@ -523,9 +527,10 @@ __device__ __forceinline__ void q4_second_steps(const QBlk &R, const Q4 &q, int 
     }
   }
 }
+template <bool EXACT>
 __device__ __forceinline__ void q4_two_loop(const Q4 &q, gcd2_t hS, gcd2_t hR, int npad, int m, int n, int l, int bound, int ne, bool exact, double sc0, double &d0,
                                             double &d1) {
-  const int la = l < n ? l : 0, lb = 16 + l < n ? 16 + l : 0;
+  const int la = l, lb = 16 + l;
   QBlk A, B;
   int j = ne;
   int jl = ne == 0 ? m - 1 : ne - 1;
@@ -534,10 +539,10 @@ __device__ __forceinline__ void q4_two_loop(const Q4 &q, gcd2_t hS, gcd2_t hR, i
   for (int i0 = 0; i0 < bound; i0 += 2 * kQB) {
     q4_pin_blk(A);
     q4_load_blk<-1>(B, hS, hR, npad, m, la, lb, jl);
-    q4_first_steps(A, q, i0, bound, m, n, l, exact, j, d0, d1);
+    q4_first_steps<EXACT>(A, q, i0, bound, m, n, l, exact, j, d0, d1);
     q4_pin_blk(B);
     q4_load_blk<-1>(A, hS, hR, npad, m, la, lb, jl);
-    q4_first_steps(B, q, i0 + kQB, bound, m, n, l, exact, j, d0, d1);
+    q4_first_steps<EXACT>(B, q, i0 + kQB, bound, m, n, l, exact, j, d0, d1);
   }
   d0 = d0 * sc0;
   d1 = d1 * sc0;
@@ -548,10 +553,10 @@ __device__ __forceinline__ void q4_two_loop(const Q4 &q, gcd2_t hS, gcd2_t hR, i
   for (int i0 = 0; i0 < bound; i0 += 2 * kQB) {
     q4_pin_blk(A);
     q4_load_blk<+1>(B, hS, hR, npad, m, la, lb, jl);
-    q4_second_steps(A, q, i0, bound, m, n, l, exact, j, d0, d1);
+    q4_second_steps<EXACT>(A, q, i0, bound, m, n, l, exact, j, d0, d1);
     q4_pin_blk(B);
     q4_load_blk<+1>(A, hS, hR, npad, m, la, lb, jl);
-    q4_second_steps(B, q, i0 + kQB, bound, m, n, l, exact, j, d0, d1);
+    q4_second_steps<EXACT>(B, q, i0 + kQB, bound, m, n, l, exact, j, d0, d1);
   }
 }
 
@@ -769,7 +774,9 @@ __device__ __forceinline__ void q4_advance(const DevBatch &D, const Q4 &q, QVec 
     __threadfence_block(); // the newest pair's row and (ys, 1 / ys) are read back below
     const bool exact = q.ist[iSLOWDIV] != 0;
     double d0 = v.d0, d1 = v.d1;
-    q4_two_loop(q, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, l, bound, ne, exact, ys / yy, d0, d1);
+    // (the division mode is a wave-level choice of code: the reciprocal route has no branch in its steps)
+    if (__builtin_amdgcn_ballot_w64(exact) != 0ull) q4_two_loop<true>(q, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, l, bound, ne, exact, ys / yy, d0, d1);
+    else q4_two_loop<false>(q, (gcd2_t)hS, (gcd2_t)hR, npad, m, n, l, bound, ne, exact, ys / yy, d0, d1);
     v.d0 = e0 ? d0 : 0.0;
     v.d1 = e1 ? d1 : 0.0;
     if (l == 0) {
