@@ -165,6 +165,7 @@ struct dftpav_batch {
   RefPlan ref_plan_wt{}; // QUAD shape: the TEAM / WAVE plan of the same batch (what the QUAD kernel leaves to solver_ref.hip: the coefficient read-out)
   double *d_cor_t = nullptr; // QUAD shape: the corridor as [B][4 H][Kmax + 1][16] (solver_ref4.hip), refreshed when the corridor changes
   bool cor_t_dirty = true;
+  bool coef_override = false; // test hook dftpav_debug_batch_set_coeffs: validate / sample_states take the coefficients as they are
   int residency = -1; // the caller's residency hint (dftpav_batch_create_shaped); 2 = many such batches in flight: the throughput shapes whatever B
   // dftpav_plan_cycle: work buffers that live from the call to dftpav_plan_cycle_fetch (reused by the next cycle)
   struct PlanCycle {
@@ -1274,6 +1275,7 @@ extern "C" int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d) 
   b->epis = d->help_eps;
   b->uploaded = true;
   b->solved = false;
+  b->coef_override = false;
   b->dev_version = -1; // t_now / help_eps live in the device copy of the launch descriptor: refresh it
   return DFTPAV_OK;
 }
@@ -1593,16 +1595,23 @@ extern "C" int dftpav_debug_cr_sincos(int n, const double *x, double *s, double 
 // test hook (host only): which = 0 exp, 1 log, 2 x^3 -- the correctly rounded functions of cr_trig.h for n arguments; 3 / 4: exp / log
 // by their accurate phase alone (what the quick phase with its rounding test stands in front of)
 extern "C" int dftpav_debug_cr_fn(int which, int n, const double *x, double *y) {
-  if (n < 0 || !x || !y || which < 0 || which > 4) return DFTPAV_E_INVALID;
+  if (n < 0 || !x || !y || which < 0 || which > 6) return DFTPAV_E_INVALID;
   for (int i = 0; i < n; i++) {
     switch (which) {
       case 0: y[i] = dftpav::crt::exp_cr(x[i]); break;
       case 1: y[i] = dftpav::crt::log_cr(x[i]); break;
       case 2: y[i] = dftpav::crt::cube_cr(x[i]); break;
       case 3: y[i] = dftpav::crt::exp_cr_impl<false>(x[i]); break;
-      default: y[i] = dftpav::crt::log_cr_impl<false>(x[i]); break;
+      case 4: y[i] = dftpav::crt::log_cr_impl<false>(x[i]); break;
+      case 5: y[i] = dftpav::crt::atan(x[i]); break;   // (the step kernels' reference order: validate / states / frontend)
+      default: y[i] = dftpav::crt::tan(x[i]); break;
     }
   }
+  return DFTPAV_OK;
+}
+extern "C" int dftpav_debug_cr_atan2(int n, const double *y, const double *x, double *out) {
+  if (n < 0 || !x || !y || !out) return DFTPAV_E_INVALID;
+  for (int i = 0; i < n; i++) out[i] = dftpav::crt::atan2(y[i], x[i]);
   return DFTPAV_OK;
 }
 // test hook (host only): the sweep tables of a segment of N pieces, [4][6N][8]; returns 1 if the middle blocks have the assumed pattern
@@ -1849,6 +1858,7 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
   HIPCHK(h, hipEventRecord(b->ev1, h->stream));
   b->timed = true;
   b->solved = true;
+  b->coef_override = false;
   return DFTPAV_OK;
 }
 
@@ -2121,6 +2131,21 @@ extern "C" int dftpav_batch_records(dftpav_batch *b, void *host_dst) {
   return DFTPAV_OK;
 }
 
+// test hook: the steps after the solve (dftpav_batch_validate, dftpav_batch_sample_states) on GIVEN coefficients [B][Ntot][6][2] and piece
+// durations [B][M] instead of a solution's -- so that the kernels can be held against committed vectors of arbitrary trajectories
+// (tests/golden/steps.npz).  Cleared by the next upload or solve.
+extern "C" int dftpav_debug_batch_set_coeffs(dftpav_batch *b, const double *coeffs, const double *piece_dt) {
+  if (!b || !coeffs || !piece_dt) return DFTPAV_E_INVALID;
+  dftpav_handle *h = b->h;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(b->d_coef, coeffs, sizeof(double) * (size_t)b->B * 12 * b->L.Ntot, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(b->d_dt, piece_dt, sizeof(double) * (size_t)b->B * b->L.M, hipMemcpyHostToDevice));
+  b->coef_override = true;
+  b->uploaded = true;
+  b->solved = true;
+  return DFTPAV_OK;
+}
 extern "C" int dftpav_batch_coeffs(dftpav_batch *b, double *coeffs, double *piece_dt) {
   if (!b || !b->uploaded || !b->solved) return DFTPAV_E_INVALID; // the coefficients are those of the solution x
   dftpav_handle *h = b->h;
@@ -2145,7 +2170,7 @@ extern "C" int dftpav_batch_validate(dftpav_batch *b, double sample_dt, double v
   if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_for(b, D, kModeCoeffs));
+  if (!b->coef_override) HIPCHK(h, launch_for(b, D, kModeCoeffs));
   // the two running sums of the reference, tabulated: sample times (traj_server_ros.cpp:387) and the spacing of the
   // outline points (shapes.cc:128)
   std::vector<double> tt, vv;
@@ -2195,7 +2220,7 @@ extern "C" int dftpav_batch_sample_states(dftpav_batch *b, double t0, double sam
   if (int rc = finish_pending(b)) return rc;
   DevBatch D;
   if (int rc = sync_dev(b, D)) return rc;
-  HIPCHK(h, launch_for(b, D, kModeCoeffs));
+  if (!b->coef_override) HIPCHK(h, launch_for(b, D, kModeCoeffs));
   double *d_states = nullptr;
   int *d_valid = nullptr;
   int rc = DFTPAV_OK;

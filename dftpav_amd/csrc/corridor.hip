@@ -118,7 +118,9 @@ __global__ void __launch_bounds__(256) corridor_kernel(CorridorArgs A) {
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= A.n) return;
   const double rx = A.states[3 * i], ry = A.states[3 * i + 1], yaw = A.states[3 * i + 2];
-  const double c = p_cos(yaw), s = p_sin(yaw), ns = -s; // egoR = [c -s; s c], traj_manager.cpp:1233-1234
+  double c, s;
+  crt::sincos(yaw, s, c); // (the reference: libm cos / sin; here the correctly rounded ones, as oracle order 2)
+  const double ns = -s; // egoR = [c -s; s c], traj_manager.cpp:1233-1234
   const double step = A.resolution * 1.0, limit = 10.0; // :1218-1219
   const double dcr = A.veh_dcr;
   double sx = rx, sy = ry, W = A.veh_width, L = A.veh_length; // sourcePt, sourceVp

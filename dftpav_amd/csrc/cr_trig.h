@@ -375,5 +375,131 @@ DFTPAV_HD inline double cube_cr(double x) {
   return dd_mul_d(p, x).hi;
 }
 
+
+// ---------------------------------------------------------------- atan, atan2, tan (the steps either side of the solve: the heading
+// of a sampled state is atan2 of its velocity -- traj_server_ros.cpp:385-397, poly_traj_utils.hpp:378-406 --, the steering angle an
+// atan, the front end's curvature a tan) -- correctly rounded for the same reason as sin / cos above: the bits of libm's belong to
+// the host.
+// atan of a double-double 0 <= t <= 1: t = c + d with c = k / 64 the nearest sixty-fourth, atan t = atan c + atan u,
+// u = (t - c) / (1 + t c), |u| <= 1 / 128, atan u by its Taylor series in double-double (u^19 / 19 < 2^-137 u); atan(k / 64) from a
+// table of binary128 values split in two doubles.  ~2^-102 relative.
+DFTPAV_HD inline dd atan_tab(int k) {
+  const double t[65][2] = {
+      {0x0p+0, 0x0p+0},       {0x1.fff555bbb729bp-7, -0x1.220c39d4dff5p-61},       {0x1.ffd55bba97625p-6, -0x1.5ec431444912cp-60},
+      {0x1.7fb818430da2ap-5, -0x1.86ef8f794f105p-63},       {0x1.ff55bb72cfdeap-5, -0x1.c934d86d23f1dp-60},       {0x1.3f59f0e7c559dp-4, 0x1.ac4ce285df847p-58},
+      {0x1.7ee182602f10fp-4, -0x1.cfb654c0c3d98p-58},       {0x1.be39ebe6f07c3p-4, 0x1.f7b8f29a05987p-58},       {0x1.fd5ba9aac2f6ep-4, -0x1.cd37686760c17p-59},
+      {0x1.1e1fafb043727p-3, -0x1.b485914dacf8cp-59},       {0x1.3d6eee8c6626cp-3, 0x1.61a3b0ce9281bp-57},       {0x1.5c9811e3ec26ap-3, -0x1.054ab2c010f3dp-58},
+      {0x1.7b97b4bce5b02p-3, 0x1.347b0b4f881cap-58},       {0x1.9a6a8e96c8626p-3, 0x1.cf601e7b4348ep-59},       {0x1.b90d7529260a2p-3, 0x1.17b10d2e0e5aap-61},
+      {0x1.d77d5df205736p-3, 0x1.c648d1534597ep-57},       {0x1.f5b75f92c80ddp-3, 0x1.8ab6e3cf7afbdp-57},       {0x1.09dc597d86362p-2, 0x1.62e47390cb865p-56},
+      {0x1.18bf5a30bf178p-2, 0x1.30ca4748b1bf8p-57},       {0x1.278372057ef46p-2, -0x1.077cdd36dfc81p-56},       {0x1.362773707ebccp-2, -0x1.963a544b672d8p-57},
+      {0x1.44aa436c2af0ap-2, -0x1.5d5e43c55b3bap-56},       {0x1.530ad9951cd4ap-2, -0x1.2566480884082p-57},       {0x1.614840309cfe2p-2, -0x1.a725715711fp-56},
+      {0x1.6f61941e4def1p-2, -0x1.c63aae6f6e918p-56},       {0x1.7d5604b63b3f7p-2, 0x1.69c885c2b249ap-56},       {0x1.8b24d394a1b25p-2, 0x1.b6d0ba3748fa8p-56},
+      {0x1.98cd5454d6b18p-2, 0x1.9e6c988fd0a77p-56},       {0x1.a64eec3cc23fdp-2, -0x1.24dec1b50b7ffp-56},       {0x1.b3a911da65c6cp-2, 0x1.ae187b1ca504p-56},
+      {0x1.c0db4c94ec9fp-2, -0x1.cc1ce70934c34p-56},       {0x1.cde53432c1351p-2, -0x1.a2cfa4418f1adp-56},       {0x1.dac670561bb4fp-2, 0x1.a2b7f222f65e2p-56},
+      {0x1.e77eb7f175a34p-2, 0x1.0e53dc1bf3435p-56},       {0x1.f40dd0b541418p-2, -0x1.a3992dc382a23p-57},       {0x1.0039c73c1a40cp-1, -0x1.b32c949c9d593p-55},
+      {0x1.0657e94db30dp-1, -0x1.d5b495f6349e6p-56},       {0x1.0c6145b5b43dap-1, 0x1.974fa13b5404fp-58},       {0x1.1255d9bfbd2a9p-1, -0x1.2bdaee1c0ee35p-58},
+      {0x1.1835a88be7c13p-1, 0x1.c621cec00c301p-55},       {0x1.1e00babdefeb4p-1, -0x1.928df287a668fp-58},       {0x1.23b71e2cc9e6ap-1, 0x1.c421c9f38224ep-57},
+      {0x1.2958e59308e31p-1, -0x1.09e73b0c6c087p-56},       {0x1.2ee628406cbcap-1, 0x1.c5d5e9ff0cf8dp-55},       {0x1.345f01cce37bbp-1, 0x1.1021137c71102p-55},
+      {0x1.39c391cd4171ap-1, -0x1.2304331d8bf46p-55},       {0x1.3f13fb89e96f4p-1, 0x1.ecf8b492644fp-56},       {0x1.445065b795b56p-1, -0x1.f76d0163f79c8p-56},
+      {0x1.4978fa3269ee1p-1, 0x1.2419a87f2a458p-56},       {0x1.4e8de5bb6ec04p-1, 0x1.4a33dbeb3796cp-55},       {0x1.538f57b89061fp-1, -0x1.1bb74abda520cp-55},
+      {0x1.587d81f732fbbp-1, -0x1.5e5c9d8c5a95p-56},       {0x1.5d58987169b18p-1, 0x1.0028e4bc5e7cap-57},       {0x1.6220d115d7b8ep-1, -0x1.2b785350ee8c1p-57},
+      {0x1.66d663923e087p-1, -0x1.6ea6febe8bbbap-56},       {0x1.6b798920b3d99p-1, -0x1.a80386188c50ep-55},       {0x1.700a7c5784634p-1, -0x1.8c34d25aadef6p-56},
+      {0x1.748978fba8e0fp-1, 0x1.7b2a6165884a2p-59},       {0x1.78f6bbd5d315ep-1, 0x1.406a08980374p-55},       {0x1.7d528289fa093p-1, 0x1.560821e2f3aa9p-55},
+      {0x1.819d0b7158a4dp-1, -0x1.bf76229d3b917p-56},       {0x1.85d69576cc2c5p-1, 0x1.6b66e7fc8b8c4p-57},       {0x1.89ff5ff57f1f8p-1, -0x1.55b9a5e177a1bp-55},
+      {0x1.8e17aa99cc05ep-1, -0x1.ec182ab042f61p-56},       {0x1.921fb54442d18p-1, 0x1.1a62633145c07p-55},
+  };
+  return dd{t[k][0], t[k][1]};
+}
+DFTPAV_HD inline dd atan_dd01(dd t) {
+  const int k = (int)(t.hi * 64.0 + 0.5);
+  const double c = (double)k * 0.015625;
+  dd u = t;
+  if (k != 0) u = dd_div(dd_add_d(t, -c), dd_add_d(dd_mul_d(t, c), 1.0));
+  const dd w = dd_mul(u, u);
+  const double inv[9][2] = {{0x1.5555555555555p-2, 0x1.5555555555555p-56},  {0x1.999999999999ap-3, -0x1.999999999999ap-57}, {0x1.2492492492492p-3, 0x1.2492492492492p-57},
+                            {0x1.c71c71c71c71cp-4, 0x1.c71c71c71c71cp-58},  {0x1.745d1745d1746p-4, -0x1.745d1745d1746p-59}, {0x1.3b13b13b13b14p-4, -0x1.3b13b13b13b14p-58},
+                            {0x1.1111111111111p-4, 0x1.1111111111111p-60},  {0x1.e1e1e1e1e1e1ep-5, 0x1.e1e1e1e1e1e1ep-61},  {0x1.af286bca1af28p-5, 0x1.af286bca1af28p-59}}; // 1/3 .. 1/19
+  dd acc = dd{inv[8][0], inv[8][1]};
+  for (int m = 7; m >= 0; m--) acc = dd_add(dd{inv[m][0], inv[m][1]}, dd_neg(dd_mul(acc, w))); // 1/(2m+3) - w (1/(2m+5) - ...)
+  // atan u = u - u^3 (1/3 - w (1/5 - ...)) = u - u w acc
+  const dd au = dd_add(u, dd_neg(dd_mul(dd_mul(acc, w), u)));
+  return k != 0 ? dd_add(atan_tab(k), au) : au;
+}
+// atan of the quotient of two positive finite doubles, as a double-double in [0, pi / 2]
+DFTPAV_HD inline dd atan_ratio_dd(double ay, double ax) {
+  const dd pio2 = dd{0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54};
+  if (ay <= ax) return atan_dd01(dd_div(dd{ay, 0.0}, dd{ax, 0.0}));
+  return dd_add(pio2, dd_neg(atan_dd01(dd_div(dd{ax, 0.0}, dd{ay, 0.0}))));
+}
+// (cos x and sin x alone: the pair's code, one result used -- a caller that takes both of one argument pays for one)
+DFTPAV_HD inline double cos(double x) {
+  double s_, c_;
+  sincos(x, s_, c_);
+  return c_;
+}
+DFTPAV_HD inline double sin(double x) {
+  double s_, c_;
+  sincos(x, s_, c_);
+  return s_;
+}
+// correctly rounded atan2(y, x), the special cases as C99 Annex F has them
+DFTPAV_HD inline double atan2(double y, double x) {
+  const double pi_hi = 0x1.921fb54442d18p+1, pio2_hi = 0x1.921fb54442d18p+0, pio4_hi = 0x1.921fb54442d18p-1, pi34_hi = 0x1.2d97c7f3321d2p+1;
+  if (x != x || y != y) return x + y;
+  const bool xneg = __builtin_signbit(x), yneg = __builtin_signbit(y);
+  const double ax = xneg ? -x : x, ay = yneg ? -y : y;
+  const bool xinf = ax > 0x1.fffffffffffffp+1023, yinf = ay > 0x1.fffffffffffffp+1023;
+  double r;
+  if (ay == 0.0) r = xneg ? pi_hi : 0.0;
+  else if (ax == 0.0) r = pio2_hi;
+  else if (xinf && yinf) r = xneg ? pi34_hi : pio4_hi;
+  else if (xinf) r = xneg ? pi_hi : 0.0;
+  else if (yinf) r = pio2_hi;
+  else {
+    // scale the pair so that neither the quotient nor the products inside dd_div leave the normal range (powers of two: exact)
+    double sx = ax, sy = ay;
+    const double big = sx > sy ? sx : sy;
+    if (big > 0x1.0p+500) { sx *= 0x1.0p-600; sy *= 0x1.0p-600; }
+    else if (big < 0x1.0p-500) { sx *= 0x1.0p+600; sy *= 0x1.0p+600; }
+    const double small = sx < sy ? sx : sy, large = sx < sy ? sy : sx;
+    if (small < large * 0x1.0p-110) { // the quotient is below 2^-110: atan q = q (1 - q^2 / 3 ...) rounds as q does
+      const dd pi = dd{0x1.921fb54442d18p+1, 0x1.1a62633145c07p-53}, pio2 = dd{0x1.921fb54442d18p+0, 0x1.1a62633145c07p-54};
+      if (sy <= sx) {
+        if (!xneg) r = ay / ax; // (the true quotient of the unscaled pair: correctly rounded by IEEE, gradual underflow included)
+        else r = dd_add(pi, dd_neg(dd_div(dd{sy, 0.0}, dd{sx, 0.0}))).hi;
+      } else {
+        const dd q = dd_div(dd{sx, 0.0}, dd{sy, 0.0});
+        r = (xneg ? dd_add(pio2, q) : dd_add(pio2, dd_neg(q))).hi;
+      }
+    } else {
+      dd a = atan_ratio_dd(sy, sx);
+      if (xneg) a = dd_add(dd{0x1.921fb54442d18p+1, 0x1.1a62633145c07p-53}, dd_neg(a));
+      r = a.hi;
+    }
+  }
+  return yneg ? -r : r;
+}
+// correctly rounded atan x
+DFTPAV_HD inline double atan(double x) {
+  if (x != x) return x;
+  const bool neg = __builtin_signbit(x);
+  const double ax = neg ? -x : x;
+  double r;
+  if (ax == 0.0) return x;
+  if (ax > 0x1.0p+110) r = 0x1.921fb54442d18p+0;            // pi / 2 - 1 / x rounds to pi / 2
+  else if (ax < 0x1.0p-55) r = ax;                           // x - x^3 / 3 rounds to x  (x^2 / 3 < 2^-111)
+  else r = atan_ratio_dd(ax, 1.0).hi;
+  return neg ? -r : r;
+}
+// correctly rounded tan x
+DFTPAV_HD inline double tan(double x) {
+  if (x == 0.0) return x;
+  if (!(x - x == 0.0)) return x - x;
+  dd r;
+  const int k = (x < 0.0 ? -x : x) < 0x1.0p+20 ? reduce(x, r) : reduce_large(x, r);
+  const dd sr = sin_dd(r), cr = cos_dd(r);
+  return (k & 1) ? dd_neg(dd_div(cr, sr)).hi : dd_div(sr, cr).hi;
+}
+
 } // namespace crt
 } // namespace dftpav

@@ -32,7 +32,9 @@ struct FitArgs {
 __device__ inline void flat_output(const double *st, double out[6]) {
   double vel = st[3];
   const double angle = st[2], acc = st[4], cur = st[5];
-  const double c = p_cos(angle), s = p_sin(angle), ns = -s;
+  double c, s;
+  crt::sincos(angle, s, c); // (the reference: libm; here correctly rounded, as oracle order 2)
+  const double ns = -s;
   if (vel == 0.0) vel = 1e-5;
   out[0] = st[0];
   out[1] = st[1];

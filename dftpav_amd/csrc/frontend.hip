@@ -66,13 +66,15 @@ __device__ inline double fe_norm2(const double *a, const double *b) {
 __device__ inline void fe_flat_state(const dftpav_frontend_params &fp, const double *pose, double v, double steer, double accel,
                                      int singul, double *out) {
   const double angle = pose[2];
-  const double c = p_cos(angle), s = p_sin(angle), ns = -s;
+  double c, s;
+  crt::sincos(angle, s, c); // (the reference: libm; here correctly rounded, as oracle order 2)
+  const double ns = -s;
   double vel = fabs(v) <= fp.non_siguav ? singul * fp.non_siguav : singul * v;
   out[0] = pose[0];
   out[1] = pose[1];
   out[2] = c * vel + ns * 0.0;
   out[3] = s * vel + c * 0.0;
-  const double lat = (p_sin(steer) / p_cos(steer)) / fp.wheel_base * (vel * vel);
+  const double lat = crt::tan(steer) / fp.wheel_base * (vel * vel);
   out[4] = c * accel + ns * lat;
   out[5] = s * accel + c * lat;
 }
@@ -95,7 +97,9 @@ __global__ void __launch_bounds__(256) frontend_kernel(FeArgs A) {
     double tmpl = 0;
     auto dir = [&](int i) {
       const double dx = P[3 * (i + 1)] - P[3 * i], dy = P[3 * (i + 1) + 1] - P[3 * i + 1];
-      return dx * p_cos(P[3 * i + 2]) + dy * p_sin(P[3 * i + 2]) >= 0 ? 1 : -1;
+      double cy, sy;
+      crt::sincos(P[3 * i + 2], sy, cy);
+      return dx * cy + dy * sy >= 0 ? 1 : -1;
     };
     auto dur = [&](double len, int S, double v0, double v1) {
       return S > 0 ? fe_duration(len, fp.max_forward_vel, fp.max_forward_acc, v0, v1)

@@ -110,13 +110,13 @@ __global__ void __launch_bounds__(256) states_kernel(StatesArgs A) {
       tn *= inner;
     }
     const double sg = (double)L.singuls[i];
-    const double angle = p_atan2(sg * vy, sg * vx);
+    const double angle = crt::atan2(sg * vy, sg * vx); // (the reference: libm; here correctly rounded, as oracle order 2)
     const double vel = sg * sqrt(vx * vx + vy * vy);
     double curv = 0.0, acc = 0.0, steer = 0.0;
     if (!(fabs(vel) < 1e-6)) {
-      curv = (vx * ay - vy * ax) / (vel * vel * vel);
+      curv = (vx * ay - vy * ax) / crt::cube_cr(vel); // (the reference: pow(vel, 3) of libm; here the correctly rounded cube)
       acc = (vx * ax + vy * ay) / vel;
-      steer = p_atan(A.wheel_base * curv);
+      steer = crt::atan(A.wheel_base * curv);
     }
     s[0] = t; s[1] = px; s[2] = py; s[3] = angle; s[4] = curv; s[5] = vel; s[6] = acc; s[7] = steer;
   }

@@ -128,9 +128,10 @@ __global__ void __launch_bounds__(256) validate_kernel(ValidateArgs A) {
       tn *= tt;
     }
     const double sg = (double)L.singuls[i];
-    const double yaw = p_atan2(sg * vy, sg * vx);
+    const double yaw = crt::atan2(sg * vy, sg * vx); // (the reference: libm; here correctly rounded, as oracle order 2)
     // CheckCollisionUsingPosAndYaw, semantic_map_manager.cc:639-662 + shapes.cc:116-147
-    const double cs = p_cos(yaw), sn = p_sin(yaw);
+    double cs, sn;
+    crt::sincos(yaw, sn, cs);
     const double W = A.veh_width, Lv = A.veh_length;
     const double x = px + A.veh_dcr * cs, y = py + A.veh_dcr * sn;
     const double c1x = x + 0.5 * Lv * cs + 0.5 * W * sn, c1y = y + 0.5 * Lv * sn - 0.5 * W * cs;

@@ -21,6 +21,7 @@
 #include <cstdint>
 
 #include "../dftpav_amd/csrc/traj_math.h"
+#include "step_trig.h"
 
 namespace {
 
@@ -60,7 +61,8 @@ extern "C" void oracle_corridor_rectangles(const unsigned char *grid, int size_x
   const double checkl = resolution / 2.0;
   for (int i = 0; i < n; i++) {
     const double rx = states[3 * i], ry = states[3 * i + 1], yaw = states[3 * i + 2];
-    const double c = order ? dftpav::p_cos(yaw) : std::cos(yaw), s = order ? dftpav::p_sin(yaw) : std::sin(yaw);
+    const step_trig::Trig T{order};
+    const double c = T.cos(yaw), s = T.sin(yaw);
     const double ns = -s;                              // egoR = [c -s; s c], :1233-1234
     auto at = [&](double sxp, double syp, double a, double b, double &ox, double &oy) { // pt + egoR * (a, b)
       ox = sxp + (c * a + ns * b);

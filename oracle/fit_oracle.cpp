@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../dftpav_amd/csrc/traj_math.h"
+#include "step_trig.h"
 
 extern "C" void oracle_fit_surround(const double *states, int S, int n_states, int order, double *dur, double *coef, double *total,
                                     double *start) {
@@ -44,7 +45,8 @@ extern "C" void oracle_fit_surround(const double *states, int S, int n_states, i
   auto flat = [&](const double *st, double out[6]) { // state_to_flat_output
     double vel = st[3];
     const double angle = st[2], acc = st[4], cur = st[5];
-    const double c = order ? p_cos(angle) : std::cos(angle), s = order ? p_sin(angle) : std::sin(angle), ns = -s;
+    const step_trig::Trig T{order};
+    const double c = T.cos(angle), s = T.sin(angle), ns = -s;
     if (vel == 0.0) vel = 1e-5;
     out[0] = st[0];
     out[1] = st[1];

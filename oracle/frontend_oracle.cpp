@@ -26,14 +26,15 @@
 
 #include "../dftpav_amd/csrc/traj_math.h"
 #include "../include/dftpav_hip.h"
+#include "step_trig.h"
 
 namespace {
 
 struct Trig {
   int order;
-  double c(double a) const { return order ? dftpav::p_cos(a) : std::cos(a); }
-  double s(double a) const { return order ? dftpav::p_sin(a) : std::sin(a); }
-  double t(double a) const { return order ? dftpav::p_sin(a) / dftpav::p_cos(a) : std::tan(a); }
+  double c(double a) const { return step_trig::Trig{order}.cos(a); }
+  double s(double a) const { return step_trig::Trig{order}.sin(a); }
+  double t(double a) const { return step_trig::Trig{order}.tan(a); }
 };
 
 // kino_astar.cpp:744-762

@@ -26,6 +26,7 @@
 #include <cstdint>
 
 #include "../dftpav_amd/csrc/traj_math.h"
+#include "step_trig.h"
 
 namespace {
 
@@ -113,14 +114,14 @@ extern "C" void oracle_sample_states(const double *coeffs, const double *piece_d
       }
       // getStateExpPos, poly_traj_utils.hpp:303-340
       const double sg = (double)singuls[i];
-      double angle = order ? dftpav::p_atan2(sg * vy, sg * vx) : std::atan2(sg * vy, sg * vx);
+      double angle = step_trig::Trig{order}.atan2(sg * vy, sg * vx);
       const double vel = sg * std::sqrt(vx * vx + vy * vy);
       double curv = 0.0, acc = 0.0, steer = 0.0;
       if (!(std::fabs(vel) < 1e-6)) {
-        const double v3 = order ? vel * vel * vel : std::pow(vel, 3);
+        const double v3 = step_trig::Trig{order}.cube(vel);
         curv = (vx * ay - vy * ax) / v3;
         acc = (vx * ax + vy * ay) / vel;
-        steer = order ? dftpav::p_atan(wheel_base * curv) : std::atan(wheel_base * curv);
+        steer = step_trig::Trig{order}.atan(wheel_base * curv);
       }
       if (filter && have_hist) { // FilterSingularityState, traj_server_ros.cpp:335-356
         const double duration = t - hist_t;

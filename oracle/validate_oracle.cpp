@@ -23,6 +23,7 @@
 #include <cstdint>
 
 #include "../dftpav_amd/csrc/traj_math.h"
+#include "step_trig.h"
 
 namespace {
 
@@ -50,7 +51,8 @@ inline bool edge_hits(const Grid &g, double ax, double ay, double bx, double by,
 
 // CheckCollisionUsingPosAndYaw (semantic_map_manager.cc:639-662)
 inline bool pose_collides(const Grid &g, double px, double py, double yaw, double W, double L, double dcr, double vres, int order) {
-  const double cs = order ? dftpav::p_cos(yaw) : std::cos(yaw), sn = order ? dftpav::p_sin(yaw) : std::sin(yaw);
+  const step_trig::Trig T{order};
+  const double cs = T.cos(yaw), sn = T.sin(yaw);
   const double x = px + dcr * cs, y = py + dcr * sn; // obb centre, :645-646
   // shapes.cc:116-127
   const double c1x = x + 0.5 * L * cs + 0.5 * W * sn, c1y = y + 0.5 * L * sn - 0.5 * W * cs;
@@ -113,7 +115,7 @@ extern "C" void oracle_validate_trajectories(const unsigned char *grid, int size
           tn *= tt;
         }
         const double sg = (double)singuls[i];
-        const double yaw = order ? dftpav::p_atan2(sg * vy, sg * vx) : std::atan2(sg * vy, sg * vx);
+        const double yaw = step_trig::Trig{order}.atan2(sg * vy, sg * vx);
         if (pose_collides(g, px, py, yaw, veh_width, veh_length, veh_dcr, vertex_res, order)) {
           hit = 1;
           first = counter;

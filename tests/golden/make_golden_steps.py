@@ -1,7 +1,9 @@
-"""Freezes small inputs and device-order (libm-free, bit-stable) outputs of the oracles of the steps around the
-solve: corridor, validation, state read-out, obstacle fit, front-end resampling, restart sampler, Reeds-Shepp shots.
-The reference has no expected values for any of them; these vectors pin OUR definition so that a later
-change of the shared arithmetic cannot go unnoticed.  Run from the repo root:
+"""Freezes small inputs and bit-stable outputs of the oracles of the steps around the solve.  Corridor, validation, state read-out,
+obstacle fit and front-end resampling: the restatement of the reference's functions with every libm call CORRECTLY ROUNDED (oracle
+order 2: cos / sin / tan / atan / atan2 / x^3 from binary128, an implementation that shares nothing with the kernels' double-double
+functions) -- what the HIP kernels must reproduce bit for bit, discrete outputs included.  Restart sampler and Reeds-Shepp shots
+(no libm call of the reference to follow: OMPL's arithmetic is not in the reference tree): the portable functions, order 1.
+The reference has no expected values for any of them.  Run from the repo root:
     python tests/golden/make_golden_steps.py
 """
 import os
@@ -24,13 +26,13 @@ def main():
     grid, origin = sc.occupancy_grid(obs, arena=60.0)
     st = np.column_stack([rng.uniform(-22, 22, 60), rng.uniform(-22, 22, 60), rng.uniform(-7, 7, 60)])
     rec.update(grid=grid, origin=np.array(origin), cor_states=st,
-               cor_out=po.corridor_rectangles(grid, sc.MAP_RESL, origin, st, order=1))
+               cor_out=po.corridor_rectangles(grid, sc.MAP_RESL, origin, st, order=2))
     # trajectories for validation / read-out: random quintic pieces (two segments, the second reversing)
     B, pn, sg = 3, np.array([3, 2], dtype=np.int32), np.array([1, -1], dtype=np.int32)
     co = rng.normal(0, 1, size=(B, 5, 6, 2)) * np.array([8.0, 2.0, 0.6, 0.2, 0.05, 0.01])[None, None, :, None]
     dts = rng.uniform(0.6, 1.4, size=(B, 2))
-    col, first = po.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, pn, sg, sample_dt=0.05, vertex_res=0.1, order=1)
-    sts, nv = po.sample_states(co, dts, pn, sg, t0=-0.1, sample_dt=0.03, n_samples=220, filter_singularity=True, order=1)
+    col, first = po.validate_trajectories(grid, sc.MAP_RESL, origin, co, dts, pn, sg, sample_dt=0.05, vertex_res=0.1, order=2)
+    sts, nv = po.sample_states(co, dts, pn, sg, t0=-0.1, sample_dt=0.03, n_samples=220, filter_singularity=True, order=2)
     rec.update(traj_coeffs=co, traj_dt=dts, traj_pn=pn, traj_sg=sg, val_col=col, val_first=first, rd_states=sts, rd_valid=nv)
     # obstacle fit
     ps = np.zeros((2, 9, 7))
@@ -38,12 +40,12 @@ def main():
     ps[..., 2] = rng.uniform(-3, 3, size=(2, 9)); ps[..., 3] = rng.uniform(0, 6, size=(2, 9))
     ps[..., 4] = rng.normal(0, 1, size=(2, 9)); ps[..., 5] = rng.normal(0, 0.1, size=(2, 9))
     ps[..., 6] = 0.5 + 0.8 * np.arange(9)[None, :]
-    ft = po.fit_surround(ps, order=1)
+    ft = po.fit_surround(ps, order=2)
     rec.update(fit_states=ps, fit_dur=ft["durations"], fit_coef=ft["coeffs"], fit_total=ft["total"], fit_start=ft["start"])
     # front end
     P, pl, ss, es, ct = sc.searched_paths(3, seed=9, gears=(1, -1), seg_duration=5.0)
     fp = FrontendParams.default(K=6, Kd=9)
-    fe = po.frontend_resample(P, pl, ss, es, ct, fp, order=1)
+    fe = po.frontend_resample(P, pl, ss, es, ct, fp, order=2)
     rec.update(fe_paths=P, fe_len=pl, fe_ss=ss, fe_es=es, fe_ct=ct)
     for k, v in fe.items():
         rec["fe_out_" + k] = v

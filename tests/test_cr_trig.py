@@ -136,3 +136,59 @@ def test_quick_phases_never_disagree_with_the_accurate_ones(tmp_path):
         handed = int(ln.split("handed over")[1].split()[0])
         if "e^[" not in ln:   # (the logarithm of a correctly rounded exponential sits next to a double: its rounding is never in doubt)
             assert 2000000 / 3000 < handed < 2000000 / 700, ln
+
+
+SRC_ATAN = r"""
+#include <quadmath.h>
+void q_atan2(int n, const double *y, const double *x, double *o) { for (int i = 0; i < n; i++) o[i] = (double)atan2q((__float128)y[i], (__float128)x[i]); }
+void q_atan(int n, const double *x, double *o) { for (int i = 0; i < n; i++) o[i] = (double)atanq((__float128)x[i]); }
+void q_tan(int n, const double *x, double *o) { for (int i = 0; i < n; i++) o[i] = (double)tanq((__float128)x[i]); }
+"""
+
+
+def test_cr_atan2_atan_tan_equal_binary128_rounded(hiplib):
+    """The correctly rounded atan2 / atan / tan of the step kernels' reference order (cr_trig.h: the heading of a sampled state, the
+    steering angle, the front end's curvature) against binary128 rounded to double: every quadrant, the axes and the signed zeros,
+    quotients from 2^-1000 to 2^1000, arguments next to the table's nodes k / 64, large arguments of tan."""
+    L = hiplib.lib()
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "q.c"), "w").write(SRC_ATAN)
+    so = os.path.join(d, "libqa.so")
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", os.path.join(d, "q.c"), "-o", so, "-lquadmath"])
+    q = C.CDLL(so)
+    dp = pods.c_double_p
+    q.q_atan2.argtypes = [C.c_int, dp, dp, dp]
+    q.q_atan.argtypes = q.q_tan.argtypes = [C.c_int, dp, dp]
+    L.dftpav_debug_cr_atan2.argtypes = [C.c_int, dp, dp, dp]
+    L.dftpav_debug_cr_fn.argtypes = [C.c_int, C.c_int, dp, dp]
+    rng = np.random.default_rng(3)
+    n = 200000
+    for scale in (1.0, 1.0e-3, 1.0e3, 1.0e-30, 1.0e30, 1.0e-200, 1.0e200, 1.0e-300, 1.0e300):
+        y = rng.normal(0, 1, n)
+        x = rng.normal(0, 1, n) * scale
+        if scale == 1.0:
+            k = rng.integers(0, 65, n // 4)
+            y[: n // 4] = (k / 64.0) * (1.0 + rng.normal(0, 1e-12, n // 4)) * np.abs(x[: n // 4])   # next to the table's nodes
+            y[n // 4: n // 4 + 12] = [0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.inf, 1.0, 5e-324, 1.0]
+            x[n // 4: n // 4 + 12] = [1.0, 1.0, -1.0, -1.0, 0.0, -0.0, np.inf, -np.inf, 1.0, np.inf, 1.0, 5e-324]
+            y[n // 2: n // 2 + 1000] = x[n // 2: n // 2 + 1000]          # the diagonal
+        o, oq = np.zeros(n), np.zeros(n)
+        assert L.dftpav_debug_cr_atan2(n, pods.dptr(y), pods.dptr(x), pods.dptr(o)) == 0
+        q.q_atan2(n, pods.dptr(y), pods.dptr(x), pods.dptr(oq))
+        assert np.array_equal(o, oq), (scale, int((o != oq).sum()), y[o != oq][:3], x[o != oq][:3])
+        assert np.array_equal(np.signbit(o), np.signbit(oq))
+    for scale in (1.0, 64.0, 1.0e-3, 1.0e-20, 1.0e6, 1.0e40, 1.0e300):
+        x = rng.normal(0, 1, n) * scale
+        x[:5] = [0.0, -0.0, 1.0, -1.0, 0.5]
+        o, oq = np.zeros(n), np.zeros(n)
+        assert L.dftpav_debug_cr_fn(5, n, pods.dptr(x), pods.dptr(o)) == 0
+        q.q_atan(n, pods.dptr(x), pods.dptr(oq))
+        assert np.array_equal(o, oq), ("atan", scale, int((o != oq).sum()))
+    for scale in (1.0, 1.5, 1.0e-3, 1.0e-20, 100.0, 1.0e6, 1.0e10, 1.0e100):
+        x = rng.uniform(-1, 1, n) * scale
+        if scale == 1.5:        # next to the poles
+            x[: n // 2] = (2 * rng.integers(-20, 20, n // 2) + 1) * (np.pi / 2) + rng.normal(0, 1e-9, n // 2)
+        o, oq = np.zeros(n), np.zeros(n)
+        assert L.dftpav_debug_cr_fn(6, n, pods.dptr(x), pods.dptr(o)) == 0
+        q.q_tan(n, pods.dptr(x), pods.dptr(oq))
+        assert np.array_equal(o, oq), ("tan", scale, int((o != oq).sum()))
