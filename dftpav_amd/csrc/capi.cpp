@@ -1999,21 +1999,25 @@ extern "C" int dftpav_comm_unique_id(void *id) {
 }
 // Is RCCL loadable here?  (dlopen + dlsym only: no bootstrap root is started, unlike dftpav_comm_unique_id.)
 extern "C" int dftpav_comm_available(void) { return rccl().ok ? 1 : 0; }
+// lets go of h's reference to its communicator; g_comm_mu is held by the caller, h's stream is drained
+static void comm_release_locked(dftpav_handle *h) {
+  if (h->comm_ref && h->comm_ref->holders.fetch_sub(1) == 1) { // the last holder (every holder has drained its own stream)
+    {
+      std::lock_guard<std::mutex> lk(h->comm_ref->mu);
+      (void)rccl().CommDestroy(h->comm_ref->comm);
+    }
+    delete h->comm_ref;
+  }
+  h->comm = nullptr;
+  h->comm_ref = nullptr;
+}
 extern "C" int dftpav_comm_destroy(dftpav_handle *h) {
   if (!h) return DFTPAV_E_INVALID;
   if (h->comm) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     std::lock_guard<std::mutex> reg(g_comm_mu);
-    if (h->comm_ref && h->comm_ref->holders.fetch_sub(1) == 1) { // the last holder (every holder has drained its own stream)
-      {
-        std::lock_guard<std::mutex> lk(h->comm_ref->mu);
-        (void)rccl().CommDestroy(h->comm_ref->comm);
-      }
-      delete h->comm_ref;
-    }
-    h->comm = nullptr;
-    h->comm_ref = nullptr;
+    comm_release_locked(h);
   }
   if (h->d_comm_send) (void)hipFree(h->d_comm_send);
   h->d_comm_send = nullptr;
@@ -2048,19 +2052,26 @@ extern "C" int dftpav_comm_create(dftpav_handle *h, int nranks, int rank, const 
 // same order of collectives on every rank -- which a round-robin over the handles is.
 extern "C" int dftpav_comm_share(dftpav_handle *h, dftpav_handle *owner) {
   if (!h || !owner || h == owner) return DFTPAV_E_INVALID;
-  {
-    std::lock_guard<std::mutex> reg(g_comm_mu);
-    if (owner->comm && owner->comm_ref && owner->comm_ref == h->comm_ref) return DFTPAV_OK; // already the same communicator
+  // h's stream is drained BEFORE the registry lock is taken (its collectives may still be in flight on the communicator it gives up)
+  if (h->comm) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
   }
-  if (int rc = dftpav_comm_destroy(h)) return rc;  // (takes g_comm_mu itself)
   std::lock_guard<std::mutex> reg(g_comm_mu);
+  if (owner->comm && owner->comm_ref && owner->comm_ref == h->comm_ref) return DFTPAV_OK; // already the same communicator
+  // the owner is checked and the new reference taken FIRST: a share that fails leaves h as it was (round 5 released h's own
+  // communicator before the check -- a failed share could then destroy it on this rank alone and hang the other ranks)
   if (!owner->comm || !owner->comm_ref || owner->device != h->device) { // read under the lock: the owner may be letting go
     h->err = "dftpav_comm_share: the other handle needs a communicator (dftpav_comm_create, or shared itself) on the same device";
     return DFTPAV_E_INVALID;
   }
+  owner->comm_ref->holders.fetch_add(1);
+  if (h->comm) comm_release_locked(h); // ... only then the old one goes
+  if (h->d_comm_send) (void)hipFree(h->d_comm_send); // (sized for the communicator it belonged to)
+  h->d_comm_send = nullptr;
+  h->comm_send_bytes = 0;
   h->comm = owner->comm;
   h->comm_ref = owner->comm_ref;
-  h->comm_ref->holders.fetch_add(1);
   h->comm_ranks = owner->comm_ranks;
   h->comm_rank = owner->comm_rank;
   return DFTPAV_OK;

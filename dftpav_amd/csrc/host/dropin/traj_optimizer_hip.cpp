@@ -23,9 +23,12 @@
 // setParam is called again on the same address or at process exit.
 //
 // Floating-point order: DFTPAV_ORDER_REFERENCE unless the environment says DFTPAV_DROPIN_ORDER=device -- the planner solves
-// one trajectory per 20 Hz cycle (traj_server_ros.cpp:100), and the reference order reproduces the CPU planner's decision
-// bit for bit (for gear shifts / moving obstacles: the reference's program with correctly rounded cos / sin / exp / log /
-// pow in place of libm's host-dependent ones).
+// one trajectory per 20 Hz cycle (traj_server_ros.cpp:100), and the reference order runs the reference's floating-point program:
+// bit-equal to the reference's statements with SEQUENTIAL reductions (what the CPU restatement executes; for gear shifts / moving
+// obstacles with correctly rounded cos / sin / exp / log / pow in place of libm's host-dependent ones).  A planner built against a
+// real, vectorising Eigen reduces its dot products in another order and differs from this -- and from any other build of itself --
+// by a perturbation of the last bit, which this chaotic solver amplifies to a different, statistically equal answer (measured:
+// profiles/r05_eigen_redux_cpu.json).
 //
 // One trajectory per call leaves 255 of 256 CUs idle.  Opt-in, DFTPAV_DROPIN_RESTARTS=K (2 .. 1024): the call's problem goes
 // into slot 0 of a batch of K, slots 1 .. K-1 are seeded restarts of it (dftpav_sample_restarts: waypoints moved by N(0, 0.3^2) m,
@@ -294,8 +297,10 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
       ROS_ERROR("dftpav_sample_restarts: %d %s", rc, dftpav_last_error(be->h));
       return false;
     }
-    for (int k = 1; k < K; k++) // a restart's duration must stay above mini_T as the call's own must (traj_optimizer.cpp:30)
-      for (int i = 0; i < M; i++) rts[(size_t)k * M + i] = std::max(rts[(size_t)k * M + i], mini_T);
+    // a restart's duration must stay ABOVE mini_T: RealT2VirtualT (traj_optimizer.cpp:365-367) divides by T - mini_T, so a duration
+    // clamped to exactly mini_T would start from a virtual time of -inf (a wasted slot at best)
+    for (int k = 1; k < K; k++)
+      for (int i = 0; i < M; i++) rts[(size_t)k * M + i] = std::max(rts[(size_t)k * M + i], mini_T * (1.0 + 1.0e-3) + 1.0e-6);
     auto tile = [&](std::vector<double> &v) {
       const size_t n1 = v.size();
       v.resize(n1 * K);
@@ -348,15 +353,19 @@ bool PolyTrajOptimizer::OptimizeTrajectory(const std::vector<Eigen::MatrixXd> &i
   be->evals = evals[0];
   iter_num_ = be->iters;
   be->solved = true;
-  // the candidate that is returned: the cheapest successful one that does not collide (slot 0 when there is none, or no restarts)
+  // the candidate that is returned: the cheapest successful one that does not collide (slot 0 when there is none, or no restarts).
+  // WITHOUT a map the restarts cannot be re-checked (their waypoints were moved by N(0, 0.3^2) m off the collision-free front-end
+  // path): slot 0 is kept whenever it succeeded, a restart only stands in for a failed slot 0.
   int chosen = 0;
+  const bool unchecked = K > 1 && !be->have_map;
   be->n_success = be->n_colliding = 0;
   for (int k = 0; k < K; k++) {
     be->n_success += success[k] != 0;
     be->n_colliding += colliding[k] != 0;
     const bool ok_k = success[k] != 0 && colliding[k] == 0, ok_c = success[chosen] != 0 && colliding[chosen] == 0;
-    if (ok_k && (!ok_c || costs[k] < costs[chosen])) chosen = k;
+    if (ok_k && (!ok_c || (costs[k] < costs[chosen] && !(unchecked && chosen == 0)))) chosen = k;
   }
+  iter_num_ = iters[chosen]; // (the member describes what is returned; slot 0's own figures stay in dftpav_dropin_last_solve)
   be->chosen = chosen;
   be->chosen_cost = costs[chosen];
   {

@@ -289,33 +289,39 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *   decision exactly, and the parity proof of the other one.  THE CONTRACT, precisely: final x, cost, status, iterations
  *   and evaluations are bit-equal to those of the reference's PROGRAM evaluated with sequential reductions (dot products,
  *   norms and matrix products as one chain from their first term), no FMA contraction and -- where the program calls libm --
- *   correctly rounded calls.  That program is what oracle/_ref (the reference's sources compiled unmodified against an
- *   Eigen stand-in with sequential reductions) executes; an upstream binary built against a real Eigen vectorises
- *   reductions into 2- or 4-lane partial sums and may differ in last bits, as two such builds differ from each other.
+ *   correctly rounded calls.  That program is what the CPU restatement executes (oracle/dftpav_oracle.c, orders 0 / 2: test
+ *   infrastructure).  The reference itself cannot be built in this project's image (it needs Eigen, ROS and protobuf-generated
+ *   code) and holds no golden vectors: PARITY IS UNPINNED against an upstream binary.  Such a binary, built against a real
+ *   Eigen, vectorises reductions into 2- or 4-lane partial sums and WILL differ in last bits -- as two such builds differ from
+ *   each other -- and this solver turns a last-bit difference into a different, statistically equal answer.
  *     - one gear segment, no moving obstacles: the reference's program has no libm call inside the loop; this mode
- *       returns the bits of oracle/_ref;
+ *       returns the bits of the restatement's order 0;
  *     - gear shifts: the reference calls libm's cos / sin of every junction angle per evaluation
  *       (traj_optimizer.cpp:273-282, 311-318), whose bits depend on the host (glibc's are not correctly rounded and are
  *       IFUNC-dispatched by CPU model): this mode uses the CORRECTLY ROUNDED cos / sin (cr_trig.h); it equals the
- *       reference build's own result whenever the host's libm rounded every junction angle's cos / sin correctly;
+ *       result of the same program over a host libm whenever that libm rounded every junction angle's cos / sin correctly;
  *     - moving obstacles: libm's exp (40 times) and log (9 times) per (constraint point, obstacle) pair and pow(|v|, 3)
  *       (traj_optimizer.cpp:1686-1707, poly_traj_utils.hpp:109) are likewise the correctly rounded exp / log / x^3;
  *     - gear shifts TOGETHER WITH moving obstacles -- the reference's live call, traj_manager.cpp:604-610 -- are covered,
  *       including trajtimes[i] = duration of segment i - 1 (traj_optimizer.cpp:230-234) and the extra gdT addends per
  *       previous segment (:1674-1676);
- *     - with libm calls in the loop the yardstick is the reference's own objects linked against a correctly rounded
- *       exp / log / pow / sin / cos (oracle/_ref/libdftpav_ref_cr.so, oracle/cr_libm.c: test infrastructure): whole solves of
- *       this mode are bit-equal to THAT build on all of the three cases above;
+ *     - with libm calls in the loop the yardstick is the restatement's order 2 (the same statements with exp / log / pow / sin /
+ *       cos from binary128): whole solves of this mode are bit-equal to it on all of the three cases above;
  *     - limits: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per constraint point, every gear segment
  *       >= 2 pieces; otherwise DFTPAV_E_UNSUPPORTED, order unchanged.  Choose the order again after the number of
  *       obstacles on the handle changed.  dftpav_batch_trace* is a device-order facility (DFTPAV_E_UNSUPPORTED here).
  *     - one step of the path is bit-equal by MEASUREMENT, not by proof: a division by a stored quantity (the diagonals of the
  *       band factorisation, y.s of a stored pair) is a multiplication by its reciprocal with one residual correction, which
  *       is the correctly rounded quotient whenever the first product is a faithful rounding of it (Markstein); no
- *       counter-example in 2^31 random pairs nor in any solve compared with the reference build, none ruled out.  The
+ *       counter-example in 2^31 random pairs nor in any solve compared with the restatement, none ruled out.  The
  *       environment variable DFTPAV_REF_EXACT_DIV=1 makes the recursion divide (slower; the bits have never differed).
- *   Launch shape by batch size: up to five trajectories per CU one workgroup each (lowest latency); beyond, one WAVE per
- *   trajectory, eight per CU, popped from the batch's ring in slices of 128 iterations (20.7 k solves/s at 4096 on MI355X). */
+ *   Launch shape by batch size (or by the residency hint of dftpav_batch_create_shaped: 2 = many batches in flight): up to five
+ *   trajectories per CU one workgroup each (lowest latency); beyond, one gear segment of <= 16 pieces and n <= 32 without moving
+ *   obstacles -- BASELINE configs[2] / [3] -- takes the QUAD shape (solver_ref4.hip): FOUR trajectories per wave, one per row of
+ *   16 lanes, a piece per lane, 16 trajectories per CU, the rows popping trajectories from the batch's ring (31-32 k solves/s on a
+ *   stream of 4096-batches on MI355X); everything else one WAVE per trajectory, eight per CU (solver_ref.hip).  A batch that has
+ *   the device to itself (the default; dftpav_batch_set_hand_over(b, 0) announces others behind it) takes every wave slot and
+ *   hands its last trajectories to the WAVE shape.  Every shape returns the same bits. */
 #define DFTPAV_ORDER_DEVICE 0
 #define DFTPAV_ORDER_REFERENCE 1
 int dftpav_batch_set_order(dftpav_batch *b, int order);
