@@ -182,7 +182,7 @@ def value_line(ctx, args, st, res, B_total):
                                    "peak_instr_per_s": peak_i, "frac": valu_per_solve * value / world / peak_i,
                                    "clock_hz": clk, "simds": ctx.n_cu * 4,
                                    "note": "wave64 VALU instructions issued per second over (SIMDs x clock / 4); the kernel is bound "
-                                           "here and by dependent latency at two waves per SIMD, not by bytes"}
+                                           "here and by dependent latency (the QUAD shape runs one wave per SIMD), not by bytes"}
     return out
 
 

@@ -44,11 +44,15 @@ def live_pmc(args, schedule):
             for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     if any(nm in r["Kernel_Name"] for nm in names) and r["Counter_Name"] == ctr:
-                        rows.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+                        rows.append((int(r["Grid_Size"]), float(r["Counter_Value"]), r["Kernel_Name"]))
             if not rows:
                 return (got or None), "no %s rows for %s" % (ctr, " / ".join(names))
-            gmax = max(g for g, _ in rows)
-            got[ctr] = sum(v for _, v in rows) / sum(1 for g, _ in rows if g == gmax)
+            # per batch = everything the batch's launches counted (the queue launch and whatever follows it: the device order's
+            # straggler launch, the reference order's hand-over of a batch's last trajectories to the WAVE shape) over the number of
+            # batches = the launches of the PRIMARY kernel (the first of `names` that ran) with its largest grid
+            prim = [nm for nm in names if any(nm in k for _, _, k in rows)][0]
+            gmax = max(g for g, _, k in rows if prim in k)
+            got[ctr] = sum(v for _, v, _ in rows) / sum(1 for g, _, k in rows if prim in k and g == gmax)
         except Exception as ex:  # noqa: BLE001
             return (got or None), "%s pass failed: %s" % (ctr, type(ex).__name__)
         finally:

@@ -378,6 +378,23 @@ __device__ inline void mat_mat(const double a[4], const double b[4], double o[4]
   o[2] = a[2] * b[0] + a[3] * b[2];
   o[3] = a[2] * b[1] + a[3] * b[3];
 }
+// the piece Trajectory::locatePieceIdx stops at, from the host's theta table (device_types.h: DevSurround::theta; traj_math.h:
+// sur_index): the number of pieces k of obstacle u with t > theta[k]
+__device__ inline int ref_sur_index(const DevSurround &S, int u, double t) {
+  const int p0 = S.piece_off[u], np = S.piece_off[u + 1] - p0;
+  const double *th = S.theta + p0;
+  int g = (int)(t * S.rate(u));
+  g = g < 0 ? 0 : (g > np - 1 ? np - 1 : g);
+  const double ta = th[g], tb = th[g > 0 ? g - 1 : 0];
+  if (t > ta) {
+    g++;
+    while (g < np && t > th[g]) g++;
+  } else if (g > 0 && !(t > tb)) {
+    g--;
+    while (g > 0 && !(t > th[g - 1])) g--;
+  }
+  return g;
+}
 // log_sum_exp, traj_optimizer.cpp:1686-1707 (mutates all_dists into the exp weights); exp / log correctly rounded
 __device__ inline double lse_cr(double alpha, double *all_dists, int n, double *exp_sum) {
   double d_0 = all_dists[0];
@@ -420,18 +437,33 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     double offsettime = t_now - st->start_time + trajtime; // OPT:1367-1369
     double pt_time = offsettime + t;
     double surround_p[2], surround_v[2], surround_a[2];
+    // Every evaluator the reference calls at pt_time (getPos, getdSigma, getddSigma, getR, getRdot) starts with the same
+    // locatePieceIdx walk: it is taken ONCE here (round 6; seven walks of up to 30 dependent subtractions per pair until then) --
+    // the same piece, the same local time, the same bits.  And before any walk: the obstacle's piece at pt_time is known from the
+    // host's theta table (the index the walk stops at, found by bisection over the doubles with that same walk), and a point
+    // farther than the gate's radius from the box that holds that whole piece fails the reference's distance gate (:1393) for
+    // certain -- the pair is dropped as the reference drops it, without evaluating anything (solver.hip does the same).
+    double tloc = pt_time;
+    int iloc = -1;
     if (pt_time < st->duration) {
-      traj_getPos(st, pt_time, surround_p);
-      traj_getdSigma(st, pt_time, surround_v);
-      traj_getddSigma(st, pt_time, surround_a);
+      if (S.has_theta() && S.has_bbox() && pt_time >= 0.0) {
+        const int ig = ref_sur_index(S, sur_id, pt_time);
+        if (ig < st->n_pieces && S.far_from_piece(S.piece_off[sur_id] + ig, sigma, P.veh_length_infl * 1.5 + 1e-6)) continue;
+      }
+      iloc = traj_locate(st->durs, st->n_pieces, tloc);
+      piece_getPos(st->coeffs + 12 * iloc, tloc, surround_p);
+      piece_getdSigma(st->coeffs + 12 * iloc, tloc, surround_v);
+      piece_getddSigma(st->coeffs + 12 * iloc, tloc, surround_a);
     } else { // OPT:1379-1389
       double vd[2], pd[2];
-      traj_getddSigma(st, st->duration, surround_a);
+      double tend = st->duration;
+      const int iend = traj_locate(st->durs, st->n_pieces, tend); // (one walk for the three evaluators at the obstacle's end)
+      piece_getddSigma(st->coeffs + 12 * iend, tend, surround_a);
       double exceed_time = pt_time - st->duration;
-      traj_getdSigma(st, st->duration, vd);
+      piece_getdSigma(st->coeffs + 12 * iend, tend, vd);
       surround_v[0] = vd[0] + exceed_time * surround_a[0];
       surround_v[1] = vd[1] + exceed_time * surround_a[1];
-      traj_getPos(st, st->duration, pd);
+      piece_getPos(st->coeffs + 12 * iend, tend, pd);
       surround_p[0] = pd[0] + exceed_time * vd[0] + 0.5 * surround_a[0] * exceed_time * exceed_time;
       surround_p[1] = pd[1] + exceed_time * vd[1] + 0.5 * surround_a[1] * exceed_time * exceed_time;
     }
@@ -440,7 +472,8 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
       if (sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5) continue; // OPT:1393
     }
     double surround_R[4];
-    traj_getR(st, pt_time, surround_R); // OPT:1410
+    if (iloc < 0) iloc = traj_locate(st->durs, st->n_pieces, tloc); // (pt_time beyond the obstacle's duration: the last piece, extrapolated)
+    piece_getR(st->coeffs + 12 * iloc, tloc, surround_R); // OPT:1410: getR(pt_time)
 
     double surround2ego_sum_exp_vec[4], d_U[4], d_U_tilde[4], d_E_tilde[4];
     double ego_normal[4][2], vec_d_Uo_e[4][4], F_delta_le_v[4][4], F_le_v[4][4];
@@ -629,7 +662,7 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     // dG/dt_hat, OPT:1586-1646
     double pGthat = 0.0;
     double Rud[4];
-    traj_getRdot(st, pt_time, Rud); // OPT:1599
+    piece_getRdot(st->coeffs + 12 * iloc, tloc, Rud); // OPT:1599: getRdot(pt_time)
     for (int e = 0; e < nE; e++) {
       double d_Uo_e_exp_sum = surround2ego_sum_exp_vec[e];
       const double *Hn = ego_normal[e];

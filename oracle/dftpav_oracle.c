@@ -1,23 +1,24 @@
 /*
  * dftpav_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT CODE (see dftpav_oracle.h).
  *
- * fp64 CPU restatement of the Dftpav solve path.  PINNED: bit-equal to the
- * reference's own sources compiled unmodified (oracle/_ref, oracle/Makefile.ref;
- * tests/test_ref_pin.py: L-BFGS, BandedSystem, MinJerkOpt, every evaluation and
- * whole solves of every BASELINE config; order 2 against the same objects on a
- * correctly rounded libm).  The reference itself holds no golden vectors.
+ * fp64 CPU restatement of the Dftpav solve path.  PARITY UNPINNED: the reference holds no golden vectors, known-answer
+ * tests or fixtures for this path, and it cannot be built in this project's image (traj_optimizer.cpp needs Eigen, ROS and a
+ * protobuf-generated header), so nothing the reference itself produced anchors this file.  What stands behind it: every function
+ * cites the reference lines it follows; properties (finite differences, MINCO invariants, adjoint identities, L-BFGS test
+ * functions: tests/test_oracle_units.py, test_oracle_orders.py); vectors it wrote itself (tests/golden).  Rounds 3-5 also found
+ * it bit-equal to a build of the reference's own sources against STAND-IN Eigen / ROS / protobuf headers written in this
+ * repository; such a build is not a reference build and was retired in round 6 (oracle/pyref.py).
  *
  * Shorthand for citations:
  *   OPT   = src/Plan/traj_planner/src/traj_optimizer.cpp
  *   MINCO = src/Plan/traj_planner/include/plan_utils/poly_traj_utils.hpp
  *   LBFGS = src/Plan/traj_planner/include/geo_utils2d/lbfgs.hpp
  *
- * Arithmetic is written scalar-by-scalar in the reference's left-to-right
- * operator order.  Eigen's internal summation order inside fixed-size
- * products/reductions is not pinned by the reference (Eigen version unpinned,
- * TP/CMakeLists.txt:14): the pin is against the build over oracle/ref_shim's
- * Eigen stand-in (sequential reductions; its contract is stated in that file).  Build with -ffp-contract=off
- * (the reference is built -O3 without -march, i.e. no FMA contraction).
+ * Arithmetic is written scalar-by-scalar in the reference's left-to-right operator order, reductions (dot products, norms,
+ * matrix products) as ONE chain from their first term.  Eigen's internal summation order inside reductions is not pinned by the
+ * reference (Eigen version unpinned, TP/CMakeLists.txt:14; a vectorising Eigen uses 2- or 4-lane partial sums): "the
+ * reference's order" here means the order of its statements with sequential reductions.  Build with -ffp-contract=off (the
+ * reference is built -O3 without -march, i.e. no FMA contraction).
  */
 #include "oracle_internal.h"
 

@@ -8,7 +8,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for B in [int(a) for a in sys.argv[2:]] or [1, 32, 256, 2048]:
     p = capi.default_params()
     s = sc.baseline_config(cfg, B=B); s.apply_resolution(p)
-    h = capi.Handle(p); bt = capi.Batch(h, s.layout, B); bt.upload(s)
+    h = capi.Handle(p); h.set_surround(s.surround); bt = capi.Batch(h, s.layout, B); bt.upload(s)
     bt.set_order(capi.ORDER_REFERENCE)
     bt.solve_async(); bt.sync()
     ms = []
