@@ -51,8 +51,12 @@ def live_pmc(args, schedule):
             # straggler launch, the reference order's hand-over of a batch's last trajectories to the WAVE shape) over the number of
             # batches = the launches of the PRIMARY kernel (the first of `names` that ran) with its largest grid
             prim = [nm for nm in names if any(nm in k for _, _, k in rows)][0]
-            gmax = max(g for g, _, k in rows if prim in k)
-            got[ctr] = sum(v for _, v, _ in rows) / sum(1 for g, _, k in rows if prim in k and g == gmax)
+            if prim == "solver_kernel":   # device order: a batch is a queue launch (the largest grid) + a straggler launch of the same kernel
+                gmax = max(g for g, _, k in rows if prim in k)
+                nb = sum(1 for g, _, k in rows if prim in k and g == gmax)
+            else:                         # reference order: one launch of the primary kernel per batch (its grid depends on what follows it)
+                nb = sum(1 for _, _, k in rows if prim in k)
+            got[ctr] = sum(v for _, v, _ in rows) / nb
         except Exception as ex:  # noqa: BLE001
             return (got or None), "%s pass failed: %s" % (ctr, type(ex).__name__)
         finally:
