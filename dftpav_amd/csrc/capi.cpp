@@ -1690,7 +1690,7 @@ extern "C" int dftpav_batch_set_order(dftpav_batch *b, int order) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (order == DFTPAV_ORDER_REFERENCE) {
     if (!reference_order_supported(b->L, b->P, h->S)) {
-      h->err = "reference order: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per point, every gear segment >= 2 pieces";
+      h->err = "reference order: n <= 256 variables, H <= 12 half-planes, 5 H + S + 4 <= 64 terms per point, every gear segment >= 2 pieces, 159 KB of LDS";
       return DFTPAV_E_UNSUPPORTED;
     }
     {

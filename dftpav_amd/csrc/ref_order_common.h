@@ -4,6 +4,7 @@
 // Moved out of solver_ref.hip unchanged (round 6).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "device_types.h"
 #include "cr_trig.h"
 
@@ -758,16 +759,19 @@ struct PtState {
 // whose records surround_terms writes to `sur_rec` [S][kRec] at once: its test IS its cost); then velocity, acceleration,
 // curvature left / right (:642-705).  pl: the point's half-planes (load_planes), (n_x, n_y, p_x, p_y) of plane k at 4 k.
 // cor: &corridor[b][0][pt] (component-major, pitch NptsPad); planes past H are never used.
-__device__ __forceinline__ void load_planes(gcd_t cor, size_t pitch, int H, double pl[20]) {
+// HMAX: the plane slots a point keeps in registers -- 5 for every kernel of the live path (H = 4 rectangles), 12 for the generic TEAM
+// kernel that takes whatever the term mask can number (5 H + S + 4 <= 64)
+template <int HMAX = 5>
+__device__ __forceinline__ void load_planes(gcd_t cor, size_t pitch, int H, double (&pl)[4 * HMAX]) {
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < HMAX; k++) {
 #pragma unroll
     for (int q = 0; q < 4; q++) pl[4 * k + q] = k < H ? cor[(size_t)(4 * k + q) * pitch] : 0.0; // (uniform: planes past H are not fetched)
   }
 }
-template <bool SUR>
+template <bool SUR, int HMAX = 5>
 __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1, int singul_,
-                                            double epis, int H, const double pl[20], gd_t sur_rec, const DevSurround &S, double t_now, double t_piece,
+                                            double epis, int H, const double (&pl)[4 * HMAX], gd_t sur_rec, const DevSurround &S, double t_now, double t_piece,
                                             int trajid, double trajtime, PtState &st) {
   double cc[12];
 #pragma unroll
@@ -819,9 +823,9 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
   mask_t mask = 0ull;
   // ---- corridor: for (auto le : vec_le_) for (k < corr_k), traj_optimizer.cpp:592-634: the 5 H tests (term v H + k: the order
   // of the reference's nested loops)
-  double pn0[5], pn1[5], pq0[5], pq1[5];
+  double pn0[HMAX], pn1[HMAX], pq0[HMAX], pq1[HMAX];
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < HMAX; k++) {
     pn0[k] = pl[4 * k + 0];
     pn1[k] = pl[4 * k + 1];
     pq0[k] = pl[4 * k + 2];
@@ -829,8 +833,8 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
   }
   // (vec_le_ holds the first vertex twice, traj_optimizer.cpp:1765-1775, and the reference tests it twice: the fifth vertex's
   // tests are the first's, expression for expression -- their bits are copied, not recomputed; capi.cpp fills vec_le[4] from
-  // vec_le[0].  H <= 5, so 5 H <= 25 tests: collected in 32 bits.)
-  unsigned cm = 0u;
+  // vec_le[0].  H <= 5: 5 H <= 25 tests, collected in 32 bits; the generic kernel's H <= 12 takes the 64-bit mask.)
+  typename std::conditional<(HMAX > 5), mask_t, unsigned>::type cm = 0;
 #pragma unroll
   for (int v = 0; v < 4; v++) {
     const double le0 = P.vec_le[v][0], le1 = P.vec_le[v][1];
@@ -838,12 +842,12 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
     const double rl1 = ego_R[2] * le0 + ego_R[3] * le1;
     const double bpt0 = sigma[0] + rl0, bpt1 = sigma[1] + rl1;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < HMAX; k++) {
       const double violaPos = pn0[k] * (bpt0 - pq0[k]) + pn1[k] * (bpt1 - pq1[k]);
-      if (k < H && violaPos > 0) cm |= 1u << (v * H + k);
+      if (k < H && violaPos > 0) cm |= (decltype(cm))1 << (v * H + k);
     }
   }
-  cm |= (cm & ((1u << H) - 1u)) << (4 * H);
+  cm |= (cm & (((decltype(cm))1 << H) - 1)) << (4 * H);
   mask = (mask_t)cm;
   // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1)
   if (SUR && S.S > 0)
@@ -997,15 +1001,15 @@ __device__ __forceinline__ void point_emit(const DevParams &P, const PtState &st
 }
 
 // TEAM shape: the point's tests, then a record per active term in the point's own slots rec[t][kRec] (global scratch)
-template <bool SUR>
+template <bool SUR, int HMAX = 5>
 __device__ __forceinline__ mask_t point_terms(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1,
                                             int singul_, double epis, int H, gcd_t cor, size_t pitch, gd_t rec, const DevSurround &S,
                                             double t_now, double t_piece, int trajid, double trajtime) {
   PtState st;
   const int nS = SUR ? S.S : 0, tS0 = 5 * H, t0 = tS0 + nS;
-  double pl[20];
-  load_planes(cor, pitch, H, pl);
-  const mask_t mask = point_masks<SUR>(P, cc_, i, N, j, K, step, s1, singul_, epis, H, pl, rec + (size_t)tS0 * kRec, S, t_now, t_piece, trajid, trajtime, st);
+  double pl[4 * HMAX];
+  load_planes<HMAX>(cor, pitch, H, pl);
+  const mask_t mask = point_masks<SUR, HMAX>(P, cc_, i, N, j, K, step, s1, singul_, epis, H, pl, rec + (size_t)tS0 * kRec, S, t_now, t_piece, trajid, trajtime, st);
   for (mask_t m = mask; m;) {
     const int t = __builtin_ctzll(m);
     m &= m - 1;

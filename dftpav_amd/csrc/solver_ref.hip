@@ -219,7 +219,7 @@ template <bool WAVE> __device__ __forceinline__ void team_sync() {
 // ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350)
 // x -> g (LDS), f in st[sF].  rec_b: this trajectory's term records [Npts][nterm][kRec].  The gear segments are independent
 // up to the sums of :292-297 and the junction variables' gradients (:307-320), so every stage runs them side by side.
-template <bool SUR, bool WAVE>
+template <bool SUR, bool WAVE, int HMAX = 5>
 __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd_t rec_b, const Sm &sm, ldscd_t x, ldsd_t g, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
@@ -658,7 +658,7 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
     const double s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
     // trajtimes[sg] of traj_optimizer.cpp:230-234: 0, then the real duration of the PREVIOUS segment
     const double trajtime = (SUR && sg > 0) ? sm.seg[16 * (sg - 1)] : 0.0;
-    sm.set_mask(pt, point_terms<SUR>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
+    sm.set_mask(pt, point_terms<SUR, HMAX>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
                                      rec_b + (size_t)pt * nterm * kRec, D.sur, D.t_now, SUR ? sm.pA[p] : 0.0, sg, trajtime));
   }
   __threadfence_block(); // the records are read back by other lanes of this team
@@ -1398,6 +1398,298 @@ __device__ __forceinline__ void lbfgs_advance(const DevBatch &D, const Sm &sm, g
   pr.tick(6);
 }
 
+
+// ------------------------------------------------ the same step for ANY number of variables (TEAM shape, n > 64)
+// lbfgs_advance keeps one decision variable per lane and chains a dot product through the lanes; a plan of more than 32 pieces
+// (traj_manager.cpp:543 sets no limit, lbfgs.hpp:512-513 none either) has more variables than a wave has lanes.  This is the slow,
+// plain form for those: the vectors live in LDS (they do anyway), a lane takes the elements lane, lane + 64, ..., and a sequential
+// sum is what it is in the reference -- one chain over the n products, read back from LDS by every lane (the same bits in each).
+// True divisions throughout.  Same state, same scalars, same history layout as lbfgs_advance: ring, slices and suspend / resume
+// are not used in this path (it runs in the TEAM shape only).
+__device__ __forceinline__ double gen_sum(ldsd_t buf, int n) { // 0.0 + buf[0] + buf[1] + ... (the products were written by this wave)
+  wave_lds_order();
+  double s_ = 0.0;
+  for (int e = 0; e < n; e++) s_ += buf[e];
+  wave_lds_order();
+  return s_;
+}
+__device__ __forceinline__ bool gen_begin_iteration(const DevParams &P, const Sm &sm, int n, int lane) {
+  for (int e = lane; e < n; e += 64) {
+    sm.xp[e] = sm.x[e];
+    const double gv = sm.g[e];
+    sm.gp[e] = gv;
+    sm.dot[e] = gv * sm.d[e];
+  }
+  const double dginit = gen_sum(sm.dot, n);
+  const double step = sm.st[sSTEP];
+  if (!(step > 0.0)) {
+    if (lane == 0) sm.ist[iRET] = -1006;
+    return false;
+  }
+  if (0.0 < dginit) {
+    if (lane == 0) sm.ist[iRET] = -1005;
+    return false;
+  }
+  if (lane == 0) {
+    sm.st[sFINIT] = sm.st[sFX];
+    sm.st[sDGINIT] = dginit;
+    sm.st[sDGTEST] = P.f_dec_coeff * dginit;
+    sm.st[sDSTEST] = P.s_curv_coeff * dginit;
+    sm.st[sMU] = 0.0;
+    sm.st[sNU] = P.max_step;
+    sm.st[sSTP] = step;
+    sm.ist[iCOUNT] = 0;
+    sm.ist[iBRACKT] = 0;
+    sm.ist[iTOUCHED] = 0;
+  }
+  for (int e = lane; e < n; e += 64) sm.x[e] = sm.xp[e] + step * sm.d[e];
+  return true;
+}
+__device__ __noinline__ void lbfgs_advance_generic(const DevBatch &D, const Sm &sm, gd_t hS, gd_t hR, int lane, Prof &pr) {
+  const DevParams &P = D.P;
+  const int n = D.L.n, m = P.mem_size, npad = D.L.npad;
+  const double f = sm.st[sF];
+  int action = kActEval;
+  auto vmax = [&](ldscd_t v) { // max |v[e]| (order-free)
+    double mx = 0.0;
+    for (int e = lane; e < n; e += 64) mx = fmax(mx, fabs(v[e]));
+    return wave_max64(mx);
+  };
+  if (sm.ist[iPHASE] == 0) { // after the first evaluation: lbfgs.hpp:524-551
+    for (int e = lane; e < n; e += 64) {
+      const double gv = sm.g[e];
+      sm.d[e] = -gv;
+      sm.dot[e] = (-gv) * (-gv);
+    }
+    const double gmax = vmax(sm.g), xmax = vmax(sm.x);
+    const double dd = gen_sum(sm.dot, n);
+    if (lane == 0) {
+      sm.st[sFX] = f;
+      sm.st[sPF0] = f;
+      sm.ist[iEVALS] = 1;
+      sm.ist[iEND] = 0;
+      sm.ist[iBOUND] = 0;
+      sm.ist[iHISTLO] = 0;
+      sm.ist[iHISTHI] = 0;
+      sm.ist[iPHASE] = 1;
+    }
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      if (lane == 0) {
+        sm.ist[iRET] = 0;
+        sm.ist[iK] = 0;
+      }
+      action = kActDone;
+    } else {
+      if (lane == 0) {
+        sm.st[sSTEP] = 1.0 / sqrt(dd);
+        sm.ist[iK] = 1;
+      }
+      __threadfence_block();
+      if (!gen_begin_iteration(P, sm, n, lane)) action = kActDone;
+    }
+    if (lane == 0) sm.ist[iACTION] = action;
+    return;
+  }
+  // ---- after a line-search trial: lbfgs.hpp:317-389
+  const double fx = f;
+  const double finit = sm.st[sFINIT];
+  double stp = sm.st[sSTP];
+  const int count = sm.ist[iCOUNT] + 1;
+  int ls = 0;
+  bool decided = false;
+  const int evals_before = sm.ist[iEVALS];
+  __threadfence_block();
+  if (lane == 0) {
+    sm.st[sFX] = fx;
+    sm.ist[iEVALS] = evals_before + 1;
+    sm.ist[iCOUNT] = count;
+  }
+  if (isinf(fx) || isnan(fx)) {
+    ls = -1012;
+    decided = true;
+  } else if (P.past > 0 && fabs(finit - fx) / (fabs(finit) + 1.0) < P.delta / P.past) { // lbfgs.hpp:326-329
+    ls = count;
+    decided = true;
+  } else {
+    double mu = sm.st[sMU], nu = sm.st[sNU];
+    bool brackt = sm.ist[iBRACKT] != 0;
+    const int touched = sm.ist[iTOUCHED];
+    if (fx > finit + stp * sm.st[sDGTEST]) {
+      nu = stp;
+      brackt = true;
+    } else {
+      for (int e = lane; e < n; e += 64) sm.dot[e] = sm.g[e] * sm.d[e];
+      const double gs = gen_sum(sm.dot, n);
+      if (gs < sm.st[sDSTEST]) {
+        mu = stp;
+      } else {
+        ls = count;
+        decided = true;
+      }
+    }
+    bool touch_now = false;
+    if (!decided) {
+      if (P.max_linesearch <= count) {
+        ls = -1009;
+        decided = true;
+      } else if (brackt && (nu - mu) < P.machine_prec * nu) {
+        ls = -1007;
+        decided = true;
+      } else {
+        if (brackt) stp = 0.5 * (mu + nu);
+        else stp *= 2.0;
+        if (stp < P.min_step) {
+          ls = -1011;
+          decided = true;
+        } else if (stp > P.max_step) {
+          if (touched) {
+            ls = -1010;
+            decided = true;
+          } else {
+            touch_now = true;
+            stp = P.max_step;
+          }
+        }
+      }
+    }
+    __threadfence_block();
+    if (lane == 0) {
+      sm.st[sMU] = mu;
+      sm.st[sNU] = nu;
+      sm.ist[iBRACKT] = brackt ? 1 : 0;
+      sm.st[sSTP] = stp;
+      if (touch_now) sm.ist[iTOUCHED] = 1;
+    }
+    if (!decided) {
+      for (int e = lane; e < n; e += 64) sm.x[e] = sm.xp[e] + stp * sm.d[e];
+      if (lane == 0) sm.ist[iACTION] = kActEval;
+      pr.tick(6);
+      return;
+    }
+  }
+  if (lane == 0) sm.st[sSTEP] = stp; // lbfgs.hpp:574 passes `step` by reference
+  if (ls < 0) { // lbfgs.hpp:604-611: x, g reverted; fx is not
+    for (int e = lane; e < n; e += 64) {
+      sm.x[e] = sm.xp[e];
+      sm.g[e] = sm.gp[e];
+    }
+    if (lane == 0) {
+      sm.ist[iRET] = ls;
+      sm.ist[iACTION] = kActDone;
+    }
+    return;
+  }
+  // ---- convergence / stopping tests (lbfgs.hpp:628-666)
+  int k = sm.ist[iK];
+  {
+    const double gmax = vmax(sm.g), xmax = vmax(sm.x);
+    const int kGoOn = 12345;
+    int ret = kGoOn;
+    if (gmax / fmax(1.0, xmax) < P.g_epsilon) {
+      ret = 0;
+    } else {
+      if (0 < P.past) {
+        const int slot = k % P.past;
+        const double pf = sm.st[sPF0 + slot];
+        __threadfence_block();
+        if (P.past <= k) {
+          const double rate = fabs(pf - fx) / fmax(1.0, fabs(fx));
+          if (rate < P.delta) ret = 1;
+        }
+        if (ret == kGoOn && lane == 0) sm.st[sPF0 + slot] = fx;
+      }
+      if (ret == kGoOn && P.max_iterations != 0 && P.max_iterations <= k) ret = -1008;
+    }
+    if (ret != kGoOn) {
+      if (lane == 0) {
+        sm.ist[iRET] = ret;
+        sm.ist[iACTION] = kActDone;
+      }
+      return;
+    }
+  }
+  ++k;
+  pr.tick(6);
+  const int end = sm.ist[iEND];
+  int bound = sm.ist[iBOUND];
+  __threadfence_block();
+  if (lane == 0) sm.ist[iK] = k;
+  // ---- history update (lbfgs.hpp:676-694): s = x - xp, y = g - gp, the four dot products
+  double ys, yy, ss, gpgp;
+  {
+    for (int e = lane; e < n; e += 64) {
+      const double sv = sm.x[e] - sm.xp[e], yv = sm.g[e] - sm.gp[e];
+      d2_t sy;
+      sy.x = sv;
+      sy.y = yv;
+      ((gd2_t)hS)[(size_t)end * npad + e] = sy;
+      sm.d[e] = -sm.g[e];
+      sm.dot[e] = yv * sv;
+    }
+    ys = gen_sum(sm.dot, n);
+    for (int e = lane; e < n; e += 64) {
+      const double yv = sm.g[e] - sm.gp[e];
+      sm.dot[e] = yv * yv;
+    }
+    yy = gen_sum(sm.dot, n);
+    for (int e = lane; e < n; e += 64) {
+      const double sv = sm.x[e] - sm.xp[e];
+      sm.dot[e] = sv * sv;
+    }
+    ss = gen_sum(sm.dot, n);
+    for (int e = lane; e < n; e += 64) sm.dot[e] = sm.gp[e] * sm.gp[e];
+    gpgp = gen_sum(sm.dot, n);
+  }
+  if (lane == 0) {
+    d2_t yr;
+    yr.x = ys;
+    yr.y = 1.0 / ys;
+    ((gd2_t)hR)[end] = yr;
+  }
+  const double cau = ss * sqrt(gpgp) * P.cautious_factor;
+  pr.tick(7);
+  if (ys > cau) { // ---- the two-loop recursion (lbfgs.hpp:716-739), plain
+    ++bound;
+    bound = m < bound ? m : bound;
+    const int ne = end + 1 == m ? 0 : end + 1;
+    __threadfence_block(); // the newest pair's row and y . s are read back below
+    const gcd2_t cS = (gcd2_t)hS, cR = (gcd2_t)hR;
+    int j = ne;
+    for (int i = 0; i < bound; i++) {
+      j = j == 0 ? m - 1 : j - 1;
+      for (int e = lane; e < n; e += 64) sm.dot[e] = cS[(size_t)j * npad + e].x * sm.d[e];
+      const double a = gen_sum(sm.dot, n) / cR[j].x; // lm_alpha[j] = lm_s.col(j).dot(d) / lm_ys[j]
+      if (lane == 0) sm.alpha[j] = a;
+      const double na = -a;
+      for (int e = lane; e < n; e += 64) sm.d[e] = sm.d[e] + na * cS[(size_t)j * npad + e].y; // d += (-alpha) * lm_y.col(j)
+    }
+    const double sc0 = ys / yy;
+    for (int e = lane; e < n; e += 64) sm.d[e] = sm.d[e] * sc0;
+    wave_lds_order();
+    for (int i = 0; i < bound; i++) {
+      for (int e = lane; e < n; e += 64) sm.dot[e] = cS[(size_t)j * npad + e].y * sm.d[e];
+      const double beta = gen_sum(sm.dot, n) / cR[j].x;
+      const double cf = sm.alpha[j] - beta;
+      for (int e = lane; e < n; e += 64) sm.d[e] = sm.d[e] + cf * cS[(size_t)j * npad + e].x; // d += (alpha - beta) * lm_s.col(j)
+      j = j == m - 1 ? 0 : j + 1;
+    }
+    if (lane == 0) {
+      sm.ist[iEND] = ne;
+      sm.ist[iBOUND] = bound;
+      long long hs = ((long long)sm.ist[iHISTHI] << 32) | (unsigned int)sm.ist[iHISTLO];
+      hs += bound;
+      sm.ist[iHISTLO] = (int)(hs & 0xffffffffLL);
+      sm.ist[iHISTHI] = (int)(hs >> 32);
+    }
+  }
+  if (lane == 0) sm.st[sSTEP] = 1.0; // lbfgs.hpp:743
+  pr.tick(8);
+  __threadfence_block();
+  const bool ok = gen_begin_iteration(P, sm, n, lane);
+  if (lane == 0) sm.ist[iACTION] = ok ? kActEval : kActDone;
+  pr.tick(6);
+}
+
 // ------------------------------------------------ the kernel
 // solver state of a suspended trajectory <-> its record in DevBatch::state (layout as solver.hip's: five vectors at pitch
 // npad, the scalars, the integers); the history and (ys, 1 / ys) of the stored pairs live in HBM anyway
@@ -1431,7 +1723,9 @@ __device__ inline void state_io(const DevBatch &D, const Sm &sm, int b, int lane
 // runs each for `slice` iterations and pushes it back unfinished.
 // Registers: 256 per lane (two waves per SIMD) for the kernels that fit them -- a second trajectory fills the issue slots the
 // dependent chains of the first leave empty; the wide (n > 32) and the moving-obstacle kernels take 512.
-template <int CAP, bool SUR, bool WAVE>
+// GEN (TEAM shape only): more variables than a wave has lanes (lbfgs_advance_generic) and / or more than five half-planes per point
+// (twelve plane slots per point, the 64-bit test mask)
+template <int CAP, bool SUR, bool WAVE, bool GEN = false>
 __global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 256, (!WAVE && CAP <= 32 && !SUR) ? 2 : 1)
     ref_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, double *__restrict__ scratch, int source, int slice) {
   extern __shared__ double lds_raw[];
@@ -1511,7 +1805,7 @@ __global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 25
 
     bool finished = true;
     while (true) { // (one call site of the evaluation: the kernel is instruction-cache-sized as it is)
-      ref_eval<SUR, WAVE>(D, cor_b, rec_b, sm, sm.x, sm.g, pr); // x0 / the trial point the trajectory was suspended on / the next trial point
+      ref_eval<SUR, WAVE, GEN ? 12 : 5>(D, cor_b, rec_b, sm, sm.x, sm.g, pr); // x0 / the trial point the trajectory was suspended on / the next trial point
       if (mode == kModeEval) {
         for (int e = tid; e < n; e += T) D.g_out[(size_t)b * n + e] = sm.g[e];
         if (tid == 0) D.f_eval[b] = sm.st[sF];
@@ -1522,7 +1816,10 @@ __global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 25
         for (int sg = tid; sg < L.M; sg += T) D.dt_out[(size_t)b * L.M + sg] = sm.seg[16 * sg + 1];
         return;
       }
-      if (tid < 64) lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
+      if (tid < 64) {
+        if constexpr (GEN) lbfgs_advance_generic(D, sm, hS, hR, lane, pr);
+        else lbfgs_advance<CAP>(D, sm, hS, hR, lane, pr);
+      }
       team_sync<WAVE>();
       if (sm.ist[iACTION] == kActDone) break;
       if (ring && slice > 0 && sm.ist[iK] - k_start >= slice) { // uniform
@@ -1584,8 +1881,8 @@ void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int B, in
 #if DFTPAV_REF_PART != 2
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
-  if (L.M < 1 || L.n > 64 || L.Npts >= (1 << 25)) return false;
-  if (L.H < 1 || L.H > 5) return false; // a point's half-planes are held in five register slots (rectangles: H = 4)
+  if (L.M < 1 || L.n > 256 || L.Npts >= (1 << 25)) return false; // (n > 64: the plain L-BFGS step of lbfgs_advance_generic, TEAM shape; its sums use the 256-double buffer)
+  if (L.H < 1 || L.H > 12) return false; // (H > 5: the generic TEAM kernel with twelve plane slots per point; rectangles: H = 4)
   if (S < 0 || 5 * L.H + S + 4 > 64) return false; // the mask of a point's active terms has 64 bits
   for (int i = 0; i < L.M; i++)
     if (L.piece_nums[i] < 2) return false;
@@ -1668,10 +1965,11 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
   }
   // up to four per CU the TEAM shape (128 threads, 34 KB of LDS with the compact tables) holds them all at once, each one faster:
   // 171 against 195 ms at 1024, 133 against 189 at 512; at 2048 the WAVE shape is ahead, 262 against 320 ms
-  bool wave = best_w > 0 && (B > 5 * n_cu || throughput);
+  const bool wide_n = L.n > 64 || L.H > 5; // more variables than a wave has lanes, or more than five half-planes per point: the generic TEAM kernel, whatever B
+  bool wave = best_w > 0 && !wide_n && (B > 5 * n_cu || throughput);
   if (const char *e = std::getenv("DFTPAV_REF_SHAPE")) { // developer knob: "team" / "wave"
     if (e[0] == 't') wave = false;
-    if (e[0] == 'w' && best_w > 0) wave = true;
+    if (e[0] == 'w' && best_w > 0 && !wide_n) wave = true;
   }
   if (const char *e = std::getenv("DFTPAV_REF_WAVES")) { // developer knob: waves per workgroup in the WAVE shape
     const int w = std::atoi(e);
@@ -1745,6 +2043,14 @@ template hipError_t launch_ref_cap<48>(DFTPAV_REF_CAP_ARGS);
 template hipError_t launch_ref_cap<64>(DFTPAV_REF_CAP_ARGS);
 #endif
 #if DFTPAV_REF_PART != 2
+template <bool SUR>
+static hipError_t launch_ref_variant_gen(const DevBatch *d_dev, int grid, int threads, size_t lds, int mode, const double *tabs, double *scratch, int source, int slice,
+                                         hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&reford::ref_kernel<64, SUR, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((reford::ref_kernel<64, SUR, false, true>), dim3(grid), dim3(threads), lds, stream, d_dev, mode, tabs, scratch, source, slice);
+  return hipGetLastError();
+}
 // scheduled != 0: a solve in the WAVE shape whose waves pop from the batch's ring (the caller has reset it)
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
                              hipStream_t stream) {
@@ -1761,6 +2067,10 @@ hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode,
   if (std::getenv("DFTPAV_VERBOSE"))
     std::fprintf(stderr, "[dftpav] reference order, %s shape: grid %d x %d threads, %zu B of LDS, source %d slice %d\n", wave ? "WAVE" : "TEAM", grid, pl.threads,
                  pl.lds, source, slice);
+  if (D.L.n > 64 || D.L.H > 5) { // (reference_order_plan keeps these in the TEAM shape)
+    if (sur) return launch_ref_variant_gen<true>(d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+    return launch_ref_variant_gen<false>(d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
+  }
   switch (reford::ref_cap_of(D.L.n)) {
   case 16: return launch_ref_cap<16>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);
   case 32: return launch_ref_cap<32>(sur, wave, d_dev, grid, pl.threads, pl.lds, mode, tabs, scratch, source, slice, stream);

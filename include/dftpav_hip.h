@@ -307,8 +307,10 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *       previous segment (:1674-1676);
  *     - with libm calls in the loop the yardstick is the restatement's order 2 (the same statements with exp / log / pow / sin /
  *       cos from binary128): whole solves of this mode are bit-equal to it on all of the three cases above;
- *     - limits: n <= 64 variables, H <= 5 half-planes, 5 H + S + 4 <= 64 terms per constraint point, every gear segment
- *       >= 2 pieces; otherwise DFTPAV_E_UNSUPPORTED, order unchanged.  Choose the order again after the number of
+ *     - limits: n <= 256 variables, H <= 12 half-planes, 5 H + S + 4 <= 64 terms per constraint point, every gear segment
+ *       >= 2 pieces, 159 KB of LDS for one trajectory's state; otherwise DFTPAV_E_UNSUPPORTED, order unchanged.  (n > 64 or H > 5 --
+ *       a plan of more than 32 pieces, corridors that are not rectangles -- run in a slow generic kernel: the plain L-BFGS step
+ *       over vectors in LDS, twelve plane slots per point.)  Choose the order again after the number of
  *       obstacles on the handle changed.  dftpav_batch_trace* is a device-order facility (DFTPAV_E_UNSUPPORTED here).
  *     - one step of the path is bit-equal by MEASUREMENT, not by proof: a division by a stored quantity (the diagonals of the
  *       band factorisation, y.s of a stored pair) is a multiplication by its reciprocal with one residual correction, which

@@ -207,7 +207,11 @@ def test_launch_shapes_of_the_reference_order(hiplib):
     assert q["supported"] == 1 and q["cap"] == 64 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] <= 256 and q["lds"] <= 160 * 1024
     # the reference's live case, 12 obstacles (5 H + S + 4 = 36 terms: the 64-bit mask)
     assert plan([5, 4, 6], [1, -1, 1], 12, 16, 12, 64)["supported"] == 1
-    # outside the mode: more than 64 variables, more than five half-planes, more than 64 terms per point
-    assert plan([40], [1], 8, 8, 0, 1)["supported"] == 0
-    assert plan([8], [1], 8, 8, 0, 1, H=6)["supported"] == 0
+    # beyond a wave of variables / five half-planes: the generic TEAM kernel whatever the batch size (round 6)
+    for kw in (dict(pieces=[40]), dict(pieces=[8], H=6), dict(pieces=[8], H=12)):
+        q = plan(kw["pieces"], [1], 8, 8, 0, 4096, H=kw.get("H", 4))
+        assert q["supported"] == 1 and q["wave"] == 0 and q["lds"] <= 160 * 1024, (kw, q)
+    # outside the mode: more than 12 half-planes, more than 64 terms per point, more than 256 variables
+    assert plan([8], [1], 8, 8, 0, 1, H=13)["supported"] == 0
     assert plan([8], [1], 8, 8, 45, 1)["supported"] == 0
+    assert plan([130], [1], 4, 4, 0, 1)["supported"] == 0

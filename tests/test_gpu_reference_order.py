@@ -557,11 +557,66 @@ def test_trace_is_a_device_order_facility(hiplib):
     h.close()
 
 
-def test_six_half_planes_and_wide_layouts_are_refused_cleanly(hiplib):
-    """H > 5 (the term mask has 32 bits) and n > 64 stay with the device order"""
+def _extra_planes(base, H):
+    """the scenario `base` (H = 4 rectangles) with H half-planes per point: the extra ones are copies of the first ones pulled 0.2 m
+    inwards (so that they are the active ones), their normals un-normalised"""
+    cor = np.zeros((base.B, base.n_points, H, 4))
+    cor[:, :, :4] = base.corridor
+    for k in range(4, H):
+        cor[:, :, k] = base.corridor[:, :, k % 4]
+        cor[:, :, k, 2:] -= (0.2 + 0.05 * (k - 4)) * base.corridor[:, :, k % 4, :2]
+        cor[:, :, k, :2] *= 3.0
+    lay = type(base.layout)(base.layout.piece_nums, base.layout.singuls, H=H)
+    return sc.Scenario("planes_%d" % H, lay, base.K, base.Kd, base.B, base.ini_states, base.fin_states, base.inner_pts, base.init_Ts, np.ascontiguousarray(cor))
+
+
+@pytest.mark.parametrize("case", ["n79", "n77_two_segments", "H6", "H11", "n79_H7"])
+def test_beyond_a_wave_of_variables_and_five_half_planes(hiplib, oracle, case):
+    """What the reference accepts and the fast kernels do not -- more decision variables than a wave has lanes (N_i = max(round(dur / 1.0),
+    2) is unbounded, traj_manager.cpp:543; lbfgs.hpp:512-513 sizes its history for any n) and more than four or five half-planes per point
+    (H is the column count of hPoly, traj_optimizer.cpp:592-622) -- runs in the generic TEAM kernel (solver_ref.hip: lbfgs_advance_generic,
+    twelve plane slots): every evaluation and every whole solve bit-equal to the restatement."""
     p = hiplib.default_params()
-    from dftpav_amd.pods import LayoutSpec
-    s = sc.make_scenario([40], [1], 8, 8, 1, seed=5)       # n = 79
+    order = 0
+    if case == "n79":
+        s = sc.make_scenario([40], [1], 8, 8, 3, seed=5)                 # n = 79
+    elif case == "n77_two_segments":
+        s, order = sc.make_scenario([20, 18], [1, -1], 6, 9, 3, seed=6), 2  # n = 2 * 36 + 2 + 2 + 1 = 77, a gear shift: cos / sin
+    elif case == "H6":
+        s = _extra_planes(sc.baseline_config(1, B=3), 6)
+    elif case == "H11":
+        s = _extra_planes(sc.baseline_config(1, B=2), 11)                # 5 H + 4 = 59 terms per point: the 64-bit masks
+    else:
+        s = _extra_planes(sc.make_scenario([40], [1], 8, 8, 2, seed=7), 7)
+    s.apply_resolution(p)
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    x0 = bt.x0()
+    for x in (x0, x0 + np.random.default_rng(3).normal(0, 0.3, x0.shape)):
+        f, g = bt.eval(x)
+        for b in range(s.B):
+            fo, go = oracle.OracleProblem(p, s, b, order=order).eval(x[b])
+            assert f[b] == fo and np.array_equal(g[b], go), (case, b)
+    r = bt.solve()
+    want = oracle.solve_batch(p, s, nthreads=4, order=order)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], want[k]), (case, k)
+    c, dt = bt.coeffs()
+    lp = oracle.OracleProblem(p, s, 0, order=order)
+    lp.eval(r["x"][0])
+    co, dto = lp.coeffs()
+    assert np.array_equal(c[0], co) and np.array_equal(dt[0], dto)
+    bt.close()
+    h.close()
+
+
+def test_what_the_reference_order_still_refuses_is_refused_cleanly(hiplib):
+    """more than 12 half-planes per point or more than 64 terms per point (the term mask), more than 256 variables: DFTPAV_E_UNSUPPORTED,
+    the batch stays usable in device order"""
+    p = hiplib.default_params()
+    s = _extra_planes(sc.baseline_config(1, B=1), 13)
     s.apply_resolution(p)
     h = hiplib.Handle(p)
     bt = hiplib.Batch(h, s.layout, 1)
