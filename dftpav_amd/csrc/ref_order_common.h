@@ -396,6 +396,27 @@ __device__ inline int ref_sur_index(const DevSurround &S, int u, double t) {
   }
   return g;
 }
+// The local time locatePieceIdx leaves for a time t that stops at piece idx (idx from the theta table): the reference's subtractions
+// t -= duration_0, t -= duration_1, ... in their order -- but with the durations requested in blocks in front of them instead of one
+// dependent load per comparison (the comparisons only decide where the walk stops, and that is known).  traj_math.h: sur_local.
+__device__ inline int ref_sur_local(const double *durs, int np, int idx, double &t) {
+  const int nsub = idx < np ? idx : np;
+  int k = 0;
+  for (; k + 8 <= nsub; k += 8) {
+    const double d0 = durs[k], d1 = durs[k + 1], d2 = durs[k + 2], d3 = durs[k + 3], d4 = durs[k + 4], d5 = durs[k + 5], d6 = durs[k + 6], d7 = durs[k + 7];
+    t -= d0; t -= d1; t -= d2; t -= d3; t -= d4; t -= d5; t -= d6; t -= d7;
+  }
+  for (; k + 4 <= nsub; k += 4) {
+    const double d0 = durs[k], d1 = durs[k + 1], d2 = durs[k + 2], d3 = durs[k + 3];
+    t -= d0; t -= d1; t -= d2; t -= d3;
+  }
+  for (; k < nsub; k++) t -= durs[k];
+  if (idx == np) {
+    idx--;
+    t += durs[idx];
+  }
+  return idx;
+}
 // log_sum_exp, traj_optimizer.cpp:1686-1707 (mutates all_dists into the exp weights); exp / log correctly rounded
 __device__ inline double lse_cr(double alpha, double *all_dists, int n, double *exp_sum) {
   double d_0 = all_dists[0];
@@ -418,21 +439,23 @@ __device__ inline double lse_cr(double alpha, double *all_dists, int n, double *
 // obstacles, which the reference adds to costs(1) once per point -- goes into slot [13] of the first such record.
 // trajtime: what the reference passes for gear segment trajid, trajtimes[trajid] = 0 for the first segment and the DURATION OF
 // THE PREVIOUS SEGMENT (not the time since the start) for the others (traj_optimizer.cpp:230-234, 291, 1367-1369).
-__device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurround &S, double t_now, double omg, double step, double t,
-                                                const double beta0[6], const double beta1[6], double gama, int pieceid, int trajres,
-                                                const double sigma[2], const double dsigma[2], const double ddsigma[2], const double ego_R[4],
-                                                int singul_, int trajid, double trajtime, int Nseg, int t_first, gd_t rec) {
+// One obstacle of the loop of dynamicObsGradCostP for one constraint point, statement by statement.  Returns 0 when the reference
+// `continue`s (the distance gate, the bound, costp <= 0); else writes the pair's record (term t_first + sur_id; slot [13] = 0.0) and
+// returns 1 with pen = what the point's penalty gets from this obstacle.  GATE_ONLY: stops after the last test that needs no exponential
+// (1: the pair goes on, nothing written) -- the TEAM shape collects the pairs that pass and evaluates them densely packed.
+template <bool GATE_ONLY>
+__device__ __forceinline__ int surround_one(const DevParams &P, const DevSurround &S, int sur_id, double t_now, double omg, double step, double t,
+                                            const double beta0[6], const double beta1[6], double gama, int pieceid, int trajres, const double sigma[2],
+                                            const double dsigma[2], const double ddsigma[2], const double ego_R[4], int singul_, int trajid, double trajtime,
+                                            int Nseg, int t_first, gd_t rec, double &pen) {
   const double B_h[4] = {0.0, -1.0, 1.0, 0.0}, B_hT[4] = {0.0, 1.0, -1.0, 0.0}; // traj_optimizer.cpp:1741-1742
-  mask_t mask = 0ull;
-  int first_active = -1;
   const double alpha = 100.0, d_min = P.surround_clearance + crt::log_cr(8.0) / alpha; // traj_optimizer.cpp:1336 (the reference: std::log(8.0))
   double temp0 = sqrt(dsigma[0] * dsigma[0] + dsigma[1] * dsigma[1]);
   double temp0_reci = (temp0 != 0.0) ? 1.0 / temp0 : 0.0;
   double temp3 = temp0_reci * temp0_reci;
   const int nE = 4, nO = 4;
-  double totalPenalty = 0.0;
-
-  for (int sur_id = 0; sur_id < S.S; sur_id++) {
+  pen = 0.0;
+  {
     const SurTraj st_{S.durations + S.piece_off[sur_id], S.coeffs + 12 * (size_t)S.piece_off[sur_id], S.piece_off[sur_id + 1] - S.piece_off[sur_id], S.total[sur_id], S.start[sur_id]};
     const SurTraj *st = &st_;
     double offsettime = t_now - st->start_time + trajtime; // OPT:1367-1369
@@ -449,9 +472,11 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     if (pt_time < st->duration) {
       if (S.has_theta() && S.has_bbox() && pt_time >= 0.0) {
         const int ig = ref_sur_index(S, sur_id, pt_time);
-        if (ig < st->n_pieces && S.far_from_piece(S.piece_off[sur_id] + ig, sigma, P.veh_length_infl * 1.5 + 1e-6)) continue;
+        if (ig < st->n_pieces && S.far_from_piece(S.piece_off[sur_id] + ig, sigma, P.veh_length_infl * 1.5 + 1e-6)) return 0;
+        iloc = ref_sur_local(st->durs, st->n_pieces, ig, tloc); // (the walk's subtractions without its dependent loads)
+      } else {
+        iloc = traj_locate(st->durs, st->n_pieces, tloc);
       }
-      iloc = traj_locate(st->durs, st->n_pieces, tloc);
       piece_getPos(st->coeffs + 12 * iloc, tloc, surround_p);
       piece_getdSigma(st->coeffs + 12 * iloc, tloc, surround_v);
       piece_getddSigma(st->coeffs + 12 * iloc, tloc, surround_a);
@@ -470,7 +495,7 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     }
     {
       double dx = surround_p[0] - sigma[0], dy = surround_p[1] - sigma[1];
-      if (sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5) continue; // OPT:1393
+      if (sqrt(dx * dx + dy * dy) > P.veh_length_infl * 1.5) return 0; // OPT:1393
     }
     double surround_R[4];
     if (iloc < 0) iloc = traj_locate(st->durs, st->n_pieces, tloc); // (pt_time beyond the obstacle's duration: the last piece, extrapolated)
@@ -561,8 +586,9 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
         best = a > best ? a : best;
         best = b > best ? b : best;
       }
-      if (d_min + 1.38629436111989061883e+00 / alpha - best < -1.0e-9) continue;
+      if (d_min + 1.38629436111989061883e+00 / alpha - best < -1.0e-9) return 0;
     }
+    if (GATE_ONLY) return 1; // (the cheap part ends here: the pair goes on to its forty exponentials)
     for (int e = 0; e < nE; e++) {
       double exp_sum;
       d_U[e] = lse_cr(-alpha, vec_d_Uo_e[e], nO, &exp_sum) + d_U_tilde[e];
@@ -580,10 +606,10 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     double exp_sum_d = 0;
     double d_value_test = d_min - lse_cr(alpha, d_test, 8, &exp_sum_d); // OPT:1498-1502
     double costp = d_value_test;
-    if (costp <= 0) continue;
+    if (costp <= 0) return 0;
     double pena, penaD;
     smoothed_l1(costp, pena, penaD);
-    totalPenalty += omg * step * P.wei_surround * pena;
+    pen = omg * step * P.wei_surround * pena; // (what the point's penalty gets from this obstacle; the caller adds them in obstacle order)
 
     // dG/dsigma, OPT:1511-1523
     double pGs[2] = {0.0, 0.0};
@@ -720,6 +746,27 @@ __device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurro
     r_[14] = omg * step * P.wei_surround * pGthat * penaD;
     r_[15] = omg * step * P.wei_surround * gama * pGthat * penaD;
     r_[13] = 0.0;
+    return 1;
+    }
+}
+// The obstacle loop of dynamicObsGradCostP for one constraint point.  Every obstacle with a positive
+// penalty writes a record (term t_first + sur_id) and sets its bit in `mask`; the point's penalty -- the inner sum over the
+// obstacles, which the reference adds to costs(1) once per point -- goes into slot [13] of the first such record.
+// trajtime: what the reference passes for gear segment trajid, trajtimes[trajid] = 0 for the first segment and the DURATION OF
+// THE PREVIOUS SEGMENT (not the time since the start) for the others (traj_optimizer.cpp:230-234, 291, 1367-1369).
+__device__ __noinline__ mask_t surround_terms(const DevParams &P, const DevSurround &S, double t_now, double omg, double step, double t,
+                                                const double beta0[6], const double beta1[6], double gama, int pieceid, int trajres,
+                                                const double sigma[2], const double dsigma[2], const double ddsigma[2], const double ego_R[4],
+                                                int singul_, int trajid, double trajtime, int Nseg, int t_first, gd_t rec) {
+  mask_t mask = 0ull;
+  int first_active = -1;
+  double totalPenalty = 0.0;
+  for (int sur_id = 0; sur_id < S.S; sur_id++) {
+    double pen;
+    if (!surround_one<false>(P, S, sur_id, t_now, omg, step, t, beta0, beta1, gama, pieceid, trajres, sigma, dsigma, ddsigma, ego_R, singul_, trajid, trajtime, Nseg,
+                             t_first, rec, pen))
+      continue;
+    totalPenalty += pen;
     if (first_active < 0) first_active = sur_id;
     mask |= (mask_t)1 << (t_first + sur_id);
   }
@@ -769,7 +816,9 @@ __device__ __forceinline__ void load_planes(gcd_t cor, size_t pitch, int H, doub
     for (int q = 0; q < 4; q++) pl[4 * k + q] = k < H ? cor[(size_t)(4 * k + q) * pitch] : 0.0; // (uniform: planes past H are not fetched)
   }
 }
-template <bool SUR, int HMAX = 5>
+// SKIP_SUR: the moving-obstacle terms are left to the caller (the TEAM shape collects the pairs that pass the cheap tests and
+// evaluates them densely packed); the term numbers stay those of a layout WITH obstacles
+template <bool SUR, int HMAX = 5, bool SKIP_SUR = false>
 __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double cc_[12], int i, int N, int j, int K, double step, double s1, int singul_,
                                             double epis, int H, const double (&pl)[4 * HMAX], gd_t sur_rec, const DevSurround &S, double t_now, double t_piece,
                                             int trajid, double trajtime, PtState &st) {
@@ -850,7 +899,7 @@ __device__ __forceinline__ mask_t point_masks(const DevParams &P, const double c
   cm |= (cm & (((decltype(cm))1 << H) - 1)) << (4 * H);
   mask = (mask_t)cm;
   // ---- moving obstacles, traj_optimizer.cpp:636-638 (terms 5 H .. 5 H + S - 1)
-  if (SUR && S.S > 0)
+  if (SUR && !SKIP_SUR && S.S > 0)
     mask |= surround_terms(P, S, t_now, omg, step, t_piece + step * j, beta0, beta1, alpha, i, K, sigma, dsigma, ddsigma, ego_R, singul_, trajid, trajtime,
                            N, 5 * H, sur_rec - (size_t)(5 * H) * kRec);
   const int t0 = 5 * H + (SUR ? S.S : 0);
@@ -985,6 +1034,21 @@ __device__ __forceinline__ void point_emit_pf(const DevParams &P, const PtState 
     }
     r_[13] = omg * step * P.wei_feas * 10.0 * pena;
   }
+}
+
+// One (constraint point, obstacle) pair from the point's kept state: the arguments point_masks hands to surround_terms, formed again with
+// the same expressions (the same bits).  lp: the piece's index inside its segment, N: the segment's pieces, t_piece: the piece's start time.
+template <bool GATE_ONLY>
+__device__ __forceinline__ int point_surround_one(const DevParams &P, const DevSurround &S, const PtState &st, int sur_id, double t_now, int j, int lp, int N,
+                                                  double t_piece, int singul_, int trajid, double trajtime, int t_first, gd_t rec, double &pen) {
+  const double s1 = st.s1, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1;
+  const double beta0[6] = {1.0, s1, s2, s3, s4, s5};
+  const double beta1[6] = {0.0, 1.0, 2.0 * s1, 3.0 * s2, 4.0 * s3, 5.0 * s4};
+  const double sigma[2] = {st.bp0, st.bp1};
+  const double sg = st.sg, z_h0 = st.z_h0;
+  const double ego_R[4] = {sg * st.dsigma[0] * z_h0, sg * -st.dsigma[1] * z_h0, sg * st.dsigma[1] * z_h0, sg * st.dsigma[0] * z_h0};
+  return surround_one<GATE_ONLY>(P, S, sur_id, t_now, st.omg, st.step, t_piece + st.step * j, beta0, beta1, st.alpha, lp, st.K, sigma, st.dsigma, st.ddsigma, ego_R,
+                                 singul_, trajid, trajtime, N, t_first, rec, pen);
 }
 
 // the half-plane fetched again from the corridor (TEAM / WAVE shapes: the point's planes are not kept across the numbering)

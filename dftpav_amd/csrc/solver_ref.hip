@@ -642,24 +642,108 @@ __device__ DFTPAV_REF_EVAL_ATTR void ref_eval(const DevBatch &D, gcd_t cor_b, gd
   } else {
   // ================= TEAM shape
   // ---- the constraint points, each on a lane of its own
-  for (int pt = tid; pt < Npts; pt += T) {
-    const int p = D.pt_piece[pt], j = D.pt_j[pt];
-    const int sg = sm.pinfo[4 * p], lp = sm.pinfo[4 * p + 1], K = sm.pinfo[4 * p + 3];
-    int N = 0, singul_ = 1;
+  // what a point needs from its piece and segment
+  auto point_ctx = [&](int pt, int &p, int &j, int &sg, int &lp, int &K, int &N, int &singul_, double (&cc)[12], double &step, double &s1, double &trajtime) {
+    p = D.pt_piece[pt];
+    j = D.pt_j[pt];
+    sg = sm.pinfo[4 * p];
+    lp = sm.pinfo[4 * p + 1];
+    K = sm.pinfo[4 * p + 3];
+    N = 0;
+    singul_ = 1;
     for (int q = 0; q < M; q++) {
       N = q == sg ? L.piece_nums[q] : N;
       singul_ = q == sg ? L.singuls[q] : singul_;
     }
     const bool edge = lp == 0 || lp == N - 1;
-    double cc[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) cc[k] = sm.c[12 * p + k];
-    const double step = sm.seg[16 * sg + 1] / K;
-    const double s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
+    step = sm.seg[16 * sg + 1] / K;
+    s1 = sm.spow[(2 * sg + (edge ? 1 : 0)) * Kmax1 + j];
     // trajtimes[sg] of traj_optimizer.cpp:230-234: 0, then the real duration of the PREVIOUS segment
-    const double trajtime = (SUR && sg > 0) ? sm.seg[16 * (sg - 1)] : 0.0;
-    sm.set_mask(pt, point_terms<SUR, HMAX>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
-                                     rec_b + (size_t)pt * nterm * kRec, D.sur, D.t_now, SUR ? sm.pA[p] : 0.0, sg, trajtime));
+    trajtime = (SUR && sg > 0) ? sm.seg[16 * (sg - 1)] : 0.0;
+  };
+  if (SUR && nS > 0) {
+    // Moving obstacles: a (point, obstacle) pair that reaches its forty correctly rounded exponentials costs 40 k cycles, and one such
+    // lane holds its whole wave.  So the pairs are COLLECTED first -- every point runs its static tests and, per obstacle, the cheap tests
+    // (hull box, distance gate, the bound before any exponential) -- and then evaluated densely packed, one pair per lane; a pair's record
+    // has a place of its own, so who evaluates it changes nothing, and the point's penalty (the reference's sum over the obstacles in
+    // order) is formed afterwards from the pairs' shares.  (round 6: configs[4] at 1024 1.90 -> see docs/HISTORY.md)
+    const int tS0 = 5 * H, cap = sm.list_cap;
+    int *npairs = (int *)(sm.ist + 15);
+    if (tid == 0) *npairs = 0;
+    team_sync<WAVE>();
+    // a pair, evaluated in full by whoever holds it: the point's state is formed again from scratch (the same expressions, the same bits)
+    auto pair_eval = [&](int pt, int sur_id) {
+      int p, j, sg, lp, K, N, singul_;
+      double cc[12], step, s1, trajtime;
+      point_ctx(pt, p, j, sg, lp, K, N, singul_, cc, step, s1, trajtime);
+      PtState st;
+      double pl[4 * HMAX];
+      load_planes<HMAX>(cor_b + pt, (size_t)D.NptsPad, H, pl);
+      (void)point_masks<SUR, HMAX, true>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, pl, (gd_t) nullptr, D.sur, D.t_now, sm.pA[p], sg, trajtime, st);
+      const gd_t rec_pt = rec_b + (size_t)pt * nterm * kRec;
+      double pen;
+      if (point_surround_one<false>(P, D.sur, st, sur_id, D.t_now, j, lp, N, sm.pA[p], singul_, sg, trajtime, tS0, rec_pt, pen)) {
+        rec_pt[(size_t)(tS0 + sur_id) * kRec + 13] = pen; // (the pair's share; the point's sum is formed below)
+        const int bit = tS0 + sur_id;
+        atomicOr((int *)(sm.pmask + (sm.mw == 2 ? 2 * pt + (bit >> 5) : pt)), 1 << (bit & 31));
+      }
+    };
+    for (int pt = tid; pt < Npts; pt += T) {
+      int p, j, sg, lp, K, N, singul_;
+      double cc[12], step, s1, trajtime;
+      point_ctx(pt, p, j, sg, lp, K, N, singul_, cc, step, s1, trajtime);
+      PtState st;
+      st.K = -1; // (stays -1 for a point the reference skips, traj_optimizer.cpp:550-553)
+      double pl[4 * HMAX];
+      load_planes<HMAX>(cor_b + pt, (size_t)D.NptsPad, H, pl);
+      const mask_t mask = point_masks<SUR, HMAX, true>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, pl, (gd_t) nullptr, D.sur, D.t_now, sm.pA[p], sg, trajtime, st);
+      const gd_t rec_pt = rec_b + (size_t)pt * nterm * kRec;
+      for (mask_t mm = mask; mm;) {
+        const int t = __builtin_ctzll(mm);
+        mm &= mm - 1;
+        point_emit(P, st, t, H, tS0 + nS, cor_b + pt, (size_t)D.NptsPad, rec_pt + (size_t)t * kRec);
+      }
+      sm.set_mask(pt, mask);
+      if (st.K >= 0) {
+        for (int sur_id = 0; sur_id < nS; sur_id++) {
+          double pen;
+          if (!point_surround_one<true>(P, D.sur, st, sur_id, D.t_now, j, lp, N, sm.pA[p], singul_, sg, trajtime, tS0, rec_pt, pen)) continue;
+          const int slot = atomicAdd(npairs, 1);
+          if (slot < cap) sm.list[slot] = (pt << 4) | sur_id;
+          else pair_eval(pt, sur_id); // (more pairs than the list holds: this one at once)
+        }
+      }
+    }
+    __threadfence_block();
+    team_sync<WAVE>();
+    const int np = *npairs < cap ? *npairs : cap;
+    for (int q = tid; q < np; q += T) pair_eval(sm.list[q] >> 4, sm.list[q] & 15);
+    __threadfence_block(); // the pairs' records and shares are read by other lanes below
+    team_sync<WAVE>();
+    // the point's penalty: the shares of its active obstacles added in obstacle order from 0.0, kept in slot [13] of the first one
+    for (int pt = tid; pt < Npts; pt += T) {
+      const mask_t m = sm.mask(pt);
+      const unsigned sb = (unsigned)((m >> tS0) & (((mask_t)1 << nS) - 1ull));
+      if (!sb) continue;
+      const gd_t rec_pt = rec_b + (size_t)pt * nterm * kRec;
+      double total = 0.0;
+      for (int sur_id = 0; sur_id < nS; sur_id++)
+        if (sb & (1u << sur_id)) {
+          total += rec_pt[(size_t)(tS0 + sur_id) * kRec + 13];
+          rec_pt[(size_t)(tS0 + sur_id) * kRec + 13] = 0.0;
+        }
+      rec_pt[(size_t)(tS0 + __builtin_ctz(sb)) * kRec + 13] = total;
+    }
+  } else {
+    for (int pt = tid; pt < Npts; pt += T) {
+      int p, j, sg, lp, K, N, singul_;
+      double cc[12], step, s1, trajtime;
+      point_ctx(pt, p, j, sg, lp, K, N, singul_, cc, step, s1, trajtime);
+      sm.set_mask(pt, point_terms<SUR, HMAX>(P, cc, lp, N, j, K, step, s1, singul_, D.epis, H, cor_b + pt, (size_t)D.NptsPad,
+                                             rec_b + (size_t)pt * nterm * kRec, D.sur, D.t_now, SUR ? sm.pA[p] : 0.0, sg, trajtime));
+    }
   }
   __threadfence_block(); // the records are read back by other lanes of this team
   team_sync<WAVE>();
