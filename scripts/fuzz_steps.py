@@ -39,7 +39,7 @@ for c in range(n_cases):
     n = int(rng.integers(1, 800))
     st = np.column_stack([rng.uniform(origin[0] - 8, ex + 8, n), rng.uniform(origin[1] - 8, ey + 8, n), rng.uniform(-10, 10, n)])
     h.set_grid_map(grid, res, origin)
-    check("corridor", c, np.array_equal(h.corridor_rectangles(st), po.corridor_rectangles(grid, res, origin, st, veh=veh, order=1)))
+    check("corridor", c, np.array_equal(h.corridor_rectangles(st), po.corridor_rectangles(grid, res, origin, st, veh=veh, order=2)))
     # ---- Reeds-Shepp shots (on the map above)
     m = int(rng.integers(1, 400))
     sp = float(rng.choice([1.0, 5.0, 40.0]))
@@ -60,7 +60,7 @@ for c in range(n_cases):
                                           seg_duration=float(rng.uniform(1.5, 12.0)))
     fp = FrontendParams.default(K=K, Kd=Kd)
     got = h.frontend_resample(P, pl, ss, es, ct, fp)
-    want = po.frontend_resample(P, pl, ss, es, ct, fp, order=1)
+    want = po.frontend_resample(P, pl, ss, es, ct, fp, order=2)
     check("frontend", c, all(np.array_equal(got[k], want[k]) for k in want))
     # ---- restarts
     nh, ni, M = int(rng.integers(1, 20)), int(rng.integers(1, 12)) * 2, int(rng.integers(1, 4))
@@ -81,7 +81,7 @@ for c in range(n_cases):
     ps[..., 6] = rng.uniform(0, 5) + float(rng.uniform(0.2, 2.0)) * np.arange(ns)[None, :]
     h.fit_surround(ps)
     g = h.get_surround()
-    w = po.fit_surround(ps, order=1)
+    w = po.fit_surround(ps, order=2)
     check("fit", c, np.array_equal(g["durations"].reshape(S, -1), w["durations"]) and
           np.array_equal(g["coeffs"].reshape(S, ns - 1, 12), w["coeffs"]) and np.array_equal(g["total"], w["total"]) and
           np.array_equal(g["start"], w["start"]))
@@ -105,12 +105,12 @@ for c in range(n_cases):
         sdt, vres = float(rng.uniform(0.01, 0.4)), float(rng.uniform(0.03, 0.6))
         col, first = bt.validate(sample_dt=sdt, vertex_res=vres)
         oc, of = po.validate_trajectories(g2, sc.MAP_RESL, o2, co, dts, s.layout.piece_nums, s.layout.singuls, sample_dt=sdt,
-                                          vertex_res=vres, order=1)
+                                          vertex_res=vres, order=2)
         check("validate", c, np.array_equal(col, oc) and np.array_equal(first, of))
         tt0, sd2, nsm, flt = float(rng.uniform(-1, 3)), float(rng.uniform(0.003, 0.5)), int(rng.integers(1, 3000)), bool(rng.integers(0, 2))
         sts, nv = bt.sample_states(t0=tt0, sample_dt=sd2, n_samples=nsm, filter_singularity=flt)
         so, no = po.sample_states(co, dts, s.layout.piece_nums, s.layout.singuls, t0=tt0, sample_dt=sd2, n_samples=nsm,
-                                  filter_singularity=flt, wheel_base=p2.veh_wheel_base, order=1)
+                                  filter_singularity=flt, wheel_base=p2.veh_wheel_base, order=2)
         check("states", c, np.array_equal(sts, so) and np.array_equal(nv, no))
         bt.close(); h2.close()
     h.close()
