@@ -1,10 +1,14 @@
-"""PARITY PIN: the restatement oracle/dftpav_oracle.c (literal order) against the reference's OWN code.
+"""RETIRED CROSS-CHECK (rounds 3-5; NOT a parity pin): the restatement oracle/dftpav_oracle.c (literal order) against a build of the
+reference's sources over STAND-IN headers.
 
-oracle/_ref/libdftpav_ref.so is /root/reference/src/Plan/traj_planner/{src/traj_optimizer.cpp,
+oracle/_ref/libdftpav_ref.so was /root/reference/src/Plan/traj_planner/{src/traj_optimizer.cpp,
 include/plan_utils/poly_traj_utils.hpp, include/geo_utils2d/lbfgs.hpp} compiled unmodified (oracle/Makefile.ref) against
-interface stand-ins for Eigen / ROS / the protobuf config (oracle/ref_shim).  Two kinds of test:
-  * `ref` tests call the reference build beside the oracle (they skip where the library is absent);
-  * golden tests check the oracle against vectors the reference build wrote (tests/golden/ref_*.npz), anywhere.
+interface stand-ins for Eigen / ROS / the protobuf config written in this repository (oracle/ref_shim).  The reference needs those
+libraries, so it is unbuildable here and such a build is not a reference build: since round 6 nothing builds it and the `ref` tests
+below SKIP (they run only for a developer who sets DFTPAV_STANDIN_BUILD=1, oracle/pyref.py).  Two kinds of test:
+  * `ref` tests call that build beside the oracle (skipped);
+  * golden tests check the oracle against the vectors that build once wrote (tests/golden/ref_*.npz: regression data, see
+    tests/golden/README.md) -- they run anywhere.
 The bar is bit equality: same evaluation points, same costs, same gradients, same iterates, same counts.
 """
 import hashlib
@@ -153,7 +157,7 @@ def test_scalar_pieces_match_the_reference(ref, oracle):
 
 # ---------------------------------------------------------------- golden vectors written by the reference build
 @pytest.mark.parametrize("name", CASES)
-def test_oracle_reproduces_the_reference_builds_vectors(oracle, name):
+def test_oracle_reproduces_the_retired_standin_builds_vectors(oracle, name):
     s, _ = load(name)
     z = np.load(os.path.join(GOLDEN_DIR, "ref_" + name + ".npz"))
     p = oracle.default_params()
@@ -173,7 +177,7 @@ def test_oracle_reproduces_the_reference_builds_vectors(oracle, name):
             assert o.eval(xi[k])[0] == fi[k]
 
 
-def test_oracle_lbfgs_and_minco_reproduce_the_reference_builds_vectors(oracle):
+def test_oracle_lbfgs_and_minco_reproduce_the_retired_standin_builds_vectors(oracle):
     z = np.load(os.path.join(GOLDEN_DIR, "ref_units.npz"))
     p = oracle.default_params()
     got = ref_cases.run_lbfgs(oracle, p)
@@ -611,7 +615,7 @@ def test_frontend_oracle_is_bit_equal_to_getKinoNode_and_RunMINCOParking(refnext
         assert np.array_equal(a[k], b[k]), k
 
 
-def test_step_oracles_reproduce_the_reference_codes_vectors(oracle):
+def test_step_oracles_reproduce_the_retired_standin_builds_step_vectors(oracle):
     """anywhere (no /root/reference needed): order 0 of the five restatements against tests/golden/ref_steps.npz, written by the
     reference's own code on the inputs of tests/golden/steps.npz (tests/golden/make_golden_ref_steps.py).  Same libm as the
     writer's (this image): bit equality."""
