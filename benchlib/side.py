@@ -232,6 +232,17 @@ def side_reference_order_batch(ctx, args, po, cores, cfg, B, golden):
             row["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] = bool(
                 all(np.array_equal(o5[k_], r5[k_][pick5]) for k_ in SOLVE_FIELDS))
         b5.close(); h5.close()
+        if cfg == 2:   # the gear shift also as the value line is measured: a stream of such batches, args.depth in flight (the isolated figure
+            # above is the batch alone on the device: it lasts as long as its longest solve)
+            stG = Stream(ctx, B, cfg, args.seed, depth=max(2, args.depth), order=capi.ORDER_REFERENCE)
+            rG = stG.run(2 * max(2, args.depth), max(2, args.depth))
+            rs = [q_ for q_ in rG["rs"] if q_ is not None]
+            eb = sum(float(algorithmic_bytes(lay5, s5.n_points, lay5.H, lay5.M, q_["iters"], q_["evals"], q_["hist_sum"]).sum()) for q_ in rs) / len(rs)
+            row["isolated_solves_per_s"] = row["solves_per_s"]
+            row["overlapped"] = {"solves_per_s": rG["value"], "ms_per_step": rG["ms_per_step"], "steps": rG["steps"], "steps_in_flight": stG.D,
+                                 "roofline_frac": eb / (rG["gpu_ms"] / rG["steps"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "first_batch_equals_the_isolated_solve": bool(all(np.array_equal(rs[0][k_], r5[k_]) for k_ in SOLVE_FIELDS))}
+            stG.close()
         return row
     except capi.DftpavError as ex:
         return {"unsupported": str(ex)}

@@ -389,15 +389,23 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
     if (total > 0) {
       for (int p = 0; p < N; p++) {
         const int c = q.tcnt[p];
-        if (c == 0) continue;
+        if (__builtin_amdgcn_ballot_w64(c != 0) == 0ull) continue; // (uniform: no row of this wave has a term in this piece)
         const int pp0 = p == 0 ? 0 : (L.Kd + 1) + (p - 1) * (L.K + 1);
         const gcd_t og = (gcd_t)(ovf + (size_t)pp0 * nterm * 3);
-        const int cl = c < kQLcap ? c : kQLcap;
-        for (int i = 0; i < cl; i++) {
-          ldscd_t e = q.tl + (p * kQLcap + i) * 3;
-          gdT += e[0];
-          cost0 += e[1];
-          cost2 += e[2];
+        // the piece's LDS window in one go (the eight entries' reads go out together; what lies beyond the piece's count adds -0.0),
+        // the four rows of the wave in step: a loop over the count would run each row's trips one after the other
+        {
+          double e[kQLcap][3];
+#pragma unroll
+          for (int i = 0; i < kQLcap; i++)
+#pragma unroll
+            for (int w = 0; w < 3; w++) e[i][w] = q.tl[(p * kQLcap + i) * 3 + w];
+#pragma unroll
+          for (int i = 0; i < kQLcap; i++) {
+            gdT += i < c ? e[i][0] : -0.0;
+            cost0 += i < c ? e[i][1] : -0.0;
+            cost2 += i < c ? e[i][2] : -0.0;
+          }
         }
         for (int i0 = kQLcap; i0 < c; i0 += 8) { // beyond the LDS window: eight terms' loads in flight, then their additions in order
           double e[8][3];

@@ -147,6 +147,7 @@ def test_every_side_run_of_the_one_gpu_line():
         assert out[k]["reference_order"]["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] is True
     ro = out["gear_shift_4096_reference_order"]
     assert ro["batch"] == 4 and ro["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls_on_4_sampled"] is True and ro["roofline"]["frac"] > 0
+    assert ro["overlapped"]["first_batch_equals_the_isolated_solve"] is True and ro["overlapped"]["steps_in_flight"] == 4   # the gear shift as a stream, like the value line
     assert out["single"]["reference_order"]["best_of_64_restarts_in_one_launch"]["slot0_bit_equal_to_the_lone_solve_on_all"] is True
     live = par["reference_order_other_configs"]["gear_shifts_with_moving_obstacles"]
     assert live["bit_equal_to_the_reference_program_with_correctly_rounded_libm_calls"] == live["trajectories"] == 8
