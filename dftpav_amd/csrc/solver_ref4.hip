@@ -44,7 +44,6 @@ namespace dftpav {
 namespace reford {
 
 constexpr int kQLcap = 8; // parked terms of a piece kept in LDS (the rest in global scratch)
-constexpr int kQReg = 3;  // ... the first of which also stay in the lane's registers (q4_parked_chains)
 // Waves per SIMD the kernel is built for.  At 2 (256 registers) it spills 205 of them and its scratch traffic alone is HBM-sized
 // (measured: the point loop 3 x slower than at 1); at 1 the allocator takes 455 registers, nothing goes to scratch, and four waves
 // per CU hold 16 trajectories -- twice the WAVE shape's 8 -- each of them at the speed of a wave that has its SIMD to itself.
@@ -202,27 +201,6 @@ __device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int
   }
 }
 
-// acc += v0[piece 0] + v1[piece 0] + v2[piece 0] + v0[piece 1] + ... : the parked terms of the pieces in (piece, term) order, three
-// accumulators side by side (what the terms add to gdT, to the corridor cost, to the feasibility cost)
-#define DFTPAV_Q4_PK(K)                                                                                   \
-  "v_fmac_f64_dpp %0, %3, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %1, %6, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %2, %9, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %0, %4, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %1, %7, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %2, %10, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                          \
-  "v_fmac_f64_dpp %0, %5, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %1, %8, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"                           \
-  "v_fmac_f64_dpp %2, %11, %12 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void q4_parked_chains(double &a0, double &a1, double &a2, const double (&p0)[3], const double (&p1)[3], const double (&p2)[3]) {
-  static_assert(kQReg == 3, "the chain below takes three terms per piece");
-  const double one = 1.0;
-  asm volatile("s_nop 1\n\t" DFTPAV_Q4_PK(0) DFTPAV_Q4_PK(1) DFTPAV_Q4_PK(2) DFTPAV_Q4_PK(3) DFTPAV_Q4_PK(4) DFTPAV_Q4_PK(5) DFTPAV_Q4_PK(6) DFTPAV_Q4_PK(7)
-                   DFTPAV_Q4_PK(8) DFTPAV_Q4_PK(9) DFTPAV_Q4_PK(10) DFTPAV_Q4_PK(11) DFTPAV_Q4_PK(12) DFTPAV_Q4_PK(13) DFTPAV_Q4_PK(14) DFTPAV_Q4_PK(15)
-               : "+v"(a0), "+v"(a1), "+v"(a2)
-               : "v"(p0[0]), "v"(p0[1]), "v"(p0[2]), "v"(p1[0]), "v"(p1[1]), "v"(p1[2]), "v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(one));
-}
-
 // ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350), one gear segment
 // x (q.xs) -> g (q.gs), returns f.  The statements are solver_ref.hip's ref_eval, stage by stage; what changes is where a value
 // lives.  cor: &cor_t[b][0][0][l] (component pitch cpitch = 16 (Kmax + 1), a round's 16 pieces contiguous); ovf: this
@@ -307,9 +285,6 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   const int singul_ = L.singuls[0];
   double s1 = 0.0;
   int cnt = 0;
-  double pk0[kQReg], pk1[kQReg], pk2[kQReg]; // this piece's first parked terms (absent: -0.0, which adds nothing)
-#pragma unroll
-  for (int u = 0; u < kQReg; u++) pk0[u] = pk1[u] = pk2[u] = -0.0;
   const gd_t ovf_l = ovf + (size_t)pt0 * nterm * 3;
   // a round's half-planes are requested one round ahead (the copy holds zeros where a piece has no such point: every lane
   // loads, whatever its piece): 33 rounds of a dependent HBM round trip each were 3/4 of this kernel's time
@@ -350,12 +325,6 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
         e[0] = e0;
         e[1] = e1;
         e[2] = e2;
-#pragma unroll
-        for (int u = 0; u < kQReg; u++) {
-          pk0[u] = cnt == u ? e0 : pk0[u];
-          pk1[u] = cnt == u ? e1 : pk1[u];
-          pk2[u] = cnt == u ? e2 : pk2[u];
-        }
       } else {
         gd_t e = ovf_l + (size_t)cnt * 3;
         e[0] = e0;
@@ -375,14 +344,9 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   double gdT = row_chain16(0.0, piece ? pG : -0.0);
   const double en = row_chain16(0.0, piece ? pE : -0.0);
   double cost0 = 0.0, cost2 = 0.0;
-  // no piece of this row has more parked terms than a lane keeps: the three chains straight from the registers -- piece after piece,
-  // a piece's terms in order -- as DPP steps (a term that is not there adds -0.0)
-  const int cmax = (int)row_max16((double)(piece ? cnt : 0));
-  if (cmax <= kQReg) {
-    if (cmax > 0) q4_parked_chains(gdT, cost0, cost2, pk0, pk1, pk2);
-    const int total = (int)row_chain16(0.0, (double)(piece ? cnt : 0)); // (small integers: exact)
-    pr.count(9, total);
-  } else {
+  // (round 6, measured and taken out: the first three terms of a piece kept in the lane's registers and chained by DPP when no piece of the
+  // row has more -- on this workload a piece that has terms has more than three)
+  {
     int total = 0;
     for (int p = 0; p < N; p++) total += q.tcnt[p];
     pr.count(9, total);
