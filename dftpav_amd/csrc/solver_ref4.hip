@@ -299,6 +299,12 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
     if (piece && j <= Kl)
       m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
     s1 += step; // the running sum of traj_optimizer.cpp:513
+    if (D.prof != nullptr) { // (profiling only) trips of the loop below for the wave: the longest list of active terms among its 64 points
+      const int pc = __builtin_popcount(m);
+      int trips = 0;
+      while (__builtin_amdgcn_ballot_w64(pc > trips) != 0ull) trips++;
+      pr.count(11, trips);
+    }
     for (unsigned mm = m; mm;) {
       const int t = __builtin_ctz(mm);
       mm &= mm - 1;

@@ -382,7 +382,7 @@ def test_quad_shape_is_what_a_full_batch_takes_and_equals_the_other_shapes(hipli
     h.close()
 
 
-@pytest.mark.parametrize("shape", ["team", "wave"])
+@pytest.mark.parametrize("shape", ["team", "wave", "quad"])
 def test_recursion_with_true_divisions_gives_the_same_bits(hiplib, oracle, monkeypatch, shape):
     """The two-loop recursion divides by the stored y . s of a pair through its stored reciprocal (Markstein's correctly rounded
     quotient); a pair whose y . s lies beyond 2^+-500 switches the trajectory to true divisions for good (solver_ref.hip:
@@ -394,7 +394,7 @@ def test_recursion_with_true_divisions_gives_the_same_bits(hiplib, oracle, monke
     want = oracle.solve_batch(p, s, nthreads=8, order=0)
     monkeypatch.setenv("DFTPAV_REF_EXACT_DIV", "1")
     monkeypatch.setenv("DFTPAV_REF_SHAPE", shape)
-    if shape == "wave":
+    if shape in ("wave", "quad"):
         monkeypatch.setenv("DFTPAV_REF_SLOTS", "1")
         monkeypatch.setenv("DFTPAV_REF_SLICE", "11")
     h, bt = _batch(hiplib, s, p)
@@ -608,6 +608,39 @@ def test_beyond_a_wave_of_variables_and_five_half_planes(hiplib, oracle, case):
     lp.eval(r["x"][0])
     co, dto = lp.coeffs()
     assert np.array_equal(c[0], co) and np.array_equal(dt[0], dto)
+    bt.close()
+    h.close()
+
+
+@pytest.mark.parametrize("H", [3, 5])
+def test_quad_shape_with_other_than_four_half_planes(hiplib, oracle, monkeypatch, H):
+    """the QUAD shape's generic instantiation (H != 4: three half-planes -- a corridor open on one side -- and five): bit-equal to the
+    restatement, as the FAST one (H = 4, help_eps = 0) is"""
+    p = hiplib.default_params()
+    base = sc.baseline_config(3, B=13)
+    if H == 5:
+        s = _extra_planes(base, 5)
+    else:
+        lay = type(base.layout)(base.layout.piece_nums, base.layout.singuls, H=3)
+        s = sc.Scenario("planes_3", lay, base.K, base.Kd, base.B, base.ini_states, base.fin_states, base.inner_pts, base.init_Ts,
+                        np.ascontiguousarray(base.corridor[:, :, :3]))
+    s.apply_resolution(p)
+    monkeypatch.setenv("DFTPAV_REF_SHAPE", "quad")
+    monkeypatch.setenv("DFTPAV_REF_SLOTS", "2")
+    monkeypatch.setenv("DFTPAV_REF_SLICE", "9")
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    x = bt.x0() + np.random.default_rng(8).normal(0, 0.3, bt.x0().shape)
+    f, g = bt.eval(x)
+    for b in range(0, s.B, 3):
+        fo, go = oracle.OracleProblem(p, s, b, order=0).eval(x[b])
+        assert f[b] == fo and np.array_equal(g[b], go), (H, b)
+    r = bt.solve()
+    want = oracle.solve_batch(p, s, nthreads=8, order=0)
+    for k in ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success"):
+        assert np.array_equal(r[k], want[k]), (H, k)
     bt.close()
     h.close()
 
