@@ -60,6 +60,10 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
 // the QUAD shape (solver_ref4.hip): four trajectories per wave; its copy of the corridor and its launches
 size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B);
 hipError_t launch_quad_corridor(const DevBatch &D, double *cor_t, hipStream_t stream);
+hipError_t launch_ring_reset(const DevBatch &D, hipStream_t stream); // solver_ref.hip
+hipError_t launch_quadm_corridor(const DevBatch &D, double *cor_t, hipStream_t stream); // solver_ref4m.hip: the QUAD shape for several gear segments (RefPlan::quad == 2)
+hipError_t launch_solver_ref4m(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, const double *cor_t, double *scratch, const RefPlan &pl,
+                               int scheduled, int slots, int hand, hipStream_t stream);
 hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, const double *cor_t, double *scratch, const RefPlan &pl,
                               int scheduled, int slots, int hand, hipStream_t stream);
 hipError_t launch_solver_ref(const DevBatch &D, const DevBatch *d_dev, int mode, const double *tabs, double *scratch, const RefPlan &pl, int scheduled,
@@ -1518,7 +1522,7 @@ extern "C" int dftpav_batch_get_trace(dftpav_batch *b, double *out, int *n_evals
 static hipError_t launch_ref(dftpav_batch *b, const DevBatch &D, int mode, int scheduled) {
   if (b->ref_plan.quad && mode != kModeCoeffs) {
     if (b->cor_t_dirty) { // the QUAD shape reads its own layout of the corridor
-      const hipError_t e = launch_quad_corridor(D, b->d_cor_t, b->h->stream);
+      const hipError_t e = b->ref_plan.quad == 2 ? launch_quadm_corridor(D, b->d_cor_t, b->h->stream) : launch_quad_corridor(D, b->d_cor_t, b->h->stream);
       if (e != hipSuccess) return e;
       b->cor_t_dirty = false;
     }
@@ -1529,7 +1533,9 @@ static hipError_t launch_ref(dftpav_batch *b, const DevBatch &D, int mode, int s
     const bool alone = b->hand_over != 0 && scheduled && mode == kModeSolve;
     const int slots = alone ? b->ref_plan.slots_wide : b->ref_plan.slots;
     const int hand = alone && b->ref_plan_wt.wave ? std::min(b->ref_plan.hand, b->B / 2) : 0;
-    hipError_t e = launch_solver_ref4(D, b->d_dev, mode, b->d_ref_tab, b->d_cor_t, b->d_ref_scratch, b->ref_plan, scheduled, slots, hand, b->h->stream);
+    hipError_t e = b->ref_plan.quad == 2
+                       ? launch_solver_ref4m(D, b->d_dev, mode, b->d_ref_tab, b->d_cor_t, b->d_ref_scratch, b->ref_plan, scheduled, slots, hand, b->h->stream)
+                       : launch_solver_ref4(D, b->d_dev, mode, b->d_ref_tab, b->d_cor_t, b->d_ref_scratch, b->ref_plan, scheduled, slots, hand, b->h->stream);
     if (e == hipSuccess && hand > 0) e = launch_solver_ref(D, b->d_dev, kModeSolve, b->d_ref_tab, b->d_ref_scratch, b->ref_plan_wt, 1, b->h->stream);
     return e;
   }
@@ -1820,9 +1826,7 @@ static int solve_impl(dftpav_batch *b, dftpav_batch *prev, bool chained) {
     if (b->ref_plan.wave && b->ref_plan.slots > 0 && b->ref_plan.slice > 0 && (b->ref_plan.quad || b->ref_plan.slots * (b->ref_plan.threads / 64) < b->B)) {
       // more trajectories than resident waves: persistent workgroups whose waves pop trajectories from the ring and run them a
       // slice of iterations at a time (solver_ref.hip); queue = all trajectories, flags cleared, counters reset on the stream
-      HIPCHK(h, hipMemcpyAsync(b->d_queue, b->d_iota, sizeof(int) * (size_t)b->B, hipMemcpyDeviceToDevice, h->stream));
-      HIPCHK(h, hipMemsetAsync(b->d_sflag, 0, sizeof(int) * (size_t)b->B, h->stream));
-      HIPCHK(h, hipMemcpyAsync(b->d_qctl, b->d_qctl + 8, sizeof(unsigned) * 8, hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, launch_ring_reset(D, h->stream));
       HIPCHK(h, launch_ref(b, D, kModeSolve, 1));
     } else {
       HIPCHK(h, launch_for(b, D, kModeSolve)); // every trajectory has its team from the start

@@ -103,7 +103,14 @@ DFTPAV_HD inline int reduce(double x, dd &r) {
 // multiples of 4 and are dropped, the next nine words (288 bits) are multiplied by m exactly in 32-bit limbs, the words after
 // them add less than 2^-202.  The two bits above the binary point are k mod 4, the 320 bits below it the fraction f (made
 // |f| <= 1/2 by rounding k), and r = f pi/2 in double-double keeps >= 107 significant bits after a cancellation of up to 62.
-DFTPAV_HD __attribute__((noinline)) inline int reduce_large(double x, dd &r) {
+// (returned by value: on the device three registers, where a reference parameter of a function that is not inlined is a slot of
+// the caller's stack -- scratch memory, and a kernel that needs none without it)
+struct reduced {
+  dd r;
+  int k;
+};
+DFTPAV_HD __attribute__((noinline)) inline reduced reduce_large_v(double x) {
+  dd r;
   const unsigned W[41] = { // 2/pi = 0.W[0] W[1] ... in base 2^32
       0xa2f9836eu, 0x4e441529u, 0xfc2757d1u, 0xf534ddc0u, 0xdb629599u, 0x3c439041u, 0xfe5163abu, 0xdebbc561u, 0xb7246e3au, 0x424dd2e0u, 0x06492eeau,
       0x09d1921cu, 0xfe1deb1cu, 0xb129a73eu, 0xe88235f5u, 0x2ebb4484u, 0xe99c7026u, 0xb45f7e41u, 0x3991d639u, 0x835339f4u, 0x9c845f8bu, 0xbdf9283bu,
@@ -170,7 +177,12 @@ DFTPAV_HD __attribute__((noinline)) inline int reduce_large(double x, dd &r) {
     r = dd_neg(r);
     k = -k;
   }
-  return k;
+  return reduced{r, k};
+}
+DFTPAV_HD inline int reduce_large(double x, dd &r) {
+  const reduced t = reduce_large_v(x);
+  r = t.r;
+  return t.k;
 }
 // sin and cos of a double-double |r| <= ~pi/4 by their Taylor series in double-double (Horner in r^2)
 DFTPAV_HD inline dd sin_dd(dd r) {

@@ -1962,6 +1962,8 @@ __global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 25
 #endif
 bool reference_order_quad_supported(const DevLayout &L, const DevParams &P, int S); // solver_ref4.hip
 void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int B, int n_cu, RefPlan &pl);
+bool reference_order_quadm_supported(const DevLayout &L, const DevParams &P, int S); // solver_ref4m.hip: several gear segments
+void reference_order_quadm_plan(const DevLayout &L, const DevParams &P, int B, int n_cu, RefPlan &pl);
 #if DFTPAV_REF_PART != 2
 // what the layout must satisfy for the reference-order kernel (solver_ref.hip header)
 bool reference_order_supported(const DevLayout &L, const DevParams &P, int S) {
@@ -2024,6 +2026,26 @@ void reference_order_pack_tables(int N, const double *full, double *packed) {
 // the non-zero pattern the middle blocks of a sweep assume (solver_ref.hip: kInterior_), for the host's check
 int reference_order_interior_mask(int sweep, int row_mod_6) { return reford::kInterior_(sweep, row_mod_6); }
 
+// The ring of a scheduled launch, reset on the stream in front of it: queue = every trajectory, flags cleared, counters {head 0, tail B,
+// reserved B, unfinished B}.  ONE launch of workgroups of ONE wave each.  (Until round 6 this was two copies and a fill by the runtime:
+// three blit kernels with workgroups of several waves.  In a stream of batches the device is full of persistent waves that hold a SIMD's
+// whole register file each; a blit's workgroup was seen to wait 200-670 ms for a CU with room for all of its waves -- and the solve behind
+// it with it -- while single SIMDs were free: rocprofv3 --kernel-trace of scripts/ref_stream_time.py, configs[1].)
+namespace reford {
+__global__ void __launch_bounds__(64) ring_reset_kernel(int *__restrict__ queue, int *__restrict__ sflag, unsigned *__restrict__ qctl, int B) {
+  const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (i < B) {
+    queue[i] = i;
+    sflag[i] = 0;
+  }
+  if (i < 8) qctl[i] = (i >= 1 && i <= 3) ? (unsigned)B : 0u;
+}
+} // namespace reford
+hipError_t launch_ring_reset(const DevBatch &D, hipStream_t stream) {
+  hipLaunchKernelGGL(reford::ring_reset_kernel, dim3((D.B + 63) / 64), dim3(64), 0, stream, D.queue, D.sflag, D.qctl, D.B);
+  return hipGetLastError();
+}
+
 // The launch shape of a batch (see the header).  TEAM: four waves per trajectory while the batch leaves CUs to spare (the
 // parallel stages finish sooner: 70 against 73 ms at batch 32, 133 against 140 at 256), two for more.  WAVE: as many waves per
 // workgroup as keep the most trajectories resident on a CU -- 8 waves of 256 registers (4 for the kernels that take 512), the
@@ -2070,6 +2092,17 @@ RefPlan reference_order_plan(const DevLayout &L, const DevParams &P, int S, int 
   pl.quad = 0;
   if (quad) {
     reference_order_quad_plan(L, P, B, n_cu, pl);
+    return pl;
+  }
+  // several gear segments (solver_ref4m.hip)
+  bool quadm = allow_quad && wave && L.M > 1 && reference_order_quadm_supported(L, P, S);
+  if (const char *e = std::getenv("DFTPAV_REF_QUADM_OFF")) quadm = quadm && !(e[0] != 0 && e[0] != '0'); // developer knob: several segments stay with the WAVE shape
+  if (const char *e = std::getenv("DFTPAV_REF_SHAPE")) {
+    if (e[0] == 'q') quadm = allow_quad && reference_order_quadm_supported(L, P, S);
+    else quadm = false;
+  }
+  if (quadm) {
+    reference_order_quadm_plan(L, P, B, n_cu, pl);
     return pl;
   }
   pl.wave = wave ? 1 : 0;

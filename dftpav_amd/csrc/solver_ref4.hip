@@ -39,6 +39,7 @@
 #include <algorithm>
 
 #include "ref_order_common.h"
+#include "quad_common.h"
 
 namespace dftpav {
 namespace reford {
@@ -80,20 +81,6 @@ __device__ inline void q4_carve(Q4 &q, char *team, int mem) {
   q.tcnt = i;
 }
 
-// acc + v[lane 0 of the row] + v[lane 1] + ... + v[lane 15]: sixteen dependent additions, every lane of a row ends with its
-// row's sum.  (fma(v, 1.0, acc) == acc + v rounded once.  A VALU write followed by a DPP read needs two wait states and the asm
-// block is opaque to the hazard recogniser: s_nop 1 in front.)
-__device__ __forceinline__ double row_chain16(double acc, double v) {
-  const double one = 1.0;
-  asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST16 : "+v"(acc) : "v"(v), "v"(one));
-  return acc;
-}
-// acc + v[lane 0 of the row]
-__device__ __forceinline__ double row_add_lane0(double acc, double v) {
-  const double one = 1.0;
-  asm volatile("s_nop 1\n\t" DFTPAV_FMAC_BCAST(0) : "+v"(acc) : "v"(v), "v"(one));
-  return acc;
-}
 // 0.0 + p[0] + p[1] + ... + p[n-1] for a vector held as (element l, element 16 + l); elements from n on contribute -0.0, and
 // x + (-0.0) == x for every x: the second half of the chain is left out when it has nothing but those
 __device__ __forceinline__ double row_sum32(double p0, double p1, int n, int l) {
@@ -101,22 +88,6 @@ __device__ __forceinline__ double row_sum32(double p0, double p1, int n, int l) 
   if (n > 16) acc = row_chain16(acc, 16 + l < n ? p1 : -0.0); // (uniform)
   return acc;
 }
-// max over the 16 lanes of a row (order-free), the same value in every lane of the row
-__device__ __forceinline__ double row_max16(double v) {
-  v = fmax(v, mov_dpp<0xB1>(v));
-  v = fmax(v, mov_dpp<0x4E>(v));
-  v = fmax(v, mov_dpp<0x141>(v));
-  v = fmax(v, mov_dpp<0x140>(v));
-  return v;
-}
-// the neighbour's value: lane l - 1 (row_shr:1) / lane l + 1 (row_shl:1) of the same row; 0.0 where there is none
-template <int CTRL> __device__ __forceinline__ double nb_dpp(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-
 // One substitution sweep over the 6 N rows of the band system (solver_ref.hip: sweep / rows_end / rows_pack -- the same rows, the
 // same order of a row's updates), the rows in registers: bq[2 r + d] = row 6 l + r, dimension d, of this lane's piece.  Step s of
 // the traversal belongs to piece s (ascending sweeps) or N - 1 - s (descending); the six previous results it starts from are the

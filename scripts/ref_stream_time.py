@@ -11,8 +11,8 @@ from benchlib.stream import Stream
 
 ctx = Ctx("overlap", 0, 1, 0, False, capi.default_params(), n_cu=torch.cuda.get_device_properties(0).multi_processor_count)
 for depth in [int(a) for a in sys.argv[1:]] or [4]:
-    st = Stream(ctx, 4096, 3, 20240, depth=depth, order=capi.ORDER_REFERENCE)
+    st = Stream(ctx, 4096, int(os.environ.get('CFG', 3)), 20240, depth=depth, order=capi.ORDER_REFERENCE)
     res = st.run(int(os.environ.get('STEPS', 3 * depth)), int(os.environ.get('WARMUP', depth)))
-    print("shape", os.environ.get("DFTPAV_REF_SHAPE", "default"), "depth", depth, "solves/s", round(res["value"]), "ms per step", round(res["ms_per_step"], 1),
+    print("cfg", os.environ.get("CFG", "3"), "shape", os.environ.get("DFTPAV_REF_SHAPE", "default"), "quadm off" if os.environ.get("DFTPAV_REF_QUADM_OFF") else "", "depth", depth, "solves/s", round(res["value"]), "ms per step", round(res["ms_per_step"], 1),
           "to result ms", round(res["to_result_ms"]), flush=True)
     st.close()

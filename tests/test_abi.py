@@ -194,11 +194,19 @@ def test_launch_shapes_of_the_reference_order(hiplib):
     # 8 + 9 pieces in ONE segment do not fit a row of 16 lanes: the WAVE shape, as before
     q = plan([17], [1], 16, 16, 0, 4096)
     assert q["supported"] == 1 and q["wave"] == 1 and q["cap"] == 40
-    # configs[1]: 8 + 8 pieces with a gear shift, n = 33: sums of 40 terms.  Since round 5 that kernel is built for 256 registers too
-    # (kNarrowCap = 40: residency won over a spill-free 414 registers, 450 against 467 ms at 4096); two segments' tables and state
-    # leave room for seven waves in the 160 KB
+    # configs[1]: 8 + 8 pieces with a gear shift, n = 33: sums of 40 terms (the WAVE shape's kernel, built for 256 registers since round 5)
+    # -- in the WAVE shape, which only the hand-over of a batch's last trajectories still uses: a full batch takes the QUAD shape
+    # for several gear segments (solver_ref4m.hip, "wave" = 5): the two segments' pieces side by side on a row's sixteen lanes, the two
+    # segments of eight pieces sharing one copy of the sweep tables, four waves per CU
     q = plan([8, 8], [1, -1], 32, 32, 0, 4096)
-    assert q["supported"] == 1 and q["cap"] == 40 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] == 448 and q["lds"] <= 160 * 1024
+    assert q["supported"] == 1 and q["cap"] == 40 and q["wave"] == 5 and q["threads"] == 64 and q["wg_per_cu"] == 4 and q["slots"] == 512
+    assert q["wg_per_cu"] * q["lds"] <= 160 * 1024 and q["slice"] == 64
+    q = plan([8, 8], [1, -1], 32, 32, 0, 1024)        # up to five per CU: the TEAM shape, as before
+    assert q["supported"] == 1 and q["wave"] == 0
+    q = plan([5, 4, 6], [1, -1, 1], 16, 16, 0, 4096)  # three segments of unequal length: three tables, workgroups of two waves
+    assert q["supported"] == 1 and q["wave"] == 5 and q["threads"] * q["wg_per_cu"] == 256 and q["wg_per_cu"] * q["lds"] <= 160 * 1024
+    q = plan([5, 4, 6], [1, -1, 1], 16, 16, 3, 4096)  # with moving obstacles: the WAVE shape
+    assert q["supported"] == 1 and q["wave"] == 1
     # 48 terms and more: the wide kernels, four waves per CU
     q = plan([11, 12], [1, -1], 16, 16, 0, 4096)
     assert q["supported"] == 1 and q["cap"] == 48 and q["wave"] == 1 and q["threads"] * q["wg_per_cu"] <= 256

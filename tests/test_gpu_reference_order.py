@@ -382,6 +382,62 @@ def test_quad_shape_is_what_a_full_batch_takes_and_equals_the_other_shapes(hipli
     h.close()
 
 
+@pytest.mark.parametrize("case,B,slots,slice_", [("cfg2", 24, 0, 0), ("cfg2", 37, 3, 2), ("5-4-6", 21, 2, 5), ("3-2-4-3", 18, 1, 64), ("2-2", 9, 0, 0),
+                                                 ("8-8-mem40", 13, 1, 7)])
+def test_quad_shape_with_gear_shifts_is_bit_identical(hiplib, oracle, monkeypatch, case, B, slots, slice_):
+    """The QUAD shape for several gear segments (solver_ref4m.hip): the pieces of up to four segments side by side on a row's sixteen
+    lanes, the junction position / angle variables and their gradients, vectors of up to 48 variables in three registers per lane.
+    BASELINE configs[1] (8 + 8 pieces, forward + reverse, n = 33) and layouts of three and four segments of unequal length, forced on
+    small batches: every evaluation and every field of every solve equal to the restatement with correctly rounded cos / sin (oracle
+    order 2), from rows of their own and through the ring with slices of 2 / 5 / 7 / 64 evaluations, with and without the hand-over of
+    the last trajectories to the WAVE shape; the plan says which kernel ran."""
+    p = hiplib.default_params()
+    if case == "cfg2":
+        s = sc.baseline_config(2, B=B)
+    else:
+        pieces = [int(t) for t in case.split("-")[:-1]] if case.endswith("mem40") else [int(t) for t in case.split("-")]
+        sing = [1 if i % 2 == 0 else -1 for i in range(len(pieces))]
+        s = sc.make_scenario(pieces, sing, 9, 14, B, seed=4242 + len(pieces), n_obs=30)
+        if case.endswith("mem40"):
+            p.lbfgs_mem_size = 40
+    s.apply_resolution(p)
+    want = oracle.solve_batch(p, s, nthreads=8, order=2)
+    keys = ("final_cost", "x", "status", "iters", "evals", "hist_sum", "success")
+    monkeypatch.setenv("DFTPAV_REF_SHAPE", "quad")
+    if slots:
+        monkeypatch.setenv("DFTPAV_REF_SLOTS", str(slots))
+        monkeypatch.setenv("DFTPAV_REF_SLICE", str(slice_))
+    h = hiplib.Handle(p)
+    bt = hiplib.Batch(h, s.layout, s.B)
+    bt.upload(s)
+    bt.set_order(hiplib.ORDER_REFERENCE)
+    import ctypes as C
+    fn = hiplib.lib().dftpav_debug_reference_plan
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    out = (C.c_longlong * 8)()
+    assert fn(C.byref(s.layout.c_struct()), C.byref(p), 0, s.B, 256, out) == 0
+    assert int(out[1]) == 5, "the plan did not pick the QUAD shape for several segments"
+    rng = np.random.default_rng(4)
+    for x in (bt.x0(), bt.x0() + rng.normal(0, 0.2, bt.x0().shape), bt.x0() + rng.normal(0, 0.7, bt.x0().shape)):
+        f, g = bt.eval(x)
+        for b in range(0, s.B, 3):
+            fo, go = oracle.OracleProblem(p, s, b, order=2).eval(x[b])
+            assert f[b] == fo and np.array_equal(g[b], go), (case, b)
+    for rep in range(3):
+        bt.set_hand_over(0 if rep == 2 else -1)
+        r = bt.solve()
+        for k in keys:
+            assert np.array_equal(r[k], want[k]), (case, slots, rep, k)
+    bt.set_hand_over(-1)
+    c, dt = bt.coeffs()
+    lp = oracle.OracleProblem(p, s, s.B - 1, order=2)
+    lp.eval(r["x"][s.B - 1])
+    co, dto = lp.coeffs()
+    assert np.array_equal(c[s.B - 1], co) and np.array_equal(dt[s.B - 1], dto)
+    bt.close()
+    h.close()
+
+
 @pytest.mark.parametrize("shape", ["team", "wave", "quad"])
 def test_recursion_with_true_divisions_gives_the_same_bits(hiplib, oracle, monkeypatch, shape):
     """The two-loop recursion divides by the stored y . s of a pair through its stored reciprocal (Markstein's correctly rounded
