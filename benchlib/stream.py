@@ -52,7 +52,7 @@ class Stream:
             if order is not None:   # capi.ORDER_REFERENCE: the same stream of cycles in the reference's floating-point order
                 b_.set_order(order)
             if self.c.schedule == "overlap":
-                b_.set_hand_over(0)
+                b_.set_hand_over(int(os.environ.get("DFTPAV_STREAM_HAND_OVER", "0")))   # (developer knob; 0: other batches follow on other streams)
             self.bts.append(b_)
         self.rec_dev = [torch.zeros((self.shard.B, dd.RECORD_BYTES), dtype=torch.uint8, device=common.DEV) for _ in range(D)]
         # the collective: RCCL behind the C-ABI (dftpav_comm_create / dftpav_batch_allgather_results, one communicator per

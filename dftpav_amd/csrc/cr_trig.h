@@ -201,8 +201,28 @@ DFTPAV_HD inline dd cos_dd(dd r) {
   return dd_add_d(dd_neg(dd_mul(acc, r2)), 1.0);
 }
 
-// correctly rounded sin x and cos x
-DFTPAV_HD inline void sincos(double x, double &s, double &c) {
+// Ziv's rounding test (used by every two-phase function below).  e (normalised) approximates a value v to within rel |e.hi|: when
+// e.hi + (e.lo - d) and e.hi + (e.lo + d), d = rel |e.hi|, round to the same double, every number between them does (rounding is
+// monotonic), v among them: that double IS v correctly rounded.  (The two inner sums are themselves rounded, by at most 2^-106 |e.hi|:
+// the callers' rel leaves a factor of four for it.)
+DFTPAV_HD inline bool round_if_certain(dd e, double rel, double &out) {
+  const double d = rel * (e.hi < 0.0 ? -e.hi : e.hi);
+  const double a = e.hi + (e.lo - d), b = e.hi + (e.lo + d);
+  out = a;
+  return a == b;
+}
+
+// correctly rounded sin x and cos x, in two phases (Ziv) since round 6 -- the junction angles of a gear-shift trajectory cost one call per
+// evaluation, on one lane while its wave waits:
+//   quick     w = r^2 in double-double; sin r = r (1 + w (-1/3! + w (1/5! + w (-1/7! + w Ts)))), cos r = 1 + w (-1/2! + w (1/4! + w (-1/6!
+//             + w Tc))) with the three leading coefficients and the Horner steps in double-double and the tails Ts = 1/9! - w/11! + ...
+//             - w^5/19!, Tc = 1/8! - w/10! + ... + w^6/20! in plain fp64 (|r| <= 0.786, w <= 0.617: w^4 Ts <= 2^-21 of sin r, w^4 Tc <= 2^-18
+//             of cos r >= 0.707; a few ulp of them, the neglected w.lo, the series' remainders r^21/21!, r^22/22!: below 2^-68 relative);
+//             the rounding test asks for 2^-64 of each of the two.  About one angle in 500 fails one of them and takes
+//   accurate  the Taylor series of both in double-double to ~2^-100 (all there was until round 6).
+// Both return the correctly rounded values (tests/test_cr_trig.py: against binary128; scripts/cr_quick_check.cpp: against each other).
+template <bool QUICK>
+DFTPAV_HD inline void sincos_impl(double x, double &s, double &c) {
   if (x == 0.0) { // sin keeps the sign of zero
     s = x;
     c = 1.0;
@@ -214,15 +234,48 @@ DFTPAV_HD inline void sincos(double x, double &s, double &c) {
   }
   dd r;
   const int k = (x < 0.0 ? -x : x) < 0x1.0p+20 ? reduce(x, r) : reduce_large(x, r);
-  const dd sr = sin_dd(r), cr = cos_dd(r);
+  double sq = 0.0, cq = 0.0;
+  bool quick = false;
+  if (QUICK) {
+    const dd w = dd_mul(r, r);
+    const double wh = w.hi;
+    double Ts = -0x1.2f49b46814157p-57;              // -1 / 19!
+    Ts = __builtin_fma(Ts, wh, 0x1.952c77030ad4ap-49);  //  1 / 17!
+    Ts = __builtin_fma(Ts, wh, -0x1.ae7f3e733b81fp-41); // -1 / 15!
+    Ts = __builtin_fma(Ts, wh, 0x1.6124613a86d09p-33);  //  1 / 13!
+    Ts = __builtin_fma(Ts, wh, -0x1.ae64567f544e4p-26); // -1 / 11!
+    Ts = __builtin_fma(Ts, wh, 0x1.71de3a556c734p-19);  //  1 / 9!
+    double Tq = 0x1.e542ba4020225p-62;               //  1 / 20!
+    Tq = __builtin_fma(Tq, wh, -0x1.6827863b97d97p-53); // -1 / 18!
+    Tq = __builtin_fma(Tq, wh, 0x1.ae7f3e733b81fp-45);  //  1 / 16!
+    Tq = __builtin_fma(Tq, wh, -0x1.93974a8c07c9dp-37); // -1 / 14!
+    Tq = __builtin_fma(Tq, wh, 0x1.1eed8eff8d898p-29);  //  1 / 12!
+    Tq = __builtin_fma(Tq, wh, -0x1.27e4fb7789f5cp-22); // -1 / 10!
+    Tq = __builtin_fma(Tq, wh, 0x1.a01a01a01a01ap-16);  //  1 / 8!
+    dd a = dd_add_d(dd_neg(inv_fact(7)), wh * Ts);          // -1/7! + w Ts
+    a = dd_add(inv_fact(5), dd_mul(a, w));                  //  1/5! + w (...)
+    a = dd_add(dd_neg(inv_fact(3)), dd_mul(a, w));          // -1/3! + w (...)
+    const dd sr = dd_add(r, dd_mul(dd_mul(a, w), r));       // r + r w (...)
+    dd b = dd_add_d(dd_neg(inv_fact(6)), wh * Tq);          // -1/6! + w Tc
+    b = dd_add(inv_fact(4), dd_mul(b, w));                  //  1/4! + w (...)
+    b = dd_add(dd_neg(inv_fact(2)), dd_mul(b, w));          // -1/2! + w (...)
+    const dd cr = dd_add_d(dd_mul(b, w), 1.0);              // 1 + w (...)
+    quick = round_if_certain(sr, DFTPAV_CR_QUICK_REL, sq);
+    quick = round_if_certain(cr, DFTPAV_CR_QUICK_REL, cq) && quick;
+    if (!quick) DFTPAV_CR_FALLBACK(2);
+  }
+  if (!quick) {
+    sq = sin_dd(r).hi;
+    cq = cos_dd(r).hi;
+  }
   switch (k & 3) {
-    case 0: s = sr.hi; c = cr.hi; break;
-    case 1: s = cr.hi; c = -sr.hi; break;
-    case 2: s = -sr.hi; c = -cr.hi; break;
-    default: s = -cr.hi; c = sr.hi; break;
+    case 0: s = sq; c = cq; break;
+    case 1: s = cq; c = -sq; break;
+    case 2: s = -sq; c = -cq; break;
+    default: s = -cq; c = sq; break;
   }
 }
-
+DFTPAV_HD inline void sincos(double x, double &s, double &c) { sincos_impl<true>(x, s, c); }
 
 // ---------------------------------------------------------------- exp, log, x^3 (the moving-obstacle term of the reference:
 // 40 exponentials and 9 logarithms per (constraint point, obstacle) pair, traj_optimizer.cpp:1686-1707; pow(|v|, 3) in
@@ -247,16 +300,6 @@ DFTPAV_HD inline double scale2(double v, int k) { // v 2^k, in two steps so that
   a.u = (unsigned long long)(1023 + k1) << 52;
   b.u = (unsigned long long)(1023 + k2) << 52;
   return (v * a.d) * b.d;
-}
-// Ziv's rounding test.  e (normalised) approximates a value v to within rel |e.hi|: when e.hi + (e.lo - d) and e.hi + (e.lo + d),
-// d = rel |e.hi|, round to the same double, every number between them does (rounding is monotonic), v among them: that double IS v
-// correctly rounded.  (The two inner sums are themselves rounded, by at most 2^-106 |e.hi|: the callers' rel leaves a factor of
-// four for it.)
-DFTPAV_HD inline bool round_if_certain(dd e, double rel, double &out) {
-  const double d = rel * (e.hi < 0.0 ? -e.hi : e.hi);
-  const double a = e.hi + (e.lo - d), b = e.hi + (e.lo + d);
-  out = a;
-  return a == b;
 }
 // exp x: x = k ln2 + r (ln2 in three 33-bit chunks and a tail), then two phases (Ziv):
 //   quick     s = r / 32 (|s| <= 0.0109): exp s = 1 + s + s^2 / 2 in double-double + s^3 (1/6 + s/24 + ... + s^5 / 8!) in plain fp64

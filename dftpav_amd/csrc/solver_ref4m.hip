@@ -1167,6 +1167,13 @@ void reference_order_quadm_plan(const DevLayout &L, const DevParams &P, int B, i
       best_wg = wg;
     }
   }
+  if (const char *e = std::getenv("DFTPAV_REF_QUAD_WAVES")) { // developer knob: waves per workgroup
+    const int w = std::atoi(e);
+    if (w >= 1 && w <= 4 && shared + (size_t)w * 4 * team <= budget) {
+      best_w = w;
+      best_wg = (int)std::min<size_t>((size_t)(4 / w), budget / (shared + (size_t)w * 4 * team));
+    }
+  }
   pl.quad = 2;
   pl.wave = 1;
   pl.threads = 64 * best_w;

@@ -120,9 +120,9 @@ def test_cr_exp_log_cube_equal_binary128_rounded(hiplib):
 
 
 def test_quick_phases_never_disagree_with_the_accurate_ones(tmp_path):
-    """scripts/cr_quick_check.cpp (the header compiled for the host, OpenMP): exp / log through their quick phase + rounding test
-    against the double-double series alone on 2M random arguments per range -- no mismatch, and the quick phase hands over for
-    about one argument in 1 400 (a test that never hands over would not be a test)."""
+    """scripts/cr_quick_check.cpp (the header compiled for the host, OpenMP): exp / log / sincos through their quick phase + rounding
+    test against the double-double series alone on 2M random arguments per range -- no mismatch, and the quick phase hands over for
+    about one argument in 1 400 (exp, log) / 640 (sincos: two roundings) -- a test that never hands over would not be a test."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "cr_quick_check")
     subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "dftpav_amd", "csrc"),
@@ -130,11 +130,13 @@ def test_quick_phases_never_disagree_with_the_accurate_ones(tmp_path):
     out = subprocess.run([exe, "2000000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout
     lines = [ln for ln in out.stdout.splitlines() if "arguments" in ln]
-    assert len(lines) == 7
+    assert len(lines) == 12
     for ln in lines:
         assert " 0 mismatches" in ln, ln
         handed = int(ln.split("handed over")[1].split()[0])
-        if "e^[" not in ln:   # (the logarithm of a correctly rounded exponential sits next to a double: its rounding is never in doubt)
+        if ln.startswith("sin / cos"):
+            assert 2000000 / 1300 < handed < 2000000 / 300, ln
+        elif "e^[" not in ln:   # (the logarithm of a correctly rounded exponential sits next to a double: its rounding is never in doubt)
             assert 2000000 / 3000 < handed < 2000000 / 700, ln
 
 
