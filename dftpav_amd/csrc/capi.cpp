@@ -149,6 +149,7 @@ struct dftpav_batch {
   int *d_status = nullptr, *d_success = nullptr, *d_iters = nullptr, *d_evals = nullptr;
   long long *d_hist = nullptr, *d_ticks = nullptr, *d_prof = nullptr;
   unsigned char *d_records = nullptr; // [B + 1][16] result records written by the solver's epilogue (+ one zero record of padding)
+  unsigned char *h_records = nullptr; // [B][16] the same in pinned host memory, written by the epilogues too (DevBatch::records_host)
   DevBatch *d_dev = nullptr; // device copy of the launch descriptor
   int dev_version = -1;
   // pinned host staging of the two descriptors and the event behind their last copy: refreshing the device copies then
@@ -909,6 +910,7 @@ extern "C" void dftpav_batch_destroy(dftpav_batch *b) {
   }
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (b->h_records) (void)hipHostFree(b->h_records);
   for (int w = 0; w < 2; w++)
     for (int t = 0; t < 5; t++)
       if (b->d_e4[w][t]) (void)hipFree(b->d_e4[w][t]);
@@ -1139,6 +1141,13 @@ static int batch_create_impl(dftpav_handle *h, const dftpav_layout *layout, int 
   BCHK(hipMalloc(&b->d_prof, sizeof(long long) * (size_t)B * 12));
   BCHK(hipMalloc(&b->d_records, (size_t)16 * (B + 1)));
   BCHK(hipMemset(b->d_records, 0, (size_t)16 * (B + 1)));
+  // (pinned host memory the kernels can write; without it dftpav_batch_records copies from the device)
+  if (std::getenv("DFTPAV_RECORDS_ON_HOST_OFF") == nullptr && hipHostMalloc(reinterpret_cast<void **>(&b->h_records), (size_t)16 * B, hipHostMallocDefault) == hipSuccess) {
+    std::memset(b->h_records, 0, (size_t)16 * B);
+  } else {
+    (void)hipGetLastError();
+    b->h_records = nullptr;
+  }
   BCHK(hipMalloc(&b->d_dev, sizeof(DevBatch)));
   BCHK(hipMalloc(&b->d_dev2, sizeof(DevBatch)));
   if (b->sched) {
@@ -1391,6 +1400,7 @@ static DevBatch make_dev(dftpav_batch *b) {
   D.hist_sum = b->d_hist;
   D.ticks = b->d_ticks;
   D.records = b->d_records;
+  D.records_host = b->h_records;
   D.prof = b->prof_on ? b->d_prof : nullptr;
   D.coef_out = b->d_coef;
   D.dt_out = b->d_dt;
@@ -2134,13 +2144,21 @@ extern "C" int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst) {
   return DFTPAV_OK;
 }
 
-// The 16-byte records of the last solve on the host: waits for the solve, then one device-to-host copy (a DMA engine: no
-// workgroup slot is needed, so delivery does not queue behind another stream's persistent workgroups)
+// The 16-byte records of the last solve on the host: waits for the solve; no work on the device behind it
 extern "C" int dftpav_batch_records(dftpav_batch *b, void *host_dst) {
   if (!b || !host_dst || !b->solved) return DFTPAV_E_INVALID;
   dftpav_handle *h = b->h;
   if (int rc = finish_pending(b)) return rc;
   HIPCHK(h, hipSetDevice(h->device));
+  // The epilogues wrote every record a second time into pinned host memory of the batch (DevBatch::records_host): when the stream has
+  // drained they are there.  (A copy from the device -- to pageable or to pinned memory -- is a blit KERNEL of the runtime,
+  // __amd_rocclr_copyBuffer in a kernel trace; in a stream of batches it queued for a CU behind the other streams' persistent waves and was
+  // seen to take 240-300 ms per delivery on configs[1], the host's loop with it: round 6.)
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (b->h_records) {
+    std::memcpy(host_dst, b->h_records, (size_t)16 * b->B);
+    return DFTPAV_OK;
+  }
   HIPCHK(h, hipMemcpyAsync(host_dst, b->d_records, (size_t)16 * b->B, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFTPAV_OK;

@@ -150,6 +150,10 @@ struct DevBatch {
   // [B + 1] 16-byte result records {f64 final cost, i32 status, i32 iterations} (what the all-gather carries),
   // written by the solver's epilogue when a trajectory finishes -- no packing kernel between the solve and the collective
   unsigned char *records;
+  // the same records once more in PINNED HOST memory (or nullptr): a single-GPU caller reads them there after the solve without a copy on
+  // the device -- the runtime's device-to-host copy of 64 KB is a blit kernel, and in a stream of batches a kernel of several waves queues for
+  // a CU behind the other streams' persistent waves (capi.cpp: dftpav_batch_records)
+  unsigned char *records_host;
   long long *ticks; // per-trajectory solve time in wall_clock64 ticks (100 MHz)
   long long *prof;  // optional [B][12] shader-clock phase profile (nullptr = off)
   double *coef_out; // [B][Ntot][6][2]

@@ -2121,6 +2121,13 @@ __global__ void __launch_bounds__(MAXT) solver_kernel(const DevBatch *__restrict
           ri[0] = ret;
           ri[1] = sm.ist[iK];
         }
+        if (Db.records_host != nullptr) { // (see device_types.h)
+          double *rh = reinterpret_cast<double *>(Db.records_host + (size_t)16 * b);
+          rh[0] = fx;
+          int *rj = reinterpret_cast<int *>(rh + 1);
+          rj[0] = ret;
+          rj[1] = sm.ist[iK];
+        }
         Db.ticks[b] = (resume ? Db.ticks[b] : 0) + spent; // time in service
         // flag_success, traj_optimizer.cpp:176-201
         int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0;

@@ -1929,6 +1929,13 @@ __global__ void __launch_bounds__((WAVE && CAP <= kNarrowCap && !SUR) ? 512 : 25
           ri[0] = ret;
           ri[1] = sm.ist[iK];
         }
+        if (D.records_host != nullptr) { // (see device_types.h)
+          double *rh = reinterpret_cast<double *>(D.records_host + (size_t)16 * b);
+          rh[0] = fx;
+          int *rj = reinterpret_cast<int *>(rh + 1);
+          rj[0] = ret;
+          rj[1] = sm.ist[iK];
+        }
         D.ticks[b] = (resume ? D.ticks[b] : 0) + spent; // time in service
         int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
         if (fx >= D.P.fail_cost) ok = 0;

@@ -1089,6 +1089,13 @@ __global__ void __launch_bounds__(256, 1)
               ri[0] = ret;
               ri[1] = q.ist[iK];
             }
+            if (D.records_host != nullptr) { // (see device_types.h)
+              double *rh = reinterpret_cast<double *>(D.records_host + (size_t)16 * b);
+              rh[0] = fx;
+              int *rj = reinterpret_cast<int *>(rh + 1);
+              rj[0] = ret;
+              rj[1] = q.ist[iK];
+            }
             D.ticks[b] = (resumed ? D.ticks[b] : 0) + (wall_clock64() - tick0); // time in service
             int ok = (ret == 0 || ret == 1 || ret == 2 || ret == -1008 || ret == -1009) ? 1 : 0; // traj_optimizer.cpp:176-201
             if (fx >= D.P.fail_cost) ok = 0;

@@ -24,6 +24,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $O/r06_pmc_cfg5_sq -- $C5 > $O/r06_pmc_cfg5_sq.log 2>&1; echo "cfg5 sq rc=$?"
 cd $R
-{ ORDER=ref timeout 600 python scripts/profile_phases.py 3 4096; ORDER=ref DFTPAV_REF_SHAPE=quad timeout 300 python scripts/profile_phases.py 3 8; ORDER=ref timeout 900 python scripts/profile_phases.py 5 1024; } > $O/r06_phases_reference_order.txt 2>&1
+{ ORDER=ref timeout 600 python scripts/profile_phases.py 3 4096; ORDER=ref DFTPAV_REF_SHAPE=quad timeout 300 python scripts/profile_phases.py 3 8; ORDER=ref timeout 600 python scripts/profile_phases.py 2 4096; ORDER=ref timeout 900 python scripts/profile_phases.py 5 1024; for c in 2 3; do CFG=$c timeout 300 python scripts/ref_stream_time.py 2 4 8; CFG=$c timeout 300 python scripts/stream_profile.py 4; done; } > $O/r06_phases_reference_order.txt 2>&1
 timeout 1500 python bench.py --steps 20 --warmup 5 > $O/r06_bench_line.json 2> $O/r06_bench_line.err; echo "bench rc=$?"
 tail -c 400 $O/r06_bench_line.err
