@@ -17,7 +17,7 @@
 #pragma once
 #include "device_types.h"
 
-// (scripts/cr_quick_check.cpp counts how often the quick phases of exp / log hand over to the accurate ones)
+// (scripts/cr_quick_check.cpp counts how often the quick phases of exp / log / sincos hand over to the accurate ones)
 #ifndef DFTPAV_CR_FALLBACK
 #define DFTPAV_CR_FALLBACK(which) ((void)0)
 #endif
@@ -218,7 +218,8 @@ DFTPAV_HD inline bool round_if_certain(dd e, double rel, double &out) {
 //             + w Tc))) with the three leading coefficients and the Horner steps in double-double and the tails Ts = 1/9! - w/11! + ...
 //             - w^5/19!, Tc = 1/8! - w/10! + ... + w^6/20! in plain fp64 (|r| <= 0.786, w <= 0.617: w^4 Ts <= 2^-21 of sin r, w^4 Tc <= 2^-18
 //             of cos r >= 0.707; a few ulp of them, the neglected w.lo, the series' remainders r^21/21!, r^22/22!: below 2^-68 relative);
-//             the rounding test asks for 2^-64 of each of the two.  About one angle in 500 fails one of them and takes
+//             the rounding test asks for 2^-64 of each of the two (built with 2^-72 the first wrong roundings appear in 5e8 arguments, with
+//             2^-70 none: scripts/cr_quick_check.cpp).  One angle in 640 fails one of the two tests and takes
 //   accurate  the Taylor series of both in double-double to ~2^-100 (all there was until round 6).
 // Both return the correctly rounded values (tests/test_cr_trig.py: against binary128; scripts/cr_quick_check.cpp: against each other).
 template <bool QUICK>

@@ -1190,7 +1190,7 @@ void reference_order_quadm_plan(const DevLayout &L, const DevParams &P, int B, i
   pl.slots = std::max(1, std::min(n_cu * best_wg, (B + 2 * per_wg - 1) / (2 * per_wg)));
   pl.slice = 64;
   pl.slots_wide = n_cu * best_wg;
-  pl.hand = 768;
+  pl.hand = 2048; // (a batch alone on the device, configs[1] at 4096: 401 ms with the hand-over at 768 unfinished trajectories, 386 at 1280, 373-390 at 2048)
   if (const char *e = std::getenv("DFTPAV_REF_QUAD_HANDOVER")) pl.hand = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("DFTPAV_REF_SLICE")) pl.slice = std::atoi(e);
   if (const char *e = std::getenv("DFTPAV_REF_SLOTS")) pl.slots = pl.slots_wide = std::max(1, std::atoi(e));

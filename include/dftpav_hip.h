@@ -320,8 +320,10 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *   Launch shape by batch size (or by the residency hint of dftpav_batch_create_shaped: 2 = many batches in flight): up to five
  *   trajectories per CU one workgroup each (lowest latency); beyond, one gear segment of <= 16 pieces and n <= 32 without moving
  *   obstacles -- BASELINE configs[2] / [3] -- takes the QUAD shape (solver_ref4.hip): FOUR trajectories per wave, one per row of
- *   16 lanes, a piece per lane, 16 trajectories per CU, the rows popping trajectories from the batch's ring (31-32 k solves/s on a
- *   stream of 4096-batches on MI355X); everything else one WAVE per trajectory, eight per CU (solver_ref.hip).  A batch that has
+ *   16 lanes, a piece per lane, 16 trajectories per CU, the rows popping trajectories from the batch's ring (32-33 k solves/s on a
+ *   stream of 4096-batches on MI355X); up to four gear segments of <= 16 pieces in all and n <= 48 without moving obstacles -- BASELINE
+ *   configs[1], the reference's live layouts -- the same shape with the segments' pieces side by side on a row (solver_ref4m.hip;
+ *   24-25 k solves/s on such a stream); everything else one WAVE per trajectory, eight per CU (solver_ref.hip).  A batch that has
  *   the device to itself (the default; dftpav_batch_set_hand_over(b, 0) announces others behind it) takes every wave slot and
  *   hands its last trajectories to the WAVE shape.  Every shape returns the same bits. */
 #define DFTPAV_ORDER_DEVICE 0
@@ -423,7 +425,9 @@ int dftpav_batch_set_hand_over(dftpav_batch *b, int hand_over);
  * finishes; there is no packing kernel between the solve and the collective (it used to wait up to 110 ms for a workgroup
  * slot behind the other stream's persistent workgroups).
  *   dftpav_batch_pack_results: copies the records into caller-owned DEVICE memory, asynchronously on the handle's stream.
- *   dftpav_batch_records:      waits for the solve and copies them to HOST memory [B][16] (a DMA copy, no kernel). */
+ *   dftpav_batch_records:      waits for the solve and hands them over in HOST memory [B][16]: the epilogues write every record a
+ *                              second time into pinned host memory of the batch, so nothing runs on the device behind the solve (the
+ *                              runtime's device-to-host copy is a blit kernel that queues behind other streams' persistent waves). */
 int dftpav_batch_pack_results(dftpav_batch *b, void *device_dst);
 int dftpav_batch_records(dftpav_batch *b, void *host_dst);
 
