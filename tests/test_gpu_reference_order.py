@@ -383,11 +383,12 @@ def test_quad_shape_is_what_a_full_batch_takes_and_equals_the_other_shapes(hipli
 
 
 @pytest.mark.parametrize("case,B,slots,slice_", [("cfg2", 24, 0, 0), ("cfg2", 37, 3, 2), ("5-4-6", 21, 2, 5), ("3-2-4-3", 18, 1, 64), ("2-2", 9, 0, 0),
-                                                 ("8-8-mem40", 13, 1, 7)])
+                                                 ("8-8-mem40", 13, 1, 7), ("6-5-5", 10, 2, 9), ("4-4-4-4", 7, 1, 33)])
 def test_quad_shape_with_gear_shifts_is_bit_identical(hiplib, oracle, monkeypatch, case, B, slots, slice_):
     """The QUAD shape for several gear segments (solver_ref4m.hip): the pieces of up to four segments side by side on a row's sixteen
     lanes, the junction position / angle variables and their gradients, vectors of up to 48 variables in three registers per lane.
-    BASELINE configs[1] (8 + 8 pieces, forward + reverse, n = 33) and layouts of three and four segments of unequal length, forced on
+    BASELINE configs[1] (8 + 8 pieces, forward + reverse, n = 33), layouts of three and four segments of unequal length and two with 35 / 37
+    variables (the third register of a vector holds more than one element: the 48-step chain), forced on
     small batches: every evaluation and every field of every solve equal to the restatement with correctly rounded cos / sin (oracle
     order 2), from rows of their own and through the ring with slices of 2 / 5 / 7 / 64 evaluations, with and without the hand-over of
     the last trajectories to the WAVE shape; the plan says which kernel ran."""
