@@ -39,6 +39,37 @@ def counters(dirs, names):
 
 
 cmd = open(os.path.join(G, "r06_profile_command.txt")).read().strip() if os.path.exists(os.path.join(G, "r06_profile_command.txt")) else ""
+def dispatch_union():
+    """the profiled bench command's timed region in its kernel trace: union of the dispatch intervals of the solve kernels launched by the 4 timed
+    steps (the launches of a stream overlap: their average duration is not a per-batch time) / 4, beside that run's own ms_per_step"""
+    f = newest(os.path.join(G, "r06_prof", "*", "*_kernel_trace.csv"))
+    if not f:
+        return None
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))
+            if "ref4_kernel" in r["Kernel_Name"] or "ref_kernel" in r["Kernel_Name"]]
+    rows.sort()
+    quad = [r for r in rows if "ref4_kernel" in r[2]]
+    if len(quad) < 5:
+        return None
+    t_first = quad[-4][0]                      # 1 warm-up step (a batch alone), then 4 timed steps
+    timed = sorted((a, b) for a, b, _ in rows if a >= t_first)
+    total, cur_a, cur_b = 0, timed[0][0], timed[0][1]
+    for a, b in timed[1:]:
+        if a > cur_b:
+            total += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    total += cur_b - cur_a
+    out = {"dispatch_union_ms_per_batch": total / 4 / 1e6, "launches_in_the_timed_region": len(timed)}
+    log = os.path.join(G, "r06_prof.log")
+    if os.path.exists(log):
+        lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
+        if lines:
+            out["ms_per_step_of_that_run_by_its_own_clock"] = json.loads(lines[-1])["ms_per_step"]
+    return out
+
+
 c = counters(["r06_pmc_fetch", "r06_pmc_write", "r06_pmc_sq1", "r06_pmc_sq2"], ("ref4_kernel", "ref_kernel"))
 B = 4096
 if c:
@@ -57,6 +88,11 @@ if c:
                      "lds_instructions_per_solve": c["SQ_INSTS_LDS"]["per_batch"] / B, "vmem_reads_per_solve": c["SQ_INSTS_VMEM_RD"]["per_batch"] / B}}
     json.dump(j, open(os.path.join(P, "r06_pmc.json"), "w"), indent=1)
     json.dump(j, open(os.path.join(P, "pmc_latest.json"), "w"), indent=1)
+    du = dispatch_union()
+    if du:
+        j["kernel_trace_of_the_same_command"] = du
+        json.dump(j, open(os.path.join(P, "r06_pmc.json"), "w"), indent=1)
+        print("r06_pmc.json: kernel trace", du)
     print("r06_pmc.json: traffic %.1f GB corrected / %.1f raw, %.2f M VALU per solve, VALU active %.2f, waiting %.2f" % (
         j["hbm_bytes_per_launch"] / 1e9, j["hbm_bytes_per_launch_uncorrected"] / 1e9, j["valu_instructions_per_solve"] / 1e6,
         j["derived"]["valu_active_fraction_of_wave_cycles"], j["derived"]["waiting_fraction_of_wave_cycles"]))
