@@ -270,11 +270,17 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
     if (piece && j <= Kl)
       m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
     s1 += step; // the running sum of traj_optimizer.cpp:513
-    if (D.prof != nullptr) { // (profiling only) trips of the loop below for the wave: the longest list of active terms among its 64 points
+    [[maybe_unused]] long long emit_t0 = 0;
+    if (D.prof != nullptr) { // (profiling only) trips of the loop below for the wave: the longest list of active terms among its 64 points;
+      // DFTPAV_PROF_EMIT_CYCLES (a build flag): the cycles of that loop instead -- the clock behind it is read when the wave has reconverged
+#ifdef DFTPAV_PROF_EMIT_CYCLES
+      emit_t0 = clock64();
+#else
       const int pc = __builtin_popcount(m);
       int trips = 0;
       while (__builtin_amdgcn_ballot_w64(pc > trips) != 0ull) trips++;
       pr.count(11, trips);
+#endif
     }
     for (unsigned mm = m; mm;) {
       const int t = __builtin_ctz(mm);
@@ -310,6 +316,9 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
       }
       cnt++;
     }
+#ifdef DFTPAV_PROF_EMIT_CYCLES
+    if (D.prof != nullptr) pr.count(11, clock64() - emit_t0);
+#endif
 #pragma unroll
     for (int u = 0; u < 20; u++) pl[u] = nx[u];
   }
