@@ -44,7 +44,28 @@
 namespace dftpav {
 namespace reford {
 
-constexpr int kQLcap = 8; // parked terms of a piece kept in LDS (the rest in global scratch)
+constexpr int kQLcap = 7; // parked terms of a piece kept in LDS (the rest in global scratch)
+// DENSE emission (round 6): the active terms the lanes of a wave find in the point loop are listed -- (owner lane, point, term, the
+// point's running offset s1, the half-plane of a corridor term) -- and evaluated kDense at a time, one per lane, by whichever lanes
+// the list numbers: the owner's coefficients come over by ds_bpermute, the point's state is formed again by the same expressions
+// (the same bits), what the term adds goes back through LDS and the owner adds its terms in list order = (point, term) order.  In
+// place, a lane with k active terms ran k trips of the emission while the other 63 waited: 26-29 trips of ~2.2 k cycles per evaluation
+// of four trajectories with three lanes active on average (55-65 k cycles, 15 % of a pass).
+constexpr int kDense = 24;
+struct DenseLds {
+  ldsi_t id;   // [kDense] owner lane | term << 6 | point << 12
+  ldsd_t s1;   // [kDense]
+  ldsd_t pl;   // [kDense][4] the half-plane of a corridor term
+  ldsd_t out;  // [kDense][15] gdC (12), gdT, corridor cost, feasibility cost
+};
+__host__ __device__ inline size_t q4_dense_bytes() { return ((size_t)kDense * (4 + 8 + 32 + 120) + 15) & ~(size_t)15; }
+__device__ inline void q4_carve_dense(DenseLds &d, char *base) {
+  ldsd_t p = (ldsd_t)reinterpret_cast<double *>(base);
+  d.s1 = p; p += kDense;
+  d.pl = p; p += 4 * kDense;
+  d.out = p; p += 15 * kDense;
+  d.id = (ldsi_t)p;
+}
 // Waves per SIMD the kernel is built for.  At 2 (256 registers) it spills 205 of them and its scratch traffic alone is HBM-sized
 // (measured: the point loop 3 x slower than at 1); at 1 the allocator takes 455 registers, nothing goes to scratch, and four waves
 // per CU hold 16 trajectories -- twice the WAVE shape's 8 -- each of them at the speed of a wave that has its SIMD to itself.
@@ -178,8 +199,8 @@ __device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int
 // trajectory's global scratch for the parked terms beyond the LDS window.
 // FAST: the live path's constants known at compile time -- H = 4 half-planes per point (rectangles, traj_manager.cpp:1225) and
 // help_eps = 0.0 (:610): the fifth plane slot and the second reciprocal of the curvature term drop out of the point loop.
-template <bool FAST>
-__device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_t tab, gcd_t cor, size_t cpitch, gd_t ovf, int l, Prof &pr) {
+template <bool FAST, bool DENSE>
+__device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, const DenseLds &dl, ldscd_t tab, gcd_t cor, size_t cpitch, gd_t ovf, int l, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
   const int N = L.Ntot, H = FAST ? 4 : L.H, nterm = 5 * H + 4, t0 = 5 * H;
@@ -261,14 +282,101 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
   // loads, whatever its piece): 33 rounds of a dependent HBM round trip each were 3/4 of this kernel's time
   double pl[20];
   load_planes(cor, cpitch, H, pl);
+  // what an active term adds: to the lane's gdC in place, to gdT and to its cost parked (the other cost gets -0.0: x + (-0.0) == x)
+  auto take = [&](const double (&r12)[12], double e0, double e1, double e2) {
+#pragma unroll
+    for (int u = 0; u < 12; u++) gdC[u] += r12[u];
+    if (cnt < kQLcap) {
+      ldsd_t e = q.tl + (l * kQLcap + cnt) * 3;
+      e[0] = e0;
+      e[1] = e1;
+      e[2] = e2;
+    } else {
+      gd_t e = ovf_l + (size_t)cnt * 3;
+      e[0] = e0;
+      e[1] = e1;
+      e[2] = e2;
+    }
+    cnt++;
+  };
+  // DENSE: the list of the wave
+  const int lane64 = (int)(threadIdx.x & 63);
+  int listed = 0;       // (uniform) entries in the list
+  unsigned mine = 0u;   // the list's slots that hold terms of this lane's piece
+  // (the rows of a wave that have no trajectory are not here: EXEC holds whole rows of 16 lanes, any of the four)
+  const unsigned long long here = __builtin_amdgcn_ballot_w64(true);
+  const int row_here[4] = {(int)(here & 1ull), (int)((here >> 16) & 1ull), (int)((here >> 32) & 1ull), (int)((here >> 48) & 1ull)};
+  const int my_row = lane64 >> 4;
+  const int rank = ((my_row > 0 ? row_here[0] : 0) + (my_row > 1 ? row_here[1] : 0) + (my_row > 2 ? row_here[2] : 0)) * 16 + l; // among the lanes here
+  const int n_here = 16 * (row_here[0] + row_here[1] + row_here[2] + row_here[3]);
+  // inclusive prefix sum of c over the lanes that are here, and its total (wave_incl_scan_i32 wants all 64 lanes)
+  auto scan_here = [&](int c, int &total) {
+    int v = c;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    const int t0_ = row_here[0] ? __builtin_amdgcn_readlane(v, 15) : 0, t1_ = row_here[1] ? __builtin_amdgcn_readlane(v, 31) : 0;
+    const int t2_ = row_here[2] ? __builtin_amdgcn_readlane(v, 47) : 0, t3_ = row_here[3] ? __builtin_amdgcn_readlane(v, 63) : 0;
+    total = t0_ + t1_ + t2_ + t3_;
+    return v + (my_row > 0 ? t0_ : 0) + (my_row > 1 ? t1_ : 0) + (my_row > 2 ? t2_ : 0);
+  };
+  auto flush = [&]() {
+    for (int first = 0; first < listed; first += n_here) { // (uniform; one pass unless a single row is here and the list is longer than 16)
+    const int slot = first + rank;
+    const bool work = slot < listed;
+    const int id = dl.id[work ? slot : 0];
+    const int o = id & 63, t = (id >> 6) & 63, jo = id >> 12;
+    // the owner's piece: its coefficients and the piece duration of its row come over from the owner's registers
+    double cco[12];
+#pragma unroll
+    for (int u = 0; u < 12; u++) cco[u] = __shfl(cc[u], o);
+    const double t1o = __shfl(t1, o);
+    const int lo = o & 15;
+    const int Ko = (lo == 0 || lo == N - 1) ? L.Kd : L.K;
+    const double stepo = t1o / Ko; // (the owner's expression: the same bits)
+    if (work) {
+      const double nopl[20] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      PtState ps;
+      // the state of the owner's point by the expressions that found the term (its tests are not needed again: no half-planes)
+      (void)point_masks<false>(P, cco, lo, N, jo, Ko, stepo, dl.s1[slot], singul_, epis, H, nopl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, ps);
+      double r_[16];
+      const ldscd_t pk = dl.pl + 4 * slot;
+      point_emit_pf(P, ps, t, H, t0, [&](int, double &on0, double &on1, double &q0, double &q1) { on0 = pk[0]; on1 = pk[1]; q0 = pk[2]; q1 = pk[3]; },
+                    (double *)r_);
+      const bool corr = t < t0;
+      ldsd_t w = dl.out + 15 * slot;
+#pragma unroll
+      for (int u = 0; u < 13; u++) w[u] = r_[u];
+      w[13] = corr ? r_[13] : -0.0;
+      w[14] = corr ? -0.0 : r_[13];
+    }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (unsigned mm = mine; mm;) { // the owner adds its terms in list order: (point, term) order
+      const int i = __builtin_ctz(mm);
+      mm &= mm - 1;
+      ldscd_t w = dl.out + 15 * i;
+      double r12[12];
+#pragma unroll
+      for (int u = 0; u < 12; u++) r12[u] = w[u];
+      take(r12, w[12], w[13], w[14]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the list is written again below
+    listed = 0;
+    mine = 0u;
+  };
+  // (DENSE: one more round than the pieces have points -- it only empties the list: the emission's code exists once)
 #pragma unroll 1
-  for (int j = 0; j <= L.Kmax; j++) {
+  for (int j = 0; j <= L.Kmax + (DENSE ? 1 : 0); j++) {
+    const bool extra = j > L.Kmax; // (uniform)
     unsigned m = 0u;
     PtState pst;
     double nx[20];
-    load_planes(cor + (size_t)(j < L.Kmax ? j + 1 : j) * 16, cpitch, H, nx);
-    if (piece && j <= Kl)
+    load_planes(cor + (size_t)(j < L.Kmax ? j + 1 : L.Kmax) * 16, cpitch, H, nx);
+    if (piece && j <= Kl && !extra)
       m = (unsigned)point_masks<false>(P, cc, l, N, j, Kl, step, s1, singul_, epis, H, pl, (gd_t) nullptr, D.sur, 0.0, 0.0, 0, 0.0, pst);
+    const double s1_pt = s1;
     s1 += step; // the running sum of traj_optimizer.cpp:513
     [[maybe_unused]] long long emit_t0 = 0;
     if (D.prof != nullptr) { // (profiling only) trips of the loop below for the wave: the longest list of active terms among its 64 points;
@@ -282,39 +390,63 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, ldscd_
       pr.count(11, trips);
 #endif
     }
-    for (unsigned mm = m; mm;) {
-      const int t = __builtin_ctz(mm);
-      mm &= mm - 1;
-      double r_[16];
-      point_emit_pf(P, pst, t, H, t0,
-                    [&](int k, double &on0, double &on1, double &q0, double &q1) { // the planes point_masks tested, still in registers
-                      on0 = pl[0]; on1 = pl[1]; q0 = pl[2]; q1 = pl[3];
+    auto plane_of = [&](int k, double &on0, double &on1, double &q0, double &q1) { // the planes point_masks tested, still in registers
+      on0 = pl[0]; on1 = pl[1]; q0 = pl[2]; q1 = pl[3];
 #pragma unroll
-                      for (int u = 1; u < 5; u++) {
-                        on0 = k == u ? pl[4 * u] : on0;
-                        on1 = k == u ? pl[4 * u + 1] : on1;
-                        q0 = k == u ? pl[4 * u + 2] : q0;
-                        q1 = k == u ? pl[4 * u + 3] : q1;
-                      }
-                    },
-                    (double *)r_);
-#pragma unroll
-      for (int u = 0; u < 12; u++) gdC[u] += r_[u];
-      // what the term adds to gdT and to its cost, parked (the other cost gets -0.0: x + (-0.0) == x)
-      const bool corr = t < t0;
-      const double e0 = r_[12], e1 = corr ? r_[13] : -0.0, e2 = corr ? -0.0 : r_[13];
-      if (cnt < kQLcap) {
-        ldsd_t e = q.tl + (l * kQLcap + cnt) * 3;
-        e[0] = e0;
-        e[1] = e1;
-        e[2] = e2;
-      } else {
-        gd_t e = ovf_l + (size_t)cnt * 3;
-        e[0] = e0;
-        e[1] = e1;
-        e[2] = e2;
+      for (int u = 1; u < 5; u++) {
+        on0 = k == u ? pl[4 * u] : on0;
+        on1 = k == u ? pl[4 * u + 1] : on1;
+        q0 = k == u ? pl[4 * u + 2] : q0;
+        q1 = k == u ? pl[4 * u + 3] : q1;
       }
-      cnt++;
+    };
+    bool in_place = !DENSE;
+    if (DENSE) {
+      const int c = __builtin_popcount(m);
+      const bool any = __builtin_amdgcn_ballot_w64(c != 0) != 0ull; // (uniform) some point of this round has active terms
+      int incl = 0, total = 0;
+      if (any) incl = scan_here(c, total);
+      // the list is emptied when this round's terms do not fit behind what it holds, and by the extra round
+      if (listed > 0 && (extra || listed + total > kDense)) flush(); // (uniform)
+      if (any && total > kDense) { // (uniform, rare) more than a list's worth in one round: in place, behind the earlier points' terms
+        in_place = true;
+      } else if (any) {
+        int e = listed + incl - c;
+        for (unsigned mm = m; mm;) {
+          const int t = __builtin_ctz(mm);
+          mm &= mm - 1;
+          dl.id[e] = lane64 | (t << 6) | (j << 12);
+          dl.s1[e] = s1_pt;
+          if (t < t0) { // a corridor term: vertex v against half-plane k = t - v H
+            int v = 0;
+#pragma unroll
+            for (int qv = 1; qv < 5; qv++) v += t >= qv * H ? 1 : 0;
+            double on0, on1, q0, q1;
+            plane_of(t - v * H, on0, on1, q0, q1);
+            ldsd_t w = dl.pl + 4 * e;
+            w[0] = on0;
+            w[1] = on1;
+            w[2] = q0;
+            w[3] = q1;
+          }
+          mine |= 1u << e;
+          e++;
+        }
+        listed += total;
+      }
+    }
+    if (in_place) {
+      for (unsigned mm = m; mm;) {
+        const int t = __builtin_ctz(mm);
+        mm &= mm - 1;
+        double r_[16];
+        point_emit_pf(P, pst, t, H, t0, plane_of, (double *)r_);
+        const bool corr = t < t0;
+        double r12[12];
+#pragma unroll
+        for (int u = 0; u < 12; u++) r12[u] = r_[u];
+        take(r12, r_[12], corr ? r_[13] : -0.0, corr ? -0.0 : r_[13]);
+      }
     }
 #ifdef DFTPAV_PROF_EMIT_CYCLES
     if (D.prof != nullptr) pr.count(11, clock64() - emit_t0);
@@ -857,7 +989,7 @@ __device__ inline void q4_state_io(const DevBatch &D, const Q4 &q, QVec &v, int 
 // r of wave w of workgroup i takes trajectory (i W + w) 4 + r; bit 1: test hook, true divisions in the recursion from the start.
 // slice: evaluations of a wave after which its unfinished trajectories go back to the ring (all four rows together, so that the
 // rows of a wave are refilled together and the last trajectories of a batch gather in few waves).  hand: see the slice's end.
-template <bool FAST>
+template <bool FAST, bool DENSE>
 __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     ref4_kernel(const DevBatch *__restrict__ Dp, int mode, const double *__restrict__ tabs, const double *__restrict__ cor_t, double *__restrict__ scratch, int source,
                 int slice, int hand) {
@@ -868,6 +1000,8 @@ __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
   const int n = L.n, N = L.Ntot, H = L.H, mem = D.P.mem_size;
   Q4 q;
   q4_carve(q, reinterpret_cast<char *>(lds_raw) + q4_shared_bytes(N) + (size_t)(wv * 4 + row) * q4_team_bytes(mem), mem);
+  DenseLds dl; // the wave's list of active terms (behind the rows of all waves)
+  q4_carve_dense(dl, reinterpret_cast<char *>(lds_raw) + q4_shared_bytes(N) + (size_t)W * 4 * q4_team_bytes(mem) + (size_t)wv * q4_dense_bytes());
   const ldscd_t tab = (ldscd_t)lds_raw;
   for (int i = tidb; i < pk_segment_doubles(N); i += Tb) ((ldsd_t)lds_raw)[i] = tabs[i];
   __syncthreads(); // the only time the waves of the workgroup meet
@@ -924,7 +1058,7 @@ __global__ void __launch_bounds__(256, DFTPAV_Q4_WAVES_PER_EU)
     if (act) {
       const gcd_t cor = (gcd_t)(cor_t + (size_t)b * L.H * 4 * cpitch + l);
       const gd_t ovf = (gd_t)(scratch + (size_t)b * scratch_per_traj);
-      const double f = q4_eval<FAST>(D, q, tab, cor, cpitch, ovf, l, pr);
+      const double f = q4_eval<FAST, DENSE>(D, q, dl, tab, cor, cpitch, ovf, l, pr);
       if (mode == kModeEval) {
         for (int h = 0; h < 2; h++) {
           const int e = 16 * h + l;
@@ -1030,13 +1164,14 @@ __global__ void q4_corridor_kernel(const double *__restrict__ cor, double *__res
 // what the layout must satisfy for the QUAD shape (header)
 bool reference_order_quad_supported(const DevLayout &L, const DevParams &P, int S) {
   if (L.M != 1 || S != 0 || L.n > 32 || L.Ntot > 16 || L.Ntot < 2 || L.H < 1 || L.H > 5) return false;
-  return reford::q4_shared_bytes(L.Ntot) + 4 * reford::q4_team_bytes(P.mem_size) <= 160 * 1024;
+  return reford::q4_shared_bytes(L.Ntot) + 4 * reford::q4_team_bytes(P.mem_size) + reford::q4_dense_bytes() <= 160 * 1024;
 }
 size_t reference_order_quad_corridor_doubles(const DevLayout &L, int B) { return (size_t)B * L.H * 4 * (L.Kmax + 1) * 16; }
 // fills RefPlan for the QUAD shape: as many waves per workgroup (at most 4) and workgroups per CU as the LDS holds, eight waves
 // per CU at most (256 registers)
 void reference_order_quad_plan(const DevLayout &L, const DevParams &P, int B, int n_cu, RefPlan &pl) {
-  const size_t shared = reford::q4_shared_bytes(L.Ntot), team = reford::q4_team_bytes(P.mem_size), budget = 160 * 1024;
+  // (a wave: its four rows and its list of active terms)
+  const size_t shared = reford::q4_shared_bytes(L.Ntot), team = reford::q4_team_bytes(P.mem_size) + (reford::q4_dense_bytes() + 3) / 4, budget = 160 * 1024;
   int best_w = 1, best_wg = 1, best_res = 0;
   for (int w = std::min(4, reford::kQ4WavesPerCU); w >= 1; w--) {
     const size_t lds = shared + (size_t)w * 4 * team;
@@ -1100,11 +1235,14 @@ hipError_t launch_solver_ref4(const DevBatch &D, const DevBatch *d_dev, int mode
   if (std::getenv("DFTPAV_VERBOSE"))
     std::fprintf(stderr, "[dftpav] reference order, QUAD shape: grid %d x %d threads, %zu B of LDS, source %d slice %d hand-over at %d\n", grid, pl.threads, pl.lds, source, slice, hand);
   const bool fast = D.L.H == 4 && D.epis == 0.0 && !std::getenv("DFTPAV_REF_QUAD_GENERIC"); // the live path's constants (q4_eval)
-  const void *fn = fast ? reinterpret_cast<const void *>(&reford::ref4_kernel<true>) : reinterpret_cast<const void *>(&reford::ref4_kernel<false>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  bool dense = true; // the active terms evaluated densely packed (DFTPAV_REF_QUAD_DENSE=0: in place, as until late in round 6)
+  if (const char *e = std::getenv("DFTPAV_REF_QUAD_DENSE")) dense = std::atoi(e) != 0;
+  using Kern = void (*)(const DevBatch *, int, const double *, const double *, double *, int, int, int);
+  const Kern fn = fast ? (dense ? &reford::ref4_kernel<true, true> : &reford::ref4_kernel<true, false>)
+                       : (dense ? &reford::ref4_kernel<false, true> : &reford::ref4_kernel<false, false>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
   if (e != hipSuccess) return e;
-  if (fast) hipLaunchKernelGGL(reford::ref4_kernel<true>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice, hand);
-  else hipLaunchKernelGGL(reford::ref4_kernel<false>, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice, hand);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(pl.threads), pl.lds, stream, d_dev, mode, tabs, cor_t, scratch, source, slice, hand);
   return hipGetLastError();
 }
 
