@@ -36,5 +36,30 @@ template <int CTRL> __device__ __forceinline__ double nb_dpp(double v) {
   return __hiloint2double(hi, lo);
 }
 
+
+// DENSE emission (round 6): the active terms the lanes of a wave find in the point loop are listed -- (owner lane, point, term, the
+// point's running offset s1, the half-plane of a corridor term) -- and evaluated kDense at a time, one per lane, by whichever lanes
+// the list numbers: the owner's coefficients come over by ds_bpermute, the point's state is formed again by the same expressions
+// (the same bits), what the term adds goes back through LDS and the owner adds its terms in list order = (point, term) order.  In
+// place, a lane with k active terms ran k trips of the emission while the other 63 waited: 26-29 trips of ~2.2 k cycles per evaluation
+// of four trajectories with three lanes active on average (55-65 k cycles, 15 % of a pass).
+// (solver_ref4m.hip, several gear segments: tried and not kept -- its kernel has no registers left for the list's code: 64 bytes of
+// scratch per lane and 165 -> 171 ms per step of configs[1]'s stream)
+constexpr int kDense = 24;
+struct DenseLds {
+  ldsi_t id;   // [kDense] owner lane | term << 6 | point << 12
+  ldsd_t s1;   // [kDense]
+  ldsd_t pl;   // [kDense][4] the half-plane of a corridor term
+  ldsd_t out;  // [kDense][15] gdC (12), gdT, corridor cost, feasibility cost
+};
+__host__ __device__ inline size_t q4_dense_bytes() { return ((size_t)kDense * (4 + 8 + 32 + 120) + 15) & ~(size_t)15; }
+__device__ inline void q4_carve_dense(DenseLds &d, char *base) {
+  ldsd_t p = (ldsd_t)reinterpret_cast<double *>(base);
+  d.s1 = p; p += kDense;
+  d.pl = p; p += 4 * kDense;
+  d.out = p; p += 15 * kDense;
+  d.id = (ldsi_t)p;
+}
+
 } // namespace reford
 } // namespace dftpav

@@ -45,27 +45,6 @@ namespace dftpav {
 namespace reford {
 
 constexpr int kQLcap = 7; // parked terms of a piece kept in LDS (the rest in global scratch)
-// DENSE emission (round 6): the active terms the lanes of a wave find in the point loop are listed -- (owner lane, point, term, the
-// point's running offset s1, the half-plane of a corridor term) -- and evaluated kDense at a time, one per lane, by whichever lanes
-// the list numbers: the owner's coefficients come over by ds_bpermute, the point's state is formed again by the same expressions
-// (the same bits), what the term adds goes back through LDS and the owner adds its terms in list order = (point, term) order.  In
-// place, a lane with k active terms ran k trips of the emission while the other 63 waited: 26-29 trips of ~2.2 k cycles per evaluation
-// of four trajectories with three lanes active on average (55-65 k cycles, 15 % of a pass).
-constexpr int kDense = 24;
-struct DenseLds {
-  ldsi_t id;   // [kDense] owner lane | term << 6 | point << 12
-  ldsd_t s1;   // [kDense]
-  ldsd_t pl;   // [kDense][4] the half-plane of a corridor term
-  ldsd_t out;  // [kDense][15] gdC (12), gdT, corridor cost, feasibility cost
-};
-__host__ __device__ inline size_t q4_dense_bytes() { return ((size_t)kDense * (4 + 8 + 32 + 120) + 15) & ~(size_t)15; }
-__device__ inline void q4_carve_dense(DenseLds &d, char *base) {
-  ldsd_t p = (ldsd_t)reinterpret_cast<double *>(base);
-  d.s1 = p; p += kDense;
-  d.pl = p; p += 4 * kDense;
-  d.out = p; p += 15 * kDense;
-  d.id = (ldsi_t)p;
-}
 // Waves per SIMD the kernel is built for.  At 2 (256 registers) it spills 205 of them and its scratch traffic alone is HBM-sized
 // (measured: the point loop 3 x slower than at 1); at 1 the allocator takes 455 registers, nothing goes to scratch, and four waves
 // per CU hold 16 trajectories -- twice the WAVE shape's 8 -- each of them at the speed of a wave that has its SIMD to itself.
