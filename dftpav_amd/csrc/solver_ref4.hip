@@ -172,6 +172,109 @@ __device__ __forceinline__ void sweep4(ldscd_t tab, double (&bq)[12], int N, int
   }
 }
 
+// The same sweep for N = 16 with the two DIMENSIONS of a piece on two LANES (round 6).  In sweep4 the lane that owns block s computes its
+// twelve rows -- six per dimension, two independent chains -- while fifteen lanes wait; here a lane holds two SETS of six rows:
+//   X = (piece l, dimension 0) for l < 8, (piece l - 8, dimension 1) for l >= 8;   Y = (piece l + 8, dimension 1) for l < 8, (piece l, dimension 0) for l >= 8
+// so that block p of both dimensions is in one set on the two lanes p mod 8 and p mod 8 + 8, and a step of the traversal is SIX rows of
+// one instruction stream for both.  Pieces 0 .. 7 are in X, 8 .. 15 in Y: an ascending sweep runs eight steps on X, then eight on Y (a
+// descending one Y, then X); the previous block's results are the neighbour lane's rows of the same set (lanes 7 / 8 and 15 / 0 are not
+// neighbours in the chains they split: harmless, a chain's first block starts from zeros), except at the ninth step, which takes them from
+// the other set one lane around the row (row_ror).  Per row the same products and differences in the same order: the same bits.
+__device__ __forceinline__ void q4_split(const double (&bq)[12], double (&X)[6], double (&Y)[6], int l) {
+  const bool lo = (l & 8) == 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const double own = bq[2 * r], far = nb_dpp<0x128>(bq[2 * r + 1]); // dimension 1 of piece (l + 8) mod 16
+    X[r] = lo ? own : far;
+    Y[r] = lo ? far : own;
+  }
+}
+__device__ __forceinline__ void q4_unsplit(const double (&X)[6], const double (&Y)[6], double (&bq)[12], int l) {
+  const bool lo = (l & 8) == 0;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    bq[2 * r] = lo ? X[r] : Y[r];
+    bq[2 * r + 1] = nb_dpp<0x128>(lo ? Y[r] : X[r]); // this piece's dimension 1, from the lane eight around the row
+  }
+}
+template <int Q>
+__device__ __forceinline__ void sweep4_split(ldscd_t tab, double (&X)[6], double (&Y)[6], int l) {
+  constexpr bool DESC = Q == 1 || Q == 3, DIV = Q == 1 || Q == 2;
+  constexpr int N = 16;
+  ldscd_t ip = tab + 48;
+  const int l8 = l & 7;
+  // eight steps of the traversal on one set: pieces p0, p0 + dp, ...; first: the rows the first step starts from
+  auto phase = [&](double (&R)[6], int s0, const double (&first)[6]) {
+    // the table of this lane's own block of the set (an interior block: pk_size(Q) doubles), read once
+    v2d_t c[pk_size(Q) / 2];
+    {
+      const int sl = s0 + (DESC ? 7 - l8 : l8); // the step this lane's block of the set is taken in
+      const int bi = sl >= 1 && sl <= N - 2 ? sl - 1 : 0;
+      const ldscv2_t a = (ldscv2_t)(ip + bi * pk_size(Q));
+#pragma unroll
+      for (int u = 0; u < pk_size(Q) / 2; u++) c[u] = a[u];
+    }
+#pragma unroll 1
+    for (int s = s0; s < s0 + 8; s++) {
+      const int p8 = (DESC ? N - 1 - s : s) & 7;
+      double w[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) w[r] = DESC ? nb_dpp<0x101>(R[5 - r]) : nb_dpp<0x111>(R[r]);
+      if (s == s0) { // (uniform)
+#pragma unroll
+        for (int r = 0; r < 6; r++) w[r] = first[r];
+      }
+      if (l8 != p8) continue;
+      if (s == 0 || s == N - 1) { // a block of the ends: every coefficient is tested, as the reference does (`if (a != 0.0)`)
+        const ldscv2_t a = (ldscv2_t)(s == 0 ? tab : ip + (N - 2) * pk_size(Q));
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          v2d_t ce[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) ce[u] = a[4 * r + u];
+          const int rr = DESC ? 5 - r : r;
+          double acc = R[rr];
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            const double ck = (k & 1) ? ce[k >> 1].y : ce[k >> 1].x;
+            const double t = ck * w[(r + k) % 6];
+            acc = ck != 0.0 ? acc - t : acc;
+          }
+          if (DIV) acc = div_by_rcp(acc, ce[3].x, ce[3].y);
+          w[r] = acc;
+          R[rr] = acc;
+        }
+      } else { // an interior block: the non-zero terms only, no test
+        auto at = [&](int o) { return (o & 1) ? c[o >> 1].y : c[o >> 1].x; };
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const int rr = DESC ? 5 - r : r;
+          double acc = R[rr];
+#pragma unroll
+          for (int k = 0; k < 6; k++)
+            if (pk_mask(Q, r) & (1 << k)) acc = acc - at(pk_off(Q, r, k)) * w[(r + k) % 6];
+          if (DIV) acc = div_by_rcp(acc, at(pk_diag0(Q) + 2 * r), at(pk_diag0(Q) + 2 * r + 1));
+          w[r] = acc;
+          R[rr] = acc;
+        }
+      }
+    }
+  };
+  const double zeros[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double mid[6]; // what the ninth step starts from: the eighth block's results, from the other set one lane around the row
+  if (!DESC) {
+    phase(X, 0, zeros);
+#pragma unroll
+    for (int r = 0; r < 6; r++) mid[r] = nb_dpp<0x121>(X[r]); // lane 8 <- lane 7 (piece 7, dimension 0), lane 0 <- lane 15 (piece 7, dimension 1)
+    phase(Y, 8, mid);
+  } else {
+    phase(Y, 0, zeros);
+#pragma unroll
+    for (int r = 0; r < 6; r++) mid[r] = nb_dpp<0x12F>(Y[5 - r]); // lane 7 <- lane 8 (piece 8, dimension 0), lane 15 <- lane 0 (piece 8, dimension 1)
+    phase(X, 8, mid);
+  }
+}
+
 // ------------------------------------------------ costFunctionCallback (traj_optimizer.cpp:206-350), one gear segment
 // x (q.xs) -> g (q.gs), returns f.  The statements are solver_ref.hip's ref_eval, stage by stage; what changes is where a value
 // lives.  cor: &cor_t[b][0][0][l] (component pitch cpitch = 16 (Kmax + 1), a round's 16 pieces contiguous); ovf: this
@@ -182,6 +285,7 @@ template <bool FAST, bool DENSE>
 __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, const DenseLds &dl, ldscd_t tab, gcd_t cor, size_t cpitch, gd_t ovf, int l, Prof &pr) {
   const DevLayout &L = D.L;
   const DevParams &P = D.P;
+  constexpr bool SPLIT = DENSE; // (the round's two late changes share the switch DFTPAV_REF_QUAD_DENSE: the sweeps of 16 pieces with a dimension per lane)
   const int N = L.Ntot, H = FAST ? 4 : L.H, nterm = 5 * H + 4, t0 = 5 * H;
   const double epis = FAST ? 0.0 : D.epis;
   // ---- durations (VirtualT2RealT, :371-379), their powers (poly_traj_utils.hpp:961-966)
@@ -213,8 +317,16 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, const 
     bq[11] = q.xs[2 * l + 1];
   }
   // ---- BandedSystem::solve (poly_traj_utils.hpp:805-826)
-  sweep4<0>(tab, bq, N, l);
-  sweep4<1>(tab + pk_sweep_offset(1, N), bq, N, l);
+  if (N == 16 && SPLIT) { // (uniform)
+    double X[6], Y[6];
+    q4_split(bq, X, Y, l);
+    sweep4_split<0>(tab, X, Y, l);
+    sweep4_split<1>(tab + pk_sweep_offset(1, 16), X, Y, l);
+    q4_unsplit(X, Y, bq, l);
+  } else {
+    sweep4<0>(tab, bq, N, l);
+    sweep4<1>(tab + pk_sweep_offset(1, N), bq, N, l);
+  }
   pr.tick(0);
   // ---- c = b * tInv (:979-984)
   double cc[12];
@@ -507,8 +619,16 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, const 
   double adj[12];
 #pragma unroll
   for (int u = 0; u < 12; u++) adj[u] = gdC[u] * tI[u >> 1];
-  sweep4<2>(tab + pk_sweep_offset(2, N), adj, N, l);
-  sweep4<3>(tab + pk_sweep_offset(3, N), adj, N, l);
+  if (N == 16 && SPLIT) { // (uniform)
+    double X[6], Y[6];
+    q4_split(adj, X, Y, l);
+    sweep4_split<2>(tab + pk_sweep_offset(2, 16), X, Y, l);
+    sweep4_split<3>(tab + pk_sweep_offset(3, 16), X, Y, l);
+    q4_unsplit(X, Y, adj, l);
+  } else {
+    sweep4<2>(tab + pk_sweep_offset(2, N), adj, N, l);
+    sweep4<3>(tab + pk_sweep_offset(3, N), adj, N, l);
+  }
   pr.tick(4);
   // ---- gradient and cost (traj_optimizer.cpp:299-344)
   if (l < N - 1) { // gdP: rows 6 i + 5 of the adjoint
