@@ -57,8 +57,10 @@ from benchlib.parity import (cpu_baseline, parity_device_order, reference_order_
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (defaults = the driver's settings: a run of 5 steps ends with one batch's tail in five and reads 15-20 % lower; the timed region of 20
+    # steps is 2.3 s of a run that takes minutes for its side measurements)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--depth", type=int, default=4,
                     help="overlap schedule: steps in flight = resident batches = HIP streams per GPU (a step launches one batch and "
