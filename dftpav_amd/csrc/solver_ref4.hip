@@ -373,6 +373,10 @@ __device__ __forceinline__ double q4_eval(const DevBatch &D, const Q4 &q, const 
   // loads, whatever its piece): 33 rounds of a dependent HBM round trip each were 3/4 of this kernel's time
   double pl[20];
   load_planes(cor, cpitch, H, pl);
+  // (the first round's half-planes are waited for HERE: left pending into the loop, they make the compiler wait for ALL vector loads in front of
+  // every round's first use of a half-plane -- its count of the loads in flight merges to zero at the loop's head -- and that includes the
+  // next round's, requested a few hundred instructions earlier: the request ahead bought half a round instead of a whole one)
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
   // what an active term adds: to the lane's gdC in place, to gdT and to its cost parked (the other cost gets -0.0: x + (-0.0) == x)
   auto take = [&](const double (&r12)[12], double e0, double e1, double e2) {
 #pragma unroll

@@ -318,6 +318,7 @@ __device__ __forceinline__ double q4m_eval(const DevBatch &D, const Q4M &q, ldsc
   const gd_t ovf_l = ovf + (size_t)S.pt0 * nterm * 3;
   double pl[20];
   load_planes(cor, cpitch, H, pl);
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the first round's half-planes are waited for here, not inside the loop (solver_ref4.hip)
 #pragma unroll 1
   for (int j = 0; j <= L.Kmax; j++) {
     unsigned m = 0u;
