@@ -320,7 +320,7 @@ int dftpav_batch_upload(dftpav_batch *b, const dftpav_batch_data *d);
  *   Launch shape by batch size (or by the residency hint of dftpav_batch_create_shaped: 2 = many batches in flight): up to five
  *   trajectories per CU one workgroup each (lowest latency); beyond, one gear segment of <= 16 pieces and n <= 32 without moving
  *   obstacles -- BASELINE configs[2] / [3] -- takes the QUAD shape (solver_ref4.hip): FOUR trajectories per wave, one per row of
- *   16 lanes, a piece per lane, 16 trajectories per CU, the rows popping trajectories from the batch's ring (35-37 k solves/s on a
+ *   16 lanes, a piece per lane, 16 trajectories per CU, the rows popping trajectories from the batch's ring (35-38 k solves/s on a
  *   stream of 4096-batches on MI355X); up to four gear segments of <= 16 pieces in all and n <= 48 without moving obstacles -- BASELINE
  *   configs[1], the reference's live layouts -- the same shape with the segments' pieces side by side on a row (solver_ref4m.hip;
  *   22-25 k solves/s on such a stream); everything else one WAVE per trajectory, eight per CU (solver_ref.hip).  A batch that has
