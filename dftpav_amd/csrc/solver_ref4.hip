@@ -11,12 +11,15 @@
 //     b / c / gdC / adj at all (they were 6.1 of the WAVE shape's 18.2 KB per trajectory);
 //   * BandedSystem::solve / solveAdj (poly_traj_utils.hpp:805-852): the row sweeps of solver_ref.hip, piece by piece -- at step s
 //     the lane that owns block s takes the six results of the previous block from its neighbour's registers (DPP row_shr / row_shl)
-//     and computes its own six rows, both dimensions side by side; the row's multiply-subtract pairs in the reference's order;
+//     and computes its own six rows, both dimensions side by side; the row's multiply-subtract pairs in the reference's order
+//     (16 pieces: the two dimensions of a piece on two lanes, six rows per step -- sweep4_split below);
 //   * addPVAGradCost2CT (traj_optimizer.cpp:486-705): lane l walks the K + 1 constraint points of ITS piece in order (the running
 //     s1 += step of :513 is a register), and what an active term adds to gdC goes straight into the lane's own gdC registers --
 //     the order a gdC entry receives its additions in is (point, term) order within the piece, which is all the reference's order
 //     says about it.  No 16-double records, no chain pass.  Only what the term adds to the segment's gdT and to the two costs
-//     (three doubles) is parked, per piece, and chained afterwards over the pieces in order;
+//     (three doubles) is parked, per piece, and chained afterwards over the pieces in order.  The active terms themselves are
+//     EVALUATED densely packed: listed by the lanes that find them, taken 24 at a time one per lane, their results handed back to
+//     the owners through LDS in list order (quad_common.h: DenseLds; q4_eval: flush);
 //   * the corridor is read from a copy laid out [component][j][piece]: the 16 lanes of a row read 128 contiguous bytes;
 //   * lbfgs_optimize / line_search_lewisoverton (lbfgs.hpp:276-390, 440-751): solver_ref.hip's lbfgs_advance, per row; a vector of
 //     n <= 32 variables is two registers per lane (elements l and 16 + l), a sequential dot product is the 32-step DPP chain --
@@ -27,10 +30,11 @@
 // another, with the restatement and with the golden vectors).  Scope: one gear segment, N <= 16 pieces, n <= 32, no moving
 // obstacles, H <= 5 -- the BASELINE configs[2] / [3] workload; everything else stays with solver_ref.hip.
 //
-// Residency: ONE wave per SIMD (the kernel takes 435 registers; built for two waves per SIMD it spilled 205 of them and its scratch
+// Residency: ONE wave per SIMD (the kernel takes 460 registers; built for two waves per SIMD it spilled 205 of them and its scratch
 // traffic alone was HBM-sized), four waves = 16 trajectories per CU (8 in the WAVE shape), each wave at the speed of a wave that has
-// its SIMD to itself; 6.1 KB of LDS per trajectory (x, g, the boundary states, the scalars of the line search, alpha[mem], the first
-// eight parked terms of every piece), workgroups of one wave with a copy of the sweep tables each (37 KB; a wave that has nothing
+// its SIMD to itself; 5.7 KB of LDS per trajectory (x, g, the boundary states, the scalars of the line search, alpha[mem], the first
+// seven parked terms of every piece) and 3.9 KB per wave for the list of active terms, workgroups of one wave with a copy of the sweep
+// tables each (39 KB; a wave that has nothing
 // left to do frees its slot at once).  Scheduling as the WAVE shape: the rows pop trajectories from the batch's ring, run them a
 // slice of evaluations and push them back unfinished, so that a wave's rows stay filled until the batch runs out.
 #include <hip/hip_runtime.h>
